@@ -1,0 +1,152 @@
+/*
+ * pt_api.h -- C ABI of libptmi.so, the MI355X (gfx950) path-tracing backend that sits where the
+ * reference's Vulkan renderers sit (reference: src/renderer.h:30-48; the two implementations it
+ * replaces are src/rayquery.cpp:40-109 and src/rtx_pipeline.cpp:45-276).
+ *
+ * Conventions
+ *  - every entry point returns pt_Status (0 == ok, negative == error); the text of the last error
+ *    is available from pt_last_error().  Nothing here aborts the process.  (The reference has no
+ *    error convention at all: its methods are void and VkResults are asserted,
+ *    src/rtx_pipeline.cpp:209,237.)
+ *  - a context is externally synchronised: any thread may call, never two at once.
+ *  - host arrays passed to pt_set_* are copied before the call returns.
+ *  - pt_render_frame is asynchronous on the context's HIP stream; pt_read_accum, pt_tonemap,
+ *    pt_get_stats and pt_synchronize wait for it.
+ *  - there is no CPU fallback: without a gfx950 device pt_create fails with PT_ERR_NO_DEVICE.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context pt_context;
+
+typedef enum pt_Status {
+  PT_OK            = 0,
+  PT_ERR_INVALID   = -1, /* bad argument / inconsistent scene description */
+  PT_ERR_NO_DEVICE = -2, /* no HIP device with that ordinal (or not gfx950) */
+  PT_ERR_HIP       = -3, /* a HIP runtime call failed; see pt_last_error */
+  PT_ERR_STATE     = -4, /* call order violated (e.g. render before build_accel) */
+  PT_ERR_OOM       = -5
+} pt_Status;
+
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* replaces Renderer::setup(device, physicalDevice, familyIndex, allocator)  [src/renderer.h:33-36,
+ * src/rayquery.cpp:40-46]: binds the context to one GPU and creates its stream. */
+int pt_create(int device_ordinal, pt_context** out_ctx);
+
+/* replaces Renderer::destroy() [src/renderer.h:37, src/rayquery.cpp:51-58] plus the destroy() of
+ * Scene / AccelStructure / HdrSampling / RenderOutput, whose device memory the context owns. */
+int pt_destroy(pt_context* ctx);
+
+/* "HIP" -- replaces Renderer::name() [src/renderer.h:43; "RQ" src/rayquery.hpp:51, "Rtx" src/rtx_pipeline.hpp:57] */
+const char* pt_renderer_name(void);
+
+const char* pt_last_error(const pt_context* ctx); /* ctx may be NULL: last pt_create error */
+
+/* ---- scene (descriptor set 2 of the reference, shaders/layouts.glsl:42-46) ------------------- */
+
+/* replaces the uploads done by Scene::load [src/scene.cpp:56-118]: createMaterialBuffer :339-382,
+ * createLightBuffer :304-333, createTextureImages :488-580, createVertexBuffer :190-274,
+ * createInstanceDataBuffer :161-176.  The arrays are the ones those functions upload. */
+int pt_set_scene(pt_context* ctx, const pt_SceneDesc* scene);
+
+/* replaces AccelStructure::create [src/accelstruct.cpp:55-65] (BLAS per prim-mesh :110-127, TLAS
+ * instance per node with opaque / cull-disable flags :132-162): builds the device LBVH over the
+ * world-space triangles of every node. */
+int pt_build_accel(pt_context* ctx);
+
+/* replaces Scene::updateCamera's UBO upload [src/scene.cpp:629-668] */
+int pt_set_camera(pt_context* ctx, const pt_SceneCamera* cam);
+
+/* ---- environment (descriptor set 3, shaders/layouts.glsl:48-50) ------------------------------ */
+
+/* replaces HdrSampling::loadEnvironment after stbi_loadf [src/hdr_sampling.cpp:56-99]: uploads the
+ * RGBA32F lat-long image (row 0 = +Y pole) and the alias table built by createEnvironmentAccel
+ * [:187-248]; returns getIntegral()/getAverage() [src/hdr_sampling.hpp:44-45].  The caller sets
+ * fireflyClampThreshold = 4 * integral like src/sample_example.cpp:110. */
+int pt_set_env(pt_context* ctx, const float* rgba32f, int width, int height, float* out_integral, float* out_average);
+
+/* replaces the SunAndSky UBO update in SampleExample::updateUniformBuffer [src/sample_example.cpp:168-178] */
+int pt_set_sunsky(pt_context* ctx, const pt_SunAndSky* ss);
+
+/* ---- output (descriptor set 1) --------------------------------------------------------------- */
+
+/* replaces Renderer::create(size, ...) [src/renderer.h:42] + RenderOutput::update(size)
+ * [src/render_output.cpp:88-99]: (re)allocates the RGBA32F accumulation tiles and the path state. */
+int pt_resize(pt_context* ctx, int width, int height);
+
+/* Image-tile sharding for multi-GPU runs (no reference counterpart).  Rank r of n
+ * renders the PT_TILE x PT_TILE tiles with (tx + ty) % n == r; seeds use the global pixel index so
+ * the pixels are bit-identical to a 1-GPU render.  Default (0, 1).  Call before pt_resize. */
+int pt_set_shard(pt_context* ctx, int rank, int nranks);
+
+/* replaces Renderer::setPushContants(state) + Renderer::run(cmdBuf, size, profiler, descSets)
+ * [src/renderer.h:38-45; src/rayquery.cpp:97-109 -> shaders/pathtrace.comp:87-134]: renders
+ * state->maxSamples samples for every local pixel and folds them into the accumulation buffer with
+ * the reference's running mean (pathtrace.comp:122-133).  state->size must equal the pt_resize size. */
+int pt_render_frame(pt_context* ctx, const pt_RtxState* state);
+
+int pt_synchronize(pt_context* ctx);
+
+/* Reads the linear RGBA32F accumulation image, row-major width*height*4 floats (alpha == 1).
+ * With nranks > 1 only locally owned pixels are valid unless pt_scatter_shards was called. */
+int pt_read_accum(pt_context* ctx, float* rgba32f_out);
+
+/* replaces RenderOutput::run [src/render_output.cpp:174-182 -> shaders/post.frag:98-147]:
+ * tonemaps the accumulation image into row-major RGBA8. */
+int pt_tonemap(pt_context* ctx, const pt_Tonemapper* tm, uint8_t* rgba8_out);
+
+/* Device-side view of the local shard for the RCCL gather: pointer to [maxTilesPerRank][PT_TILE*PT_TILE][4]
+ * floats (owned tiles first, in increasing global tile id; padding zero). */
+int pt_local_shard(pt_context* ctx, void** device_ptr, size_t* bytes, int* num_local_tiles, int* max_tiles_per_rank);
+
+/* Rank 0 after the gather: gathered_dev holds nranks consecutive shards as returned by
+ * pt_local_shard on each rank; places every tile at its global position so that pt_read_accum /
+ * pt_tonemap see the full image. */
+int pt_scatter_shards(pt_context* ctx, const void* gathered_dev, int nranks);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+
+/* enable != 0: bracket every kernel with HIP events on the render stream and accumulate per-stage
+ * milliseconds into pt_Stats (replaces the nvvk::ProfilerVK sections "Render"/"Tonemap",
+ * src/sample_example.cpp:404, src/main.cpp:212-257). */
+int pt_set_profiling(pt_context* ctx, int enable);
+int pt_get_stats(pt_context* ctx, pt_Stats* out);
+int pt_reset_stats(pt_context* ctx);
+
+/* ---- host-side helpers restating the reference's scene packing -------------------------------- */
+
+/* shaders/compress.glsl:111-139 (host flavour used at src/scene.cpp:224-225) */
+uint32_t pt_compress_unit_vec(const float v[3]);
+
+/* src/scene.cpp:219-242: positions[3n], normals[3n], tangents[4n] (w = handedness), uvs[2n],
+ * colors[4n] (float 0..1) -> VertexAttributes[n] */
+int pt_pack_vertices(uint32_t n, const float* positions, const float* normals, const float* tangents,
+                     const float* uvs, const float* colors, pt_VertexAttributes* out);
+
+/* src/scene.cpp:629-640 with glm::lookAt / perspectiveRH_ZO(fov, aspect, 0.001, 1e5), proj[1][1] *= -1 */
+int pt_camera_lookat(const float eye[3], const float center[3], const float up[3], float fov_degrees,
+                     float aspect, pt_SceneCamera* out);
+
+/* src/hdr_sampling.cpp:107-248 on the host; pt_set_env calls this internally. */
+int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel* out_accel, float* out_integral,
+                       float* out_average);
+
+/* src/scene.cpp:447-482,561-571: glTF sampler codes -> filter / wrap enums of pt_TextureDesc
+ * (has_sampler == 0: LINEAR / REPEAT; unknown filter code: NEAREST; unknown wrap: REPEAT). */
+int pt_sampler_from_gltf(int has_sampler, int gltf_mag, int gltf_min, int gltf_wrapS, int gltf_wrapT, pt_TextureDesc* io);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PT_API_H */

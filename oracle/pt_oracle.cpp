@@ -1,0 +1,311 @@
+// TEST INFRASTRUCTURE -- the CPU oracle's C entry points (see oracle/README.md).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+// only as the checker / the reported CPU baseline.  The product (libptmi.so) never links or calls it.
+//
+// PARITY UNPINNED: the reference ships no tests, golden images or known-answer vectors for this
+// path and cannot be built or run here (no Vulkan, no glslang, nvpro_core absent -- SURVEY.md 8(c)).
+// The oracle is a restatement of the reference's GLSL + host code, pinned only by (a) integer
+// known-answer vectors minted by an independent numpy implementation (tests/golden/) and (b)
+// analytic properties (furnace, alias-table sums, brute-force == BVH).
+#include <omp.h>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "orc_path.h"
+
+using namespace orc;
+
+// post.frag + tonemapping.glsl -------------------------------------------------------------------
+namespace {
+
+// shaders/tonemapping.glsl:29-32
+inline vec3 linearTosRGB(vec3 c) { return gpow(c, vec3(1.0f / 2.2f)); }
+// :36-39
+inline vec3 sRGBToLinear(vec3 c) { return gpow(c, vec3(2.2f)); }
+// :48-57
+inline vec3 toneMapUncharted2Impl(vec3 color)
+{
+  const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+  return ((color * (color * A + C * B) + D * E) / (color * (color * A + B) + D * F)) - E / F;
+}
+// :59-65
+inline vec3 toneMapUncharted(vec3 color)
+{
+  const float W   = 11.2f;
+  color           = toneMapUncharted2Impl(color * 2.0f);
+  vec3 whiteScale = vec3(1.0f) / toneMapUncharted2Impl(vec3(W));
+  return linearTosRGB(color * whiteScale);
+}
+// shaders/post.frag:48-54
+inline vec3 dither(vec3 linear_color, vec3 noise, float quant)
+{
+  vec3 c0    = gfloor(linearTosRGB(linear_color) / quant) * quant;
+  vec3 c1    = c0 + quant;
+  vec3 discr = gmix(sRGBToLinear(c0), sRGBToLinear(c1), noise);
+  return vec3(discr.x < linear_color.x ? c1.x : c0.x, discr.y < linear_color.y ? c1.y : c0.y, discr.z < linear_color.z ? c1.z : c0.z);
+}
+// shaders/post.frag:64-70 (RGB2XYZ is a column-major mat3 constructor: XYZ.y = dot(row 1))
+inline vec3 toneExposure(vec3 RGB, float logAvgLum, const pt_Tonemapper& tm)
+{
+  // mat3(0.4124564, 0.3575761, 0.1804375, 0.2126729, 0.7151522, 0.0721750, 0.0193339, 0.1191920, 0.9503041) * RGB:
+  // columns are (0.4124564,0.3575761,0.1804375) ... so component y = 0.3575761*R + 0.7151522*G + 0.1191920*B
+  float XYZy = (0.3575761f * RGB.x + 0.7151522f * RGB.y) + 0.1191920f * RGB.z;
+  float Y    = (tm.key / logAvgLum) * XYZy;
+  float Yd   = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);
+  return RGB / XYZy * Yd;
+}
+
+}  // namespace
+
+struct orc_ctx {
+  Scene       scene;
+  Stats       stats;
+  int         threads = 0;
+  std::string err;
+};
+
+extern "C" {
+
+orc_ctx* orc_create() { return new orc_ctx(); }
+void     orc_destroy(orc_ctx* c) { delete c; }
+const char* orc_last_error(orc_ctx* c) { return c->err.c_str(); }
+
+int orc_set_threads(orc_ctx* c, int n)
+{
+  c->threads = n;
+  return 0;
+}
+int orc_set_use_bvh(orc_ctx* c, int use)
+{
+  c->scene.useBvh = use != 0;
+  return 0;
+}
+
+int orc_set_scene(orc_ctx* c, const pt_SceneDesc* d)
+{
+  if(!d || !c->scene.set(d))
+  {
+    c->err = "invalid scene description";
+    return -1;
+  }
+  return 0;
+}
+
+int orc_set_env(orc_ctx* c, const float* rgba, int w, int h, float* integral, float* average)
+{
+  if(!rgba || w <= 0 || h <= 0)
+    return -1;
+  c->scene.env.assign(rgba, rgba + size_t(w) * h * 4);
+  c->scene.envW = w;
+  c->scene.envH = h;
+  create_environment_accel(rgba, (uint32_t)w, (uint32_t)h, c->scene.envAccel, c->scene.envIntegral, c->scene.envAverage);
+  if(integral) *integral = c->scene.envIntegral;
+  if(average) *average = c->scene.envAverage;
+  return 0;
+}
+int orc_set_camera(orc_ctx* c, const pt_SceneCamera* cam)
+{
+  c->scene.camera = *cam;
+  return 0;
+}
+int orc_set_sunsky(orc_ctx* c, const pt_SunAndSky* ss)
+{
+  c->scene.sunsky = *ss;
+  return 0;
+}
+
+// Renders one frame (state->maxSamples samples per pixel) into accum (row-major W*H RGBA32F, in/out).
+// If pixel_ids != NULL only those n pixels (id = y*W + x) are rendered (bounded CPU-baseline sample).
+int orc_render_frame(orc_ctx* c, const pt_RtxState* state, float* accum, const uint32_t* pixel_ids, uint64_t n)
+{
+  const int W = state->size[0], H = state->size[1];
+  if(W <= 0 || H <= 0 || !accum)
+    return -1;
+  if(c->scene.sunsky.in_use != 1 && c->scene.env.empty())
+  {
+    c->err = "no environment set";
+    return -1;
+  }
+  const int nthreads = c->threads > 0 ? c->threads : omp_get_max_threads();
+  Stats     total;
+#pragma omp parallel num_threads(nthreads)
+  {
+    Tracer tr(c->scene, *state);
+    if(pixel_ids)
+    {
+#pragma omp for schedule(dynamic, 64)
+      for(int64_t i = 0; i < (int64_t)n; ++i)
+      {
+        uint32_t id = pixel_ids[i];
+        tr.render_pixel(int(id % W), int(id / W), accum + size_t(id) * 4);
+      }
+    }
+    else
+    {
+      const int tx = (W + 7) / 8, ty = (H + 7) / 8;
+#pragma omp for schedule(dynamic, 4)
+      for(int t = 0; t < tx * ty; ++t)
+      {
+        int x0 = (t % tx) * 8, y0 = (t / tx) * 8;
+        for(int y = y0; y < std::min(y0 + 8, H); ++y)
+          for(int x = x0; x < std::min(x0 + 8, W); ++x)
+            tr.render_pixel(x, y, accum + (size_t(y) * W + x) * 4);
+      }
+    }
+#pragma omp critical
+    total.add(tr.stats);
+  }
+  c->stats.add(total);
+  return 0;
+}
+
+// 10 uint64: samples closestRays shadowRays shadedHits misses alphaTests neeLookups nodesVisited trisTested texTaps
+int orc_get_stats(orc_ctx* c, uint64_t* out)
+{
+  const Stats& s = c->stats;
+  uint64_t     v[10] = {s.samples, s.closestRays, s.shadowRays, s.shadedHits, s.misses, s.alphaTests, s.neeLookups, s.nodesVisited, s.trisTested, s.texTaps};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+int orc_reset_stats(orc_ctx* c)
+{
+  c->stats = Stats();
+  return 0;
+}
+uint32_t orc_num_triangles(orc_ctx* c) { return (uint32_t)c->scene.tris.size(); }
+
+// shaders/post.frag:98-147 with TONEMAP_UNCHARTED.  zoom must be 1 (the viewer's de-scaling preview
+// is out of scope); auto-exposure bit 0 uses the mean of the image in place of the 1x1 mip; the
+// local-exposure variant (bit 1) is not reproduced.
+int orc_tonemap(const pt_Tonemapper* tm, const float* accum, int W, int H, uint8_t* out)
+{
+  vec3 avg(0);
+  if(tm->autoExposure & 1)
+  {
+    double s[3] = {0, 0, 0};
+    for(size_t i = 0; i < size_t(W) * H; ++i)
+      for(int k = 0; k < 3; ++k)
+        s[k] += accum[i * 4 + k];
+    avg = vec3(float(s[0] / (double(W) * H)), float(s[1] / (double(W) * H)), float(s[2] / (double(W) * H)));
+  }
+#pragma omp parallel for schedule(static)
+  for(int y = 0; y < H; ++y)
+  {
+    for(int x = 0; x < W; ++x)
+    {
+      const float* p = accum + (size_t(y) * W + x) * 4;
+      vec3         hdr(p[0], p[1], p[2]);
+      if(tm->autoExposure & 1)
+      {
+        float avgLum2 = dot(avg, vec3(0.2126f, 0.7152f, 0.0722f));
+        hdr           = toneExposure(hdr, avgLum2, *tm);
+      }
+      vec3 color = toneMapUncharted(hdr * tm->avgLum);
+      if(tm->dither > 0)
+      {
+        uint32_t r[3] = {(uint32_t)x, (uint32_t)y, 0u};
+        pcg3d(r);
+        vec3 noise(uintBitsToFloat(0x3f800000u | (r[0] >> 9)) - 1.0f, uintBitsToFloat(0x3f800000u | (r[1] >> 9)) - 1.0f,
+                   uintBitsToFloat(0x3f800000u | (r[2] >> 9)) - 1.0f);
+        color = dither(sRGBToLinear(color), noise, 1.f / 255.f);
+      }
+      color      = gclamp(gmix(vec3(0.5f), color, tm->contrast), 0.0f, 1.0f);
+      color      = gpow(color, vec3(1.0f / tm->brightness));
+      vec3  i    = vec3(dot(color, vec3(0.299f, 0.587f, 0.114f)));
+      color      = gmix(i, color, tm->saturation);
+      vec2  uvc((float(x) + 0.5f) / float(W), (float(y) + 0.5f) / float(H));
+      vec2  uv   = ((uvc * vec2(tm->renderingRatio[0], tm->renderingRatio[1])) - vec2(0.5f)) * 2.0f;
+      color *= 1.0f - dot(uv, uv) * tm->vignette;
+      uint8_t* o = out + (size_t(y) * W + x) * 4;
+      for(int k = 0; k < 3; ++k)
+      {
+        float v = gclamp(color[k], 0.0f, 1.0f);
+        o[k]    = (uint8_t)std::floor(v * 255.0f + 0.5f);
+      }
+      o[3] = (uint8_t)std::floor(gclamp(p[3], 0.0f, 1.0f) * 255.0f + 0.5f);
+    }
+  }
+  return 0;
+}
+
+// ---- small known-answer entry points ------------------------------------------------------------
+uint32_t orc_tea(uint32_t a, uint32_t b) { return tea(a, b); }
+void     orc_pcg_stream(uint32_t seed, uint32_t n, uint32_t* out_words, float* out_floats, uint32_t* out_state)
+{
+  for(uint32_t i = 0; i < n; ++i)
+  {
+    uint32_t s = seed;
+    uint32_t w = pcg(s);
+    if(out_words) out_words[i] = w;
+    if(out_floats) out_floats[i] = uintBitsToFloat(0x3f800000u | (w >> 9)) - 1.0f;
+    seed = s;
+  }
+  if(out_state) *out_state = seed;
+}
+void orc_pcg3d(uint32_t* v) { pcg3d(v); }
+uint32_t orc_compress_unit_vec(const float* v) { return compress_unit_vec(vec3(v[0], v[1], v[2])); }
+void     orc_decompress_unit_vec(uint32_t p, float* out)
+{
+  vec3 v = decompress_unit_vec(p);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+void orc_offset_ray(const float* p, const float* n, float* out)
+{
+  vec3 v = OffsetRay(vec3(p[0], p[1], p[2]), vec3(n[0], n[1], n[2]));
+  out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+void orc_pack_vertices(uint32_t n, const float* pos, const float* nrm, const float* tan4, const float* uv, const float* col4, pt_VertexAttributes* out)
+{
+  for(uint32_t i = 0; i < n; ++i)
+    pack_vertex(pos + 3 * i, nrm + 3 * i, tan4 + 4 * i, uv + 2 * i, col4 + 4 * i, out + i);
+}
+void orc_camera_lookat(const float* eye, const float* center, const float* up, float fov, float aspect, pt_SceneCamera* out)
+{
+  camera_lookat(eye, center, up, fov, aspect, out);
+}
+void orc_build_env_accel(const float* rgba, int w, int h, pt_EnvAccel* out, float* integral, float* average)
+{
+  std::vector<pt_EnvAccel> acc;
+  create_environment_accel(rgba, (uint32_t)w, (uint32_t)h, acc, *integral, *average);
+  std::memcpy(out, acc.data(), acc.size() * sizeof(pt_EnvAccel));
+}
+void orc_sampler_from_gltf(int has, int mag, int min, int ws, int wt, pt_TextureDesc* io) { sampler_from_gltf(has, mag, min, ws, wt, io); }
+void orc_sun_and_sky(const pt_SunAndSky* ss, const float* dir, float* out)
+{
+  vec3 c = sky::sun_and_sky(*ss, vec3(dir[0], dir[1], dir[2]));
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+void orc_sample_texture(orc_ctx* c, int id, float u, float v, float* out)
+{
+  vec4 t = c->scene.sample_texture(id, vec2(u, v), nullptr);
+  out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+
+// Closest-hit known answers: n rays -> (t, node, prim, u, v); seeds are per-ray RNG states (in/out)
+void orc_trace_closest(orc_ctx* c, uint32_t n, const float* org, const float* dir, uint32_t* seeds, float* out_t, int32_t* out_node,
+                       int32_t* out_prim, float* out_uv)
+{
+  pt_RtxState st{};
+#pragma omp parallel
+  {
+    Tracer tr(c->scene, st);
+#pragma omp for schedule(dynamic, 256)
+    for(int64_t i = 0; i < (int64_t)n; ++i)
+    {
+      tr.prd.seed = seeds ? seeds[i] : 0u;
+      Ray r{vec3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), vec3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2])};
+      tr.ClosestHit(r);
+      bool hit    = tr.prd.hitT != INFINITY_RT;
+      out_t[i]    = tr.prd.hitT;
+      out_node[i] = hit ? tr.prd.instanceID : -1;
+      out_prim[i] = hit ? tr.prd.primitiveID : -1;
+      out_uv[2 * i]     = hit ? tr.prd.baryCoord.x : 0.f;
+      out_uv[2 * i + 1] = hit ? tr.prd.baryCoord.y : 0.f;
+      if(seeds) seeds[i] = tr.prd.seed;
+    }
+  }
+}
+
+}  // extern "C"

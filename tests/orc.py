@@ -1,0 +1,179 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so) -- test infrastructure only.
+
+Nothing under vk_raytrace_amd/ imports this module; it is used by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from vk_raytrace_amd import host_device as hd
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_ROOT, "oracle", "liborc.so")
+
+
+def build(force=False):
+    src = os.path.join(_ROOT, "oracle")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".h", ".cpp", "Makefile")))
+    newest = max(newest, os.path.getmtime(os.path.join(_ROOT, "include", "pt_types.h")))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", src, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.orc_create.restype = C.c_void_p
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_use_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_scene.argtypes = [C.c_void_p, C.POINTER(hd.SceneDesc)]
+        L.orc_set_env.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_set_camera.argtypes = [C.c_void_p, C.POINTER(hd.SceneCamera)]
+        L.orc_set_sunsky.argtypes = [C.c_void_p, C.POINTER(hd.SunAndSky)]
+        L.orc_render_frame.argtypes = [C.c_void_p, C.POINTER(hd.RtxState), C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_reset_stats.argtypes = [C.c_void_p]
+        L.orc_num_triangles.argtypes = [C.c_void_p]
+        L.orc_num_triangles.restype = C.c_uint32
+        L.orc_tonemap.argtypes = [C.POINTER(hd.Tonemapper), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_tea.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_tea.restype = C.c_uint32
+        L.orc_pcg_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pcg3d.argtypes = [C.c_void_p]
+        L.orc_compress_unit_vec.argtypes = [C.c_void_p]
+        L.orc_compress_unit_vec.restype = C.c_uint32
+        L.orc_decompress_unit_vec.argtypes = [C.c_uint32, C.c_void_p]
+        L.orc_offset_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pack_vertices.argtypes = [C.c_uint32] + [C.c_void_p] * 6
+        L.orc_camera_lookat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(hd.SceneCamera)]
+        L.orc_build_env_accel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_sampler_from_gltf.argtypes = [C.c_int] * 5 + [C.POINTER(hd.TextureDesc)]
+        L.orc_sun_and_sky.argtypes = [C.POINTER(hd.SunAndSky), C.c_void_p, C.c_void_p]
+        L.orc_sample_texture.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orc_trace_closest.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
+    return _lib
+
+
+STAT_NAMES = ["samples", "closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups", "nodesVisited", "trisTested", "texTaps"]
+
+
+def pack_vertices(pos, nrm, tan, uv, col):
+    n = len(pos)
+    out = np.zeros(n, hd.vertex_dtype)
+    a = [np.ascontiguousarray(x, np.float32) for x in (pos, nrm, tan, uv, col)]
+    lib().orc_pack_vertices(n, *[x.ctypes.data for x in a], out.ctypes.data)
+    return out
+
+
+def camera_lookat(cam, aspect):
+    out = hd.SceneCamera()
+    e, c, u = (np.asarray(v, np.float32) for v in (cam.eye, cam.center, cam.up))
+    lib().orc_camera_lookat(e.ctypes.data, c.ctypes.data, u.ctypes.data, cam.fov, aspect, C.byref(out))
+    out.aperture = cam.aperture
+    if cam.focal_dist is not None:
+        out.focalDist = cam.focal_dist
+    return out
+
+
+class Oracle:
+    """The oracle with the same call shape as the product's HipRenderer."""
+
+    def __init__(self, threads=0):
+        self.L = lib()
+        self.ctx = self.L.orc_create()
+        if threads:
+            self.L.orc_set_threads(self.ctx, threads)
+        self.integral = 1.0
+        self.average = 1.0
+        self._keep = None
+
+    def close(self):
+        if self.ctx:
+            self.L.orc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def set_use_bvh(self, use):
+        self.L.orc_set_use_bvh(self.ctx, int(use))
+
+    def set_scene(self, scene):
+        d, keep = scene.desc()
+        if self.L.orc_set_scene(self.ctx, C.byref(d)) != 0:
+            raise RuntimeError(self.L.orc_last_error(self.ctx).decode())
+        self._keep = keep
+
+    def set_env(self, env):
+        env = np.ascontiguousarray(env, np.float32)
+        i, a = C.c_float(), C.c_float()
+        assert self.L.orc_set_env(self.ctx, env.ctypes.data, env.shape[1], env.shape[0], C.byref(i), C.byref(a)) == 0
+        self.integral, self.average = i.value, a.value
+        return self.integral, self.average
+
+    def set_camera(self, cam: hd.SceneCamera):
+        self.L.orc_set_camera(self.ctx, C.byref(cam))
+
+    def set_sunsky(self, ss: hd.SunAndSky):
+        self.L.orc_set_sunsky(self.ctx, C.byref(ss))
+
+    def render_frame(self, state: hd.RtxState, accum, pixel_ids=None):
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous
+        if pixel_ids is None:
+            rc = self.L.orc_render_frame(self.ctx, C.byref(state), accum.ctypes.data, None, 0)
+        else:
+            pixel_ids = np.ascontiguousarray(pixel_ids, np.uint32)
+            rc = self.L.orc_render_frame(self.ctx, C.byref(state), accum.ctypes.data, pixel_ids.ctypes.data, len(pixel_ids))
+        if rc != 0:
+            raise RuntimeError(self.L.orc_last_error(self.ctx).decode())
+
+    def render(self, state: hd.RtxState, frames, accum=None, first_frame=0):
+        W, H = state.size[0], state.size[1]
+        if accum is None:
+            accum = np.zeros((H, W, 4), np.float32)
+        for f in range(first_frame, first_frame + frames):
+            state.frame = f
+            self.render_frame(state, accum)
+        return accum
+
+    def stats(self):
+        v = np.zeros(10, np.uint64)
+        self.L.orc_get_stats(self.ctx, v.ctypes.data)
+        return dict(zip(STAT_NAMES, (int(x) for x in v)))
+
+    def reset_stats(self):
+        self.L.orc_reset_stats(self.ctx)
+
+    def trace_closest(self, org, dirs, seeds=None):
+        n = len(org)
+        org = np.ascontiguousarray(org, np.float32)
+        dirs = np.ascontiguousarray(dirs, np.float32)
+        t = np.zeros(n, np.float32)
+        node = np.zeros(n, np.int32)
+        prim = np.zeros(n, np.int32)
+        uv = np.zeros((n, 2), np.float32)
+        sp = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, np.uint32).copy()
+            sp = seeds.ctypes.data
+        self.L.orc_trace_closest(self.ctx, n, org.ctypes.data, dirs.ctypes.data, sp, t.ctypes.data, node.ctypes.data, prim.ctypes.data, uv.ctypes.data)
+        return t, node, prim, uv, seeds
+
+
+def tonemap(tm: hd.Tonemapper, accum):
+    H, W = accum.shape[:2]
+    out = np.zeros((H, W, 4), np.uint8)
+    lib().orc_tonemap(C.byref(tm), np.ascontiguousarray(accum, np.float32).ctypes.data, W, H, out.ctypes.data)
+    return out

@@ -1,0 +1,106 @@
+"""ctypes binding of libptmi.so (include/pt_api.h).
+
+The library is built in-tree by ``vk_raytrace_amd/csrc/Makefile`` (hipcc, gfx950 only).  There is
+no fallback of any kind: if the shared object is missing this module raises at import of the
+symbols, and without a gfx950 device ``pt_create`` fails with PT_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import host_device as hd
+
+PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptmi.so")
+
+# every symbol include/pt_api.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+API = [
+    ("pt_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("pt_destroy", C.c_int, [_P]),
+    ("pt_renderer_name", C.c_char_p, []),
+    ("pt_last_error", C.c_char_p, [_P]),
+    ("pt_set_scene", C.c_int, [_P, C.POINTER(hd.SceneDesc)]),
+    ("pt_build_accel", C.c_int, [_P]),
+    ("pt_set_camera", C.c_int, [_P, C.POINTER(hd.SceneCamera)]),
+    ("pt_set_env", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("pt_set_sunsky", C.c_int, [_P, C.POINTER(hd.SunAndSky)]),
+    ("pt_resize", C.c_int, [_P, C.c_int, C.c_int]),
+    ("pt_set_shard", C.c_int, [_P, C.c_int, C.c_int]),
+    ("pt_render_frame", C.c_int, [_P, C.POINTER(hd.RtxState)]),
+    ("pt_synchronize", C.c_int, [_P]),
+    ("pt_read_accum", C.c_int, [_P, _P]),
+    ("pt_tonemap", C.c_int, [_P, C.POINTER(hd.Tonemapper), _P]),
+    ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
+    ("pt_set_profiling", C.c_int, [_P, C.c_int]),
+    ("pt_get_stats", C.c_int, [_P, C.POINTER(hd.Stats)]),
+    ("pt_reset_stats", C.c_int, [_P]),
+    ("pt_compress_unit_vec", C.c_uint32, [_P]),
+    ("pt_pack_vertices", C.c_int, [C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    ("pt_camera_lookat", C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.POINTER(hd.SceneCamera)]),
+    ("pt_build_env_accel", C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("pt_sampler_from_gltf", C.c_int, [C.c_int] * 5 + [C.POINTER(hd.TextureDesc)]),
+]
+
+_lib = None
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libptmi error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Loads libptmi.so; raises if it has not been built (there is no Python/CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C vk_raytrace_amd/csrc` "
+                              "(or __graft_entry__.build()); the HIP library is the only implementation")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in API:
+            fn = getattr(L, name)  # AttributeError if the ABI and the header ever disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def pack_vertices(pos, nrm, tan, uv, col):
+    """pt_pack_vertices (reference: src/scene.cpp:219-242)."""
+    n = len(pos)
+    out = np.zeros(n, hd.vertex_dtype)
+    a = [np.ascontiguousarray(x, np.float32) for x in (pos, nrm, tan, uv, col)]
+    rc = lib().pt_pack_vertices(n, *[x.ctypes.data for x in a], out.ctypes.data)
+    if rc != PT_OK:
+        raise PtError(rc, "pt_pack_vertices")
+    return out
+
+
+def camera_lookat(cam, aspect, nb_lights=0):
+    """pt_camera_lookat (reference: src/scene.cpp:629-640) from a scene.Camera."""
+    out = hd.SceneCamera()
+    e, c, u = (np.asarray(v, np.float32) for v in (cam.eye, cam.center, cam.up))
+    rc = lib().pt_camera_lookat(e.ctypes.data, c.ctypes.data, u.ctypes.data, cam.fov, aspect, C.byref(out))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_camera_lookat")
+    out.aperture = cam.aperture
+    if cam.focal_dist is not None:
+        out.focalDist = cam.focal_dist
+    out.nbLights = nb_lights
+    return out
+
+
+def build_env_accel(env):
+    env = np.ascontiguousarray(env, np.float32)
+    h, w = env.shape[:2]
+    acc = np.zeros(w * h, hd.envaccel_dtype)
+    i, a = C.c_float(), C.c_float()
+    rc = lib().pt_build_env_accel(env.ctypes.data, w, h, acc.ctypes.data, C.byref(i), C.byref(a))
+    if rc != PT_OK:
+        raise PtError(rc, "pt_build_env_accel")
+    return acc, i.value, a.value

@@ -1,0 +1,742 @@
+// C ABI of libptmi.so (include/pt_api.h): context, device memory, call sequencing.
+// Mirrors the division of labour of the reference's host classes -- Scene (src/scene.cpp), AccelStructure
+// (src/accelstruct.cpp), HdrSampling (src/hdr_sampling.cpp), RenderOutput (src/render_output.cpp) and the
+// Renderer implementations (src/rayquery.cpp, src/rtx_pipeline.cpp) -- behind one opaque pt_context.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/pt_api.h"
+#include "pt_internal.h"
+
+namespace {
+std::string g_createError;
+
+struct DevBuf {
+  void*  p     = nullptr;
+  size_t bytes = 0;
+};
+}  // namespace
+
+struct pt_context {
+  int         device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // scene (host copies kept only for what build_accel needs)
+  DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dTris, dEnv, dEnvAccel;
+  uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0;
+  bool     haveScene = false, haveAccel = false, haveEnv = false;
+  DeviceScene scene{};
+
+  // output / path state
+  int      width = 0, height = 0, tilesX = 0, tilesY = 0;
+  int      rank = 0, nranks = 1;
+  uint32_t numLocalTiles = 0, maxTilesPerRank = 0, numSlots = 0;
+  uint64_t localPixels = 0;
+  DevBuf   dState[9], dQueueA, dQueueB, dQueueS, dCounts, dFrame, dSlotTile, dCounters;
+  DevBuf   dRowMajor, dRgba8, dMean, dFullTiles, dFullSlotTile, dTileLocalIndex;
+  bool     haveFull = false;
+  RenderBuffers rb{};
+
+  StageTimers timers;
+  pt_Stats    stats{};
+  double      msBuild = 0;
+
+  int fail(int code, const char* fmt, ...)
+  {
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+#define CTX_CHECK(ctx)       \
+  if(!(ctx))                 \
+    return PT_ERR_INVALID;
+#define HIP_TRY(ctx, call)                                                                                   \
+  do                                                                                                         \
+  {                                                                                                          \
+    hipError_t e_ = (call);                                                                                  \
+    if(e_ != hipSuccess)                                                                                     \
+      return (ctx)->fail(e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while(0)
+
+namespace {
+
+int dev_alloc(pt_context* c, DevBuf& b, size_t bytes)
+{
+  if(b.p && b.bytes >= bytes && b.bytes <= bytes * 2 + 4096)
+    return PT_OK;
+  if(b.p)
+    (void)hipFree(b.p);
+  b.p     = nullptr;
+  b.bytes = 0;
+  if(bytes == 0)
+    bytes = 16;
+  HIP_TRY(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return PT_OK;
+}
+void dev_free(DevBuf& b)
+{
+  if(b.p)
+    (void)hipFree(b.p);
+  b.p     = nullptr;
+  b.bytes = 0;
+}
+int upload(pt_context* c, DevBuf& b, const void* src, size_t bytes)
+{
+  int rc = dev_alloc(c, b, bytes);
+  if(rc != PT_OK)
+    return rc;
+  if(bytes)
+    HIP_TRY(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+// inverse of an affine column-major 4x4 (last row forced to 0 0 0 1), computed in double and rounded once
+bool affine_inverse(const float* m, double inv[12], double& det3)
+{
+  const double a = m[0], b = m[4], c = m[8], d = m[1], e = m[5], f = m[9], g = m[2], h = m[6], i = m[10];
+  const double tx = m[12], ty = m[13], tz = m[14];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  det3 = a * A + b * B + c * C;
+  if(det3 == 0.0)
+    return false;
+  const double r = 1.0 / det3;
+  // rows of the inverse 3x3
+  const double i00 = A * r, i01 = -(b * i - c * h) * r, i02 = (b * f - c * e) * r;
+  const double i10 = B * r, i11 = (a * i - c * g) * r, i12 = -(a * f - c * d) * r;
+  const double i20 = C * r, i21 = -(a * h - b * g) * r, i22 = (a * e - b * d) * r;
+  // column-major 3x4: columns 0..2 then translation
+  inv[0] = i00; inv[1] = i10; inv[2] = i20;
+  inv[3] = i01; inv[4] = i11; inv[5] = i21;
+  inv[6] = i02; inv[7] = i12; inv[8] = i22;
+  inv[9]  = -(i00 * tx + i01 * ty + i02 * tz);
+  inv[10] = -(i10 * tx + i11 * ty + i12 * tz);
+  inv[11] = -(i20 * tx + i21 * ty + i22 * tz);
+  return true;
+}
+
+void refresh_scene_ptrs(pt_context* c)
+{
+  DeviceScene& s = c->scene;
+  s.vertices     = (const float4*)c->dVertices.p;
+  s.indices      = (const uint32_t*)c->dIndices.p;
+  s.instances    = (const InstanceRec*)c->dInstances.p;
+  s.materials    = (const pt_GltfShadeMaterial*)c->dMaterials.p;
+  s.lights       = (const pt_Light*)c->dLights.p;
+  s.texRecs      = (const TexRec*)c->dTexRecs.p;
+  s.texels       = (const uint32_t*)c->dTexels.p;
+  s.bvh          = (const BvhNode*)c->dBvh.p;
+  s.tris         = (const TriRec*)c->dTris.p;
+  s.env          = (const float4*)c->dEnv.p;
+  s.envAccel     = (const pt_EnvAccel*)c->dEnvAccel.p;
+  s.numTris      = c->numTris;
+  s.numInstances = c->numInstances;
+}
+
+}  // namespace
+
+// ---- stage timers ------------------------------------------------------------------------------------------
+void pt_timers_begin(StageTimers* t, hipStream_t s, int stage)
+{
+  if(!t || !t->enabled)
+    return;
+  if(t->npend == t->cap)
+  {
+    size_t ncap = t->cap ? t->cap * 2 : 256;
+    auto*  np   = (StageTimers::Pending*)realloc(t->pend, ncap * sizeof(StageTimers::Pending));
+    if(!np)
+      return;
+    for(size_t i = t->cap; i < ncap; ++i)
+    {
+      (void)hipEventCreate(&np[i].a);
+      (void)hipEventCreate(&np[i].b);
+    }
+    t->pend = np;
+    t->cap  = ncap;
+  }
+  t->pend[t->npend].stage = stage;
+  (void)hipEventRecord(t->pend[t->npend].a, s);
+}
+void pt_timers_end(StageTimers* t, hipStream_t s, int stage)
+{
+  if(!t || !t->enabled || t->npend >= t->cap)
+    return;
+  (void)hipEventRecord(t->pend[t->npend].b, s);
+  if(stage == 1)
+    t->launchesClosest++;
+  t->npend++;
+  if(t->npend == t->cap && t->cap >= 8192)
+    pt_timers_collect(t);  // bound the number of live events
+}
+void pt_timers_collect(StageTimers* t)
+{
+  if(!t || !t->npend)
+    return;
+  (void)hipEventSynchronize(t->pend[t->npend - 1].b);
+  for(size_t i = 0; i < t->npend; ++i)
+  {
+    float ms = 0.f;
+    if(hipEventElapsedTime(&ms, t->pend[i].a, t->pend[i].b) == hipSuccess)
+      t->ms[t->pend[i].stage] += ms;
+  }
+  t->npend = 0;
+}
+
+extern "C" {
+
+const char* pt_renderer_name(void) { return "HIP"; }
+
+const char* pt_last_error(const pt_context* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int pt_create(int device_ordinal, pt_context** out_ctx)
+{
+  if(!out_ctx)
+    return PT_ERR_INVALID;
+  *out_ctx  = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if(e != hipSuccess || count <= 0)
+  {
+    g_createError = std::string("no HIP device available: ") + hipGetErrorString(e) + " (libptmi has no CPU fallback)";
+    return PT_ERR_NO_DEVICE;
+  }
+  if(device_ordinal < 0 || device_ordinal >= count)
+  {
+    g_createError = "device ordinal out of range";
+    return PT_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if(hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess)
+  {
+    g_createError = "hipGetDeviceProperties failed";
+    return PT_ERR_HIP;
+  }
+  if(std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+  {
+    g_createError = std::string("device is ") + prop.gcnArchName + ", libptmi.so is built for gfx950 only";
+    return PT_ERR_NO_DEVICE;
+  }
+  if(hipSetDevice(device_ordinal) != hipSuccess)
+  {
+    g_createError = "hipSetDevice failed";
+    return PT_ERR_HIP;
+  }
+  pt_context* c = new pt_context();
+  c->device     = device_ordinal;
+  if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    g_createError = "hipStreamCreate failed";
+    delete c;
+    return PT_ERR_HIP;
+  }
+  c->timers.stream = c->stream;
+  // defaults: sun & sky off, empty camera
+  std::memset(&c->scene, 0, sizeof(c->scene));
+  if(dev_alloc(c, c->dCounters, sizeof(Counters)) != PT_OK || hipMemset(c->dCounters.p, 0, sizeof(Counters)) != hipSuccess)
+  {
+    g_createError = c->err;
+    delete c;
+    return PT_ERR_HIP;
+  }
+  *out_ctx = c;
+  return PT_OK;
+}
+
+int pt_destroy(pt_context* c)
+{
+  CTX_CHECK(c);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dTris, &c->dEnv,
+                   &c->dEnvAccel, &c->dQueueA, &c->dQueueB, &c->dQueueS, &c->dCounts, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
+                   &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
+  for(DevBuf* b : all)
+    dev_free(*b);
+  for(DevBuf& b : c->dState)
+    dev_free(b);
+  for(size_t i = 0; i < c->timers.cap; ++i)
+  {
+    (void)hipEventDestroy(c->timers.pend[i].a);
+    (void)hipEventDestroy(c->timers.pend[i].b);
+  }
+  free(c->timers.pend);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return PT_OK;
+}
+
+int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
+{
+  CTX_CHECK(c);
+  if(!d || !d->vertices || !d->indices || !d->primMeshes || !d->nodes || !d->materials || d->numMaterials == 0)
+    return c->fail(PT_ERR_INVALID, "pt_set_scene: null array or no material");
+  if((d->numLights && !d->lights) || (d->numTextures && !d->textures))
+    return c->fail(PT_ERR_INVALID, "pt_set_scene: count without array");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+  // ---- validate + build the per-instance records
+  std::vector<InstanceRec> inst(d->numNodes);
+  uint64_t                 triTotal = 0;
+  for(uint32_t n = 0; n < d->numNodes; ++n)
+  {
+    const pt_Node& nd = d->nodes[n];
+    if(nd.primMesh < 0 || uint32_t(nd.primMesh) >= d->numPrimMeshes)
+      return c->fail(PT_ERR_INVALID, "node %u: primMesh %d out of range", n, nd.primMesh);
+    const pt_PrimMesh& pm = d->primMeshes[nd.primMesh];
+    if(pm.materialIndex >= int(d->numMaterials))
+      return c->fail(PT_ERR_INVALID, "primMesh %d: materialIndex %d out of range", nd.primMesh, pm.materialIndex);
+    if(uint64_t(pm.vertexOffset) + pm.vertexCount > d->numVertices || uint64_t(pm.firstIndex) + pm.indexCount > d->numIndices || pm.indexCount % 3)
+      return c->fail(PT_ERR_INVALID, "primMesh %d: vertex/index range out of bounds", nd.primMesh);
+    const pt_GltfShadeMaterial& mat = d->materials[pm.materialIndex < 0 ? 0 : pm.materialIndex];
+    InstanceRec&                I   = inst[n];
+    const float*                m   = nd.worldMatrix;
+    I.objectToWorld.r0 = make_float4(m[0], m[4], m[8], m[12]);
+    I.objectToWorld.r1 = make_float4(m[1], m[5], m[9], m[13]);
+    I.objectToWorld.r2 = make_float4(m[2], m[6], m[10], m[14]);
+    double inv[12], det3;
+    if(!affine_inverse(m, inv, det3))
+      return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
+    I.worldToObject.r0 = make_float4(float(inv[0]), float(inv[3]), float(inv[6]), float(inv[9]));
+    I.worldToObject.r1 = make_float4(float(inv[1]), float(inv[4]), float(inv[7]), float(inv[10]));
+    I.worldToObject.r2 = make_float4(float(inv[2]), float(inv[5]), float(inv[8]), float(inv[11]));
+    I.vertexOffset  = pm.vertexOffset;
+    I.firstIndex    = pm.firstIndex;
+    I.materialIndex = pm.materialIndex;
+    I.primMesh      = nd.primMesh;
+    I.triBase       = uint32_t(triTotal);
+    I.triCount      = pm.indexCount / 3;
+    // instance flags of the reference's TLAS (src/accelstruct.cpp:144-149)
+    uint32_t flags = 0;
+    if(mat.alphaMode == 0 || (mat.pbrBaseColorFactor[3] == 1.0f && mat.pbrBaseColorTexture == -1))
+      flags |= TRI_OPAQUE;
+    if(mat.doubleSided == 1)
+      flags |= TRI_NOCULL;
+    if(det3 < 0.0)
+      flags |= TRI_FLIP;
+    I.flags = flags;
+    I._pad  = 0;
+    triTotal += I.triCount;
+  }
+  if(triTotal > TRI_INDEX_MASK)
+    return c->fail(PT_ERR_INVALID, "scene has %llu triangles; the limit is %u", (unsigned long long)triTotal, TRI_INDEX_MASK);
+  for(uint32_t p = 0; p < d->numPrimMeshes; ++p)
+  {
+    const pt_PrimMesh& pm = d->primMeshes[p];
+    for(uint32_t k = 0; k < pm.indexCount; ++k)
+      if(d->indices[pm.firstIndex + k] >= pm.vertexCount)
+        return c->fail(PT_ERR_INVALID, "primMesh %u: index %u >= vertexCount", p, d->indices[pm.firstIndex + k]);
+  }
+  for(uint32_t m = 0; m < d->numMaterials; ++m)
+  {
+    const pt_GltfShadeMaterial& mt = d->materials[m];
+    const int ids[] = {mt.pbrBaseColorTexture, mt.pbrMetallicRoughnessTexture, mt.emissiveTexture, mt.normalTexture, mt.transmissionTexture, mt.clearcoatTexture, mt.clearcoatRoughnessTexture};
+    for(int id : ids)
+      if(id >= int(d->numTextures))
+        return c->fail(PT_ERR_INVALID, "material %u references texture %d of %u", m, id, d->numTextures);
+  }
+
+  // ---- uploads
+  int rc;
+  if((rc = upload(c, c->dVertices, d->vertices, sizeof(pt_VertexAttributes) * size_t(d->numVertices))) != PT_OK) return rc;
+  if((rc = upload(c, c->dIndices, d->indices, 4 * size_t(d->numIndices))) != PT_OK) return rc;
+  if((rc = upload(c, c->dInstances, inst.data(), sizeof(InstanceRec) * inst.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dMaterials, d->materials, sizeof(pt_GltfShadeMaterial) * size_t(d->numMaterials))) != PT_OK) return rc;
+  {
+    pt_Light dummy{};  // "cannot be null" (src/scene.cpp:329-330); never read because nbLights == 0 then
+    if((rc = upload(c, c->dLights, d->numLights ? d->lights : &dummy, sizeof(pt_Light) * size_t(d->numLights ? d->numLights : 1))) != PT_OK) return rc;
+  }
+  {
+    std::vector<TexRec> recs(d->numTextures ? d->numTextures : 1);
+    size_t              texels = 0;
+    for(uint32_t t = 0; t < d->numTextures; ++t)
+    {
+      const pt_TextureDesc& td = d->textures[t];
+      if(!td.rgba8 || td.width <= 0 || td.height <= 0)
+        return c->fail(PT_ERR_INVALID, "texture %u: empty image", t);
+      recs[t].offset = uint32_t(texels);
+      recs[t].w      = td.width;
+      recs[t].h      = td.height;
+      recs[t].mag    = td.magFilter;
+      recs[t].wrapS  = td.wrapS;
+      recs[t].wrapT  = td.wrapT;
+      texels += size_t(td.width) * td.height;
+      if(texels > 0xffffffffull)
+        return c->fail(PT_ERR_INVALID, "texture pool exceeds 2^32 texels");
+    }
+    if(d->numTextures == 0)
+    {  // a 1x1 white default like src/scene.cpp:513-519
+      recs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, {0, 0}};
+      texels  = 1;
+    }
+    if((rc = dev_alloc(c, c->dTexels, texels * 4)) != PT_OK) return rc;
+    if(d->numTextures == 0)
+    {
+      uint32_t white = 0xffffffffu;
+      HIP_TRY(c, hipMemcpy(c->dTexels.p, &white, 4, hipMemcpyHostToDevice));
+    }
+    for(uint32_t t = 0; t < d->numTextures; ++t)
+      HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + recs[t].offset, d->textures[t].rgba8, size_t(recs[t].w) * recs[t].h * 4, hipMemcpyHostToDevice));
+    if((rc = upload(c, c->dTexRecs, recs.data(), sizeof(TexRec) * recs.size())) != PT_OK) return rc;
+  }
+  c->numInstances = d->numNodes;
+  c->numTris      = uint32_t(triTotal);
+  c->haveScene    = true;
+  c->haveAccel    = false;
+  refresh_scene_ptrs(c);
+  return PT_OK;
+}
+
+int pt_build_accel(pt_context* c)
+{
+  CTX_CHECK(c);
+  if(!c->haveScene)
+    return c->fail(PT_ERR_STATE, "pt_build_accel before pt_set_scene");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  c->numBvhNodes = c->numTris > 1 ? c->numTris - 1 : 1;
+  if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dBvh, sizeof(BvhNode) * size_t(c->numBvhNodes))) != PT_OK) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  char msg[256];
+  if(pt_accel_build(c->stream, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
+                    (TriRec*)c->dTris.p, (BvhNode*)c->dBvh.p, msg, sizeof(msg)) != 0)
+    return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  c->haveAccel = true;
+  refresh_scene_ptrs(c);
+  return PT_OK;
+}
+
+int pt_set_camera(pt_context* c, const pt_SceneCamera* cam)
+{
+  CTX_CHECK(c);
+  if(!cam)
+    return c->fail(PT_ERR_INVALID, "pt_set_camera: null");
+  c->scene.camera = *cam;
+  return PT_OK;
+}
+
+int pt_set_sunsky(pt_context* c, const pt_SunAndSky* ss)
+{
+  CTX_CHECK(c);
+  if(!ss)
+    return c->fail(PT_ERR_INVALID, "pt_set_sunsky: null");
+  c->scene.sunsky = *ss;
+  return PT_OK;
+}
+
+int pt_set_env(pt_context* c, const float* rgba, int w, int h, float* out_integral, float* out_average)
+{
+  CTX_CHECK(c);
+  if(!rgba || w <= 0 || h <= 0)
+    return c->fail(PT_ERR_INVALID, "pt_set_env: bad image");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<pt_EnvAccel> accel(size_t(w) * h);
+  float                    integral = 1.f, average = 1.f;
+  if(pt_build_env_accel(rgba, w, h, accel.data(), &integral, &average) != PT_OK)
+    return c->fail(PT_ERR_INVALID, "pt_build_env_accel failed");
+  int rc;
+  if((rc = upload(c, c->dEnv, rgba, sizeof(float) * 4 * size_t(w) * h)) != PT_OK) return rc;
+  if((rc = upload(c, c->dEnvAccel, accel.data(), sizeof(pt_EnvAccel) * accel.size())) != PT_OK) return rc;
+  c->scene.envW = w;
+  c->scene.envH = h;
+  c->haveEnv    = true;
+  refresh_scene_ptrs(c);
+  if(out_integral) *out_integral = integral;
+  if(out_average) *out_average = average;
+  return PT_OK;
+}
+
+int pt_set_shard(pt_context* c, int rank, int nranks)
+{
+  CTX_CHECK(c);
+  if(nranks < 1 || rank < 0 || rank >= nranks)
+    return c->fail(PT_ERR_INVALID, "pt_set_shard: rank %d of %d", rank, nranks);
+  c->rank   = rank;
+  c->nranks = nranks;
+  c->width = c->height = 0;  // force a re-layout on the next pt_resize
+  return PT_OK;
+}
+
+int pt_resize(pt_context* c, int width, int height)
+{
+  CTX_CHECK(c);
+  if(width <= 0 || height <= 0)
+    return c->fail(PT_ERR_INVALID, "pt_resize: %dx%d", width, height);
+  if(width == c->width && height == c->height)
+    return PT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tilesX = (width + PT_TILE - 1) / PT_TILE;
+  c->tilesY = (height + PT_TILE - 1) / PT_TILE;
+  std::vector<uint32_t> local;
+  std::vector<uint32_t> perRank(c->nranks, 0);
+  uint64_t              localPixels = 0;
+  for(int ty = 0; ty < c->tilesY; ++ty)
+    for(int tx = 0; tx < c->tilesX; ++tx)
+    {
+      int r = (tx + ty) % c->nranks;
+      perRank[r]++;
+      if(r == c->rank)
+      {
+        local.push_back(uint32_t(ty * c->tilesX + tx));
+        localPixels += uint64_t(std::min(PT_TILE, width - tx * PT_TILE)) * uint64_t(std::min(PT_TILE, height - ty * PT_TILE));
+      }
+    }
+  c->localPixels = localPixels;
+  c->numLocalTiles   = uint32_t(local.size());
+  c->maxTilesPerRank = 0;
+  for(uint32_t v : perRank)
+    c->maxTilesPerRank = v > c->maxTilesPerRank ? v : c->maxTilesPerRank;
+  c->numSlots = c->numLocalTiles * 1024u;
+
+  int          rc;
+  const size_t n = c->numSlots ? c->numSlots : 1;
+  for(DevBuf& b : c->dState)
+    if((rc = dev_alloc(c, b, sizeof(float4) * n)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dQueueA, 4 * n)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dQueueB, 4 * n)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dQueueS, 4 * n)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dCounts, 4 * 4)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dFrame, sizeof(float4) * size_t(c->maxTilesPerRank ? c->maxTilesPerRank : 1) * 1024u)) != PT_OK) return rc;
+  if((rc = upload(c, c->dSlotTile, local.data(), 4 * local.size())) != PT_OK) return rc;
+  HIP_TRY(c, hipMemset(c->dCounts.p, 0, 16));
+  HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
+  if((rc = dev_alloc(c, c->dRowMajor, sizeof(float4) * size_t(width) * height)) != PT_OK) return rc;
+  HIP_TRY(c, hipMemset(c->dRowMajor.p, 0, sizeof(float4) * size_t(width) * height));
+  if((rc = dev_alloc(c, c->dRgba8, 4 * size_t(width) * height)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dMean, 3 * sizeof(double))) != PT_OK) return rc;
+
+  c->width    = width;
+  c->height   = height;
+  c->haveFull = false;
+  PathState& ps = c->rb.ps;
+  ps.rayO = (float4*)c->dState[0].p; ps.rayD = (float4*)c->dState[1].p; ps.thr = (float4*)c->dState[2].p; ps.rad = (float4*)c->dState[3].p;
+  ps.absorb = (float4*)c->dState[4].p; ps.neeDir = (float4*)c->dState[5].p; ps.neeRad = (float4*)c->dState[6].p; ps.hit = (float4*)c->dState[7].p;
+  ps.sum = (float4*)c->dState[8].p;
+  c->rb.queueA   = (uint32_t*)c->dQueueA.p;
+  c->rb.queueB   = (uint32_t*)c->dQueueB.p;
+  c->rb.queueS   = (uint32_t*)c->dQueueS.p;
+  c->rb.counts   = (uint32_t*)c->dCounts.p;
+  c->rb.frame    = (float4*)c->dFrame.p;
+  c->rb.slotTile = (uint32_t*)c->dSlotTile.p;
+  c->rb.counters = (Counters*)c->dCounters.p;
+  return PT_OK;
+}
+
+int pt_render_frame(pt_context* c, const pt_RtxState* st)
+{
+  CTX_CHECK(c);
+  if(!st)
+    return c->fail(PT_ERR_INVALID, "pt_render_frame: null state");
+  if(!c->haveScene || !c->haveAccel)
+    return c->fail(PT_ERR_STATE, "pt_render_frame before pt_set_scene / pt_build_accel");
+  if(!c->haveEnv && c->scene.sunsky.in_use != 1)
+    return c->fail(PT_ERR_STATE, "pt_render_frame without an environment (pt_set_env) or sun & sky");
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_render_frame before pt_resize");
+  if(st->size[0] != c->width || st->size[1] != c->height)
+    return c->fail(PT_ERR_INVALID, "RtxState.size %dx%d != pt_resize %dx%d", st->size[0], st->size[1], c->width, c->height);
+  if(st->maxSamples < 1 || st->maxDepth < 0 || st->frame < 0)
+    return c->fail(PT_ERR_INVALID, "RtxState: maxSamples %d maxDepth %d frame %d", st->maxSamples, st->maxDepth, st->frame);
+  if(c->scene.camera.nbLights < 0)
+    return c->fail(PT_ERR_INVALID, "camera.nbLights < 0");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if(c->numSlots == 0)
+    return PT_OK;
+  FrameParams fp{};
+  fp.st            = *st;
+  fp.width         = c->width;
+  fp.height        = c->height;
+  fp.tilesX        = c->tilesX;
+  fp.tilesY        = c->tilesY;
+  fp.rank          = c->rank;
+  fp.nranks        = c->nranks;
+  fp.numLocalTiles = c->numLocalTiles;
+  fp.numSlots      = c->numSlots;
+  fp.sample        = 0;
+  pt_launch_frame(c->stream, c->scene, c->rb, fp, &c->timers);
+  HIP_TRY(c, hipGetLastError());
+  c->haveFull = false;
+  c->stats.samples += uint64_t(st->maxSamples) * c->localPixels;
+  return PT_OK;
+}
+
+int pt_synchronize(pt_context* c)
+{
+  CTX_CHECK(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+static int untile_to_rowmajor(pt_context* c)
+{
+  if(c->haveFull)
+    pt_launch_untile(c->stream, (const float4*)c->dFullTiles.p, (const uint32_t*)c->dFullSlotTile.p, uint32_t(c->tilesX) * c->tilesY, c->tilesX, c->width, c->height,
+                     (float4*)c->dRowMajor.p);
+  else
+    pt_launch_untile(c->stream, c->rb.frame, c->rb.slotTile, c->numLocalTiles, c->tilesX, c->width, c->height, (float4*)c->dRowMajor.p);
+  HIP_TRY(c, hipGetLastError());
+  return PT_OK;
+}
+
+int pt_read_accum(pt_context* c, float* out)
+{
+  CTX_CHECK(c);
+  if(!out)
+    return c->fail(PT_ERR_INVALID, "pt_read_accum: null");
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_read_accum before pt_resize");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = untile_to_rowmajor(c);
+  if(rc != PT_OK)
+    return rc;
+  HIP_TRY(c, hipMemcpyAsync(out, c->dRowMajor.p, sizeof(float4) * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
+{
+  CTX_CHECK(c);
+  if(!tm || !out)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap: null");
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_tonemap before pt_resize");
+  if(tm->zoom != 1.0f)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap: zoom != 1 (the viewer's de-scaled preview) is not supported");
+  if(tm->autoExposure & 2)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap: local auto-exposure (bit 1) is not supported");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = untile_to_rowmajor(c);
+  if(rc != PT_OK)
+    return rc;
+  float avg[3] = {0, 0, 0};
+  if(tm->autoExposure & 1)
+  {
+    pt_launch_mean(c->stream, (const float4*)c->dRowMajor.p, size_t(c->width) * c->height, (double*)c->dMean.p);
+    double s[3];
+    HIP_TRY(c, hipMemcpyAsync(s, c->dMean.p, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for(int k = 0; k < 3; ++k)
+      avg[k] = float(s[k] / (double(c->width) * c->height));
+  }
+  pt_launch_tonemap(c->stream, (const float4*)c->dRowMajor.p, c->width, c->height, *tm, avg, (uint32_t*)c->dRgba8.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PT_OK;
+}
+
+int pt_local_shard(pt_context* c, void** device_ptr, size_t* bytes, int* num_local_tiles, int* max_tiles_per_rank)
+{
+  CTX_CHECK(c);
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_local_shard before pt_resize");
+  if(device_ptr) *device_ptr = c->dFrame.p;
+  if(bytes) *bytes = sizeof(float4) * size_t(c->maxTilesPerRank) * 1024u;
+  if(num_local_tiles) *num_local_tiles = int(c->numLocalTiles);
+  if(max_tiles_per_rank) *max_tiles_per_rank = int(c->maxTilesPerRank);
+  return PT_OK;
+}
+
+int pt_scatter_shards(pt_context* c, const void* gathered_dev, int nranks)
+{
+  CTX_CHECK(c);
+  if(!gathered_dev || nranks != c->nranks)
+    return c->fail(PT_ERR_INVALID, "pt_scatter_shards: nranks %d != %d", nranks, c->nranks);
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_scatter_shards before pt_resize");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t        nt = uint32_t(c->tilesX) * c->tilesY;
+  std::vector<uint32_t> localIndex(nt), identity(nt), next(nranks, 0);
+  for(uint32_t gt = 0; gt < nt; ++gt)
+  {
+    int r          = (int(gt % c->tilesX) + int(gt / c->tilesX)) % nranks;
+    localIndex[gt] = next[r]++;
+    identity[gt]   = gt;
+  }
+  int rc;
+  if((rc = dev_alloc(c, c->dFullTiles, sizeof(float4) * size_t(nt) * 1024u)) != PT_OK) return rc;
+  if((rc = upload(c, c->dTileLocalIndex, localIndex.data(), 4 * size_t(nt))) != PT_OK) return rc;
+  if((rc = upload(c, c->dFullSlotTile, identity.data(), 4 * size_t(nt))) != PT_OK) return rc;
+  pt_launch_scatter_tiles(c->stream, (const float4*)gathered_dev, nranks, int(c->maxTilesPerRank), c->tilesX, c->tilesY, (const uint32_t*)c->dTileLocalIndex.p,
+                          (float4*)c->dFullTiles.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->haveFull = true;
+  return PT_OK;
+}
+
+int pt_set_profiling(pt_context* c, int enable)
+{
+  CTX_CHECK(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  pt_timers_collect(&c->timers);
+  c->timers.enabled = enable != 0;
+  return PT_OK;
+}
+
+int pt_get_stats(pt_context* c, pt_Stats* out)
+{
+  CTX_CHECK(c);
+  if(!out)
+    return c->fail(PT_ERR_INVALID, "pt_get_stats: null");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  pt_timers_collect(&c->timers);
+  Counters k{};
+  HIP_TRY(c, hipMemcpy(&k, c->dCounters.p, sizeof(k), hipMemcpyDeviceToHost));
+  if(k.stackOverflow)
+    return c->fail(PT_ERR_STATE, "BVH traversal stack overflowed %u times (results are invalid)", k.stackOverflow);
+  pt_Stats s = c->stats;
+  s.closestRays = k.closestRays; s.shadowRays = k.shadowRays; s.shadedHits = k.shadedHits; s.misses = k.misses; s.alphaTests = k.alphaTests;
+  s.neeLookups = k.neeLookups; s.nodesVisited = k.nodesVisited; s.trisTested = k.trisTested;
+  s.msGenerate = c->timers.ms[0]; s.msTraceClosest = c->timers.ms[1]; s.msShade = c->timers.ms[2]; s.msTraceShadow = c->timers.ms[3];
+  s.msAccumulate = c->timers.ms[4];
+  s.launchesTraceClosest = c->timers.launchesClosest;
+  s.numTriangles = c->numTris;
+  s.numBvhNodes  = c->numBvhNodes;
+  s.msBuildAccel = c->msBuild;
+  uint64_t bytes = 0;
+  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dTris, &c->dEnv, &c->dEnvAccel};
+  for(const DevBuf* b : sb)
+    bytes += b->bytes;
+  s.bytesScene = bytes;
+  *out         = s;
+  return PT_OK;
+}
+
+int pt_reset_stats(pt_context* c)
+{
+  CTX_CHECK(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  pt_timers_collect(&c->timers);
+  for(double& m : c->timers.ms)
+    m = 0;
+  c->timers.launchesClosest = 0;
+  c->stats                  = pt_Stats{};
+  HIP_TRY(c, hipMemset(c->dCounters.p, 0, sizeof(Counters)));
+  return PT_OK;
+}
+
+}  // extern "C"

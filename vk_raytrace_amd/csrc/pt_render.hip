@@ -1,0 +1,719 @@
+// Wavefront path tracing pipeline for gfx950.
+//
+// The reference runs one megakernel invocation per pixel (shaders/pathtrace.comp:87-134 ->
+// shaders/pathtrace.glsl:193-343).  Here the same per-pixel computation is cut at the two ray-trace
+// calls into stages that communicate through an SoA path state in HBM and compacted queues of path
+// slots, so that every stage runs with full 64-lane wavefronts of live paths:
+//
+//   k_generate      seed (pathtrace.comp:97), jitter + camera ray (pathtrace.glsl:348-372)      all local pixels
+//   per bounce:
+//   k_closest       ClosestHit incl. stochastic alpha (traceray_rq.glsl:108-147)                 queue[in]
+//   k_shade         miss/env, GetShadeState, material, emission, absorption, DirectLight,
+//                   BSDF sample, throughput, RR probability, next ray (pathtrace.glsl:201-325)   queue[in] -> queueS
+//   k_shadow_rr     AnyHit for the deferred NEE contribution, Russian roulette
+//                   (pathtrace.glsl:327-338)                                                     queueS -> queue[out]
+//   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean (pathtrace.comp:122-133)
+//
+// Random numbers are drawn in the reference's order from one PCG state per
+// path that travels with the path state.  Queue order never influences a pixel's value.
+#include <hip/hip_runtime.h>
+#include "pt_bsdf.h"
+#include "pt_internal.h"
+#include "pt_sky.h"
+#include "pt_trace.h"
+
+namespace {
+
+constexpr int SHADE_BLOCK = 64;
+
+// ---- wave-aggregated helpers ---------------------------------------------------------------------------
+PT_DEV void count_event(unsigned long long* ctr)
+{
+  unsigned long long m = __ballot(1);
+  if(int(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+    atomicAdd(ctr, (unsigned long long)__popcll(m));
+}
+// Appends `slot` for every active lane with one atomic per wave (ballot + mbcnt-style rank).
+PT_DEV void enqueue(uint32_t* queue, uint32_t* count, uint32_t slot)
+{
+  unsigned long long m      = __ballot(1);
+  int                lane   = threadIdx.x & 63;
+  int                leader = __ffsll((long long)m) - 1;
+  uint32_t           base   = 0;
+  if(lane == leader)
+    base = atomicAdd(count, (uint32_t)__popcll(m));
+  base                   = __shfl(base, leader);
+  queue[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+
+// Path slot -> pixel.  A local tile is 32x32 pixels = 16 waves of 8x8 pixels, so that the 64 lanes of a
+// wavefront start out as a compact 8x8 pixel block (coherent primary rays, coalesced state accesses).
+PT_DEV bool slot_pixel(const FrameParams& fp, const uint32_t* slotTile, uint32_t slot, int& px, int& py)
+{
+  uint32_t gt = slotTile[slot >> 10];
+  uint32_t in = slot & 1023u, blk = in >> 6, lane = in & 63u;
+  px          = int(gt % uint32_t(fp.tilesX)) * PT_TILE + int(blk & 3u) * 8 + int(lane & 7u);
+  py          = int(gt / uint32_t(fp.tilesX)) * PT_TILE + int(blk >> 2) * 8 + int(lane >> 3);
+  return px < fp.width && py < fp.height;
+}
+
+// column-major mat4 * vec4 with the reference's association order
+PT_DEV f4 mat4_mul(const float* m, f4 v)
+{
+  f4 c0 = f4{m[0], m[1], m[2], m[3]}, c1 = f4{m[4], m[5], m[6], m[7]}, c2 = f4{m[8], m[9], m[10], m[11]}, c3 = f4{m[12], m[13], m[14], m[15]};
+  return ((c0 * v.x + c1 * v.y) + c2 * v.z) + c3 * v.w;
+}
+
+// shaders/common.glsl:67-74
+PT_DEV f2 spherical_uv(f3 v)
+{
+  float gamma = asinf(-v.y);
+  float theta = atan2f(v.z, v.x);
+  return f2{theta * PT_1_OVER_PI * 0.5f + 0.5f, gamma * PT_1_OVER_PI + 0.5f};
+}
+// shaders/common.glsl:98-113 (Ray Tracing Gems ch. 6)
+PT_DEV f3 offset_ray(f3 p, f3 n)
+{
+  const float intScale = 256.0f, floatScale = 1.0f / 65536.0f, origin = 1.0f / 32.0f;
+  int         ox = int(intScale * n.x), oy = int(intScale * n.y), oz = int(intScale * n.z);
+  f3          pi = f3{__int_as_float(__float_as_int(p.x) + ((p.x < 0) ? -ox : ox)), __int_as_float(__float_as_int(p.y) + ((p.y < 0) ? -oy : oy)),
+                      __int_as_float(__float_as_int(p.z) + ((p.z < 0) ? -oz : oz))};
+  return f3{fabsf(p.x) < origin ? p.x + floatScale * n.x : pi.x, fabsf(p.y) < origin ? p.y + floatScale * n.y : pi.y,
+            fabsf(p.z) < origin ? p.z + floatScale * n.z : pi.z};
+}
+
+// ---- k_generate -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
+{
+  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    rb.counts[1] = 0;
+  if(slot >= fp.numSlots)
+    return;
+  int px, py;
+  if(!slot_pixel(fp, rb.slotTile, slot, px, py))
+    return;
+  const pt_RtxState& st = fp.st;
+  uint32_t           seed;
+  if(fp.sample == 0)
+    seed = rng_tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(st.frame * st.maxSamples));
+  else
+    seed = __float_as_uint(rb.ps.rayD[slot].w);  // the stream continues across the samples of a frame (pathtrace.comp:97-105)
+
+  f2 jitter = f2{0.5f, 0.5f};
+  if(st.frame != 0)
+  {
+    jitter.x = rng_next(seed);
+    jitter.y = rng_next(seed);
+  }
+  f2 center = f2{float(px), float(py)} + jitter;
+  f2 inUV   = f2{center.x / float(st.size[0]), center.y / float(st.size[1])};
+  f2 d      = inUV * 2.0f - f2{1.0f, 1.0f};
+
+  const pt_SceneCamera& cam = S.camera;
+  f4 origin    = mat4_mul(cam.viewInverse, f4{0, 0, 0, 1});
+  f4 target    = mat4_mul(cam.projInverse, f4{d.x, d.y, 1, 1});
+  f3 tn        = unit(xyz(target));
+  f4 direction = mat4_mul(cam.viewInverse, f4{tn.x, tn.y, tn.z, 0});
+
+  f3    focalPoint = xyz(direction) * cam.focalDist;
+  float cam_r1     = rng_next(seed) * PT_TWO_PI;
+  float cam_r2     = rng_next(seed) * cam.aperture;
+  f4    cam_right  = mat4_mul(cam.viewInverse, f4{1, 0, 0, 0});
+  f4    cam_up     = mat4_mul(cam.viewInverse, f4{0, 1, 0, 0});
+  f3    lens       = (xyz(cam_right) * cosf(cam_r1) + xyz(cam_up) * sinf(cam_r1)) * sqrtf(cam_r2);
+  f3    dir        = unit(focalPoint - lens);
+  f3    org        = xyz(origin) + lens;
+
+  rb.ps.rayO[slot]   = make_float4(org.x, org.y, org.z, 0.f);
+  rb.ps.rayD[slot]   = make_float4(dir.x, dir.y, dir.z, __uint_as_float(seed));
+  rb.ps.thr[slot]    = make_float4(1.f, 1.f, 1.f, 1.f);
+  rb.ps.rad[slot]    = make_float4(0.f, 0.f, 0.f, 0.f);
+  rb.ps.absorb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+  enqueue(rb.queueA, &rb.counts[0], slot);
+}
+
+// ---- k_closest --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int countIdx)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    rb.counts[2] = 0;  // the shadow-stage queue is idle during this stage
+  const uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  if(i >= rb.counts[countIdx])
+    return;
+  const uint32_t slot = queueIn[i];
+  const f3       o    = xyz(rb.ps.rayO[slot]);
+  const float4   dw   = rb.ps.rayD[slot];
+  const f3       d    = xyz(dw);
+  uint32_t       seed = __float_as_uint(dw.w);
+  const uint32_t seed0 = seed;
+  count_event(&rb.counters->closestRays);
+
+  float    tPrev = 0.0f;
+  uint32_t wPrev = 0xffffffffu;
+  RayHit   h;
+  for(;;)
+  {
+    bool opq;
+    traverse<0>(S, o, d, PT_INFINITY, tPrev, wPrev, stack + threadIdx.x, h, opq, rb.counters);
+    if(h.slot == BVH_NONE)
+      break;
+    if((h.w >> 29) & TRI_OPAQUE)
+      break;
+    count_event(&rb.counters->alphaTests);
+    if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+      break;
+    tPrev = h.t;
+    wPrev = h.w & TRI_INDEX_MASK;
+  }
+  if(h.slot == BVH_NONE)
+    rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
+  else
+    rb.ps.hit[slot] = make_float4(h.t, __uint_as_float(h.slot), h.u, h.v);
+  if(seed != seed0)
+    rb.ps.rayD[slot].w = __uint_as_float(seed);
+}
+
+// ---- environment (shaders/env_sampling.glsl:38-135) ---------------------------------------------------------
+PT_DEV f3 env_importance_sample(const DeviceScene& S, f3 xi, f3& toLight, float& pdf)
+{
+  const uint32_t    width = uint32_t(S.envW), height = uint32_t(S.envH);
+  const uint32_t    size = width * height;
+  uint32_t          idx  = uint32_t(xi.x * float(size));
+  idx                    = idx < size - 1 ? idx : size - 1;
+  const pt_EnvAccel e    = S.envAccel[idx];
+  uint32_t          envIdx;
+  if(xi.y < e.q)
+  {
+    envIdx = idx;
+    xi.y /= e.q;
+    pdf = e.pdf;
+  }
+  else
+  {
+    envIdx = e.alias;
+    xi.y   = (xi.y - e.q) / (1.0f - e.q);
+    pdf    = e.aliasPdf;
+  }
+  const uint32_t px = envIdx % width, py = envIdx / width;
+  const float    u        = (float(px) + xi.y) / float(width);
+  const float    phi      = u * (2.0f * PT_PI) - PT_PI;
+  const float    sin_phi  = sinf(phi), cos_phi = cosf(phi);
+  const float    step     = PT_PI / float(height);
+  const float    theta0   = float(py) * step;
+  const float    cosTheta = cosf(theta0) * (1.0f - xi.z) + cosf(theta0 + step) * xi.z;
+  const float    theta    = acosf(cosTheta);
+  const float    sinTheta = sinf(theta);
+  const float    v        = theta * PT_1_OVER_PI;
+  toLight                 = f3{cos_phi * sinTheta, cosTheta, sin_phi * sinTheta};
+  return sample_env(S, f2{u, v});
+}
+
+PT_DEV float range_attenuation(float range, float distance)  // shaders/punctual.glsl:28-36
+{
+  if(range <= 0.0f)
+    return 1.0f;
+  return fmax2(fmin2(1.0f - powf(distance / range, 4.0f), 1.0f), 0.0f) / powf(distance, 2.0f);
+}
+PT_DEV float spot_attenuation(f3 pointToLight, f3 spotDir, float outerCos, float innerCos)  // shaders/punctual.glsl:39-51
+{
+  float c = dot3(unit(spotDir), unit(-pointToLight));
+  if(c > outerCos)
+  {
+    if(c < innerCos)
+      return smooth(outerCos, innerCos, c);
+    return 1.0f;
+  }
+  return 0.0f;
+}
+
+PT_DEV f3 bsdf_eval(int pbrMode, const Surface& s, f3 V, f3 N, f3 L, float& pdf) { return pbrMode == 0 ? disney_eval(s, V, N, L, pdf) : gltf_eval(s, V, N, L, pdf); }
+PT_DEV f3 bsdf_sample(int pbrMode, const Surface& s, f3 V, f3 N, f3& L, float& pdf, uint32_t& seed)
+{
+  return pbrMode == 0 ? disney_sample(s, V, N, L, pdf, seed) : gltf_sample(s, V, N, L, pdf, seed);
+}
+
+// ---- k_shade ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int countIdx, int outIdx, int depth)
+{
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    rb.counts[outIdx] = 0;  // the queue the following k_shadow_rr fills
+  const uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+  if(i >= rb.counts[countIdx])
+    return;
+  const uint32_t     slot = queueIn[i];
+  const pt_RtxState& st   = fp.st;
+  const float4       dw   = rb.ps.rayD[slot];
+  const f3           rdir = xyz(dw);
+  uint32_t           seed = __float_as_uint(dw.w);
+  const float4       hit  = rb.ps.hit[slot];
+  f3                 radiance   = xyz(rb.ps.rad[slot]);
+  f3                 throughput = xyz(rb.ps.thr[slot]);
+  const int          dbg        = st.debugging_mode;
+
+  // ---- miss: environment (pathtrace.glsl:204-228) ----
+  if(__float_as_uint(hit.y) == BVH_NONE)
+  {
+    f3   result;
+    bool done = false;
+    if(dbg != PT_DEBUG_NONE)
+    {
+      done = true;
+      if(depth != st.maxDepth - 1)
+        result = splat3(0.0f);
+      else if(dbg == PT_DEBUG_RADIANCE)
+        result = radiance;
+      else if(dbg == PT_DEBUG_WEIGHT)
+        result = throughput;
+      else if(dbg == PT_DEBUG_RAYDIR)
+        result = (rdir + splat3(1.0f)) * 0.5f;
+      else
+        done = false;
+    }
+    if(!done)
+    {
+      count_event(&rb.counters->misses);
+      f3 env = (S.sunsky.in_use == 1) ? sun_and_sky(S.sunsky, rdir) : sample_env(S, spherical_uv(rdir));
+      result = radiance + (env * st.hdrMultiplier * throughput);
+    }
+    rb.ps.rad[slot] = make_float4(result.x, result.y, result.z, 0.f);
+    return;
+  }
+
+  // ---- hit ----
+  count_event(&rb.counters->shadedHits);
+  const TriRec       tr = S.tris[__float_as_uint(hit.y)];
+  const InstanceRec& I  = S.instances[__float_as_uint(tr.e1n.w)];
+  Surface            sf;
+  f3                 vcolor;
+  surface_at_hit(S, I, __float_as_uint(tr.e2p.w), hit.z, hit.w, sf, vcolor);
+  const f3 hitPos = sf.position;
+  sf.ffnormal     = dot3(sf.normal, rdir) <= 0.0f ? sf.normal : -sf.normal;
+  resolve_material(S, S.materials[I.materialIndex < 0 ? 0 : I.materialIndex], rdir, sf);
+  sf.albedo *= vcolor;
+
+  if(dbg != PT_DEBUG_NONE && dbg < PT_DEBUG_RADIANCE)  // pathtrace.glsl:61-83,255-256
+  {
+    f3 r = f3{1000.f, 0.f, 0.f};
+    switch(dbg)
+    {
+      case PT_DEBUG_METALLIC: r = splat3(sf.metallic); break;
+      case PT_DEBUG_NORMAL: r = (sf.normal + splat3(1.0f)) * .5f; break;
+      case PT_DEBUG_BASECOLOR: r = sf.albedo; break;
+      case PT_DEBUG_EMISSIVE: r = sf.emission; break;
+      case PT_DEBUG_ALPHA: r = splat3(sf.alpha); break;
+      case PT_DEBUG_ROUGHNESS: r = splat3(sf.roughness); break;
+      case PT_DEBUG_TEXCOORD: r = f3{sf.uv.x, sf.uv.y, 0.f}; break;
+      case PT_DEBUG_TANGENT: r = (sf.tangent + splat3(1.0f)) * .5f; break;
+    }
+    rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
+    return;
+  }
+  if(sf.unlit)  // KHR_materials_unlit
+  {
+    f3 r            = radiance + sf.albedo * throughput;
+    rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
+    return;
+  }
+
+  f3 absorption = xyz(rb.ps.absorb[slot]);
+  if(dot3(sf.normal, sf.ffnormal) > 0.0f)
+    absorption = splat3(0.0f);
+  radiance += sf.emission * throughput;
+  throughput *= exp3(-absorption * hit.x);
+
+  // ---- DirectLight (pathtrace.glsl:97-188): the contribution is added after the shadow ray ----
+  f3    neeRadiance = splat3(0.0f), lightDir = splat3(0.0f);
+  float lightDist = 1e32f;
+  bool  visible   = false;
+  {
+    f3    lightContrib;
+    float lightPdf;
+    bool  isLight = false;
+    float pSelect = st.hdrMultiplier > 0.0f ? 0.5f : 1.0f;
+    if(S.camera.nbLights != 0 && rng_next(seed) <= pSelect)
+    {
+      isLight            = true;
+      int            li  = int(fmin2(rng_next(seed) * float(S.camera.nbLights), float(S.camera.nbLights)));
+      li                 = li < S.camera.nbLights - 1 ? li : S.camera.nbLights - 1;
+      const pt_Light lt  = S.lights[li];
+      const f3       ldir = f3{lt.direction[0], lt.direction[1], lt.direction[2]};
+      f3             pointToLight = -ldir;
+      float          rangeAtt = 1.0f, spotAtt = 1.0f;
+      if(lt.type != PT_LIGHT_DIRECTIONAL)
+        pointToLight = f3{lt.position[0], lt.position[1], lt.position[2]} - sf.position;
+      lightDist = len3(pointToLight);
+      if(lt.type != PT_LIGHT_DIRECTIONAL)
+        rangeAtt = range_attenuation(lt.range, lightDist);
+      if(lt.type == PT_LIGHT_SPOT)
+        spotAtt = spot_attenuation(pointToLight, ldir, lt.outerConeCos, lt.innerConeCos);
+      lightContrib = f3{lt.color[0], lt.color[1], lt.color[2]} * (rangeAtt * spotAtt * lt.intensity);
+      lightDir     = unit(pointToLight);
+      lightPdf     = 1.0f;
+    }
+    else if(S.sunsky.in_use == 1)
+    {
+      float sunRadius = (0.00465f * 10.0f) * S.sunsky.sun_disk_scale;
+      f3    sd        = f3{S.sunsky.sun_direction[0], S.sunsky.sun_direction[1], S.sunsky.sun_direction[2]};
+      f3    T, B;
+      make_frame(sd, T, B);
+      f3 dd;
+      dd.x         = rng_next(seed) * sunRadius;
+      dd.y         = rng_next(seed) * sunRadius;
+      dd.z         = sqrtf(fmax2(0.0f, 1.0f - dd.x * dd.x - dd.y * dd.y));
+      lightDir     = unit(T * dd.x + B * dd.y + sd * dd.z);
+      lightContrib = sun_and_sky(S.sunsky, lightDir);
+      lightPdf     = 0.5f;
+      lightContrib *= st.hdrMultiplier;
+    }
+    else
+    {
+      float a = rng_next(seed), b = rng_next(seed), c = rng_next(seed);
+      count_event(&rb.counters->neeLookups);
+      lightContrib = env_importance_sample(S, f3{a, b, c}, lightDir, lightPdf);
+      lightContrib *= st.hdrMultiplier;
+    }
+    if(dot3(lightDir, sf.ffnormal) > 0.0f)  // (state.isSubsurface is always false here: Sample() works on a copy)
+    {
+      float bsdfPdf = 0.0f;
+      f3    f       = bsdf_eval(st.pbrMode, sf, -rdir, sf.ffnormal, lightDir, bsdfPdf);
+      float mis     = isLight ? 1.0f : fmax2(0.0f, power_heuristic(lightPdf, bsdfPdf));
+      neeRadiance   = f * mis * fabsf(dot3(lightDir, sf.ffnormal)) * lightContrib / lightPdf;
+      visible       = true;
+    }
+  }
+  neeRadiance *= throughput;
+
+  // ---- BSDF sample ----
+  f3    L;
+  float pdf = 0.0f;
+  f3    f   = bsdf_sample(st.pbrMode, sf, -rdir, sf.ffnormal, L, pdf, seed);
+
+  if(dot3(sf.ffnormal, L) < 0.0f)
+    absorption = -log3(sf.attenuationColor) / splat3(sf.attenuationDistance);
+
+  if(pdf > 0.0f)
+  {
+    throughput *= f * fabsf(dot3(sf.ffnormal, L)) / pdf;
+  }
+  else
+  {  // `break`: the path ends before its shadow ray
+    rb.ps.rad[slot]    = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
+    rb.ps.rayD[slot].w = __uint_as_float(seed);
+    return;
+  }
+
+  if(dbg != PT_DEBUG_NONE && depth == st.maxDepth - 1)
+  {
+    f3   r;
+    bool ret = true;
+    if(dbg == PT_DEBUG_RADIANCE)
+      r = neeRadiance;
+    else if(dbg == PT_DEBUG_WEIGHT)
+      r = throughput;
+    else if(dbg == PT_DEBUG_RAYDIR)
+      r = (L + splat3(1.0f)) * 0.5f;
+    else
+      ret = false;
+    if(ret)
+    {
+      rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
+      return;
+    }
+  }
+
+  // Russian roulette probability (RR_DEPTH 0) from the updated throughput
+  float rrPcont = fmin2(fmax2(throughput.x, fmax2(throughput.y, throughput.z)) * sf.eta * sf.eta + 0.001f, 0.95f);
+
+  f3 nextO = offset_ray(hitPos, dot3(L, sf.ffnormal) > 0 ? sf.ffnormal : -sf.ffnormal);
+
+  rb.ps.rayO[slot]   = make_float4(nextO.x, nextO.y, nextO.z, 0.f);
+  rb.ps.rayD[slot]   = make_float4(L.x, L.y, L.z, __uint_as_float(seed));
+  rb.ps.thr[slot]    = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
+  rb.ps.rad[slot]    = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
+  rb.ps.absorb[slot] = make_float4(absorption.x, absorption.y, absorption.z, lightDist);
+  rb.ps.neeDir[slot] = make_float4(lightDir.x, lightDir.y, lightDir.z, visible ? 1.f : 0.f);
+  rb.ps.neeRad[slot] = make_float4(neeRadiance.x, neeRadiance.y, neeRadiance.z, 0.f);
+  enqueue(rb.queueS, &rb.counts[2], slot);
+}
+
+// ---- k_shadow_rr --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_rr(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int outIdx, int lastBounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  if(i >= rb.counts[2])
+    return;
+  const uint32_t slot = rb.queueS[i];
+  const float4   nd   = rb.ps.neeDir[slot];
+  uint32_t       seed = __float_as_uint(rb.ps.rayD[slot].w);
+
+  if(nd.w != 0.f)
+  {
+    count_event(&rb.counters->shadowRays);
+    const f3    o       = xyz(rb.ps.rayO[slot]);
+    const f3    d       = xyz(nd);
+    const float maxDist = rb.ps.absorb[slot].w;
+    bool        inShadow;
+    RayHit      h;
+    traverse<2>(S, o, d, maxDist, 0.0f, 0xffffffffu, stack + threadIdx.x, h, inShadow, rb.counters);
+    if(!inShadow)
+    {
+      // no opaque occluder: stochastic alpha on the non-opaque candidates in key order (trace contract T6)
+      while(h.slot != BVH_NONE)
+      {
+        count_event(&rb.counters->alphaTests);
+        if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+        {
+          inShadow = true;
+          break;
+        }
+        bool        dummy;
+        const float tp = h.t;
+        const uint32_t wp = h.w & TRI_INDEX_MASK;
+        traverse<1>(S, o, d, maxDist, tp, wp, stack + threadIdx.x, h, dummy, rb.counters);
+      }
+    }
+    if(!inShadow)
+    {
+      float4 r = rb.ps.rad[slot];
+      float4 c = rb.ps.neeRad[slot];
+      r.x += c.x;
+      r.y += c.y;
+      r.z += c.z;
+      rb.ps.rad[slot] = r;
+    }
+  }
+
+  // Russian roulette (pathtrace.glsl:333-338)
+  float4      t  = rb.ps.thr[slot];
+  const float pc = t.w;
+  const bool  die = rng_next(seed) >= pc;
+  rb.ps.rayD[slot].w = __uint_as_float(seed);
+  if(die)
+    return;
+  t.x /= pc;
+  t.y /= pc;
+  t.z /= pc;
+  rb.ps.thr[slot] = t;
+  if(!lastBounce)
+    enqueue(queueOut, &rb.counts[outIdx], slot);
+}
+
+// ---- k_accumulate ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParams fp)
+{
+  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+    rb.counts[0] = 0;  // ready for the next k_generate
+  if(slot >= fp.numSlots)
+    return;
+  int px, py;
+  if(!slot_pixel(fp, rb.slotTile, slot, px, py))
+    return;
+  const pt_RtxState& st = fp.st;
+  f3                 r  = xyz(rb.ps.rad[slot]);
+  float              lum = dot3(r, f3{0.212671f, 0.715160f, 0.072169f});
+  if(lum > st.fireflyClampThreshold)
+    r *= st.fireflyClampThreshold / lum;
+
+  f3 sum = (fp.sample == 0) ? splat3(0.0f) : xyz(rb.ps.sum[slot]);
+  sum += r;
+  if(fp.sample + 1 < st.maxSamples)
+  {
+    rb.ps.sum[slot] = make_float4(sum.x, sum.y, sum.z, 0.f);
+    return;
+  }
+  f3 pixel = sum / float(st.maxSamples);
+  if(st.frame > 0)
+  {
+    f3 old         = xyz(rb.frame[slot]);
+    f3 nw          = lerp(old, pixel, 1.0f / float(st.frame + 1));
+    rb.frame[slot] = make_float4(nw.x, nw.y, nw.z, 1.f);
+  }
+  else
+    rb.frame[slot] = make_float4(pixel.x, pixel.y, pixel.z, 1.f);
+}
+
+// ---- framebuffer plumbing ---------------------------------------------------------------------------------------
+__global__ void k_untile(const float4* __restrict__ tiles, const uint32_t* __restrict__ slotTile, uint32_t numSlots, int tilesX, int width, int height, float4* __restrict__ out)
+{
+  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if(slot >= numSlots)
+    return;
+  uint32_t gt = slotTile[slot >> 10];
+  uint32_t in = slot & 1023u, blk = in >> 6, lane = in & 63u;
+  int      px = int(gt % uint32_t(tilesX)) * PT_TILE + int(blk & 3u) * 8 + int(lane & 7u);
+  int      py = int(gt / uint32_t(tilesX)) * PT_TILE + int(blk >> 2) * 8 + int(lane >> 3);
+  if(px < width && py < height)
+    out[size_t(py) * width + px] = tiles[slot];
+}
+
+// gathered: [nranks][maxTilesPerRank][1024] float4; rank r's j-th tile is the j-th global tile with (tx+ty)%nranks == r
+__global__ void k_scatter_tiles(const float4* __restrict__ gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* __restrict__ tileLocalIndex,
+                                float4* __restrict__ full)
+{
+  uint32_t gslot = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t total = uint32_t(tilesX) * uint32_t(tilesY) * 1024u;
+  if(gslot >= total)
+    return;
+  uint32_t gt = gslot >> 10;
+  int      tx = int(gt % uint32_t(tilesX)), ty = int(gt / uint32_t(tilesX));
+  int      r  = (tx + ty) % nranks;
+  uint32_t j  = tileLocalIndex[gt];
+  full[gslot] = gathered[(size_t(r) * maxTilesPerRank + j) * 1024u + (gslot & 1023u)];
+}
+
+// shaders/post.frag:98-147 (TONEMAP_UNCHARTED) + shaders/tonemapping.glsl:29-65
+PT_DEV f3 uncharted2(f3 c)
+{
+  const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+  return ((c * (c * A + C * B) + D * E) / (c * (c * A + B) + D * F)) - E / F;
+}
+PT_DEV uint32_t pcg3d_x(uint32_t* v)
+{
+  v[0] = v[0] * 1664525u + 1013904223u;
+  v[1] = v[1] * 1664525u + 1013904223u;
+  v[2] = v[2] * 1664525u + 1013904223u;
+  v[0] += v[1] * v[2];
+  v[1] += v[2] * v[0];
+  v[2] += v[0] * v[1];
+  v[0] ^= v[0] >> 16u;
+  v[1] ^= v[1] >> 16u;
+  v[2] ^= v[2] >> 16u;
+  v[0] += v[1] * v[2];
+  v[1] += v[2] * v[0];
+  v[2] += v[0] * v[1];
+  return v[0];
+}
+__global__ void k_tonemap(const float4* __restrict__ img, int width, int height, pt_Tonemapper tm, float avgR, float avgG, float avgB, uint32_t* __restrict__ out)
+{
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if(x >= width || y >= height)
+    return;
+  float4 p   = img[size_t(y) * width + x];
+  f3     hdr = xyz(p);
+  if(tm.autoExposure & 1)
+  {
+    float avgLum2 = dot3(f3{avgR, avgG, avgB}, f3{0.2126f, 0.7152f, 0.0722f});
+    float XYZy    = (0.3575761f * hdr.x + 0.7151522f * hdr.y) + 0.1191920f * hdr.z;
+    float Y       = (tm.key / avgLum2) * XYZy;
+    float Yd      = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);
+    hdr           = hdr / XYZy * Yd;
+  }
+  f3 color = uncharted2(hdr * tm.avgLum * 2.0f);
+  f3 white = splat3(1.0f) / uncharted2(splat3(11.2f));
+  color    = pow3(color * white, 1.0f / 2.2f);
+  if(tm.dither > 0)
+  {
+    uint32_t r[3] = {uint32_t(x), uint32_t(y), 0u};
+    pcg3d_x(r);
+    f3 noise = f3{__uint_as_float(0x3f800000u | (r[0] >> 9)) - 1.0f, __uint_as_float(0x3f800000u | (r[1] >> 9)) - 1.0f, __uint_as_float(0x3f800000u | (r[2] >> 9)) - 1.0f};
+    const float q = 1.f / 255.f;
+    f3 lin   = pow3(color, 2.2f);
+    f3 s     = pow3(lin, 1.0f / 2.2f) / q;
+    f3 c0    = f3{floorf(s.x), floorf(s.y), floorf(s.z)} * q;
+    f3 c1    = c0 + q;
+    f3 l0 = pow3(c0, 2.2f), l1 = pow3(c1, 2.2f);
+    f3 discr = f3{lerp(l0.x, l1.x, noise.x), lerp(l0.y, l1.y, noise.y), lerp(l0.z, l1.z, noise.z)};
+    color    = f3{discr.x < lin.x ? c1.x : c0.x, discr.y < lin.y ? c1.y : c0.y, discr.z < lin.z ? c1.z : c0.z};
+  }
+  color    = f3{clampf(lerp(0.5f, color.x, tm.contrast), 0.f, 1.f), clampf(lerp(0.5f, color.y, tm.contrast), 0.f, 1.f), clampf(lerp(0.5f, color.z, tm.contrast), 0.f, 1.f)};
+  color    = pow3(color, 1.0f / tm.brightness);
+  float i  = dot3(color, f3{0.299f, 0.587f, 0.114f});
+  color    = lerp(splat3(i), color, tm.saturation);
+  f2 uvc   = f2{(float(x) + 0.5f) / float(width), (float(y) + 0.5f) / float(height)};
+  f2 uv    = f2{(uvc.x * tm.renderingRatio[0] - 0.5f) * 2.0f, (uvc.y * tm.renderingRatio[1] - 0.5f) * 2.0f};
+  color *= 1.0f - (uv.x * uv.x + uv.y * uv.y) * tm.vignette;
+  auto q8 = [](float v) { return uint32_t(floorf(clampf(v, 0.f, 1.f) * 255.0f + 0.5f)); };
+  out[size_t(y) * width + x] = q8(color.x) | (q8(color.y) << 8) | (q8(color.z) << 16) | (q8(p.w) << 24);
+}
+
+__global__ void k_mean(const float4* __restrict__ img, size_t n, double* out3)
+{
+  __shared__ double sh[3][256];
+  double            s[3] = {0, 0, 0};
+  for(size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+  {
+    float4 p = img[i];
+    s[0] += p.x;
+    s[1] += p.y;
+    s[2] += p.z;
+  }
+  for(int k = 0; k < 3; ++k)
+    sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for(int off = 128; off > 0; off >>= 1)
+  {
+    if(threadIdx.x < (unsigned)off)
+      for(int k = 0; k < 3; ++k)
+        sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if(threadIdx.x == 0)
+    for(int k = 0; k < 3; ++k)
+      atomicAdd(&out3[k], sh[k][0]);
+}
+
+}  // namespace
+
+// ---- host-side launchers ----------------------------------------------------------------------------------------
+void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm)
+{
+  FrameParams    fp       = fpIn;
+  const uint32_t n        = fp.numSlots;
+  const uint32_t gridAll  = (n + 255) / 256;
+  const uint32_t gridWave = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  for(int s = 0; s < fp.st.maxSamples; ++s)
+  {
+    fp.sample = s;
+    pt_timers_begin(tm, stream, 0);
+    k_generate<<<gridAll, 256, 0, stream>>>(scene, rb, fp);
+    pt_timers_end(tm, stream, 0);
+    uint32_t* qIn   = rb.queueA;
+    uint32_t* qOut  = rb.queueB;
+    int       inIdx = 0, outIdx = 1;
+    for(int depth = 0; depth < fp.st.maxDepth; ++depth)
+    {
+      pt_timers_begin(tm, stream, 1);
+      k_closest<<<gridWave, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, inIdx);
+      pt_timers_end(tm, stream, 1);
+      pt_timers_begin(tm, stream, 2);
+      k_shade<<<gridWave, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, inIdx, outIdx, depth);
+      pt_timers_end(tm, stream, 2);
+      pt_timers_begin(tm, stream, 3);
+      k_shadow_rr<<<gridWave, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, outIdx, depth == fp.st.maxDepth - 1 ? 1 : 0);
+      pt_timers_end(tm, stream, 3);
+      std::swap(qIn, qOut);
+      std::swap(inIdx, outIdx);
+    }
+    pt_timers_begin(tm, stream, 4);
+    k_accumulate<<<gridAll, 256, 0, stream>>>(rb, fp);
+    pt_timers_end(tm, stream, 4);
+  }
+}
+
+void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor)
+{
+  uint32_t n = numLocalTiles * 1024u;
+  k_untile<<<(n + 255) / 256, 256, 0, stream>>>(frameTiles, slotTile, n, tilesX, width, height, outRowMajor);
+}
+
+void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles)
+{
+  uint32_t n = uint32_t(tilesX) * uint32_t(tilesY) * 1024u;
+  k_scatter_tiles<<<(n + 255) / 256, 256, 0, stream>>>(gathered, nranks, maxTilesPerRank, tilesX, tilesY, tileLocalIndex, fullTiles);
+}
+
+void pt_launch_tonemap(hipStream_t stream, const float4* rowMajor, int width, int height, const pt_Tonemapper& tm, const float avg[3], uint32_t* outRgba8)
+{
+  dim3 b(16, 16), g((width + 15) / 16, (height + 15) / 16);
+  k_tonemap<<<g, b, 0, stream>>>(rowMajor, width, height, tm, avg[0], avg[1], avg[2], outRgba8);
+}
+
+void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double* out3)
+{
+  (void)hipMemsetAsync(out3, 0, 3 * sizeof(double), stream);
+  k_mean<<<256, 256, 0, stream>>>(rowMajor, n, out3);
+}

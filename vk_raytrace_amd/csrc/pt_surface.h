@@ -1,0 +1,279 @@
+// Surface reconstruction at a hit for the gfx950 path tracer: software texture sampling, the
+// octahedral unit-vector decode, the shading frame and the glTF material resolve.
+//
+// Behavioural contract (file:line = reference):
+//   decode_oct          shaders/compress.glsl:142-180
+//   surface_at_hit      shaders/shade_state.glsl:63-145 (handedness of vertex 0 only, :114)
+//   resolve_material    shaders/gltf_material.glsl:52-93,104-193 (ffnormal re-derived after normal mapping)
+//   alpha_test          shaders/traceray_rq.glsl:32-102 (uv handedness bit NOT cleared, one RNG draw)
+//   texture taps        Vulkan unnormalised-coordinate rules at LOD 0
+#pragma once
+#include "pt_device.h"
+
+// ---- textures -------------------------------------------------------------------------------------
+PT_DEV int wrap_index(int i, int n, int mode)
+{
+  if(mode == PT_WRAP_CLAMP_TO_EDGE)
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+  if(mode == PT_WRAP_MIRRORED_REPEAT)
+  {
+    int p = 2 * n;
+    int m = i % p;
+    if(m < 0)
+      m += p;
+    m -= n;
+    int mir = m >= 0 ? m : -(1 + m);
+    return (n - 1) - mir;
+  }
+  int m = i % n;
+  return m < 0 ? m + n : m;
+}
+
+PT_DEV f4 texel_bytes(const uint32_t* pool, const TexRec& tr, int ix, int iy)
+{
+  uint32_t p = pool[tr.offset + uint32_t(wrap_index(iy, tr.h, tr.wrapT)) * uint32_t(tr.w) + uint32_t(wrap_index(ix, tr.w, tr.wrapS))];
+  return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)};
+}
+
+// RGBA8 texels are filtered as 0..255 floats and scaled by 1/255 once (the numerical contract both
+// sides of the parity tests use; Vulkan leaves filter precision to the implementation).
+PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv)
+{
+  const TexRec tr   = S.texRecs[id];
+  const float  s255 = 1.0f / 255.0f;
+  float        x = uv.x * float(tr.w), y = uv.y * float(tr.h);
+  if(tr.mag == PT_FILTER_NEAREST)
+    return texel_bytes(S.texels, tr, (int)floorf(x), (int)floorf(y)) * s255;
+  x -= 0.5f;
+  y -= 0.5f;
+  float fx = floorf(x), fy = floorf(y);
+  float a = x - fx, b = y - fy;
+  int   x0 = (int)fx, y0 = (int)fy;
+  f4    top = texel_bytes(S.texels, tr, x0, y0) * (1.0f - a) + texel_bytes(S.texels, tr, x0 + 1, y0) * a;
+  f4    bot = texel_bytes(S.texels, tr, x0, y0 + 1) * (1.0f - a) + texel_bytes(S.texels, tr, x0 + 1, y0 + 1) * a;
+  return (top * (1.0f - b) + bot * b) * s255;
+}
+
+// Environment: RGBA32F, LINEAR, U repeat / V clamp (reference: src/hdr_sampling.cpp:68-77)
+PT_DEV f3 sample_env(const DeviceScene& S, f2 uv)
+{
+  float x = uv.x * float(S.envW) - 0.5f, y = uv.y * float(S.envH) - 0.5f;
+  float fx = floorf(x), fy = floorf(y);
+  float a = x - fx, b = y - fy;
+  int   x0 = (int)fx, y0 = (int)fy;
+  int   xa = wrap_index(x0, S.envW, PT_WRAP_REPEAT), xb = wrap_index(x0 + 1, S.envW, PT_WRAP_REPEAT);
+  int   ya = wrap_index(y0, S.envH, PT_WRAP_CLAMP_TO_EDGE), yb = wrap_index(y0 + 1, S.envH, PT_WRAP_CLAMP_TO_EDGE);
+  f3    t00 = xyz(S.env[size_t(ya) * S.envW + xa]), t10 = xyz(S.env[size_t(ya) * S.envW + xb]);
+  f3    t01 = xyz(S.env[size_t(yb) * S.envW + xa]), t11 = xyz(S.env[size_t(yb) * S.envW + xb]);
+  f3    top = t00 * (1.0f - a) + t10 * a;
+  f3    bot = t01 * (1.0f - a) + t11 * a;
+  return top * (1.0f - b) + bot * b;
+}
+
+// ---- unit-vector codec ---------------------------------------------------------------------------
+PT_DEV float snorm15(int v)
+{
+  return (v >= 0) ? (__uint_as_float(0x3F800000u | (uint32_t(v) << 8)) - 1.0f) : (__uint_as_float(0xBF800000u | (uint32_t(-v) << 8)) + 1.0f);
+}
+PT_DEV f3 decode_oct(uint32_t packed)
+{
+  if(packed == ~0u)
+    return splat3(3.402823466e+38f);
+  int       x  = int(packed & 0xFFFFu) - 32767;
+  int       y  = int(packed >> 16) - 32767;
+  const int mx = x >> 31, my = y >> 31;
+  const int t0 = 32767 + mx + my;
+  const int ym = y ^ my;
+  const int t1 = t0 - (x ^ mx);
+  const int z  = t1 - ym;
+  float     zf;
+  if(z < 0)
+  {
+    x  = (t0 - ym) ^ mx;
+    y  = t1 ^ my;
+    zf = __uint_as_float(0xBF800000u | (uint32_t(-z) << 8)) + 1.0f;
+  }
+  else
+  {
+    zf = __uint_as_float(0x3F800000u | (uint32_t(z) << 8)) - 1.0f;
+  }
+  return unit(f3{snorm15(x), snorm15(y), zf});
+}
+PT_DEV f4 unpack_unorm4(uint32_t p) { return f4{float(p & 0xffu) / 255.0f, float((p >> 8) & 0xffu) / 255.0f, float((p >> 16) & 0xffu) / 255.0f, float(p >> 24) / 255.0f}; }
+
+// ---- material after textures (reference: shaders/globals.glsl:67-97 Material + the State fields the BSDFs read)
+struct Surface {
+  // frame
+  f3 position, normal, ffnormal, tangent, bitangent;
+  f2 uv;
+  // material
+  f3    albedo, emission, f0, sheenTint, attenuationColor;
+  float metallic, roughness, ax, ay, anisotropy, clearcoat, clearcoatRoughness, transmission, ior, eta;
+  float attenuationDistance, alpha, sheen;
+  float specular, specularTint, subsurface;  // constants 0.5 / 1 / 0 (gltf_material.glsl:108-112)
+  bool  unlit, thinwalled;
+};
+
+struct VertexTriple {
+  float4 a0, b0, a1, b1, a2, b2;  // a = pos.xyz + normal bits, b = uv.xy + tangent bits + colour bits
+};
+PT_DEV VertexTriple fetch_triangle(const DeviceScene& S, const InstanceRec& I, uint32_t prim)
+{
+  const uint32_t* t  = S.indices + I.firstIndex + 3 * size_t(prim);
+  const uint32_t  i0 = I.vertexOffset + t[0], i1 = I.vertexOffset + t[1], i2 = I.vertexOffset + t[2];
+  VertexTriple    v;
+  v.a0 = S.vertices[size_t(i0) * 2];
+  v.b0 = S.vertices[size_t(i0) * 2 + 1];
+  v.a1 = S.vertices[size_t(i1) * 2];
+  v.b1 = S.vertices[size_t(i1) * 2 + 1];
+  v.a2 = S.vertices[size_t(i2) * 2];
+  v.b2 = S.vertices[size_t(i2) * 2 + 1];
+  return v;
+}
+
+// shaders/common.glsl:80-92 (== shade_state.glsl:34-39)
+PT_DEV void make_frame(f3 N, f3& T, f3& B)
+{
+  T = unit((fabsf(N.z) > 0.99999f) ? f3{-N.x * N.y, 1.0f - N.y * N.y, -N.y * N.z} : f3{-N.x * N.z, -N.y * N.z, 1.0f - N.z * N.z});
+  B = cross3(T, N);
+}
+
+// Stochastic alpha (any-hit): returns true when the candidate is kept.  Draws exactly one random number.
+PT_DEV bool alpha_test(const DeviceScene& S, const TriRec& tr, float bu, float bv, uint32_t& seed)
+{
+  const InstanceRec&          I   = S.instances[__float_as_uint(tr.e1n.w)];
+  const pt_GltfShadeMaterial& mat = S.materials[I.materialIndex < 0 ? 0 : I.materialIndex];
+  float                       a   = mat.pbrBaseColorFactor[3];
+  if(mat.pbrBaseColorTexture > -1)
+  {
+    const VertexTriple v  = fetch_triangle(S, I, __float_as_uint(tr.e2p.w));
+    const float        b0 = 1.0f - bu - bv;
+    // the handedness bit in the LSB of v is left in place here (reference quirk, Appendix C-8)
+    f2 uv = f2{v.b0.x, v.b0.y} * b0 + f2{v.b1.x, v.b1.y} * bu + f2{v.b2.x, v.b2.y} * bv;
+    // (vec4(uv,1,1) * uvTransform).xy : component i = dot(vec4, column i)
+    const float* m = mat.uvTransform;
+    f2           tuv = f2{((uv.x * m[0] + uv.y * m[1]) + 1.0f * m[2]) + 1.0f * m[3], ((uv.x * m[4] + uv.y * m[5]) + 1.0f * m[6]) + 1.0f * m[7]};
+    a *= sample_rgba8(S, mat.pbrBaseColorTexture, tuv).w;
+  }
+  float opacity = (mat.alphaMode == PT_ALPHA_MASK) ? (a > mat.alphaCutoff ? 1.0f : 0.0f) : a;
+  return !(rng_next(seed) > opacity);
+}
+
+// Interpolated attributes -> world-space shading frame.  Returns vertex colour in `vcolor`.
+PT_DEV void surface_at_hit(const DeviceScene& S, const InstanceRec& I, uint32_t prim, float bu, float bv, Surface& sf, f3& vcolor)
+{
+  const VertexTriple v  = fetch_triangle(S, I, prim);
+  const float        b0 = 1.0f - bu - bv;
+  const f3           p0 = xyz(v.a0), p1 = xyz(v.a1), p2 = xyz(v.a2);
+  const f3           pos = p0 * b0 + p1 * bu + p2 * bv;
+  sf.position            = xform_point(I.objectToWorld, pos);
+
+  f3 n  = unit(decode_oct(__float_as_uint(v.a0.w)) * b0 + decode_oct(__float_as_uint(v.a1.w)) * bu + decode_oct(__float_as_uint(v.a2.w)) * bv);
+  f3 wn = unit(xform_rowvec(n, I.worldToObject));
+  f3 gn = unit(cross3(p1 - p0, p2 - p0));
+  f3 wg = unit(xform_rowvec(gn, I.worldToObject));
+
+  float h0 = (__float_as_int(v.b0.y) & 1) == 1 ? 1.0f : -1.0f;
+  f3    tg = decode_oct(__float_as_uint(v.b0.z)) * b0 + decode_oct(__float_as_uint(v.b1.z)) * bu + decode_oct(__float_as_uint(v.b2.z)) * bv;
+  tg       = unit(tg);
+  f3 wt    = unit(xform_dir(I.objectToWorld, tg));
+  wt       = unit(wt - wn * dot3(wt, wn));
+  f3 wb    = cross3(wn, wt) * h0;
+
+  auto clear_lsb = [](float y) { return __uint_as_float(__float_as_uint(y) & ~1u); };
+  sf.uv          = f2{v.b0.x, clear_lsb(v.b0.y)} * b0 + f2{v.b1.x, clear_lsb(v.b1.y)} * bu + f2{v.b2.x, clear_lsb(v.b2.y)} * bv;
+
+  f4 col = unpack_unorm4(__float_as_uint(v.b0.w)) * b0 + unpack_unorm4(__float_as_uint(v.b1.w)) * bu + unpack_unorm4(__float_as_uint(v.b2.w)) * bv;
+  vcolor = f3{col.x, col.y, col.z};
+
+  if(dot3(wn, wg) <= 0)
+    wn *= -1.0f;
+  sf.normal    = wn;
+  sf.tangent   = wt;
+  sf.bitangent = wb;
+}
+
+PT_DEV f4 srgb_to_linear(f4 c)
+{
+  f3 l = pow3(f3{c.x, c.y, c.z}, 2.2f);
+  return f4{l.x, l.y, l.z, c.w};
+}
+
+// glTF material + KHR extensions -> Surface (everything the BSDFs need).  `rayDir` is the incoming ray.
+PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m, f3 rayDir, Surface& sf)
+{
+  sf.specular     = 0.5f;
+  sf.subsurface   = 0.0f;
+  sf.specularTint = 1.0f;
+
+  const float* um = m.uvTransform;
+  sf.uv           = f2{((sf.uv.x * um[0] + sf.uv.y * um[1]) + 1.0f * um[2]) + 1.0f * um[3], ((sf.uv.x * um[4] + sf.uv.y * um[5]) + 1.0f * um[6]) + 1.0f * um[7]};
+  const f3 T0 = sf.tangent, B0 = sf.bitangent, N0 = sf.normal;  // TBN before normal mapping
+
+  if(m.normalTexture > -1)
+  {
+    f3 nv       = xyz(sample_rgba8(S, m.normalTexture, sf.uv));
+    nv          = unit(nv * 2.0f - 1.0f);
+    nv          = nv * f3{m.normalTextureScale, m.normalTextureScale, 1.0f};
+    sf.normal   = unit(basis_mul(T0, B0, N0, nv));
+    sf.ffnormal = dot3(sf.normal, rayDir) <= 0.0f ? sf.normal : -sf.normal;
+    make_frame(sf.ffnormal, sf.tangent, sf.bitangent);
+  }
+
+  sf.emission = f3{m.emissiveFactor[0], m.emissiveFactor[1], m.emissiveFactor[2]};
+  if(m.emissiveTexture > -1)
+    sf.emission *= xyz(srgb_to_linear(sample_rgba8(S, m.emissiveTexture, sf.uv)));
+
+  // metallic-roughness (gltf_material.glsl:52-93)
+  float dielectricSpecular = (m.ior - 1) / (m.ior + 1);
+  dielectricSpecular *= dielectricSpecular;
+  float rough = m.pbrRoughnessFactor, metal = m.pbrMetallicFactor;
+  if(m.pbrMetallicRoughnessTexture > -1)
+  {
+    f4 mr = sample_rgba8(S, m.pbrMetallicRoughnessTexture, sf.uv);
+    rough = mr.y * rough;
+    metal = mr.z * metal;
+  }
+  f4 base = f4{m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2], m.pbrBaseColorFactor[3]};
+  if(m.pbrBaseColorTexture > -1)
+    base = base * srgb_to_linear(sample_rgba8(S, m.pbrBaseColorTexture, sf.uv));
+  sf.f0        = lerp(splat3(dielectricSpecular), f3{base.x, base.y, base.z}, metal);
+  sf.albedo    = f3{base.x, base.y, base.z};
+  sf.metallic  = metal;
+  sf.alpha     = base.w;
+  sf.roughness = fmax2(rough, 0.001f);
+
+  sf.transmission = m.transmissionFactor;
+  if(m.transmissionTexture > -1)
+    sf.transmission *= sample_rgba8(S, m.transmissionTexture, sf.uv).x;
+
+  sf.ior = m.ior;
+  sf.eta = dot3(sf.normal, sf.ffnormal) > 0.0f ? (1.0f / sf.ior) : sf.ior;
+
+  sf.unlit      = (m.unlit == 1);
+  sf.anisotropy = m.anisotropy;
+  float aspect  = sqrtf(1.0f - m.anisotropy * 0.9f);
+  sf.ax         = fmax2(0.001f, sf.roughness / aspect);
+  sf.ay         = fmax2(0.001f, sf.roughness * aspect);
+  if(m.anisotropy > 0)
+  {
+    sf.tangent   = unit(basis_mul(T0, B0, N0, f3{m.anisotropyDirection[0], m.anisotropyDirection[1], m.anisotropyDirection[2]}));
+    sf.bitangent = unit(cross3(sf.normal, sf.tangent));
+  }
+
+  sf.attenuationColor    = f3{m.attenuationColor[0], m.attenuationColor[1], m.attenuationColor[2]};
+  sf.attenuationDistance = m.attenuationDistance;
+  sf.thinwalled          = m.thicknessFactor == 0;
+
+  sf.clearcoat          = m.clearcoatFactor;
+  sf.clearcoatRoughness = m.clearcoatRoughness;
+  if(m.clearcoatTexture > -1)
+    sf.clearcoat *= sample_rgba8(S, m.clearcoatTexture, sf.uv).x;
+  if(m.clearcoatRoughnessTexture > -1)
+    sf.clearcoatRoughness *= sample_rgba8(S, m.clearcoatRoughnessTexture, sf.uv).y;
+  sf.clearcoatRoughness = fmax2(sf.clearcoatRoughness, 0.001f);
+
+  f4 sh        = unpack_unorm4(m.sheen);
+  sf.sheenTint = f3{sh.x, sh.y, sh.z};
+  sf.sheen     = sh.w;
+}

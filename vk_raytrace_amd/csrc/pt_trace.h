@@ -1,0 +1,175 @@
+// BVH traversal and ray/triangle test for gfx950 -- the part of the reference that lives in the
+// Vulkan driver + RT cores (shaders/traceray_rq.glsl:110-134 rayQueryProceedEXT loops).
+//
+// Semantics (DESIGN.md "Trace contract"):
+//  * candidates are ordered by the key (t, world triangle index); a query returns the smallest key
+//    strictly greater than a previous key inside (0, tmax) -- independent of the BVH shape, so the
+//    result is bit-identical for any builder;
+//  * back faces are culled unless the instance is double sided; facing is an object-space property,
+//    so a mirrored instance flips the sign test (TRI_FLIP);
+//  * opaque instances commit directly; non-opaque ones go through the stochastic alpha test.
+//
+// Per-lane traversal stack: the first STACK_LDS entries live in LDS laid out [level][lane] (one bank
+// per lane, conflict free: 64 lanes x 4 B = one 256-byte bank row per level), deeper entries spill to
+// a small private array.  LBVH depth is unbounded in theory; overflow beyond STACK_LDS+STACK_SPILL is
+// counted in Counters::stackOverflow and asserted zero by the tests.
+#pragma once
+#include "pt_device.h"
+
+#define TRACE_BLOCK 64
+#define STACK_LDS 32
+#define STACK_SPILL 32
+
+struct RayHit {
+  float    t, u, v;
+  uint32_t slot;  // TriRec slot (leaf order); BVH_NONE: nothing
+  uint32_t w;     // world triangle index | flags << 29
+};
+
+PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta < tb || (ta == tb && wa < wb); }
+
+// Moeller-Trumbore on (p0, e1, e2) in the exact operation order of the trace contract (T2, T3).
+PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
+{
+  f3    e1  = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
+  f3    pv  = cross3(d, e2);
+  float det = dot3(e1, pv);
+  if(det == 0.0f)
+    return false;
+  if(!(flags & TRI_NOCULL))
+  {
+    bool front = (flags & TRI_FLIP) ? (det < 0.0f) : (det > 0.0f);
+    if(!front)
+      return false;
+  }
+  float inv = 1.0f / det;
+  f3    tv  = o - p0;
+  u         = dot3(tv, pv) * inv;
+  if(u < 0.0f || u > 1.0f)
+    return false;
+  f3 qv = cross3(tv, e1);
+  v     = dot3(d, qv) * inv;
+  if(v < 0.0f || u + v > 1.0f)
+    return false;
+  t = dot3(e2, qv) * inv;
+  return true;
+}
+
+// MODE 0: all triangles, closest key.  MODE 1: non-opaque only, closest key.
+// MODE 2: shadow -- returns immediately with `opaqueHit` when any opaque triangle is inside (0,tmax);
+//         meanwhile tracks the closest non-opaque candidate (so the first alpha test needs no second pass).
+template <int MODE>
+PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, uint32_t wPrev, uint32_t* ldsStack, RayHit& best, bool& opaqueHit,
+                     Counters* counters)
+{
+  best.slot = BVH_NONE;
+  best.t    = tmax;
+  best.w    = 0xffffffffu;
+  opaqueHit = false;
+  if(S.numTris == 0)
+    return;
+
+  const f3 idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+#define PT_TLIMIT (MODE == 2 ? tmax : best.t)  // shadow rays must still see opaque triangles behind the best alpha candidate
+  uint32_t spill[STACK_SPILL];
+  int      sp  = 0;
+  uint32_t cur = 0;  // root (inner node 0; a one-triangle scene has a single node with one leaf child)
+#ifdef PT_STATS
+  uint32_t nNodes = 0, nTris = 0;
+#endif
+
+  for(;;)
+  {
+    if(!(cur & BVH_LEAF))
+    {
+      const BvhNode* np = S.bvh + cur;
+      const float4   a = np->a, b = np->b, c = np->c;
+      const uint4    ch = np->d;
+#ifdef PT_STATS
+      ++nNodes;
+#endif
+      // slab test of both children; (bound - o) * idir keeps NaN confined to the degenerate 0*inf case,
+      // which fminf/fmaxf (IEEE minNum/maxNum) then ignore -> conservative
+      float lx0 = (a.x - o.x) * idir.x, lx1 = (a.w - o.x) * idir.x;
+      float ly0 = (a.y - o.y) * idir.y, ly1 = (b.x - o.y) * idir.y;
+      float lz0 = (a.z - o.z) * idir.z, lz1 = (b.y - o.z) * idir.z;
+      float rx0 = (b.z - o.x) * idir.x, rx1 = (c.y - o.x) * idir.x;
+      float ry0 = (b.w - o.y) * idir.y, ry1 = (c.z - o.y) * idir.y;
+      float rz0 = (c.x - o.z) * idir.z, rz1 = (c.w - o.z) * idir.z;
+      float lnear = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f)) * 0.9999996f;
+      float lfar  = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), PT_TLIMIT)) * 1.0000004f;
+      float rnear = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f)) * 0.9999996f;
+      float rfar  = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), PT_TLIMIT)) * 1.0000004f;
+      bool  hl = lnear <= lfar, hr = (rnear <= rfar) && (ch.y != BVH_NONE);
+      if(hl && hr)
+      {
+        uint32_t nearC = ch.x, farC = ch.y;
+        if(rnear < lnear)
+        {
+          nearC = ch.y;
+          farC  = ch.x;
+        }
+        if(sp < STACK_LDS)
+          ldsStack[sp++ * TRACE_BLOCK] = farC;
+        else if(sp < STACK_LDS + STACK_SPILL)
+          spill[sp++ - STACK_LDS] = farC;
+        else
+          atomicAdd(&counters->stackOverflow, 1u);  // far child dropped (flagged; tests assert this stays 0)
+        cur = nearC;
+        continue;
+      }
+      if(hl || hr)
+      {
+        cur = hl ? ch.x : ch.y;
+        continue;
+      }
+    }
+    else
+    {
+      const uint32_t slot  = cur & ~BVH_LEAF;
+      const TriRec   tr    = S.tris[slot];
+      const uint32_t wbits = __float_as_uint(tr.p0w.w);
+      const uint32_t flags = wbits >> 29;
+      bool           skip  = false;
+      if(MODE == 1 && (flags & TRI_OPAQUE))
+        skip = true;
+      if(!skip)
+      {
+#ifdef PT_STATS
+        ++nTris;
+#endif
+        float t, u, v;
+        if(tri_test(tr, flags, o, d, t, u, v) && t < tmax)
+        {
+          const uint32_t w = wbits & TRI_INDEX_MASK;
+          if(MODE == 2 && (flags & TRI_OPAQUE))
+          {
+            if(t > 0.0f)
+            {
+              opaqueHit = true;
+              break;
+            }
+          }
+          else if(key_less(tPrev, wPrev, t, w) && (best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK)))
+          {
+            best.t    = t;
+            best.u    = u;
+            best.v    = v;
+            best.slot = slot;
+            best.w    = wbits;
+          }
+        }
+      }
+    }
+    // pop
+    if(sp == 0)
+      break;
+    --sp;
+    cur = sp < STACK_LDS ? ldsStack[sp * TRACE_BLOCK] : spill[sp - STACK_LDS];
+  }
+#undef PT_TLIMIT
+#ifdef PT_STATS
+  atomicAdd(&counters->nodesVisited, (unsigned long long)nNodes);
+  atomicAdd(&counters->trisTested, (unsigned long long)nTris);
+#endif
+}

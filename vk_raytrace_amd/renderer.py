@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's renderer interface for the gfx950 backend.
+
+``Renderer`` has the reference's method set and call order (reference: src/renderer.h:30-48);
+``HipRenderer`` is the implementation that takes the place of ``RayQuery`` (src/rayquery.cpp:40-109)
+and ``RtxPipeline`` (src/rtx_pipeline.cpp:45-276).  ``SampleExample`` is the headless part of the
+reference's orchestrator that the hot path needs (src/sample_example.cpp:77-82 setup loop,
+:90-111 load, :183-207 frame counter, :322-337 createRender, :390-429 renderScene, :362-384 drawPost).
+
+Vulkan handles do not exist on the target: what reached the shaders through descriptor sets
+(TLAS, output image, scene buffers, environment) is handed over with explicit ``set_*`` calls, and
+the command buffer is the context's own HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from . import host_device as hd
+
+
+class Renderer:
+    """reference: src/renderer.h:30-48"""
+
+    def __init__(self):
+        self.m_state = hd.RtxState()
+
+    def setup(self, device, physicalDevice=None, familyIndex=0, allocator=None):
+        raise NotImplementedError
+
+    def destroy(self):
+        raise NotImplementedError
+
+    def run(self, cmdBuf, size, profiler, extraDescSets):
+        raise NotImplementedError
+
+    def create(self, size, extraDescSetsLayout, scene=None):
+        raise NotImplementedError
+
+    def name(self):
+        raise NotImplementedError
+
+    def setPushContants(self, state):  # (sic) the reference's spelling, src/renderer.h:44
+        self.m_state = state
+
+
+class HipRenderer(Renderer):
+    """libptmi.so behind the reference's Renderer interface."""
+
+    def __init__(self):
+        super().__init__()
+        self._lib = capi.lib()
+        self._ctx = None
+        self._keep = None
+        self.size = (0, 0)
+        self.env_integral = 1.0
+        self.env_average = 1.0
+
+    # -- Renderer interface ------------------------------------------------------------------------
+    def setup(self, device=0, physicalDevice=None, familyIndex=0, allocator=None):
+        """Renderer::setup: bind to one GPU (`device` is the HIP ordinal)."""
+        if self._ctx is not None:
+            return
+        ctx = C.c_void_p()
+        rc = self._lib.pt_create(int(device), C.byref(ctx))
+        if rc != capi.PT_OK:
+            raise capi.PtError(rc, self._lib.pt_last_error(None).decode())
+        self._ctx = ctx
+
+    def destroy(self):
+        if self._ctx is not None:
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def name(self):
+        return self._lib.pt_renderer_name().decode()
+
+    def create(self, size, extraDescSetsLayout=None, scene=None):
+        """Renderer::create(size, layouts, scene): allocate the output for `size` = (width, height);
+        if a scene is given it is uploaded and its acceleration structure built."""
+        if scene is not None:
+            self.set_scene(scene)
+        self._check(self._lib.pt_resize(self._ctx, int(size[0]), int(size[1])))
+        self.size = (int(size[0]), int(size[1]))
+
+    def run(self, cmdBuf=None, size=None, profiler=None, extraDescSets=None):
+        """Renderer::run: one frame with the state given to setPushContants (asynchronous)."""
+        if size is not None and tuple(size) != self.size:
+            self.create(size)
+        self.m_state.size[0], self.m_state.size[1] = self.size
+        self._check(self._lib.pt_render_frame(self._ctx, C.byref(self.m_state)))
+
+    # -- what the descriptor sets carried -------------------------------------------------------------
+    def set_scene(self, scene):
+        d, keep = scene.desc()
+        self._check(self._lib.pt_set_scene(self._ctx, C.byref(d)))
+        self._check(self._lib.pt_build_accel(self._ctx))
+        self._keep = keep
+
+    def set_env(self, env_rgba32f):
+        env = np.ascontiguousarray(env_rgba32f, np.float32)
+        assert env.ndim == 3 and env.shape[2] == 4
+        i, a = C.c_float(), C.c_float()
+        self._check(self._lib.pt_set_env(self._ctx, env.ctypes.data, env.shape[1], env.shape[0], C.byref(i), C.byref(a)))
+        self.env_integral, self.env_average = i.value, a.value
+        return self.env_integral, self.env_average
+
+    def set_camera(self, cam: hd.SceneCamera):
+        self._check(self._lib.pt_set_camera(self._ctx, C.byref(cam)))
+
+    def set_sunsky(self, ss: hd.SunAndSky):
+        self._check(self._lib.pt_set_sunsky(self._ctx, C.byref(ss)))
+
+    def set_shard(self, rank, nranks):
+        self._check(self._lib.pt_set_shard(self._ctx, rank, nranks))
+
+    # -- output --------------------------------------------------------------------------------------
+    def synchronize(self):
+        self._check(self._lib.pt_synchronize(self._ctx))
+
+    def read_accum(self):
+        w, h = self.size
+        out = np.empty((h, w, 4), np.float32)
+        self._check(self._lib.pt_read_accum(self._ctx, out.ctypes.data))
+        return out
+
+    def tonemap(self, tm: hd.Tonemapper):
+        w, h = self.size
+        out = np.empty((h, w, 4), np.uint8)
+        self._check(self._lib.pt_tonemap(self._ctx, C.byref(tm), out.ctypes.data))
+        return out
+
+    def local_shard(self):
+        ptr, nbytes, nloc, nmax = C.c_void_p(), C.c_size_t(), C.c_int(), C.c_int()
+        self._check(self._lib.pt_local_shard(self._ctx, C.byref(ptr), C.byref(nbytes), C.byref(nloc), C.byref(nmax)))
+        return ptr.value, nbytes.value, nloc.value, nmax.value
+
+    def scatter_shards(self, gathered_device_ptr, nranks):
+        self._check(self._lib.pt_scatter_shards(self._ctx, C.c_void_p(gathered_device_ptr), nranks))
+
+    # -- measurement -----------------------------------------------------------------------------------
+    def set_profiling(self, enable):
+        self._check(self._lib.pt_set_profiling(self._ctx, int(enable)))
+
+    def stats(self):
+        s = hd.Stats()
+        self._check(self._lib.pt_get_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self._lib.pt_reset_stats(self._ctx))
+
+    def _check(self, rc):
+        if rc != capi.PT_OK:
+            raise capi.PtError(rc, self._lib.pt_last_error(self._ctx).decode())
+
+
+class SampleExample:
+    """The headless slice of the reference's orchestrator (src/sample_example.{hpp,cpp})."""
+
+    def __init__(self, device=0, renderer=None):
+        self.m_rtxState = hd.default_rtx_state()       # sample_example.hpp:162-174
+        self.m_sunAndSky = hd.default_sun_and_sky()    # sample_example.hpp:176-193
+        self.m_tonemapper = hd.default_tonemapper()    # render_output.hpp:37-49
+        self.m_maxFrames = 100000                      # sample_example.hpp:195
+        self.m_pRender = renderer if renderer is not None else HipRenderer()
+        self.m_pRender.setup(device)                   # sample_example.cpp:77-82
+        self.m_scene = None
+        self.m_size = (0, 0)
+        self.resetFrame()
+
+    # sample_example.cpp:90-98 loadScene + main.cpp:186-189
+    def loadScene(self, scene):
+        if scene.vertices is None:
+            scene.finalize(capi.pack_vertices)
+        self.m_scene = scene
+        self.m_pRender.set_scene(scene)
+        self.resetFrame()
+
+    # sample_example.cpp:103-111 (the image arrives decoded: stbi_loadf has no counterpart here)
+    def loadEnvironmentHdr(self, env_rgba32f):
+        integral, _ = self.m_pRender.set_env(env_rgba32f)
+        self.m_rtxState.fireflyClampThreshold = integral * 4.0  # "magic", sample_example.cpp:110
+        self.resetFrame()
+
+    def setRenderRegion(self, width, height):
+        self.m_size = (int(width), int(height))
+        self.m_pRender.create(self.m_size)
+        self.resetFrame()
+
+    # sample_example.cpp:168-178
+    def updateUniformBuffer(self):
+        cam = capi.camera_lookat(self.m_scene.camera, self.m_size[0] / self.m_size[1], nb_lights=len(self.m_scene.lights))
+        self.m_pRender.set_camera(cam)
+        self.m_pRender.set_sunsky(self.m_sunAndSky)
+
+    # sample_example.cpp:183-199 (camera-change detection is the caller's resetFrame())
+    def updateFrame(self):
+        if self.m_rtxState.frame < self.m_maxFrames:
+            self.m_rtxState.frame += 1
+
+    def resetFrame(self):  # sample_example.cpp:204-207
+        self.m_rtxState.frame = -1
+
+    # sample_example.cpp:390-429
+    def renderScene(self):
+        if self.m_rtxState.frame >= self.m_maxFrames:
+            return
+        self.m_rtxState.size[0], self.m_rtxState.size[1] = self.m_size
+        self.m_pRender.setPushContants(self.m_rtxState)
+        self.m_pRender.run(None, self.m_size, None, None)
+
+    # sample_example.cpp:362-384 -> RenderOutput::run
+    def drawPost(self):
+        return self.m_pRender.tonemap(self.m_tonemapper)
+
+    def render(self, frames):
+        """`frames` iterations of the reference's main loop body (src/main.cpp:201-264)."""
+        self.updateUniformBuffer()
+        for _ in range(frames):
+            self.updateFrame()
+            self.renderScene()
+        self.m_pRender.synchronize()
+        return self.m_pRender.read_accum()
+
+    def destroy(self):
+        self.m_pRender.destroy()
