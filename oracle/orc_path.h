@@ -189,7 +189,10 @@ struct Tracer {
   bool AnyHit(const Ray& r, float maxDist)
   {
     stats.shadowRays++;
-    Candidate o = sc.query(r.origin, r.direction, maxDist, 0.0f, ~0u, 2, &stats);
+    const uint64_t n0 = stats.nodesVisited, t0 = stats.trisTested;
+    Candidate      o  = sc.query(r.origin, r.direction, maxDist, 0.0f, ~0u, 2, &stats);
+    stats.nodesShadow += stats.nodesVisited - n0;
+    stats.trisShadow += stats.trisTested - t0;
     if(o.found)
       return true;
     float    tPrev = 0.0f;

@@ -59,11 +59,12 @@ struct BvhNode {
 struct Stats {
   uint64_t samples = 0, closestRays = 0, shadowRays = 0, shadedHits = 0, misses = 0, alphaTests = 0, neeLookups = 0;
   uint64_t nodesVisited = 0, trisTested = 0, texTaps = 0;
+  uint64_t nodesShadow = 0, trisShadow = 0;  // the part of nodesVisited / trisTested spent on shadow rays
   void     add(const Stats& o)
   {
     samples += o.samples; closestRays += o.closestRays; shadowRays += o.shadowRays; shadedHits += o.shadedHits;
     misses += o.misses; alphaTests += o.alphaTests; neeLookups += o.neeLookups; nodesVisited += o.nodesVisited;
-    trisTested += o.trisTested; texTaps += o.texTaps;
+    trisTested += o.trisTested; texTaps += o.texTaps; nodesShadow += o.nodesShadow; trisShadow += o.trisShadow;
   }
 };
 

@@ -161,11 +161,11 @@ int orc_render_frame(orc_ctx* c, const pt_RtxState* state, float* accum, const u
   return 0;
 }
 
-// 10 uint64: samples closestRays shadowRays shadedHits misses alphaTests neeLookups nodesVisited trisTested texTaps
+// 12 uint64: samples closestRays shadowRays shadedHits misses alphaTests neeLookups nodesVisited trisTested texTaps nodesShadow trisShadow
 int orc_get_stats(orc_ctx* c, uint64_t* out)
 {
   const Stats& s = c->stats;
-  uint64_t     v[10] = {s.samples, s.closestRays, s.shadowRays, s.shadedHits, s.misses, s.alphaTests, s.neeLookups, s.nodesVisited, s.trisTested, s.texTaps};
+  uint64_t     v[12] = {s.samples, s.closestRays, s.shadowRays, s.shadedHits, s.misses, s.alphaTests, s.neeLookups, s.nodesVisited, s.trisTested, s.texTaps, s.nodesShadow, s.trisShadow};
   std::memcpy(out, v, sizeof(v));
   return 0;
 }

@@ -66,7 +66,7 @@ def lib():
     return _lib
 
 
-STAT_NAMES = ["samples", "closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups", "nodesVisited", "trisTested", "texTaps"]
+STAT_NAMES = ["samples", "closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups", "nodesVisited", "trisTested", "texTaps", "nodesShadow", "trisShadow"]
 
 
 def pack_vertices(pos, nrm, tan, uv, col):
@@ -149,7 +149,7 @@ class Oracle:
         return accum
 
     def stats(self):
-        v = np.zeros(10, np.uint64)
+        v = np.zeros(12, np.uint64)
         self.L.orc_get_stats(self.ctx, v.ctypes.data)
         return dict(zip(STAT_NAMES, (int(x) for x in v)))
 

@@ -150,22 +150,52 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest(DeviceScene S, RenderBu
   const uint32_t seed0 = seed;
   count_event(&rb.counters->closestRays);
 
-  float    tPrev = 0.0f;
-  uint32_t wPrev = 0xffffffffu;
-  RayHit   h;
-  for(;;)
+  // pass A: nearest certain hit; pass B (only if transparent candidates were seen): count the draws they consume
+  RayHit h;
+  bool   dummy;
+  traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+  bool     exact = (h.flags & TF_SAW_FRAC) != 0;
+  uint32_t nDraw = 0;
+  if(!exact && (h.flags & TF_SAW_ZERO))
   {
-    bool opq;
-    traverse<0>(S, o, d, PT_INFINITY, tPrev, wPrev, stack + threadIdx.x, h, opq, rb.counters);
-    if(h.slot == BVH_NONE)
-      break;
-    if((h.w >> 29) & TRI_OPAQUE)
-      break;
-    count_event(&rb.counters->alphaTests);
-    if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
-      break;
-    tPrev = h.t;
-    wPrev = h.w & TRI_INDEX_MASK;
+    RayHit c;
+    traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                       rb.counters);
+    exact = (c.flags & TF_SAW_FRAC) != 0;
+    nDraw = c.count;
+  }
+  if(!exact)
+  {
+    if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+      ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
+    uint32_t s2 = seed;
+    if(consume_rejected_draws(s2, nDraw))
+    {
+      seed = s2;
+      if(nDraw)
+        atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
+    }
+    else
+      exact = true;
+  }
+  if(exact)
+  {  // exact key-ordered loop (fractional opacity in front of the hit, or a draw of exactly 0.0)
+    float    tPrev = 0.0f;
+    uint32_t wPrev = 0xffffffffu;
+    seed           = seed0;
+    for(;;)
+    {
+      traverse<TM_RAW_ALL>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+      if(h.slot == BVH_NONE)
+        break;
+      if((h.w >> 29) & TRI_OPAQUE)
+        break;
+      atomicAdd(&rb.counters->alphaTests, 1ull);
+      if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+        break;
+      tPrev = h.t;
+      wPrev = h.w & TRI_INDEX_MASK;
+    }
   }
   if(h.slot == BVH_NONE)
     rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
@@ -456,23 +486,57 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_rr(DeviceScene S, Render
     const f3    d       = xyz(nd);
     const float maxDist = rb.ps.absorb[slot].w;
     bool        inShadow;
+    bool        dummy;
     RayHit      h;
-    traverse<2>(S, o, d, maxDist, 0.0f, 0xffffffffu, stack + threadIdx.x, h, inShadow, rb.counters);
+    const uint32_t seed0 = seed;
+    // pass A: any opaque occluder ends the ray without a draw; otherwise the nearest certain alpha occluder
+    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
     if(!inShadow)
     {
-      // no opaque occluder: stochastic alpha on the non-opaque candidates in key order (trace contract T6)
-      while(h.slot != BVH_NONE)
+      bool     exact = (h.flags & TF_SAW_FRAC) != 0;
+      uint32_t nDraw = 0;
+      if(!exact && (h.flags & TF_SAW_ZERO))
       {
-        count_event(&rb.counters->alphaTests);
-        if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+        RayHit c;
+        traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                           rb.counters);
+        exact = (c.flags & TF_SAW_FRAC) != 0;
+        nDraw = c.count;
+      }
+      if(!exact)
+      {
+        if(h.slot != BVH_NONE)
+          ++nDraw;
+        uint32_t s2 = seed;
+        if(consume_rejected_draws(s2, nDraw))
         {
-          inShadow = true;
-          break;
+          seed     = s2;
+          inShadow = h.slot != BVH_NONE;
+          if(nDraw)
+            atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
         }
-        bool        dummy;
-        const float tp = h.t;
-        const uint32_t wp = h.w & TRI_INDEX_MASK;
-        traverse<1>(S, o, d, maxDist, tp, wp, stack + threadIdx.x, h, dummy, rb.counters);
+        else
+          exact = true;
+      }
+      if(exact)
+      {  // exact key-ordered stochastic alpha over the non-opaque candidates (trace contract T6)
+        seed           = seed0;
+        float    tPrev = 0.0f;
+        uint32_t wPrev = 0xffffffffu;
+        for(;;)
+        {
+          traverse<TM_RAW_NONOPAQUE>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+          if(h.slot == BVH_NONE)
+            break;
+          atomicAdd(&rb.counters->alphaTests, 1ull);
+          if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+          {
+            inShadow = true;
+            break;
+          }
+          tPrev = h.t;
+          wPrev = h.w & TRI_INDEX_MASK;
+        }
       }
     }
     if(!inShadow)

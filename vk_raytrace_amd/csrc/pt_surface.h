@@ -138,8 +138,9 @@ PT_DEV void make_frame(f3 N, f3& T, f3& B)
   B = cross3(T, N);
 }
 
-// Stochastic alpha (any-hit): returns true when the candidate is kept.  Draws exactly one random number.
-PT_DEV bool alpha_test(const DeviceScene& S, const TriRec& tr, float bu, float bv, uint32_t& seed)
+// Opacity of a non-opaque candidate at barycentrics (bu,bv): baseColorFactor.a x texture alpha, thresholded
+// for ALPHA_MASK (reference: shaders/traceray_rq.glsl:32-94).
+PT_DEV float hit_opacity(const DeviceScene& S, const TriRec& tr, float bu, float bv)
 {
   const InstanceRec&          I   = S.instances[__float_as_uint(tr.e1n.w)];
   const pt_GltfShadeMaterial& mat = S.materials[I.materialIndex < 0 ? 0 : I.materialIndex];
@@ -155,7 +156,14 @@ PT_DEV bool alpha_test(const DeviceScene& S, const TriRec& tr, float bu, float b
     f2           tuv = f2{((uv.x * m[0] + uv.y * m[1]) + 1.0f * m[2]) + 1.0f * m[3], ((uv.x * m[4] + uv.y * m[5]) + 1.0f * m[6]) + 1.0f * m[7]};
     a *= sample_rgba8(S, mat.pbrBaseColorTexture, tuv).w;
   }
-  float opacity = (mat.alphaMode == PT_ALPHA_MASK) ? (a > mat.alphaCutoff ? 1.0f : 0.0f) : a;
+  return (mat.alphaMode == PT_ALPHA_MASK) ? (a > mat.alphaCutoff ? 1.0f : 0.0f) : a;
+}
+
+// Stochastic alpha (any-hit): returns true when the candidate is kept.  Draws exactly one random number
+// (reference: shaders/traceray_rq.glsl:96-101).
+PT_DEV bool alpha_test(const DeviceScene& S, const TriRec& tr, float bu, float bv, uint32_t& seed)
+{
+  float opacity = hit_opacity(S, tr, bu, bv);
   return !(rng_next(seed) > opacity);
 }
 

@@ -7,23 +7,47 @@
 //    result is bit-identical for any builder;
 //  * back faces are culled unless the instance is double sided; facing is an object-space property,
 //    so a mirrored instance flips the sign test (TRI_FLIP);
-//  * opaque instances commit directly; non-opaque ones go through the stochastic alpha test.
+//  * opaque instances commit directly; non-opaque ones go through the stochastic alpha test, one RNG
+//    draw per candidate in key order (T5 closest, T6 shadow).
+//
+// Stochastic alpha without re-traversal.  Processing candidates strictly in key order would cost one
+// full traversal per rejected candidate (a ray through foliage meets dozens of transparent texels).
+// The same result is obtained with at most two traversals:
+//   pass A (TM_CLOSEST / TM_SHADOW) finds the nearest CERTAIN hit -- opaque, or opacity >= 1 (the draw
+//          r < 1 can never exceed it) -- evaluating the opacity of non-opaque candidates on the fly;
+//   pass B (TM_COUNT) only counts the zero-opacity candidates in front of it.  Each of them consumes one
+//          draw and is rejected unless that draw is exactly 0.0 (probability 2^-23).
+// The caller advances the RNG by the count; if a draw is 0.0, or a candidate with fractional opacity
+// (ALPHA_BLEND) lies in front of the certain hit, it falls back to the exact key-ordered loop
+// (TM_RAW_*).  All three routes produce identical hits and identical RNG states.
 //
 // Per-lane traversal stack: the first STACK_LDS entries live in LDS laid out [level][lane] (one bank
 // per lane, conflict free: 64 lanes x 4 B = one 256-byte bank row per level), deeper entries spill to
 // a small private array.  LBVH depth is unbounded in theory; overflow beyond STACK_LDS+STACK_SPILL is
-// counted in Counters::stackOverflow and asserted zero by the tests.
+// counted in Counters::stackOverflow and reported as an error by pt_get_stats.
 #pragma once
-#include "pt_device.h"
+#include "pt_surface.h"
 
 #define TRACE_BLOCK 64
 #define STACK_LDS 32
 #define STACK_SPILL 32
 
+enum TraceMode {
+  TM_RAW_ALL = 0,        // exact: smallest key > (tPrev,wPrev), every triangle is a candidate, no opacity evaluation
+  TM_RAW_NONOPAQUE = 1,  // exact: same, non-opaque triangles only
+  TM_CLOSEST = 2,        // pass A of ClosestHit: nearest certain hit, flags for uncertain candidates in front of it
+  TM_SHADOW = 3,         // pass A of AnyHit: any opaque hit ends the ray; else nearest certain non-opaque hit + flags
+  TM_COUNT = 4           // pass B: number of zero-opacity candidates with key < (tmax, wLimit)
+};
+#define TF_SAW_ZERO 1u  // a candidate with opacity <= 0 was seen in front of the (then) best hit
+#define TF_SAW_FRAC 2u  // a candidate with 0 < opacity < 1 was seen in front of the (then) best hit
+
 struct RayHit {
   float    t, u, v;
-  uint32_t slot;  // TriRec slot (leaf order); BVH_NONE: nothing
-  uint32_t w;     // world triangle index | flags << 29
+  uint32_t slot;   // TriRec slot (leaf order); BVH_NONE: nothing
+  uint32_t w;      // world triangle index | flags << 29
+  uint32_t flags;  // TF_*
+  uint32_t count;  // TM_COUNT result
 };
 
 PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta < tb || (ta == tb && wa < wb); }
@@ -55,22 +79,24 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
   return true;
 }
 
-// MODE 0: all triangles, closest key.  MODE 1: non-opaque only, closest key.
-// MODE 2: shadow -- returns immediately with `opaqueHit` when any opaque triangle is inside (0,tmax);
-//         meanwhile tracks the closest non-opaque candidate (so the first alpha test needs no second pass).
+// tPrev/wPrev: exclusive lower key (TM_RAW_*); wLimit: with tmax the exclusive upper key (TM_COUNT).
+// `opaqueHit` is only meaningful for TM_SHADOW.
 template <int MODE>
-PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, uint32_t wPrev, uint32_t* ldsStack, RayHit& best, bool& opaqueHit,
+PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, uint32_t wPrev, uint32_t wLimit, uint32_t* ldsStack, RayHit& best, bool& opaqueHit,
                      Counters* counters)
 {
-  best.slot = BVH_NONE;
-  best.t    = tmax;
-  best.w    = 0xffffffffu;
-  opaqueHit = false;
+  best.slot  = BVH_NONE;
+  best.t     = tmax;
+  best.w     = 0xffffffffu;
+  best.flags = 0;
+  best.count = 0;
+  opaqueHit  = false;
   if(S.numTris == 0)
     return;
 
   const f3 idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-#define PT_TLIMIT (MODE == 2 ? tmax : best.t)  // shadow rays must still see opaque triangles behind the best alpha candidate
+  // TM_SHADOW must keep looking for opaque triangles behind the best alpha candidate; TM_COUNT has a fixed range
+#define PT_TLIMIT ((MODE == TM_SHADOW || MODE == TM_COUNT) ? tmax : best.t)
   uint32_t spill[STACK_SPILL];
   int      sp  = 0;
   uint32_t cur = 0;  // root (inner node 0; a one-triangle scene has a single node with one leaf child)
@@ -114,7 +140,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
         else if(sp < STACK_LDS + STACK_SPILL)
           spill[sp++ - STACK_LDS] = farC;
         else
-          atomicAdd(&counters->stackOverflow, 1u);  // far child dropped (flagged; tests assert this stays 0)
+          atomicAdd(&counters->stackOverflow, 1u);  // far child dropped (flagged; pt_get_stats reports it)
         cur = nearC;
         continue;
       }
@@ -130,33 +156,62 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       const TriRec   tr    = S.tris[slot];
       const uint32_t wbits = __float_as_uint(tr.p0w.w);
       const uint32_t flags = wbits >> 29;
-      bool           skip  = false;
-      if(MODE == 1 && (flags & TRI_OPAQUE))
-        skip = true;
+      const bool     opq   = (flags & TRI_OPAQUE) != 0;
+      const bool     skip  = (MODE == TM_RAW_NONOPAQUE || MODE == TM_COUNT) && opq;
       if(!skip)
       {
 #ifdef PT_STATS
         ++nTris;
 #endif
         float t, u, v;
-        if(tri_test(tr, flags, o, d, t, u, v) && t < tmax)
+        // (TM_COUNT's upper key (tmax, wLimit) includes candidates that tie with the hit in t)
+        if(tri_test(tr, flags, o, d, t, u, v) && (MODE == TM_COUNT ? t <= tmax : t < tmax))
         {
           const uint32_t w = wbits & TRI_INDEX_MASK;
-          if(MODE == 2 && (flags & TRI_OPAQUE))
+          if(MODE == TM_RAW_ALL || MODE == TM_RAW_NONOPAQUE)
           {
-            if(t > 0.0f)
+            if(key_less(tPrev, wPrev, t, w) && (best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK)))
             {
-              opaqueHit = true;
-              break;
+              best.t = t; best.u = u; best.v = v; best.slot = slot; best.w = wbits;
             }
           }
-          else if(key_less(tPrev, wPrev, t, w) && (best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK)))
+          else if(MODE == TM_COUNT)
           {
-            best.t    = t;
-            best.u    = u;
-            best.v    = v;
-            best.slot = slot;
-            best.w    = wbits;
+            if(t > 0.0f && key_less(t, w, tmax, wLimit))
+            {
+              const float op = hit_opacity(S, tr, u, v);
+              if(op <= 0.0f)
+                best.count++;
+              else if(op < 1.0f)
+                best.flags |= TF_SAW_FRAC;
+              // (op >= 1 cannot occur in front of the nearest certain hit)
+            }
+          }
+          else  // TM_CLOSEST / TM_SHADOW
+          {
+            if(MODE == TM_SHADOW && opq)
+            {
+              if(t > 0.0f)
+              {
+                opaqueHit = true;
+                break;
+              }
+            }
+            else if(t > 0.0f && (best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK)))
+            {
+              bool certain = opq;
+              if(!opq)
+              {
+                const float op = hit_opacity(S, tr, u, v);
+                certain        = op >= 1.0f;
+                if(!certain)
+                  best.flags |= (op <= 0.0f) ? TF_SAW_ZERO : TF_SAW_FRAC;
+              }
+              if(certain)
+              {
+                best.t = t; best.u = u; best.v = v; best.slot = slot; best.w = wbits;
+              }
+            }
           }
         }
       }
@@ -172,4 +227,14 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   atomicAdd(&counters->nodesVisited, (unsigned long long)nNodes);
   atomicAdd(&counters->trisTested, (unsigned long long)nTris);
 #endif
+}
+
+// Advances `seed` by the `n` draws the rejected zero-opacity candidates consume.  Returns false if one of
+// the draws is exactly 0.0 (that candidate would have passed rand > 0): the caller must take the exact path.
+PT_DEV bool consume_rejected_draws(uint32_t& seed, uint32_t n)
+{
+  for(uint32_t i = 0; i < n; ++i)
+    if(rng_next(seed) == 0.0f)
+      return false;
+  return true;
 }

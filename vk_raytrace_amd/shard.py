@@ -1,0 +1,76 @@
+"""Image-tile sharding across the GPUs of one node (no reference counterpart).
+
+One process per GPU.  The scene, BVH, textures and environment are replicated; the image is cut into
+PT_TILE x PT_TILE tiles and rank r renders the tiles with (tx + ty) % nranks == r (diagonal
+interleave: sky and interior tiles are spread evenly).  Seeds depend on the global pixel index only
+(shaders/pathtrace.comp:97), so every pixel is bit-identical to a single-GPU render.  Nothing is
+exchanged while rendering; at the end ONE gather of the accumulated framebuffer shards goes to rank 0
+(RCCL over xGMI when the backend is "nccl"; each peer's shard travels on its own point-to-point link).
+"""
+import numpy as np
+
+from . import host_device as hd
+
+TILE = hd.TILE
+
+
+def tiles_of_rank(width, height, rank, nranks):
+    """Global tile ids owned by `rank`, in increasing order (the layout of pt_local_shard)."""
+    tx_n = (width + TILE - 1) // TILE
+    ty_n = (height + TILE - 1) // TILE
+    return [ty * tx_n + tx for ty in range(ty_n) for tx in range(tx_n) if (tx + ty) % nranks == rank]
+
+
+def max_tiles_per_rank(width, height, nranks):
+    return max(len(tiles_of_rank(width, height, r, nranks)) for r in range(nranks))
+
+
+def local_pixel_ids(width, height, rank, nranks):
+    """Row-major pixel ids (y*width + x) of the pixels `rank` owns."""
+    tx_n = (width + TILE - 1) // TILE
+    ids = []
+    for t in tiles_of_rank(width, height, rank, nranks):
+        tx, ty = t % tx_n, t // tx_n
+        xs = np.arange(tx * TILE, min((tx + 1) * TILE, width))
+        ys = np.arange(ty * TILE, min((ty + 1) * TILE, height))
+        ids.append((ys[:, None] * width + xs[None, :]).reshape(-1))
+    return np.concatenate(ids).astype(np.uint32) if ids else np.zeros(0, np.uint32)
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def gather_framebuffer(renderer, rank, nranks, device):
+    """The single collective of the path: gathers every rank's shard on rank 0 and lets libptmi place
+    the tiles (pt_scatter_shards).  Returns the full RGBA32F image on rank 0, None elsewhere."""
+    renderer.synchronize()
+    if nranks == 1:
+        return renderer.read_accum()
+    import torch
+    import torch.distributed as dist
+
+    ptr, nbytes, _, _ = renderer.local_shard()
+    local = torch.as_tensor(_DevArray(ptr, nbytes // 4), device=device)
+    gathered = torch.empty((nranks, nbytes // 4), dtype=torch.float32, device=device) if rank == 0 else None
+    dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    torch.cuda.synchronize(device)
+    renderer.scatter_shards(gathered.data_ptr(), nranks)
+    return renderer.read_accum()
+
+
+def assemble_rowmajor(shards, width, height):
+    """Host-side assembly used on the CPU (gloo) path: shards[r] is rank r's row-major image in which
+    only its own pixels are valid."""
+    out = np.zeros((height, width, 4), np.float32)
+    flat = out.reshape(-1, 4)
+    n = len(shards)
+    for r, s in enumerate(shards):
+        ids = local_pixel_ids(width, height, r, n)
+        flat[ids] = np.asarray(s, np.float32).reshape(-1, 4)[ids]
+    return out

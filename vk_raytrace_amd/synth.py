@@ -485,7 +485,6 @@ def sponza_like(target_tris=262_267, tex_size=1024, seed=SEED_BASE + 3, foliage_
                 xm = 0.5 * (xs[ci] + xs[ci + 1])
                 rad = 0.5 * (xs[ci + 1] - xs[ci]) - 0.35
                 a = np.linspace(0, np.pi, 25)
-                ring_r = np.concatenate([[0.12] * 1])
                 # sweep a small square cross-section along the half circle
                 prof = np.array([[-0.15, -0.3], [0.15, -0.3], [0.15, 0.3], [-0.15, 0.3], [-0.15, -0.3]])
                 pos = []
@@ -548,7 +547,6 @@ def sponza_like(target_tris=262_267, tex_size=1024, seed=SEED_BASE + 3, foliage_
     if remaining > 200:
         n = int(np.sqrt(remaining / 2.0 / 2.0))
         bump = lambda s, t: 0.06 * np.sin(s * 40) * np.sin(t * 12)
-        add(grid(2 * n, n, (-L / 2, Hh - 0.02, -Wd * 0.2), (L, 0, 0), (0, 0, 0.0001 + Wd * 0.0)), m_roof) if False else None
         add(grid(2 * n, n, (-L / 2 + 0.5, 0.02, 1.0), (L - 1.0, 0, 0), (0, 0, -2.0), uv_scale=(10, 1), height=bump), m_cloth[0])  # nave carpet
 
     sc.camera = Camera(eye=(-L / 2 + 1.6, 2.2, 0.6), center=(L / 2, 3.2, -0.4), up=(0, 1, 0), fov=60.0)
