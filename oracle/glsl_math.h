@@ -19,6 +19,50 @@
 
 namespace orc {
 
+// Transcendental functions go through these wrappers.  Mode 0 (default): the fp32 libm functions.  Mode 1:
+// the double-precision function rounded to fp32 (correctly rounded).  Rendering the same input in two modes
+// measures how sensitive an image is to ~1-ulp differences in sin/cos/pow/..., which is exactly what separates
+// the CPU's libm from the GPU's ocml; tests use it as the noise floor.
+extern int g_math_mode;
+// Mode 2: the correctly rounded result moved by one ulp in ~30 % of the calls (deterministic hash of the
+// argument).  This models a libm that is accurate to ~1.5 ulp but correctly rounded only 60-90 % of the time,
+// which is what tools/math_ulps.hip measures for the GPU's ocml (profiles/r01_ocml_ulps.txt).
+inline float perturb_ulp(float r, float x)
+{
+  uint32_t h;
+  std::memcpy(&h, &x, 4);
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  if((h % 10u) < 3u && std::isfinite(r) && r != 0.0f)
+    r = std::nextafter(r, (h & 0x80000u) ? INFINITY : -INFINITY);
+  return r;
+}
+#define ORC_MATH1(name, fn)                                                                                         \
+  inline float name(float x)                                                                                        \
+  {                                                                                                                 \
+    if(g_math_mode == 0) return ::fn##f(x);                                                                         \
+    float r = (float)::fn((double)x);                                                                               \
+    return g_math_mode == 2 ? perturb_ulp(r, x) : r;                                                                \
+  }
+ORC_MATH1(msin, sin)
+ORC_MATH1(mcos, cos)
+ORC_MATH1(mtan, tan)
+ORC_MATH1(macos, acos)
+ORC_MATH1(masin, asin)
+ORC_MATH1(mexp, exp)
+ORC_MATH1(mlog, log)
+inline float mpow(float x, float y)
+{
+  if(g_math_mode == 0) return ::powf(x, y);
+  float r = (float)::pow((double)x, (double)y);
+  return g_math_mode == 2 ? perturb_ulp(r, x + y) : r;
+}
+inline float matan2(float y, float x)
+{
+  if(g_math_mode == 0) return ::atan2f(y, x);
+  float r = (float)::atan2((double)y, (double)x);
+  return g_math_mode == 2 ? perturb_ulp(r, x - y) : r;
+}
+
 struct vec2 {
   float x, y;
   vec2() : x(0), y(0) {}
@@ -92,10 +136,10 @@ inline vec3 gmix(vec3 a, vec3 b, float t) { return a * (1.0f - t) + b * t; }
 inline vec3 gmix(vec3 a, vec3 b, vec3 t) { return vec3(gmix(a.x, b.x, t.x), gmix(a.y, b.y, t.y), gmix(a.z, b.z, t.z)); }
 inline vec3 gmax(vec3 a, vec3 b) { return vec3(gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)); }
 inline vec3 gclamp(vec3 a, float lo, float hi) { return vec3(gclamp(a.x, lo, hi), gclamp(a.y, lo, hi), gclamp(a.z, lo, hi)); }
-inline vec3 gpow(vec3 a, float e) { return vec3(std::pow(a.x, e), std::pow(a.y, e), std::pow(a.z, e)); }
-inline vec3 gpow(vec3 a, vec3 e) { return vec3(std::pow(a.x, e.x), std::pow(a.y, e.y), std::pow(a.z, e.z)); }
-inline vec3 gexp(vec3 a) { return vec3(std::exp(a.x), std::exp(a.y), std::exp(a.z)); }
-inline vec3 glog(vec3 a) { return vec3(std::log(a.x), std::log(a.y), std::log(a.z)); }
+inline vec3 gpow(vec3 a, float e) { return vec3(mpow(a.x, e), mpow(a.y, e), mpow(a.z, e)); }
+inline vec3 gpow(vec3 a, vec3 e) { return vec3(mpow(a.x, e.x), mpow(a.y, e.y), mpow(a.z, e.z)); }
+inline vec3 gexp(vec3 a) { return vec3(mexp(a.x), mexp(a.y), mexp(a.z)); }
+inline vec3 glog(vec3 a) { return vec3(mlog(a.x), mlog(a.y), mlog(a.z)); }
 inline vec3 gsqrt(vec3 a) { return vec3(std::sqrt(a.x), std::sqrt(a.y), std::sqrt(a.z)); }
 inline vec3 gfloor(vec3 a) { return vec3(std::floor(a.x), std::floor(a.y), std::floor(a.z)); }
 // GLSL reflect / refract (spec formulas)

@@ -92,18 +92,18 @@ inline vec3 ImportanceSampleGTR1(float rgh, float r1, float /*r2*/)
   float a        = gmax(0.001f, rgh);
   float a2       = a * a;
   float phi      = r1 * TWO_PI;
-  float cosTheta = std::sqrt((1.0f - std::pow(a2, 1.0f - r1)) / (1.0f - a2));
+  float cosTheta = std::sqrt((1.0f - mpow(a2, 1.0f - r1)) / (1.0f - a2));
   float sinTheta = gclamp(std::sqrt(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  float sinPhi   = std::sin(phi);
-  float cosPhi   = std::cos(phi);
+  float sinPhi   = msin(phi);
+  float cosPhi   = mcos(phi);
   return vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 // :85-94
 inline vec3 ImportanceSampleGTR2_aniso(float ax, float ay, float r1, float r2)
 {
   float phi      = r1 * TWO_PI;
-  float sinPhi   = ay * std::sin(phi);
-  float cosPhi   = ax * std::cos(phi);
+  float sinPhi   = ay * msin(phi);
+  float cosPhi   = ax * mcos(phi);
   float tanTheta = std::sqrt(r2 / (1 - r2));
   return vec3(tanTheta * cosPhi, tanTheta * sinPhi, 1.0f);
 }
@@ -114,8 +114,8 @@ inline vec3 ImportanceSampleGTR2(float rgh, float r1, float r2)
   float phi      = r1 * TWO_PI;
   float cosTheta = std::sqrt((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
   float sinTheta = gclamp(std::sqrt(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  float sinPhi   = std::sin(phi);
-  float cosPhi   = std::cos(phi);
+  float sinPhi   = msin(phi);
+  float cosPhi   = mcos(phi);
   return vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 // :114-119
@@ -143,7 +143,7 @@ inline float GTR1(float NdotH, float a)
     return M_1_OVER_PI;
   float a2 = a * a;
   float t  = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
-  return (a2 - 1.0f) / (PI * std::log(a2) * t);
+  return (a2 - 1.0f) / (PI * mlog(a2) * t);
 }
 // :152-157
 inline float GTR2(float NdotH, float a)
@@ -181,8 +181,8 @@ inline vec3 CosineSampleHemisphere(float r1, float r2)
   vec3  dir;
   float r   = std::sqrt(r1);
   float phi = TWO_PI * r2;
-  dir.x     = r * std::cos(phi);
-  dir.y     = r * std::sin(phi);
+  dir.x     = r * mcos(phi);
+  dir.y     = r * msin(phi);
   dir.z     = std::sqrt(gmax(0.0f, 1.0f - dir.x * dir.x - dir.y * dir.y));
   return dir;
 }
@@ -191,7 +191,7 @@ inline vec3 UniformSampleHemisphere(float r1, float r2)
 {
   float r   = std::sqrt(gmax(0.0f, 1.0f - r1 * r1));
   float phi = TWO_PI * r2;
-  return vec3(r * std::cos(phi), r * std::sin(phi), r1);
+  return vec3(r * mcos(phi), r * msin(phi), r1);
 }
 // :225-230
 inline float powerHeuristic(float a, float b)
@@ -425,9 +425,9 @@ inline vec3 DisneyEval(const State& state, vec3 V, vec3 N, vec3 L, float& pdf)
 
 // ================================= shaders/pbr_gltf.glsl ====================================
 // :38-41
-inline vec3 F_Schlick(vec3 f0, vec3 f90, float VdotH) { return f0 + (f90 - f0) * std::pow(gclamp(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
+inline vec3 F_Schlick(vec3 f0, vec3 f90, float VdotH) { return f0 + (f90 - f0) * mpow(gclamp(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
 // :43-46
-inline float F_Schlick(float f0, float f90, float VdotH) { return f0 + (f90 - f0) * std::pow(gclamp(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
+inline float F_Schlick(float f0, float f90, float VdotH) { return f0 + (f90 - f0) * mpow(gclamp(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
 // :54-67
 inline float V_GGX(float NdotL, float NdotV, float alphaRoughness)
 {
@@ -492,8 +492,8 @@ inline vec3 GgxSampling(float specularAlpha, float r1, float r2)
   float phi      = r1 * 2.0f * M_PI_F;
   float cosTheta = std::sqrt((1.0f - r2) / (1.0f + (specularAlpha * specularAlpha - 1.0f) * r2));
   float sinTheta = gclamp(std::sqrt(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  float sinPhi   = std::sin(phi);
-  float cosPhi   = std::cos(phi);
+  float sinPhi   = msin(phi);
+  float cosPhi   = mcos(phi);
   return vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 // :207-224

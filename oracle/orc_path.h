@@ -34,8 +34,8 @@ struct PtPayload {
 // :67-74
 inline vec2 GetSphericalUv(vec3 v)
 {
-  float gamma = std::asin(-v.y);
-  float theta = std::atan2(v.z, v.x);
+  float gamma = masin(-v.y);
+  float theta = matan2(v.z, v.x);
   return vec2(theta * M_1_OVER_PI * 0.5f + 0.5f, gamma * M_1_OVER_PI + 0.5f);
 }
 // :80-92 (identical body: shade_state.glsl:34-39 CreateTangent)
@@ -378,7 +378,7 @@ struct Tracer {
   {
     if(range <= 0.0f)
       return 1.0f;
-    return gmax(gmin(1.0f - std::pow(distance / range, 4.0f), 1.0f), 0.0f) / std::pow(distance, 2.0f);
+    return gmax(gmin(1.0f - mpow(distance / range, 4.0f), 1.0f), 0.0f) / mpow(distance, 2.0f);
   }
   static float getSpotAttenuation(vec3 pointToLight, vec3 spotDirection, float outerConeCos, float innerConeCos)
   {
@@ -421,14 +421,14 @@ struct Tracer {
 
     const float u       = (float(px) + xi.y) / float(width);  // float(px + xi.y): uint + float promotes to float
     const float phi     = u * (2.0f * M_PI_F) - M_PI_F;
-    float       sin_phi = std::sin(phi);
-    float       cos_phi = std::cos(phi);
+    float       sin_phi = msin(phi);
+    float       cos_phi = mcos(phi);
 
     const float step_theta = M_PI_F / float(height);
     const float theta0     = float(py) * step_theta;
-    const float cos_theta  = std::cos(theta0) * (1.0f - xi.z) + std::cos(theta0 + step_theta) * xi.z;
-    const float theta      = std::acos(cos_theta);
-    const float sin_theta  = std::sin(theta);
+    const float cos_theta  = mcos(theta0) * (1.0f - xi.z) + mcos(theta0 + step_theta) * xi.z;
+    const float theta      = macos(cos_theta);
+    const float sin_theta  = msin(theta);
     const float v          = theta * M_1_OVER_PI;
 
     to_light = vec3(cos_phi * sin_theta, cos_theta, sin_phi * sin_theta);
@@ -689,7 +689,7 @@ struct Tracer {
     float cam_r2            = rnd(prd.seed) * sc.camera.aperture;
     vec4  cam_right         = viewInverse * vec4(1, 0, 0, 0);
     vec4  cam_up            = viewInverse * vec4(0, 1, 0, 0);
-    vec3  randomAperturePos = (cam_right.xyz() * std::cos(cam_r1) + cam_up.xyz() * std::sin(cam_r1)) * std::sqrt(cam_r2);
+    vec3  randomAperturePos = (cam_right.xyz() * mcos(cam_r1) + cam_up.xyz() * msin(cam_r1)) * std::sqrt(cam_r2);
     vec3  finalRayDir       = normalize(focalPoint - randomAperturePos);
 
     Ray ray{origin.xyz() + randomAperturePos, finalRayDir};

@@ -82,8 +82,8 @@ inline vec2 mi_lib_square_to_disk(float inout_r, float inout_phi, float in_x, fl
 inline vec3 mi_reflection_dir_diffuse_x(vec3 in_normal, vec2 in_sample)
 {
   vec2  r_phi = mi_lib_square_to_disk(0, 0, in_sample.x, in_sample.y);
-  float x     = r_phi.x * std::cos(r_phi.y);
-  float y     = r_phi.x * std::sin(r_phi.y);
+  float x     = r_phi.x * mcos(r_phi.y);
+  float y     = r_phi.x * msin(r_phi.y);
   float z2    = 1.0f - x * x - y * y;
   float z     = z2 > 0.0f ? std::sqrt(z2) : 0.0f;
   return xyz2dir(in_normal, x, y, z);
@@ -98,7 +98,7 @@ inline vec3 calc_sun_color(vec3 sun_dir, float turbidity)
   vec3 solRad(1.0f * 127500 / 0.9878f, 0.992f * 127500 / 0.9878f, 0.911f * 127500 / 0.9878f);
   if(sun_dir.z > 0.0f)
   {
-    float m     = (1.0f / (sun_dir.z + 0.15f * std::pow(93.885f - std::acos(sun_dir.z) * 180 / SKY_PI, -1.253f)));
+    float m     = (1.0f / (sun_dir.z + 0.15f * mpow(93.885f - macos(sun_dir.z) * 180 / SKY_PI, -1.253f)));
     float beta  = 0.04608f * turbidity - 0.04586f;
     float alpha = 1.3f;
     vec3  ta    = gexp(gpow(wavelength, vec3(-alpha)) * (-m * beta));
@@ -118,10 +118,10 @@ inline vec3 sky_color_xyz(vec3 in_dir, vec3 in_sun_pos, float in_turbidity, floa
   float cos_gamma = dot(in_sun_pos, in_dir);
   if(cos_gamma > 1.0f)
     cos_gamma = 2.0f - cos_gamma;
-  float gamma         = std::acos(cos_gamma);
+  float gamma         = macos(cos_gamma);
   float cos_theta     = in_dir.z;
   float cos_theta_sun = in_sun_pos.z;
-  float theta_sun     = std::acos(cos_theta_sun);
+  float theta_sun     = macos(cos_theta_sun);
   float t2            = in_turbidity * in_turbidity;
   float ts2           = theta_sun * theta_sun;
   float ts3           = ts2 * theta_sun;
@@ -133,14 +133,14 @@ inline vec3 sky_color_xyz(vec3 in_dir, vec3 in_sun_pos, float in_turbidity, floa
                     + (+0.153467f * ts3 - 0.267568f * ts2 + 0.066698f * theta_sun + 0.266881f));
   xyz.y = in_luminance;
 
-  A = -0.019257f * in_turbidity - (0.29f - std::pow(cos_theta_sun, 0.5f) * 0.09f);
+  A = -0.019257f * in_turbidity - (0.29f - mpow(cos_theta_sun, 0.5f) * 0.09f);
   B = -0.066513f * in_turbidity + 0.000818f;
   C = -0.000417f * in_turbidity + 0.212479f;
   D = -0.064097f * in_turbidity - 0.898875f;
   E = -0.003251f * in_turbidity + 0.045178f;
 
-  float x = (((1.f + A * std::exp(B / cos_theta)) * (1.f + C * std::exp(D * gamma) + E * cos_gamma * cos_gamma))
-             / ((1 + A * std::exp(B / 1.0f)) * (1 + C * std::exp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
+  float x = (((1.f + A * mexp(B / cos_theta)) * (1.f + C * mexp(D * gamma) + E * cos_gamma * cos_gamma))
+             / ((1 + A * mexp(B / 1.0f)) * (1 + C * mexp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
 
   A = -0.016698f * in_turbidity - 0.260787f;
   B = -0.094958f * in_turbidity + 0.009213f;
@@ -148,8 +148,8 @@ inline vec3 sky_color_xyz(vec3 in_dir, vec3 in_sun_pos, float in_turbidity, floa
   D = -0.044050f * in_turbidity - 1.653694f;
   E = -0.010922f * in_turbidity + 0.052919f;
 
-  float y = (((1 + A * std::exp(B / cos_theta)) * (1 + C * std::exp(D * gamma) + E * cos_gamma * cos_gamma))
-             / ((1 + A * std::exp(B / 1.0f)) * (1 + C * std::exp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
+  float y = (((1 + A * mexp(B / cos_theta)) * (1 + C * mexp(D * gamma) + E * cos_gamma * cos_gamma))
+             / ((1 + A * mexp(B / 1.0f)) * (1 + C * mexp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
 
   float local_saturation = 1.0f;
   x = zenith_x * ((x * local_saturation) + (1.0f - local_saturation));
@@ -168,10 +168,10 @@ inline float sky_luminance(vec3 in_dir, vec3 in_sun_pos, float in_turbidity)
     cos_gamma = 0.0f;
   if(cos_gamma > 1.0f)
     cos_gamma = 2.0f - cos_gamma;
-  float gamma         = std::acos(cos_gamma);
+  float gamma         = macos(cos_gamma);
   float cos_theta     = in_dir.z;
   float cos_theta_sun = in_sun_pos.z;
-  float theta_sun     = std::acos(cos_theta_sun);
+  float theta_sun     = macos(cos_theta_sun);
 
   float A = 0.178721f * in_turbidity - 1.463037f;
   float B = -0.355402f * in_turbidity + 0.427494f;
@@ -179,16 +179,16 @@ inline float sky_luminance(vec3 in_dir, vec3 in_sun_pos, float in_turbidity)
   float D = 0.120647f * in_turbidity - 2.577052f;
   float E = -0.066967f * in_turbidity + 0.370275f;
 
-  return (((1 + A * std::exp(B / cos_theta)) * (1 + C * std::exp(D * gamma) + E * cos_gamma * cos_gamma))
-          / ((1 + A * std::exp(B / 1.0f)) * (1 + C * std::exp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
+  return (((1 + A * mexp(B / cos_theta)) * (1 + C * mexp(D * gamma) + E * cos_gamma * cos_gamma))
+          / ((1 + A * mexp(B / 1.0f)) * (1 + C * mexp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
 }
 
 // :253-267
 inline vec3 calc_env_color(vec3 in_sun_dir, vec3 in_dir, float in_turbidity)
 {
-  float theta_sun = std::acos(in_sun_dir.z);
+  float theta_sun = macos(in_sun_dir.z);
   float chi       = (4.0f / 9.0f - in_turbidity / 120.0f) * (SKY_PI - 2 * theta_sun);
-  float lum       = 1000.0f * ((4.0453f * in_turbidity - 4.9710f) * std::tan(chi) - 0.2155f * in_turbidity + 2.4192f);
+  float lum       = 1000.0f * ((4.0453f * in_turbidity - 4.9710f) * mtan(chi) - 0.2155f * in_turbidity + 2.4192f);
   lum *= sky_luminance(in_dir, in_sun_dir, in_turbidity);
   vec3 XYZ = sky_color_xyz(in_dir, in_sun_dir, in_turbidity, lum);
   vec3 env_color(3.241f * XYZ.x - 1.537f * XYZ.y - 0.499f * XYZ.z, -0.969f * XYZ.x + 1.876f * XYZ.y + 0.042f * XYZ.z,
@@ -217,7 +217,7 @@ inline vec3 calc_irrad(vec3 in_data_sun_dir, float in_data_sun_dir_haze)
 // :292-309
 inline float tweak_saturation(float inout_saturation, float in_haze)
 {
-  float lowsat = std::pow(inout_saturation, 3.0f);
+  float lowsat = mpow(inout_saturation, 3.0f);
   if(inout_saturation <= 1.0f)
   {
     float local_haze = in_haze;
@@ -227,7 +227,7 @@ inline float tweak_saturation(float inout_saturation, float in_haze)
       local_haze = 0.0f;
     if(local_haze > 1.0f)
       local_haze = 1.0f;
-    local_haze = std::pow(local_haze, 3.0f);
+    local_haze = mpow(local_haze, 3.0f);
     return ((inout_saturation * (1.0f - local_haze)) + lowsat * local_haze);
   }
   return 1.f;
@@ -268,7 +268,7 @@ inline vec2 calc_physical_scale(float sun_disk_scale, float sun_glow_intensity, 
   float sun_glow_radius    = sun_disk_radius * 10.0f;
   float glow_func_integral = sun_glow_intensity
                              * ((4.f * SKY_PI) - (24.f * SKY_PI) / (sun_glow_radius * sun_glow_radius)
-                                + (24.f * SKY_PI) * std::sin(sun_glow_radius) / (sun_glow_radius * sun_glow_radius * sun_glow_radius));
+                                + (24.f * SKY_PI) * msin(sun_glow_radius) / (sun_glow_radius * sun_glow_radius * sun_glow_radius));
   float target_sundisk_integral = sun_disk_intensity * SKY_PI;
   float sky_sunglow_scale       = 1.0f;
   float max_glow_integral       = 0.5f * target_sundisk_integral;
@@ -281,7 +281,7 @@ inline vec2 calc_physical_scale(float sun_disk_scale, float sun_glow_intensity, 
   {
     target_sundisk_integral -= glow_func_integral;
   }
-  float sundisk_area             = 2 * SKY_PI * (1 - std::cos(sun_disk_radius));
+  float sundisk_area             = 2 * SKY_PI * (1 - mcos(sun_disk_radius));
   float target_sundisk_intensity = target_sundisk_integral / sundisk_area;
   float actual_sundisk_integral  = 1.0f * sundisk_area;
   float actual_sundisk_intensity = sun_disk_intensity * 100.0f * actual_sundisk_integral / sundisk_area;
@@ -354,7 +354,7 @@ inline vec3 sun_and_sky(const pt_SunAndSky& ss, vec3 in_direction)
   vec3 data_sun_color = calc_sun_color(sun_dir, downness > 0 ? local_haze : 2.0f);
   if(ss.sun_disk_intensity > 0.0f && ss.sun_disk_scale > 0.0f)
   {
-    float sun_angle  = std::acos(dot(real_dir, real_sun_dir));
+    float sun_angle  = macos(dot(real_dir, real_sun_dir));
     float sun_radius = 0.00465f * ss.sun_disk_scale * 10.0f;
     if(sun_angle < sun_radius)
     {
@@ -367,7 +367,7 @@ inline vec3 sun_and_sky(const pt_SunAndSky& ss, vec3 in_direction)
         sky_sunglow_scale = rv.y;
       }
       float sun_factor = (1.0f - sun_angle / sun_radius) * 10.0f;
-      sun_factor       = (std::pow(sun_factor / 10.0f, 3.0f) * 2.0f * ss.sun_glow_intensity * sky_sunglow_scale
+      sun_factor       = (mpow(sun_factor / 10.0f, 3.0f) * 2.0f * ss.sun_glow_intensity * sky_sunglow_scale
                     + gsmoothstep(8.5f, 9.5f + (local_haze / 50.0f), sun_factor) * 100.0f * ss.sun_disk_intensity * sky_sundisk_scale);
       tint += data_sun_color * sun_factor;
     }

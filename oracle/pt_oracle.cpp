@@ -17,6 +17,8 @@
 
 using namespace orc;
 
+int orc::g_math_mode = 0;
+
 // post.frag + tonemapping.glsl -------------------------------------------------------------------
 namespace {
 
@@ -75,6 +77,12 @@ const char* orc_last_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_threads(orc_ctx* c, int n)
 {
   c->threads = n;
+  return 0;
+}
+// 0: fp32 libm (default), 1: double-precision functions rounded to fp32 (noise-floor calibration)
+int orc_set_math_mode(int mode)
+{
+  g_math_mode = mode;
   return 0;
 }
 int orc_set_use_bvh(orc_ctx* c, int use)

@@ -9,7 +9,7 @@ from vk_raytrace_amd import capi, host_device as hd, synth
 
 
 class Config:
-    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0):
+    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0, firefly=None):
         self.scene = scene
         if scene.vertices is None:
             scene.finalize(capi.pack_vertices)
@@ -18,6 +18,7 @@ class Config:
         self.depth, self.pbr, self.debug, self.max_samples = depth, pbr, debug, max_samples
         self.sunsky = sunsky if sunsky is not None else hd.default_sun_and_sky()
         self.hdr_multiplier = hdr_multiplier
+        self.firefly = firefly
         self.camera = capi.camera_lookat(scene.camera, width / height, nb_lights=len(scene.lights))
 
     def state(self, integral):
@@ -25,11 +26,12 @@ class Config:
         st.size[0], st.size[1] = self.width, self.height
         st.maxDepth, st.pbrMode, st.debugging_mode, st.maxSamples = self.depth, self.pbr, self.debug, self.max_samples
         st.hdrMultiplier = self.hdr_multiplier
-        st.fireflyClampThreshold = 4.0 * integral  # src/sample_example.cpp:110
+        st.fireflyClampThreshold = 4.0 * integral if self.firefly is None else self.firefly  # src/sample_example.cpp:110
         return st
 
 
-def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False):
+def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False, math_mode=0):
+    orc.set_math_mode(math_mode)
     o = orc.Oracle(threads)
     o.set_use_bvh(use_bvh)
     o.set_scene(cfg.scene)
@@ -37,6 +39,7 @@ def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False):
     o.set_camera(cfg.camera)
     o.set_sunsky(cfg.sunsky)
     acc = o.render(cfg.state(integral), frames)
+    orc.set_math_mode(0)
     if return_obj:
         return acc, o
     o.close()
@@ -76,3 +79,13 @@ def mismatch_fraction(a, b, rtol=1e-3, atol=1e-4):
     d = np.abs(a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64))
     bad = d > (atol + rtol * np.abs(b[..., :3]))
     return float(np.mean(np.any(bad, axis=-1)))
+
+
+def noise_floor(cfg, frames):
+    """Mismatch fraction between two renders of the oracle that differ only in how libm rounds its
+    transcendental functions: glibc fp32 (practically always correctly rounded) vs a model of the GPU's ocml
+    (correctly rounded result moved by 1 ulp in ~30 % of the calls, cf. profiles/r01_ocml_ulps.txt).  This is
+    the difference one must expect between the CPU oracle and ANY correct GPU implementation."""
+    a = render_oracle(cfg, frames, math_mode=0)
+    b = render_oracle(cfg, frames, math_mode=2)
+    return mismatch_fraction(b, a), a

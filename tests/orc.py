@@ -38,6 +38,7 @@ def lib():
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_use_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_math_mode.argtypes = [C.c_int]
         L.orc_set_scene.argtypes = [C.c_void_p, C.POINTER(hd.SceneDesc)]
         L.orc_set_env.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_set_camera.argtypes = [C.c_void_p, C.POINTER(hd.SceneCamera)]
@@ -67,6 +68,11 @@ def lib():
 
 
 STAT_NAMES = ["samples", "closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups", "nodesVisited", "trisTested", "texTaps", "nodesShadow", "trisShadow"]
+
+
+def set_math_mode(mode):
+    """0: fp32 libm (default); 1: double-precision functions rounded to fp32 (noise-floor calibration)."""
+    lib().orc_set_math_mode(int(mode))
 
 
 def pack_vertices(pos, nrm, tan, uv, col):

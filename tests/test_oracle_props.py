@@ -1,0 +1,189 @@
+"""Properties that pin the CPU oracle in the absence of reference test vectors (SURVEY.md 8(c) iii):
+brute force == BVH, alias-table identities, energy bounds, host helpers of oracle and product agree."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import orc
+from tests.common import Config, render_oracle, l2
+from vk_raytrace_amd import capi, host_device as hd, synth, shard
+from vk_raytrace_amd.scene import Camera, Scene
+
+
+@pytest.fixture(scope="module")
+def env_small():
+    return synth.procedural_sky(128, 64)
+
+
+def test_bvh_equals_brute_force(env_small):
+    """The trace contract is BVH independent: the oracle's BVH must never change a single bit."""
+    cfg = Config(synth.feature_box(tex_size=32), env_small, 96, 72)
+    a = render_oracle(cfg, 2, use_bvh=True)
+    b = render_oracle(cfg, 2, use_bvh=False)
+    assert np.array_equal(a, b)
+    cfg = Config(synth.feature_box(tex_size=32), env_small, 96, 72, debug=hd.eNormal)
+    assert np.array_equal(render_oracle(cfg, 1, use_bvh=True), render_oracle(cfg, 1, use_bvh=False))
+
+
+def test_trace_closest_known_answers():
+    """Rays against the single quad: hit distance, barycentrics, culling and the (t, index) tie break."""
+    sc = synth.quad_scene()
+    sc.finalize(orc.pack_vertices)
+    o = orc.Oracle()
+    o.set_scene(sc)
+    org = np.array([[0.5, 0.25, 3], [0.5, 0.25, -3], [5, 5, 3], [0.0, 0.0, 3.0], [-0.5, -0.25, 2.0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0, 0, -1], [0, 0, -1], [0, 0, -1]], np.float32)
+    t, node, prim, uv, _ = o.trace_closest(org, d)
+    assert t[0] == 3.0 and node[0] == 0 and prim[0] == 0           # lower-right triangle (0,1,2)
+    assert t[1] == 3.0                                             # double sided: hit from behind too
+    assert node[2] == -1 and t[2] == np.float32(1e32)              # miss keeps INFINITY (globals.glsl:29)
+    # (0,0) lies on the shared diagonal: both triangles give t == 3, the lower world index wins
+    assert t[3] == 3.0 and prim[3] == 0
+    assert prim[4] == 1 or prim[4] == 0
+    # barycentrics reproduce the hit point
+    p = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    tri = [(0, 1, 2), (0, 2, 3)][prim[0]]
+    hit = (1 - uv[0, 0] - uv[0, 1]) * p[tri[0]] + uv[0, 0] * p[tri[1]] + uv[0, 1] * p[tri[2]]
+    assert np.allclose(hit, [0.5, 0.25, 0.0], atol=1e-6)
+
+
+def test_backface_culling_and_mirrored_instance():
+    """Single-sided geometry is invisible from behind; a mirrored instance keeps its object-space facing (E3)."""
+    from vk_raytrace_amd.scene import scale
+    sc = Scene("cull")
+    m = sc.add_material(doubleSided=0)
+    pm = sc.add_prim_mesh([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 0, 1)] * 4, [(0, 0), (1, 0), (1, 1), (0, 1)], [0, 1, 2, 0, 2, 3], m)
+    sc.add_node(pm)                                      # faces +z
+    sc.add_node(pm, np.diag([1, 1, -1, 1]).astype(np.float32) @ np.eye(4, dtype=np.float32) + np.array([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, -5], [0, 0, 0, 0]], np.float32))
+    sc.finalize(orc.pack_vertices)
+    o = orc.Oracle()
+    o.set_scene(sc)
+    org = np.array([[0.2, 0.1, 3], [0.2, 0.1, -8], [0.2, 0.1, -3]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0, 0, -1]], np.float32)
+    t, node, prim, uv, _ = o.trace_closest(org, d)
+    assert node[0] == 0 and t[0] == 3.0                  # front face of instance 0
+    # Instance 1 is mirrored in z and sits at z = -5.  Its world-space winding normal still points to +z, but
+    # facing is an OBJECT-space property: the ray travelling +z has object-space direction -z -> front-facing -> hit
+    # (instance 0 at z = 0 would be next, but it is back-facing for this ray)
+    assert node[1] == 1 and t[1] == 3.0
+    # ... and the ray that looks at it "from the front" in world space is back-facing in object space -> culled
+    assert node[2] == -1
+
+
+def test_alias_table_identities(env_small):
+    acc, integral, average = capi.build_env_accel(env_small)
+    h, w = env_small.shape[:2]
+    assert (acc["q"] >= 0).all() and (acc["alias"] < w * h).all()
+    theta = (np.arange(h + 1) * np.pi / h)
+    area = (np.cos(theta[:-1]) - np.cos(theta[1:]))[:, None] * (2 * np.pi / w) * np.ones((1, w))
+    assert abs(float((acc["pdf"].reshape(h, w).astype(np.float64) * area).sum()) - 1.0) < 1e-3  # sum pdf * solid angle = 1
+    # alias sampling reproduces the pdf: P(texel i) = (q_i [own] + sum_{j: alias_j = i} (1 - q_j)) / N
+    q = np.minimum(acc["q"].astype(np.float64), 1.0)
+    p = q.copy()
+    np.add.at(p, acc["alias"], 1.0 - q)
+    p /= (w * h)
+    want = acc["pdf"].astype(np.float64) * area.reshape(-1)
+    assert abs(p.sum() - 1.0) < 1e-3 and np.abs(p - want).sum() < 2e-2           # total variation distance
+    assert np.array_equal(acc["aliasPdf"], acc["pdf"][acc["alias"]])
+    lum = env_small[..., 0] * 0.2126 + env_small[..., 1] * 0.7152 + env_small[..., 2] * 0.0722
+    assert abs(average - lum.mean()) < 1e-3 * lum.mean()
+
+
+def test_host_helpers_oracle_equals_product(env_small):
+    a, ia, aa = capi.build_env_accel(env_small)
+    h, w = env_small.shape[:2]
+    b = np.zeros(w * h, hd.envaccel_dtype)
+    ib, ab = C.c_float(), C.c_float()
+    orc.lib().orc_build_env_accel(np.ascontiguousarray(env_small).ctypes.data, w, h, b.ctypes.data, C.byref(ib), C.byref(ab))
+    assert a.tobytes() == b.tobytes() and ia == ib.value and aa == ab.value
+    cam = Camera(eye=(1.0, 2.0, 3.5), center=(0.1, 0.4, -0.3), up=(0, 1, 0), fov=47.0)
+    ca, cb = capi.camera_lookat(cam, 16 / 9), orc.camera_lookat(cam, 16 / 9)
+    va, vb = np.array(ca.viewInverse), np.array(cb.viewInverse)
+    assert np.abs(va - vb).max() < 1e-6 and np.abs(np.array(ca.projInverse) - np.array(cb.projInverse)).max() < 1e-6 * np.abs(np.array(cb.projInverse)).max()
+    assert abs(ca.focalDist - cb.focalDist) < 1e-6
+    # numpy third opinion: viewInverse maps camera origin to the eye and -z to the view direction
+    M = va.reshape(4, 4).T
+    assert np.allclose(M[:3, 3], cam.eye, atol=1e-6)
+    f = np.array(cam.center) - np.array(cam.eye)
+    f /= np.linalg.norm(f)
+    assert np.allclose(M[:3, :3] @ np.array([0, 0, -1.0]), f, atol=1e-6)
+    for args in [(0, 0, 0, 0, 0), (1, 9729, 9987, 33071, 33648), (1, -1, -1, -1, -1), (1, 9728, 9984, 10497, 10497)]:
+        ta, tb = hd.TextureDesc(), hd.TextureDesc()
+        capi.lib().pt_sampler_from_gltf(*args, C.byref(ta))
+        orc.lib().orc_sampler_from_gltf(*args, C.byref(tb))
+        assert (ta.magFilter, ta.minFilter, ta.wrapS, ta.wrapT) == (tb.magFilter, tb.minFilter, tb.wrapS, tb.wrapT)
+    t = hd.TextureDesc()
+    capi.lib().pt_sampler_from_gltf(1, -1, -1, -1, -1, C.byref(t))
+    assert (t.magFilter, t.wrapS) == (hd.FILTER_NEAREST, hd.WRAP_REPEAT)   # Appendix C-9
+    capi.lib().pt_sampler_from_gltf(0, 0, 0, 0, 0, C.byref(t))
+    assert (t.magFilter, t.wrapS) == (hd.FILTER_LINEAR, hd.WRAP_REPEAT)
+
+
+def test_quad_energy_and_determinism():
+    """C1: a grey quad under a white environment.  The image is finite, non-negative, bounded by the firefly
+    clamp, brighter where the env is seen directly, and two renders are bit-identical."""
+    cfg = Config(synth.quad_scene(), synth.constant_env(), 64, 64)
+    a = render_oracle(cfg, 4)
+    b = render_oracle(cfg, 4, threads=2)
+    assert np.array_equal(a, b)
+    assert np.isfinite(a).all() and (a >= 0).all() and (a[..., 3] == 1).all()
+    assert np.allclose(a[0, 0, :3], 1.0)                 # corner pixel sees the env only: radiance == env == 1
+    centre = a[24:40, 24:40, :3].mean()
+    assert 0.3 < centre < 1.3                             # albedo 0.8 with the reference's env double count (Appendix C-1)
+
+
+def test_black_env_gives_black_and_emission_survives():
+    env = np.zeros((8, 16, 4), np.float32)
+    env[..., 3] = 1
+    # a constant-zero env has zero integral -> the alias table degenerates; use a tiny positive env instead
+    env[..., :3] = 1e-6
+    sc = synth.quad_scene()
+    sc.materials[0]["emissiveFactor"] = (2.0, 1.0, 0.5)
+    cfg = Config(sc, env, 32, 32, firefly=1e9)
+    a = render_oracle(cfg, 1)
+    assert np.allclose(a[16, 16, :3], [2.0, 1.0, 0.5], atol=1e-4)      # emission * throughput(1) + ~0 env
+    assert a[0, 0, :3].max() < 1e-5
+
+
+def test_running_mean_accumulation():
+    """frame f result == mix(old, new, 1/(f+1)) (pathtrace.comp:122-133): re-rendering frame 1 alone on top of a
+    known buffer gives exactly the lerp."""
+    cfg = Config(synth.quad_scene(), synth.constant_env(), 32, 32)
+    o = orc.Oracle()
+    o.set_scene(cfg.scene); integ, _ = o.set_env(cfg.env); o.set_camera(cfg.camera); o.set_sunsky(cfg.sunsky)
+    st = cfg.state(integ)
+    f1 = np.zeros((32, 32, 4), np.float32)       # old = 0  -> result = new * (1/2) exactly
+    st.frame = 1
+    o.render_frame(st, f1)
+    f1b = np.full((32, 32, 4), 2.0, np.float32)  # old = 2 -> result = 2*(1 - 0.5) + new*0.5
+    o.render_frame(st, f1b)
+    assert np.array_equal(f1b[..., :3], np.float32(2.0) * np.float32(0.5) + f1[..., :3])
+
+
+def test_tonemap_properties():
+    acc = np.zeros((4, 4, 4), np.float32)
+    acc[..., 3] = 1
+    acc[1, 1, :3] = 1e6
+    acc[2, 2, :3] = 0.18
+    tm = hd.default_tonemapper()
+    tm.dither = 0
+    out = orc.tonemap(tm, acc)
+    assert out[0, 0, :3].max() == 0 and out[1, 1, :3].min() >= 254 and out[..., 3].min() == 255
+    v = 0.18 * 2.0
+    u2 = lambda c: ((c * (0.15 * c + 0.05) + 0.004) / (c * (0.15 * c + 0.5) + 0.06)) - 0.02 / 0.3
+    want = (u2(v) / u2(11.2)) ** (1 / 2.2)
+    assert abs(out[2, 2, 0] / 255.0 - want) < 1.5 / 255
+    tm.dither = 1
+    d = orc.tonemap(tm, acc)
+    assert np.abs(d.astype(int) - out.astype(int)).max() <= 1        # dithering moves a value by at most one step
+
+
+def test_shard_helpers_partition_the_image():
+    W, H = 200, 90
+    for n in (1, 2, 3, 8):
+        ids = [shard.local_pixel_ids(W, H, r, n) for r in range(n)]
+        allp = np.concatenate(ids)
+        assert len(allp) == W * H and len(np.unique(allp)) == W * H
+        sizes = [len(shard.tiles_of_rank(W, H, r, n)) for r in range(n)]
+        assert max(sizes) - min(sizes) <= 3 and max(sizes) == shard.max_tiles_per_rank(W, H, n)
