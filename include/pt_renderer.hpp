@@ -1,0 +1,83 @@
+// pt_renderer.hpp -- header-only C++ shim with the method set and call order of the reference's abstract
+// Renderer (reference: src/renderer.h:30-48), implemented on the C ABI of libptmi.so (pt_api.h).
+//
+// Vulkan does not exist on the target, so the Vulkan handle parameters of the reference signature are dropped
+// here; INTEGRATION.md shows the variant that keeps the reference's exact signatures inside its own tree.
+// Methods are `void` like the reference's; failures are reported through lastError() / ok() (the reference
+// itself asserts or ignores VkResults, src/rtx_pipeline.cpp:209,237).
+#pragma once
+#include <string>
+#include "pt_api.h"
+
+namespace ptmi {
+
+struct Extent2D {
+  uint32_t width, height;
+};
+
+class Renderer {  // src/renderer.h:30-48
+public:
+  virtual ~Renderer() = default;
+  virtual void              setup(int deviceOrdinal)                                          = 0;  // (VkDevice, VkPhysicalDevice, familyIndex, allocator)
+  virtual void              destroy()                                                         = 0;
+  virtual void              run(const Extent2D& size)                                         = 0;  // (cmdBuf, size, profiler, descSets)
+  virtual void              create(const Extent2D& size, const pt_SceneDesc* scene = nullptr) = 0;  // (size, layouts, Scene*)
+  virtual const std::string name()                                                            = 0;
+  void                      setPushContants(const pt_RtxState& state) { m_state = state; }          // (sic) src/renderer.h:44
+  pt_RtxState               m_state{};
+};
+
+class HipPathTracer : public Renderer {
+public:
+  ~HipPathTracer() override { destroy(); }
+  void setup(int deviceOrdinal) override
+  {
+    if(!m_ctx)
+      check(pt_create(deviceOrdinal, &m_ctx));
+  }
+  void destroy() override
+  {
+    if(m_ctx)
+      pt_destroy(m_ctx);
+    m_ctx = nullptr;
+  }
+  void create(const Extent2D& size, const pt_SceneDesc* scene = nullptr) override
+  {
+    if(scene && check(pt_set_scene(m_ctx, scene)))
+      check(pt_build_accel(m_ctx));
+    check(pt_resize(m_ctx, int(size.width), int(size.height)));
+  }
+  void run(const Extent2D& size) override
+  {
+    m_state.size[0] = int(size.width);
+    m_state.size[1] = int(size.height);
+    check(pt_render_frame(m_ctx, &m_state));
+  }
+  const std::string name() override { return pt_renderer_name(); }
+
+  // what the reference hands over through descriptor sets 2 and 3
+  void setCamera(const pt_SceneCamera& c) { check(pt_set_camera(m_ctx, &c)); }
+  void setSunAndSky(const pt_SunAndSky& s) { check(pt_set_sunsky(m_ctx, &s)); }
+  void setEnvironment(const float* rgba32f, int w, int h, float* integral, float* average) { check(pt_set_env(m_ctx, rgba32f, w, h, integral, average)); }
+  void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
+  void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
+
+  bool               ok() const { return m_status == PT_OK; }
+  int                status() const { return m_status; }
+  const std::string& lastError() const { return m_error; }
+  pt_context*        context() { return m_ctx; }
+
+private:
+  bool check(int rc)
+  {
+    m_status = rc;
+    if(rc != PT_OK)
+      m_error = pt_last_error(m_ctx);
+    return rc == PT_OK;
+  }
+  pt_context* m_ctx    = nullptr;
+  int         m_status = PT_OK;
+  std::string m_error;
+};
+
+}  // namespace ptmi
