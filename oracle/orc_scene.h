@@ -211,7 +211,8 @@ struct Scene {
     return true;
   }
 
-  // ---- a plain median-split BVH2, used only to make the oracle fast; results do not depend on it
+  // ---- a binned-SAH BVH2 (leaves <= 4 triangles).  It only makes the oracle fast -- results do not depend on it --
+  // and its node / triangle visit counts are the "binary-node equivalents" of the algorithmic-bytes model
   void build_bvh()
   {
     bvh.clear();
@@ -265,12 +266,72 @@ struct Scene {
         bvh[j.node].right = j.count | 0x80000000u;
         continue;
       }
-      int ax = 0;
-      if(cmx[1] - cmn[1] > cmx[ax] - cmn[ax]) ax = 1;
-      if(cmx[2] - cmn[2] > cmx[ax] - cmn[ax]) ax = 2;
-      uint32_t mid = j.first + j.count / 2;
-      std::nth_element(triOrder.begin() + j.first, triOrder.begin() + mid, triOrder.begin() + j.first + j.count,
-                       [&](uint32_t a, uint32_t b) { return cen[a * 3 + ax] < cen[b * 3 + ax] || (cen[a * 3 + ax] == cen[b * 3 + ax] && a < b); });
+      // binned SAH (16 bins per axis); falls back to the median of the widest axis when no split helps
+      const int NB = 16;
+      int       bestAx = -1, bestBin = -1;
+      float     bestCost = FLT_MAX;
+      auto      half_area = [](const float* mn, const float* mx) {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+      };
+      for(int ax = 0; ax < 3; ++ax)
+      {
+        float ext = cmx[ax] - cmn[ax];
+        if(!(ext > 0.0f)) continue;
+        uint32_t cnt[NB] = {0};
+        float    bmnb[NB][3], bmxb[NB][3];
+        for(int b = 0; b < NB; ++b)
+          for(int k = 0; k < 3; ++k) { bmnb[b][k] = FLT_MAX; bmxb[b][k] = -FLT_MAX; }
+        for(uint32_t i = j.first; i < j.first + j.count; ++i)
+        {
+          uint32_t w = triOrder[i];
+          int      b = std::min(NB - 1, int((cen[w * 3 + ax] - cmn[ax]) / ext * NB));
+          cnt[b]++;
+          for(int k = 0; k < 3; ++k) { bmnb[b][k] = std::min(bmnb[b][k], lo[w * 3 + k]); bmxb[b][k] = std::max(bmxb[b][k], hi[w * 3 + k]); }
+        }
+        float    la[NB], ra[NB];
+        uint32_t lc[NB], rc[NB];
+        float    mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        uint32_t c = 0;
+        for(int b = 0; b < NB; ++b)
+        {
+          c += cnt[b];
+          for(int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], bmnb[b][k]); mx[k] = std::max(mx[k], bmxb[b][k]); }
+          lc[b] = c; la[b] = c ? half_area(mn, mx) : 0.f;
+        }
+        for(int k = 0; k < 3; ++k) { mn[k] = FLT_MAX; mx[k] = -FLT_MAX; }
+        c = 0;
+        for(int b = NB - 1; b >= 0; --b)
+        {
+          c += cnt[b];
+          for(int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], bmnb[b][k]); mx[k] = std::max(mx[k], bmxb[b][k]); }
+          rc[b] = c; ra[b] = c ? half_area(mn, mx) : 0.f;
+        }
+        for(int b = 0; b < NB - 1; ++b)
+        {
+          if(lc[b] == 0 || rc[b + 1] == 0) continue;
+          float cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+          if(cost < bestCost) { bestCost = cost; bestAx = ax; bestBin = b; }
+        }
+      }
+      uint32_t mid;
+      if(bestAx >= 0)
+      {
+        float ext = cmx[bestAx] - cmn[bestAx];
+        auto  it  = std::partition(triOrder.begin() + j.first, triOrder.begin() + j.first + j.count, [&](uint32_t w) {
+          return std::min(NB - 1, int((cen[w * 3 + bestAx] - cmn[bestAx]) / ext * NB)) <= bestBin;
+        });
+        mid = uint32_t(it - triOrder.begin());
+      }
+      else
+      {
+        int ax = 0;
+        if(cmx[1] - cmn[1] > cmx[ax] - cmn[ax]) ax = 1;
+        if(cmx[2] - cmn[2] > cmx[ax] - cmn[ax]) ax = 2;
+        mid = j.first + j.count / 2;
+        std::nth_element(triOrder.begin() + j.first, triOrder.begin() + mid, triOrder.begin() + j.first + j.count,
+                         [&](uint32_t a, uint32_t b) { return cen[a * 3 + ax] < cen[b * 3 + ax] || (cen[a * 3 + ax] == cen[b * 3 + ax] && a < b); });
+      }
       uint32_t l = (uint32_t)bvh.size();
       bvh.push_back(BvhNode{});
       bvh.push_back(BvhNode{});

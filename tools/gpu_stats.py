@@ -8,10 +8,19 @@ wl = workloads.c3_sponza(1920, 1080, 8, tex_size=256); wl.scene.finalize(capi.pa
 r = HipRenderer(); r.setup(0); r.set_scene(wl.scene); integ, _ = r.set_env(wl.env)
 r.set_camera(capi.camera_lookat(wl.scene.camera, 1920 / 1080)); r.set_sunsky(hd.default_sun_and_sky()); r.create((1920, 1080))
 st = hd.default_rtx_state(); st.size[0], st.size[1] = 1920, 1080; st.maxDepth = 8; st.fireflyClampThreshold = 4 * integ
-r.set_profiling(True)
-for f in range(frames):
+import time
+prof = os.environ.get("PT_PROF", "1") == "1"
+for f in range(2):
     st.frame = f; r.setPushContants(st); r.run()
+r.synchronize(); r.reset_stats()
+r.set_profiling(prof)
+t0 = time.perf_counter()
+for f in range(2, 2 + frames):
+    st.frame = f; r.setPushContants(st); r.run()
+r.synchronize()
+wall = (time.perf_counter() - t0) / frames * 1e3
 s = r.stats()
+print("WALL ms/frame %.3f  -> %.1f Msamples/s" % (wall, 1920 * 1080 / wall / 1e3))
 print(json.dumps(s))
 rays = s["closestRays"] + s["shadowRays"]
 print("per frame: closest %.2fM shadow %.2fM alpha %.2fM" % (s["closestRays"] / frames / 1e6, s["shadowRays"] / frames / 1e6, s["alphaTests"] / frames / 1e6))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,11 +40,22 @@ struct pt_context {
   int      rank = 0, nranks = 1;
   uint32_t numLocalTiles = 0, maxTilesPerRank = 0, numSlots = 0;
   uint64_t localPixels = 0;
-  DevBuf   dState[9], dQueueA, dQueueB, dQueueS, dCounts, dFrame, dSlotTile, dCounters;
+  // Frames in flight: each has its own path state, queues, counter block and stream, so that the long tail of one
+  // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
+  // running-mean accumulate is ordered across frames (events).
+  struct FrameSlot {
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dCounts;
+    RenderBuffers rb{};
+    hipStream_t   stream    = nullptr;
+    hipEvent_t    accumDone = nullptr;
+  };
+  FrameSlot slots[PT_MAX_INFLIGHT];
+  int       inflight     = 1;
+  uint64_t  frameCounter = 0;
+  hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
+  DevBuf   dFrame, dSlotTile, dCounters;
   DevBuf   dRowMajor, dRgba8, dMean, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
-  RenderBuffers rb{};
-
   StageTimers timers;
   pt_Stats    stats{};
   double      msBuild = 0;
@@ -126,6 +138,19 @@ bool affine_inverse(const float* m, double inv[12], double& det3)
   inv[10] = -(i10 * tx + i11 * ty + i12 * tz);
   inv[11] = -(i20 * tx + i21 * ty + i22 * tz);
   return true;
+}
+
+hipError_t sync_all(pt_context* c)
+{
+  for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+    if(c->slots[i].stream)
+    {
+      hipError_t e = hipStreamSynchronize(c->slots[i].stream);
+      if(e != hipSuccess)
+        return e;
+    }
+  c->lastAccum = nullptr;
+  return hipStreamSynchronize(c->stream);
 }
 
 void refresh_scene_ptrs(pt_context* c)
@@ -234,6 +259,14 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     g_createError = "hipSetDevice failed";
     return PT_ERR_HIP;
   }
+  if(const char* tune = getenv("PT_TUNE"))
+  {  // performance A/B knobs only
+    int v;
+    if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
+    if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
+    if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
+    if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
+  }
   pt_context* c = new pt_context();
   c->device     = device_ordinal;
   if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
@@ -243,6 +276,14 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     return PT_ERR_HIP;
   }
   c->timers.stream = c->stream;
+  c->inflight      = g_tuning.framesInFlight < 1 ? 1 : (g_tuning.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : g_tuning.framesInFlight);
+  for(int i = 0; i < c->inflight; ++i)
+    if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess)
+    {
+      g_createError = "hipStreamCreate / hipEventCreate failed";
+      delete c;
+      return PT_ERR_HIP;
+    }
   // defaults: sun & sky off, empty camera
   std::memset(&c->scene, 0, sizeof(c->scene));
   if(dev_alloc(c, c->dCounters, sizeof(Counters)) != PT_OK || hipMemset(c->dCounters.p, 0, sizeof(Counters)) != hipSuccess)
@@ -259,14 +300,24 @@ int pt_destroy(pt_context* c)
 {
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)sync_all(c);
   DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dTris, &c->dEnv,
-                   &c->dEnvAccel, &c->dQueueA, &c->dQueueB, &c->dQueueS, &c->dCounts, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
+                   &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
-  for(DevBuf& b : c->dState)
-    dev_free(b);
+  for(auto& fs : c->slots)
+  {
+    for(DevBuf& b : fs.dState)
+      dev_free(b);
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dCounts};
+    for(DevBuf* b : q)
+      dev_free(*b);
+    if(fs.accumDone)
+      (void)hipEventDestroy(fs.accumDone);
+    if(fs.stream)
+      (void)hipStreamDestroy(fs.stream);
+  }
   for(size_t i = 0; i < c->timers.cap; ++i)
   {
     (void)hipEventDestroy(c->timers.pend[i].a);
@@ -286,7 +337,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   if((d->numLights && !d->lights) || (d->numTextures && !d->textures))
     return c->fail(PT_ERR_INVALID, "pt_set_scene: count without array");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
 
   // ---- validate + build the per-instance records
   std::vector<InstanceRec> inst(d->numNodes);
@@ -415,7 +466,7 @@ int pt_build_accel(pt_context* c)
   if(pt_accel_build(c->stream, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
                     (TriRec*)c->dTris.p, (BvhNode*)c->dBvh.p, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   c->haveAccel = true;
   refresh_scene_ptrs(c);
@@ -446,7 +497,7 @@ int pt_set_env(pt_context* c, const float* rgba, int w, int h, float* out_integr
   if(!rgba || w <= 0 || h <= 0)
     return c->fail(PT_ERR_INVALID, "pt_set_env: bad image");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   std::vector<pt_EnvAccel> accel(size_t(w) * h);
   float                    integral = 1.f, average = 1.f;
   if(pt_build_env_accel(rgba, w, h, accel.data(), &integral, &average) != PT_OK)
@@ -482,7 +533,7 @@ int pt_resize(pt_context* c, int width, int height)
   if(width == c->width && height == c->height)
     return PT_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   c->tilesX = (width + PT_TILE - 1) / PT_TILE;
   c->tilesY = (height + PT_TILE - 1) / PT_TILE;
   std::vector<uint32_t> local;
@@ -508,15 +559,19 @@ int pt_resize(pt_context* c, int width, int height)
 
   int          rc;
   const size_t n = c->numSlots ? c->numSlots : 1;
-  for(DevBuf& b : c->dState)
-    if((rc = dev_alloc(c, b, sizeof(float4) * n)) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dQueueA, 4 * n)) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dQueueB, 4 * n)) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dQueueS, 4 * n)) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dCounts, 4 * 4)) != PT_OK) return rc;
+  for(int i = 0; i < c->inflight; ++i)
+  {
+    pt_context::FrameSlot& fs = c->slots[i];
+    for(DevBuf& bf : fs.dState)
+      if((rc = dev_alloc(c, bf, sizeof(float4) * n)) != PT_OK) return rc;
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2};
+    for(DevBuf* bf : q)
+      if((rc = dev_alloc(c, *bf, 4 * n)) != PT_OK) return rc;
+    if((rc = dev_alloc(c, fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2))) != PT_OK) return rc;
+    HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
+  }
   if((rc = dev_alloc(c, c->dFrame, sizeof(float4) * size_t(c->maxTilesPerRank ? c->maxTilesPerRank : 1) * 1024u)) != PT_OK) return rc;
   if((rc = upload(c, c->dSlotTile, local.data(), 4 * local.size())) != PT_OK) return rc;
-  HIP_TRY(c, hipMemset(c->dCounts.p, 0, 16));
   HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
   if((rc = dev_alloc(c, c->dRowMajor, sizeof(float4) * size_t(width) * height)) != PT_OK) return rc;
   HIP_TRY(c, hipMemset(c->dRowMajor.p, 0, sizeof(float4) * size_t(width) * height));
@@ -526,17 +581,23 @@ int pt_resize(pt_context* c, int width, int height)
   c->width    = width;
   c->height   = height;
   c->haveFull = false;
-  PathState& ps = c->rb.ps;
-  ps.rayO = (float4*)c->dState[0].p; ps.rayD = (float4*)c->dState[1].p; ps.thr = (float4*)c->dState[2].p; ps.rad = (float4*)c->dState[3].p;
-  ps.absorb = (float4*)c->dState[4].p; ps.neeDir = (float4*)c->dState[5].p; ps.neeRad = (float4*)c->dState[6].p; ps.hit = (float4*)c->dState[7].p;
-  ps.sum = (float4*)c->dState[8].p;
-  c->rb.queueA   = (uint32_t*)c->dQueueA.p;
-  c->rb.queueB   = (uint32_t*)c->dQueueB.p;
-  c->rb.queueS   = (uint32_t*)c->dQueueS.p;
-  c->rb.counts   = (uint32_t*)c->dCounts.p;
-  c->rb.frame    = (float4*)c->dFrame.p;
-  c->rb.slotTile = (uint32_t*)c->dSlotTile.p;
-  c->rb.counters = (Counters*)c->dCounters.p;
+  for(int i = 0; i < c->inflight; ++i)
+  {
+    pt_context::FrameSlot& fs = c->slots[i];
+    PathState&             ps = fs.rb.ps;
+    ps.rayO = (float4*)fs.dState[0].p; ps.rayD = (float4*)fs.dState[1].p; ps.thr = (float4*)fs.dState[2].p; ps.rad = (float4*)fs.dState[3].p;
+    ps.absorb = (float4*)fs.dState[4].p; ps.neeDir = (float4*)fs.dState[5].p; ps.neeRad = (float4*)fs.dState[6].p; ps.hit = (float4*)fs.dState[7].p;
+    ps.sum = (float4*)fs.dState[8].p;
+    fs.rb.queueA   = (uint32_t*)fs.dQueueA.p;
+    fs.rb.queueB   = (uint32_t*)fs.dQueueB.p;
+    fs.rb.queueS   = (uint32_t*)fs.dQueueS.p;
+    fs.rb.queueX   = (uint32_t*)fs.dQueueX.p;
+    fs.rb.queueX2  = (uint32_t*)fs.dQueueX2.p;
+    fs.rb.counts   = (uint32_t*)fs.dCounts.p;
+    fs.rb.frame    = (float4*)c->dFrame.p;
+    fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
+    fs.rb.counters = (Counters*)c->dCounters.p;
+  }
   return PT_OK;
 }
 
@@ -553,8 +614,8 @@ int pt_render_frame(pt_context* c, const pt_RtxState* st)
     return c->fail(PT_ERR_STATE, "pt_render_frame before pt_resize");
   if(st->size[0] != c->width || st->size[1] != c->height)
     return c->fail(PT_ERR_INVALID, "RtxState.size %dx%d != pt_resize %dx%d", st->size[0], st->size[1], c->width, c->height);
-  if(st->maxSamples < 1 || st->maxDepth < 0 || st->frame < 0)
-    return c->fail(PT_ERR_INVALID, "RtxState: maxSamples %d maxDepth %d frame %d", st->maxSamples, st->maxDepth, st->frame);
+  if(st->maxSamples < 1 || st->maxDepth < 0 || st->maxDepth > PT_MAX_DEPTH || st->frame < 0)
+    return c->fail(PT_ERR_INVALID, "RtxState: maxSamples %d maxDepth %d (limit %d) frame %d", st->maxSamples, st->maxDepth, PT_MAX_DEPTH, st->frame);
   if(c->scene.camera.nbLights < 0)
     return c->fail(PT_ERR_INVALID, "camera.nbLights < 0");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -571,7 +632,11 @@ int pt_render_frame(pt_context* c, const pt_RtxState* st)
   fp.numLocalTiles = c->numLocalTiles;
   fp.numSlots      = c->numSlots;
   fp.sample        = 0;
-  pt_launch_frame(c->stream, c->scene, c->rb, fp, &c->timers);
+  {
+    pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
+    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
+    c->lastAccum = fs.accumDone;
+  }
   HIP_TRY(c, hipGetLastError());
   c->haveFull = false;
   c->stats.samples += uint64_t(st->maxSamples) * c->localPixels;
@@ -582,17 +647,20 @@ int pt_synchronize(pt_context* c)
 {
   CTX_CHECK(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   return PT_OK;
 }
 
 static int untile_to_rowmajor(pt_context* c)
 {
+  // frames run on their own streams; the last accumulate (itself ordered after all earlier ones) gates the readback
+  if(c->lastAccum)
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lastAccum, 0));
   if(c->haveFull)
     pt_launch_untile(c->stream, (const float4*)c->dFullTiles.p, (const uint32_t*)c->dFullSlotTile.p, uint32_t(c->tilesX) * c->tilesY, c->tilesX, c->width, c->height,
                      (float4*)c->dRowMajor.p);
   else
-    pt_launch_untile(c->stream, c->rb.frame, c->rb.slotTile, c->numLocalTiles, c->tilesX, c->width, c->height, (float4*)c->dRowMajor.p);
+    pt_launch_untile(c->stream, (const float4*)c->dFrame.p, (const uint32_t*)c->dSlotTile.p, c->numLocalTiles, c->tilesX, c->width, c->height, (float4*)c->dRowMajor.p);
   HIP_TRY(c, hipGetLastError());
   return PT_OK;
 }
@@ -609,7 +677,7 @@ int pt_read_accum(pt_context* c, float* out)
   if(rc != PT_OK)
     return rc;
   HIP_TRY(c, hipMemcpyAsync(out, c->dRowMajor.p, sizeof(float4) * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   return PT_OK;
 }
 
@@ -634,14 +702,14 @@ int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
     pt_launch_mean(c->stream, (const float4*)c->dRowMajor.p, size_t(c->width) * c->height, (double*)c->dMean.p);
     double s[3];
     HIP_TRY(c, hipMemcpyAsync(s, c->dMean.p, sizeof(s), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     for(int k = 0; k < 3; ++k)
       avg[k] = float(s[k] / (double(c->width) * c->height));
   }
   pt_launch_tonemap(c->stream, (const float4*)c->dRowMajor.p, c->width, c->height, *tm, avg, (uint32_t*)c->dRgba8.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   return PT_OK;
 }
 
@@ -680,7 +748,7 @@ int pt_scatter_shards(pt_context* c, const void* gathered_dev, int nranks)
   pt_launch_scatter_tiles(c->stream, (const float4*)gathered_dev, nranks, int(c->maxTilesPerRank), c->tilesX, c->tilesY, (const uint32_t*)c->dTileLocalIndex.p,
                           (float4*)c->dFullTiles.p);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   c->haveFull = true;
   return PT_OK;
 }
@@ -689,7 +757,7 @@ int pt_set_profiling(pt_context* c, int enable)
 {
   CTX_CHECK(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   pt_timers_collect(&c->timers);
   c->timers.enabled = enable != 0;
   return PT_OK;
@@ -701,7 +769,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   if(!out)
     return c->fail(PT_ERR_INVALID, "pt_get_stats: null");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   pt_timers_collect(&c->timers);
   Counters k{};
   HIP_TRY(c, hipMemcpy(&k, c->dCounters.p, sizeof(k), hipMemcpyDeviceToHost));
@@ -729,7 +797,7 @@ int pt_reset_stats(pt_context* c)
 {
   CTX_CHECK(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_all(c));
   pt_timers_collect(&c->timers);
   for(double& m : c->timers.ms)
     m = 0;

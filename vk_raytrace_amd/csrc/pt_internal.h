@@ -3,24 +3,50 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "pt_device.h"
+#define PT_REFILL_BELOW_DEFAULT 16
 
 // pt_accel.hip
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
                    TriRec* dTrisOut, BvhNode* dNodesOut, char* err, size_t errLen);
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
+// Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):
+#define CNT_STRIDE 8
+#define CNT_IN 0             // size of the bounce's input queue (bounce b+1's lives at +CNT_STRIDE)
+#define CNT_SHADOW 1         // size of queueS (paths with a shadow ray)
+#define CNT_X_CLOSEST 2      // rays handed to the exact closest-hit fallback
+#define CNT_X_SHADOW 3       // rays handed to the exact shadow fallback
+#define CNT_CHUNK_CLOSEST 4  // ray-supply chunk counter of k_closest_p
+#define CNT_CHUNK_SHADOW 5   // ray-supply chunk counter of k_shadow_p
+#define PT_MAX_DEPTH 256
+#define PT_MAX_INFLIGHT 8
+#define PT_PERSISTENT_WAVES (256u * 20u)
+
 struct RenderBuffers {
   PathState ps;
-  uint32_t* queueA;    // path-slot queues (ping-pong) + one for the shadow stage
+  uint32_t* queueA;    // path-slot queues of the bounces (ping-pong)
   uint32_t* queueB;
-  uint32_t* queueS;
-  uint32_t* counts;    // device counters: [0] queueA size, [1] queueB size, [2] queueS size
+  uint32_t* queueS;    // paths with a shadow ray
+  uint32_t* queueX;    // exact-fallback queues (normally empty)
+  uint32_t* queueX2;
+  uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
   Counters* counters;
 };
+// Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
+// the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
+struct PtTuning {
+  int simpleClosestBounces = 9999;   // bounces whose closest-hit stage uses the lock-step kernel (coherent rays)
+  int simpleShadowBounces  = 9999;
+  int refillBelow          = PT_REFILL_BELOW_DEFAULT;
+  int framesInFlight       = 3;    // independent frames overlapped on separate streams (accumulate stays ordered)
+};
+extern PtTuning g_tuning;
 struct StageTimers;  // pt_capi.hip
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers);
+// waitBeforeAccum (may be null): accumDone event of the previous frame; recordAfterAccum: this frame's
+void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
+                     hipEvent_t recordAfterAccum);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles);
 void pt_launch_tonemap(hipStream_t stream, const float4* rowMajor, int width, int height, const pt_Tonemapper& tm, const float avg[3], uint32_t* outRgba8);

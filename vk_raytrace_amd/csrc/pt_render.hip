@@ -7,12 +7,19 @@
 //
 //   k_generate      seed (pathtrace.comp:97), jitter + camera ray (pathtrace.glsl:348-372)      all local pixels
 //   per bounce:
-//   k_closest       ClosestHit incl. stochastic alpha (traceray_rq.glsl:108-147)                 queue[in]
+//   k_closest_p     ClosestHit incl. stochastic alpha (traceray_rq.glsl:108-147); persistent
+//                   wavefronts on the trace machine (pt_machine.h)                               queue[in]
 //   k_shade         miss/env, GetShadeState, material, emission, absorption, DirectLight,
-//                   BSDF sample, throughput, RR probability, next ray (pathtrace.glsl:201-325)   queue[in] -> queueS
-//   k_shadow_rr     AnyHit for the deferred NEE contribution, Russian roulette
-//                   (pathtrace.glsl:327-338)                                                     queueS -> queue[out]
+//                   BSDF sample, throughput, next ray (pathtrace.glsl:201-325); Russian roulette
+//                   right away for paths without a shadow ray                                    queue[in] -> queueS | queue[out]
+//   k_shadow_p      AnyHit for the deferred NEE contribution, then Russian roulette
+//                   (pathtrace.glsl:327-338); persistent wavefronts                              queueS -> queue[out]
+//   k_closest_x / k_shadow_x   the simple one-ray-per-lane kernels, run on the (normally empty) queues of rays
+//                   that need the exact key-ordered alpha loop
 //   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean (pathtrace.comp:122-133)
+//
+// Queue sizes live on the device in a per-bounce counter block (8 words per bounce, zeroed once per frame), so a
+// frame is enqueued without any host synchronisation.
 //
 // Random numbers are drawn in the reference's order from one PCG state per
 // path that travels with the path state.  Queue order never influences a pixel's value.
@@ -20,7 +27,7 @@
 #include "pt_bsdf.h"
 #include "pt_internal.h"
 #include "pt_sky.h"
-#include "pt_trace.h"
+#include "pt_machine.h"
 
 namespace {
 
@@ -86,8 +93,6 @@ PT_DEV f3 offset_ray(f3 p, f3 n)
 __global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
 {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-    rb.counts[1] = 0;
   if(slot >= fp.numSlots)
     return;
   int px, py;
@@ -130,65 +135,167 @@ __global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers r
   rb.ps.thr[slot]    = make_float4(1.f, 1.f, 1.f, 1.f);
   rb.ps.rad[slot]    = make_float4(0.f, 0.f, 0.f, 0.f);
   rb.ps.absorb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-  enqueue(rb.queueA, &rb.counts[0], slot);
+  enqueue(rb.queueA, &rb.counts[CNT_IN], slot);  // bounce 0 reads queueA
 }
 
-// ---- k_closest --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int countIdx)
+// ---- closest hit ----------------------------------------------------------------------------------------------
+PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off);
+  if((threadIdx.x & 63) == 0 && v)
+    atomicAdd(ctr, (unsigned long long)v);
+}
+
+PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, float t, float u, float v)
+{
+  if(bslot == BVH_NONE)
+    rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
+  else
+    rb.ps.hit[slot] = make_float4(t, __uint_as_float(bslot), u, v);
+}
+
+// Persistent wavefronts: pass A / pass B of the exact stochastic alpha scheme on the trace machine.
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int refillBelow)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-    rb.counts[2] = 0;  // the shadow-stage queue is idle during this stage
-  const uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  if(i >= rb.counts[countIdx])
+  uint32_t            spill[STACK_SPILL];
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_IN];
+  uint32_t*           lds   = stack + threadIdx.x;
+  TraceLane           L;
+  RaySupply           rs;
+  uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
+  bool                alive = false;
+  L.done                    = true;
+  for(;;)
+  {
+    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_CLOSEST], count, !alive);
+    if(qi != 0xffffffffu)
+    {
+      pslot           = queueIn[qi];
+      const float4 dw = rb.ps.rayD[pslot];
+      seed            = __float_as_uint(dw.w);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
+      alive = true;
+      ++nRays;
+    }
+    if(!__ballot(alive))
+      break;
+    for(;;)
+    {
+      if(alive && !L.done && !(L.cur & BVH_LEAF))
+        lane_inner<false>(S, L, lds, spill, rb.counters);
+      if(alive && !L.done && (L.cur & BVH_LEAF))
+        lane_leaf<false>(S, L, lds, spill);
+      if(alive && L.done)
+      {
+        bool fallback = (L.flags & TF_SAW_FRAC) != 0;
+        if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO))
+        {
+          lane_begin_count(L);  // stay alive: pass B runs in the same loop
+          L.done = S.numTris == 0;
+        }
+        else
+        {
+          if(!fallback)
+          {
+            uint32_t nDraw = (L.pass == 1) ? L.cnt : 0u;
+            if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
+              ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
+            uint32_t s2 = seed;
+            if(consume_rejected_draws(s2, nDraw))
+            {
+              store_hit(rb, pslot, L.bslot, L.bt, L.bu, L.bv);
+              if(nDraw)
+                rb.ps.rayD[pslot].w = __uint_as_float(s2);
+              nAlpha += nDraw;
+            }
+            else
+              fallback = true;
+          }
+          if(fallback)
+            enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
+          alive = false;
+        }
+      }
+      const unsigned long long run = __ballot(alive);
+      if(!run || (rs.more && __popcll(run) < refillBelow))
+        break;
+    }
+  }
+  wave_add(&rb.counters->closestRays, nRays);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Simple variant: one ray per lane for the lifetime of the wave (lock-step traversal: for coherent rays every
+// node fetch is a broadcast), pass A + pass B inline, exact fallback through queueX.
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  if(i >= C[CNT_IN])
     return;
   const uint32_t slot = queueIn[i];
   const f3       o    = xyz(rb.ps.rayO[slot]);
   const float4   dw   = rb.ps.rayD[slot];
   const f3       d    = xyz(dw);
-  uint32_t       seed = __float_as_uint(dw.w);
-  const uint32_t seed0 = seed;
+  const uint32_t seed = __float_as_uint(dw.w);
   count_event(&rb.counters->closestRays);
-
-  // pass A: nearest certain hit; pass B (only if transparent candidates were seen): count the draws they consume
   RayHit h;
   bool   dummy;
   traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-  bool     exact = (h.flags & TF_SAW_FRAC) != 0;
-  uint32_t nDraw = 0;
-  if(!exact && (h.flags & TF_SAW_ZERO))
+  bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
+  uint32_t nDraw    = 0;
+  if(!fallback && (h.flags & TF_SAW_ZERO))
   {
     RayHit c;
     traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
                        rb.counters);
-    exact = (c.flags & TF_SAW_FRAC) != 0;
-    nDraw = c.count;
+    fallback = (c.flags & TF_SAW_FRAC) != 0;
+    nDraw    = c.count;
   }
-  if(!exact)
+  if(!fallback)
   {
     if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
-      ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
+      ++nDraw;
     uint32_t s2 = seed;
     if(consume_rejected_draws(s2, nDraw))
     {
-      seed = s2;
+      store_hit(rb, slot, h.slot, h.t, h.u, h.v);
       if(nDraw)
+      {
+        rb.ps.rayD[slot].w = __uint_as_float(s2);
         atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
+      }
+      return;
     }
-    else
-      exact = true;
   }
-  if(exact)
-  {  // exact key-ordered loop (fractional opacity in front of the hit, or a draw of exactly 0.0)
-    float    tPrev = 0.0f;
-    uint32_t wPrev = 0xffffffffu;
-    seed           = seed0;
+  enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
+}
+
+// Exact fallback: one ray per lane, key-ordered stochastic alpha (trace contract T5).  Runs on the rays the
+// machine could not settle (fractional opacity in front of the hit, or a rejected-candidate draw of exactly 0.0).
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  const uint32_t      count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
+  for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t slot = rb.queueX[i];
+    const f3       o    = xyz(rb.ps.rayO[slot]);
+    const float4   dw   = rb.ps.rayD[slot];
+    const f3       d    = xyz(dw);
+    uint32_t       seed = __float_as_uint(dw.w);
+    float          tPrev = 0.0f;
+    uint32_t       wPrev = 0xffffffffu;
+    RayHit         h;
+    bool           dummy;
     for(;;)
     {
       traverse<TM_RAW_ALL>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-      if(h.slot == BVH_NONE)
-        break;
-      if((h.w >> 29) & TRI_OPAQUE)
+      if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
         break;
       atomicAdd(&rb.counters->alphaTests, 1ull);
       if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
@@ -196,13 +303,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest(DeviceScene S, RenderBu
       tPrev = h.t;
       wPrev = h.w & TRI_INDEX_MASK;
     }
-  }
-  if(h.slot == BVH_NONE)
-    rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
-  else
-    rb.ps.hit[slot] = make_float4(h.t, __uint_as_float(h.slot), h.u, h.v);
-  if(seed != seed0)
+    store_hit(rb, slot, h.slot, h.t, h.u, h.v);
     rb.ps.rayD[slot].w = __uint_as_float(seed);
+  }
 }
 
 // ---- environment (shaders/env_sampling.glsl:38-135) ---------------------------------------------------------
@@ -265,14 +368,9 @@ PT_DEV f3 bsdf_sample(int pbrMode, const Surface& s, f3 V, f3 N, f3& L, float& p
 }
 
 // ---- k_shade ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int countIdx, int outIdx, int depth)
+// One path: everything between the closest-hit trace and the shadow trace of a bounce.
+PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, uint32_t* __restrict__ queueOut, uint32_t* C, int depth)
 {
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-    rb.counts[outIdx] = 0;  // the queue the following k_shadow_rr fills
-  const uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
-  if(i >= rb.counts[countIdx])
-    return;
-  const uint32_t     slot = queueIn[i];
   const pt_RtxState& st   = fp.st;
   const float4       dw   = rb.ps.rayD[slot];
   const f3           rdir = xyz(dw);
@@ -463,96 +561,47 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuff
   rb.ps.thr[slot]    = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
   rb.ps.rad[slot]    = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
   rb.ps.absorb[slot] = make_float4(absorption.x, absorption.y, absorption.z, lightDist);
-  rb.ps.neeDir[slot] = make_float4(lightDir.x, lightDir.y, lightDir.z, visible ? 1.f : 0.f);
-  rb.ps.neeRad[slot] = make_float4(neeRadiance.x, neeRadiance.y, neeRadiance.z, 0.f);
-  enqueue(rb.queueS, &rb.counts[2], slot);
+  if(visible)
+  {
+    rb.ps.neeDir[slot] = make_float4(lightDir.x, lightDir.y, lightDir.z, 1.f);
+    rb.ps.neeRad[slot] = make_float4(neeRadiance.x, neeRadiance.y, neeRadiance.z, 0.f);
+    enqueue(rb.queueS, &C[CNT_SHADOW], slot);
+    return;
+  }
+  // no shadow ray for this bounce: the Russian-roulette draw follows the BSDF draws directly (pathtrace.glsl:333-338)
+  const bool die     = rng_next(seed) >= rrPcont;
+  rb.ps.rayD[slot].w = __uint_as_float(seed);
+  if(die)
+    return;
+  throughput /= rrPcont;
+  rb.ps.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
+  if(depth != st.maxDepth - 1)
+    enqueue(queueOut, &C[CNT_STRIDE + CNT_IN], slot);
 }
 
-// ---- k_shadow_rr --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_rr(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int outIdx, int lastBounce)
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
 {
-  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
-  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  if(i >= rb.counts[2])
-    return;
-  const uint32_t slot = rb.queueS[i];
-  const float4   nd   = rb.ps.neeDir[slot];
-  uint32_t       seed = __float_as_uint(rb.ps.rayD[slot].w);
+  uint32_t*      C     = rb.counts + depth * CNT_STRIDE;
+  const uint32_t count = C[CNT_IN];
+  for(uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < count; i += gridDim.x * SHADE_BLOCK)
+    shade_path(S, rb, fp, queueIn[i], queueOut, C, depth);
+}
 
-  if(nd.w != 0.f)
+// ---- shadow + Russian roulette ---------------------------------------------------------------------------------
+// NEE contribution if unoccluded, then Russian roulette (pathtrace.glsl:327-338); survivors go to the next bounce.
+PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t seed, uint32_t* __restrict__ queueOut, uint32_t* nextCount, bool lastBounce)
+{
+  if(!inShadow)
   {
-    count_event(&rb.counters->shadowRays);
-    const f3    o       = xyz(rb.ps.rayO[slot]);
-    const f3    d       = xyz(nd);
-    const float maxDist = rb.ps.absorb[slot].w;
-    bool        inShadow;
-    bool        dummy;
-    RayHit      h;
-    const uint32_t seed0 = seed;
-    // pass A: any opaque occluder ends the ray without a draw; otherwise the nearest certain alpha occluder
-    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
-    if(!inShadow)
-    {
-      bool     exact = (h.flags & TF_SAW_FRAC) != 0;
-      uint32_t nDraw = 0;
-      if(!exact && (h.flags & TF_SAW_ZERO))
-      {
-        RayHit c;
-        traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
-                           rb.counters);
-        exact = (c.flags & TF_SAW_FRAC) != 0;
-        nDraw = c.count;
-      }
-      if(!exact)
-      {
-        if(h.slot != BVH_NONE)
-          ++nDraw;
-        uint32_t s2 = seed;
-        if(consume_rejected_draws(s2, nDraw))
-        {
-          seed     = s2;
-          inShadow = h.slot != BVH_NONE;
-          if(nDraw)
-            atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
-        }
-        else
-          exact = true;
-      }
-      if(exact)
-      {  // exact key-ordered stochastic alpha over the non-opaque candidates (trace contract T6)
-        seed           = seed0;
-        float    tPrev = 0.0f;
-        uint32_t wPrev = 0xffffffffu;
-        for(;;)
-        {
-          traverse<TM_RAW_NONOPAQUE>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-          if(h.slot == BVH_NONE)
-            break;
-          atomicAdd(&rb.counters->alphaTests, 1ull);
-          if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
-          {
-            inShadow = true;
-            break;
-          }
-          tPrev = h.t;
-          wPrev = h.w & TRI_INDEX_MASK;
-        }
-      }
-    }
-    if(!inShadow)
-    {
-      float4 r = rb.ps.rad[slot];
-      float4 c = rb.ps.neeRad[slot];
-      r.x += c.x;
-      r.y += c.y;
-      r.z += c.z;
-      rb.ps.rad[slot] = r;
-    }
+    float4 r = rb.ps.rad[slot];
+    float4 c = rb.ps.neeRad[slot];
+    r.x += c.x;
+    r.y += c.y;
+    r.z += c.z;
+    rb.ps.rad[slot] = r;
   }
-
-  // Russian roulette (pathtrace.glsl:333-338)
-  float4      t  = rb.ps.thr[slot];
-  const float pc = t.w;
+  float4      t   = rb.ps.thr[slot];
+  const float pc  = t.w;
   const bool  die = rng_next(seed) >= pc;
   rb.ps.rayD[slot].w = __uint_as_float(seed);
   if(die)
@@ -562,15 +611,178 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_rr(DeviceScene S, Render
   t.z /= pc;
   rb.ps.thr[slot] = t;
   if(!lastBounce)
-    enqueue(queueOut, &rb.counts[outIdx], slot);
+    enqueue(queueOut, nextCount, slot);
+}
+
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int refillBelow)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t            spill[STACK_SPILL];
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_SHADOW];
+  uint32_t*           lds   = stack + threadIdx.x;
+  TraceLane           L;
+  RaySupply           rs;
+  uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
+  bool                alive = false;
+  L.done                    = true;
+  for(;;)
+  {
+    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_SHADOW], count, !alive);
+    if(qi != 0xffffffffu)
+    {
+      pslot = rb.queueS[qi];
+      seed  = __float_as_uint(rb.ps.rayD[pslot].w);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
+      alive = true;
+      ++nRays;
+    }
+    if(!__ballot(alive))
+      break;
+    for(;;)
+    {
+      if(alive && !L.done && !(L.cur & BVH_LEAF))
+        lane_inner<true>(S, L, lds, spill, rb.counters);
+      if(alive && !L.done && (L.cur & BVH_LEAF))
+        lane_leaf<true>(S, L, lds, spill);
+      if(alive && L.done)
+      {
+        bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
+        if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO))
+        {
+          lane_begin_count(L);
+          L.done = S.numTris == 0;
+        }
+        else
+        {
+          bool inShadow = L.opaqueHit;  // an opaque occluder ends the ray without a draw (trace contract T6)
+          if(!fallback && !L.opaqueHit)
+          {
+            uint32_t nDraw = (L.pass == 1) ? L.cnt : 0u;
+            if(L.bslot != BVH_NONE)
+              ++nDraw;
+            uint32_t s2 = seed;
+            if(consume_rejected_draws(s2, nDraw))
+            {
+              seed     = s2;
+              inShadow = L.bslot != BVH_NONE;
+              nAlpha += nDraw;
+            }
+            else
+              fallback = true;
+          }
+          if(fallback)
+            enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
+          else
+            finish_bounce(rb, pslot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+          alive = false;
+        }
+      }
+      const unsigned long long run = __ballot(alive);
+      if(!run || (rs.more && __popcll(run) < refillBelow))
+        break;
+    }
+  }
+  wave_add(&rb.counters->shadowRays, nRays);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Simple variant of the shadow stage (one ray per lane).
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  if(i >= C[CNT_SHADOW])
+    return;
+  const uint32_t slot    = rb.queueS[i];
+  uint32_t       seed    = __float_as_uint(rb.ps.rayD[slot].w);
+  const f3       o       = xyz(rb.ps.rayO[slot]);
+  const f3       d       = xyz(rb.ps.neeDir[slot]);
+  const float    maxDist = rb.ps.absorb[slot].w;
+  count_event(&rb.counters->shadowRays);
+  bool   inShadow, dummy;
+  RayHit h;
+  traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
+  if(!inShadow)
+  {
+    bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
+    uint32_t nDraw    = 0;
+    if(!fallback && (h.flags & TF_SAW_ZERO))
+    {
+      RayHit c;
+      traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                         rb.counters);
+      fallback = (c.flags & TF_SAW_FRAC) != 0;
+      nDraw    = c.count;
+    }
+    if(!fallback)
+    {
+      if(h.slot != BVH_NONE)
+        ++nDraw;
+      uint32_t s2 = seed;
+      if(consume_rejected_draws(s2, nDraw))
+      {
+        seed     = s2;
+        inShadow = h.slot != BVH_NONE;
+        if(nDraw)
+          atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
+      }
+      else
+        fallback = true;
+    }
+    if(fallback)
+    {
+      enqueue(rb.queueX2, &C[CNT_X_SHADOW], slot);
+      return;
+    }
+  }
+  finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+}
+
+// Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_X_SHADOW];
+  for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t slot    = rb.queueX2[i];
+    uint32_t       seed    = __float_as_uint(rb.ps.rayD[slot].w);
+    const f3       o       = xyz(rb.ps.rayO[slot]);
+    const f3       d       = xyz(rb.ps.neeDir[slot]);
+    const float    maxDist = rb.ps.absorb[slot].w;
+    bool           inShadow, dummy;
+    RayHit         h;
+    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
+    if(!inShadow)
+    {
+      float    tPrev = 0.0f;
+      uint32_t wPrev = 0xffffffffu;
+      for(;;)
+      {
+        traverse<TM_RAW_NONOPAQUE>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+        if(h.slot == BVH_NONE)
+          break;
+        atomicAdd(&rb.counters->alphaTests, 1ull);
+        if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+        {
+          inShadow = true;
+          break;
+        }
+        tPrev = h.t;
+        wPrev = h.w & TRI_INDEX_MASK;
+      }
+    }
+    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+  }
 }
 
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParams fp)
 {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-    rb.counts[0] = 0;  // ready for the next k_generate
   if(slot >= fp.numSlots)
     return;
   int px, py;
@@ -723,38 +935,57 @@ __global__ void k_mean(const float4* __restrict__ img, size_t n, double* out3)
 }  // namespace
 
 // ---- host-side launchers ----------------------------------------------------------------------------------------
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm)
+PtTuning g_tuning;
+
+void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
+                     hipEvent_t recordAfterAccum)
 {
-  FrameParams    fp       = fpIn;
-  const uint32_t n        = fp.numSlots;
-  const uint32_t gridAll  = (n + 255) / 256;
-  const uint32_t gridWave = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  FrameParams    fp        = fpIn;
+  const uint32_t n         = fp.numSlots;
+  const uint32_t gridAll   = (n + 255) / 256;
+  const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  const uint32_t gridTrace = wavesAll < PT_PERSISTENT_WAVES ? wavesAll : PT_PERSISTENT_WAVES;  // 256 CUs x 20 resident waves
+  const uint32_t gridShade = wavesAll < 256u * 12u ? wavesAll : 256u * 12u;
+  const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
+    (void)hipMemsetAsync(rb.counts, 0, sizeof(uint32_t) * CNT_STRIDE * size_t(fp.st.maxDepth + 2), stream);
     pt_timers_begin(tm, stream, 0);
     k_generate<<<gridAll, 256, 0, stream>>>(scene, rb, fp);
     pt_timers_end(tm, stream, 0);
-    uint32_t* qIn   = rb.queueA;
-    uint32_t* qOut  = rb.queueB;
-    int       inIdx = 0, outIdx = 1;
+    uint32_t* qIn  = rb.queueA;
+    uint32_t* qOut = rb.queueB;
     for(int depth = 0; depth < fp.st.maxDepth; ++depth)
     {
+      const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
       pt_timers_begin(tm, stream, 1);
-      k_closest<<<gridWave, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, inIdx);
+      if(depth < g_tuning.simpleClosestBounces)
+        k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
+      else
+        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow);
+      k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
-      k_shade<<<gridWave, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, inIdx, outIdx, depth);
+      k_shade<<<gridShade, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
       pt_timers_end(tm, stream, 2);
       pt_timers_begin(tm, stream, 3);
-      k_shadow_rr<<<gridWave, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, outIdx, depth == fp.st.maxDepth - 1 ? 1 : 0);
+      if(depth < g_tuning.simpleShadowBounces)
+        k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
+      else
+        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow);
+      k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
       pt_timers_end(tm, stream, 3);
       std::swap(qIn, qOut);
-      std::swap(inIdx, outIdx);
     }
+    // the running mean folds frames in order: wait for the previous frame's accumulate (another stream)
+    if(waitBeforeAccum && s == 0)
+      (void)hipStreamWaitEvent(stream, waitBeforeAccum, 0);
     pt_timers_begin(tm, stream, 4);
     k_accumulate<<<gridAll, 256, 0, stream>>>(rb, fp);
     pt_timers_end(tm, stream, 4);
+    if(recordAfterAccum && s == fp.st.maxSamples - 1)
+      (void)hipEventRecord(recordAfterAccum, stream);
   }
 }
 
