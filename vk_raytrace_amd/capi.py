@@ -58,6 +58,9 @@ def lib():
     """Loads libptmi.so; raises if it has not been built (there is no Python/CPU fallback)."""
     global _lib
     if _lib is None:
+        # libptmi overlaps several frames on separate HIP streams; HIP maps streams onto 4 hardware queues unless told
+        # otherwise, which serialises them.  Must be set before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C vk_raytrace_amd/csrc` "
                               "(or __graft_entry__.build()); the HIP library is the only implementation")

@@ -231,6 +231,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   if(!out_ctx)
     return PT_ERR_INVALID;
   *out_ctx  = nullptr;
+  // frames in flight need one hardware queue each; effective only if the HIP runtime is not initialised yet
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if(e != hipSuccess || count <= 0)

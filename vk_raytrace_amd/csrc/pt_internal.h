@@ -40,7 +40,7 @@ struct PtTuning {
   int simpleClosestBounces = 9999;   // bounces whose closest-hit stage uses the lock-step kernel (coherent rays)
   int simpleShadowBounces  = 9999;
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;
-  int framesInFlight       = 3;    // independent frames overlapped on separate streams (accumulate stays ordered)
+  int framesInFlight       = 7;    // independent frames overlapped on separate streams (accumulate stays ordered)
 };
 extern PtTuning g_tuning;
 struct StageTimers;  // pt_capi.hip

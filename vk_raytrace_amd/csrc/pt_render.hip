@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
       if(alive && L.done)
       {
         bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-        if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO))
+        if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
         {
           lane_begin_count(L);  // stay alive: pass B runs in the same loop
           L.done = S.numTris == 0;
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
         {
           if(!fallback)
           {
-            uint32_t nDraw = (L.pass == 1) ? L.cnt : 0u;
+            uint32_t nDraw = L.cnt;  // pass A's count when it is final, else pass B's
             if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
               ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
             uint32_t s2 = seed;
@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_s(DeviceScene S, Render
   bool   dummy;
   traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
   bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
-  uint32_t nDraw    = 0;
-  if(!fallback && (h.flags & TF_SAW_ZERO))
+  uint32_t nDraw    = h.count;
+  if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
   {
     RayHit c;
     traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
       if(alive && L.done)
       {
         bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
-        if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO))
+        if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
         {
           lane_begin_count(L);
           L.done = S.numTris == 0;
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
           bool inShadow = L.opaqueHit;  // an opaque occluder ends the ray without a draw (trace contract T6)
           if(!fallback && !L.opaqueHit)
           {
-            uint32_t nDraw = (L.pass == 1) ? L.cnt : 0u;
+            uint32_t nDraw = L.cnt;
             if(L.bslot != BVH_NONE)
               ++nDraw;
             uint32_t s2 = seed;
@@ -707,8 +707,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_s(DeviceScene S, RenderB
   if(!inShadow)
   {
     bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
-    uint32_t nDraw    = 0;
-    if(!fallback && (h.flags & TF_SAW_ZERO))
+    uint32_t nDraw    = h.count;
+    if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
     {
       RayHit c;
       traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,

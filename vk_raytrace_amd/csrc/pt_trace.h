@@ -29,8 +29,10 @@
 #include "pt_surface.h"
 
 #define TRACE_BLOCK 64
+#ifndef STACK_LDS
 #define STACK_LDS 32
-#define STACK_SPILL 32
+#endif
+#define STACK_SPILL (64 - STACK_LDS)
 
 enum TraceMode {
   TM_RAW_ALL = 0,        // exact: smallest key > (tPrev,wPrev), every triangle is a candidate, no opacity evaluation
@@ -47,8 +49,16 @@ struct RayHit {
   uint32_t slot;   // TriRec slot (leaf order); BVH_NONE: nothing
   uint32_t w;      // world triangle index | flags << 29
   uint32_t flags;  // TF_*
-  uint32_t count;  // TM_COUNT result
+  uint32_t count;  // TM_COUNT: zero-opacity candidates in range.  TM_CLOSEST / TM_SHADOW: zero-opacity candidates SEEN
+  float    zeroMaxT;  // TM_CLOSEST / TM_SHADOW: largest t among the zero-opacity candidates seen (-1: none)
 };
+
+// After pass A: if every zero-opacity candidate that was evaluated lies strictly in front of the final certain hit
+// (or there is no hit and all of them are inside the ray range), `count` is already the number of draws they
+// consume and pass B is unnecessary.  Traversal is near-to-far, so this is the common case.
+PT_DEV bool pass_a_count_is_final(const RayHit& h) { return h.slot == BVH_NONE || h.zeroMaxT < h.t; }
+PT_DEV bool pass_a_count_is_final(uint32_t bslot, float bt, float zeroMaxT) { return bslot == BVH_NONE || zeroMaxT < bt; }
+
 
 PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta < tb || (ta == tb && wa < wb); }
 
@@ -88,9 +98,10 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   best.slot  = BVH_NONE;
   best.t     = tmax;
   best.w     = 0xffffffffu;
-  best.flags = 0;
-  best.count = 0;
-  opaqueHit  = false;
+  best.flags    = 0;
+  best.count    = 0;
+  best.zeroMaxT = -1.0f;
+  opaqueHit     = false;
   if(S.numTris == 0)
     return;
 
@@ -205,7 +216,14 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
                 const float op = hit_opacity(S, tr, u, v);
                 certain        = op >= 1.0f;
                 if(!certain)
+                {
                   best.flags |= (op <= 0.0f) ? TF_SAW_ZERO : TF_SAW_FRAC;
+                  if(op <= 0.0f)
+                  {
+                    best.count++;
+                    best.zeroMaxT = fmaxf(best.zeroMaxT, t);
+                  }
+                }
               }
               if(certain)
               {
