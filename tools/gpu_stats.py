@@ -4,7 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vk_raytrace_amd import capi, workloads, host_device as hd
 from vk_raytrace_amd.renderer import HipRenderer
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-wl = workloads.c3_sponza(1920, 1080, 8, tex_size=256); wl.scene.finalize(capi.pack_vertices)
+wl = workloads.c3_sponza(1920, 1080, 8, tex_size=256)
+if os.environ.get("PT_OPAQUE_FOLIAGE") == "1":   # experiment: how much does stochastic alpha cost?
+    for m in wl.scene.materials:
+        m["alphaMode"] = 0
+wl.scene.finalize(capi.pack_vertices)
 r = HipRenderer(); r.setup(0); r.set_scene(wl.scene); integ, _ = r.set_env(wl.env)
 r.set_camera(capi.camera_lookat(wl.scene.camera, 1920 / 1080)); r.set_sunsky(hd.default_sun_and_sky()); r.create((1920, 1080))
 st = hd.default_rtx_state(); st.size[0], st.size[1] = 1920, 1080; st.maxDepth = 8; st.fireflyClampThreshold = 4 * integ

@@ -46,7 +46,7 @@ PT_DEV f3 load_pos(const float4* vertices, uint32_t v)
 
 // ---- T1: world-space triangles --------------------------------------------------------------------
 __global__ void k_world_tris(uint32_t numTris, const InstanceRec* __restrict__ inst, uint32_t numInst, const float4* __restrict__ vertices,
-                             const uint32_t* __restrict__ indices, TriRec* __restrict__ out, float4* __restrict__ cen, uint32_t* __restrict__ bounds)
+                             const uint32_t* __restrict__ indices, TriRec* __restrict__ out, AlphaRec* __restrict__ alphaOut, float4* __restrict__ cen, uint32_t* __restrict__ bounds)
 {
   uint32_t w     = blockIdx.x * blockDim.x + threadIdx.x;
   bool     valid = w < numTris;
@@ -77,6 +77,14 @@ __global__ void k_world_tris(uint32_t numTris, const InstanceRec* __restrict__ i
     r.e1n  = make_float4(e1.x, e1.y, e1.z, __uint_as_float(lo));
     r.e2p  = make_float4(e2.x, e2.y, e2.z, __uint_as_float(k));
     out[w] = r;
+    {  // any-hit inputs (raw texcoords of the three vertices + material)
+      const float4 b0 = vertices[size_t(I.vertexOffset + t[0]) * 2 + 1], b1 = vertices[size_t(I.vertexOffset + t[1]) * 2 + 1], b2 = vertices[size_t(I.vertexOffset + t[2]) * 2 + 1];
+      AlphaRec     ar;
+      ar.uv0[0] = b0.x; ar.uv0[1] = b0.y; ar.uv1[0] = b1.x; ar.uv1[1] = b1.y; ar.uv2[0] = b2.x; ar.uv2[1] = b2.y;
+      ar.material = uint32_t(I.materialIndex < 0 ? 0 : I.materialIndex);
+      ar._pad     = 0;
+      alphaOut[w] = ar;
+    }
     f3 mn  = f3{fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z))};
     f3 mx  = f3{fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z))};
     c      = (mn + mx) * 0.5f;
@@ -235,14 +243,15 @@ PT_DEV void tri_box(const TriRec& r, f3& lo, f3& hi)
   hi    = hi + pad;
 }
 
-__global__ void k_gather(uint32_t n, const uint32_t* __restrict__ vals, const TriRec* __restrict__ in, TriRec* __restrict__ out, float4* __restrict__ leafLo,
-                         float4* __restrict__ leafHi)
+__global__ void k_gather(uint32_t n, const uint32_t* __restrict__ vals, const TriRec* __restrict__ in, TriRec* __restrict__ out, const AlphaRec* __restrict__ alphaIn,
+                         AlphaRec* __restrict__ alphaOut, float4* __restrict__ leafLo, float4* __restrict__ leafHi)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  TriRec r = in[vals[i]];
-  out[i]   = r;
+  TriRec r    = in[vals[i]];
+  out[i]      = r;
+  alphaOut[i] = alphaIn[vals[i]];
   f3 lo, hi;
   tri_box(r, lo, hi);
   leafLo[i] = make_float4(lo.x, lo.y, lo.z, 0.f);
@@ -341,8 +350,16 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ childL, const uint32
   }
 }
 
+// leaf reference of sorted slot `i`: non-opaque triangles are tagged so that traversal fetches their AlphaRec up front
+PT_DEV uint32_t leaf_ref(const TriRec* __restrict__ tris, uint32_t leaf)
+{
+  const uint32_t slot  = leaf & ~BVH_LEAF;
+  const uint32_t flags = __float_as_uint(tris[slot].p0w.w) >> 29;
+  return BVH_LEAF | slot | ((flags & TRI_OPAQUE) ? 0u : BVH_ALPHA);
+}
+
 __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const uint32_t* __restrict__ childR, const float4* __restrict__ leafLo,
-                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, BvhNode* __restrict__ out)
+                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, const TriRec* __restrict__ tris, BvhNode* __restrict__ out)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= numInner)
@@ -356,19 +373,105 @@ __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const 
   nd.a   = make_float4(llo.x, llo.y, llo.z, lhi.x);
   nd.b   = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
   nd.c   = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
-  nd.d   = make_uint4(l, r, 0u, 0u);
+  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : l, (r & BVH_LEAF) ? leaf_ref(tris, r) : r, 0u, 0u);
   out[i] = nd;
 }
 
-__global__ void k_single_leaf(const float4* leafLo, const float4* leafHi, BvhNode* out)
+__global__ void k_single_leaf(const float4* leafLo, const float4* leafHi, const TriRec* tris, BvhNode* out)
 {
   BvhNode nd;
   float4  lo = leafLo[0], hi = leafHi[0];
   nd.a   = make_float4(lo.x, lo.y, lo.z, hi.x);
   nd.b   = make_float4(hi.y, hi.z, FLT_MAX, FLT_MAX);
   nd.c   = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-  nd.d   = make_uint4(0u | BVH_LEAF, BVH_NONE, 0u, 0u);
+  nd.d   = make_uint4(leaf_ref(tris, BVH_LEAF), BVH_NONE, 0u, 0u);
   out[0] = nd;
+}
+
+
+// ---- collapse BVH2 -> wide BVH (level-synchronous; one thread per wide node) -------------------------------------
+struct CollapseItem {
+  uint32_t b2;    // binary node to expand
+  uint32_t wide;  // wide node it becomes
+};
+PT_DEV float half_area(float4 lo, float4 hi)
+{
+  float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* __restrict__ qin, uint32_t nIn, CollapseItem* __restrict__ qout, uint32_t* counters /* [0]=nOut [1]=wideCount */,
+                           WideNode* __restrict__ out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= nIn)
+    return;
+  const CollapseItem it = qin[i];
+  uint32_t           id[PT_BVH_WIDTH];
+  float4             lo[PT_BVH_WIDTH], hi[PT_BVH_WIDTH];
+  int                n = 0;
+  auto               push_children = [&](uint32_t node) {
+    const BvhNode nd = b2[node];
+    id[n] = nd.d.x; lo[n] = make_float4(nd.a.x, nd.a.y, nd.a.z, 0.f); hi[n] = make_float4(nd.a.w, nd.b.x, nd.b.y, 0.f); ++n;
+    if(nd.d.y != BVH_NONE)
+    {
+      id[n] = nd.d.y; lo[n] = make_float4(nd.b.z, nd.b.w, nd.c.x, 0.f); hi[n] = make_float4(nd.c.y, nd.c.z, nd.c.w, 0.f); ++n;
+    }
+  };
+  push_children(it.b2);
+  while(n < PT_BVH_WIDTH)
+  {
+    int   best = -1;
+    float bestA = -1.f;
+    for(int k = 0; k < n; ++k)
+      if(!(id[k] & BVH_LEAF))
+      {
+        float a = half_area(lo[k], hi[k]);
+        if(a > bestA)
+        {
+          bestA = a;
+          best  = k;
+        }
+      }
+    if(best < 0)
+      break;
+    const uint32_t node = id[best];
+    // replace slot `best` by the first child, append the second
+    id[best] = id[n - 1]; lo[best] = lo[n - 1]; hi[best] = hi[n - 1];
+    --n;
+    push_children(node);
+  }
+  WideNode w;
+  for(int q = 0; q < PT_WIDE_Q; ++q)
+  {
+    float* mnx = &w.minx[q].x; float* mny = &w.miny[q].x; float* mnz = &w.minz[q].x;
+    float* mxx = &w.maxx[q].x; float* mxy = &w.maxy[q].x; float* mxz = &w.maxz[q].x;
+    uint32_t* ch = &w.child[q].x;
+    for(int k = 0; k < 4; ++k)
+    {
+      int c = q * 4 + k;
+      if(c < n)
+      {
+        mnx[k] = lo[c].x; mny[k] = lo[c].y; mnz[k] = lo[c].z; mxx[k] = hi[c].x; mxy[k] = hi[c].y; mxz[k] = hi[c].z;
+        if(id[c] & BVH_LEAF)
+          ch[k] = id[c];
+        else
+        {
+          uint32_t wid = atomicAdd(&counters[1], 1u);
+          uint32_t qi  = atomicAdd(&counters[0], 1u);
+          qout[qi]     = CollapseItem{id[c], wid};
+          ch[k]        = wid;
+        }
+      }
+      else
+      {
+        mnx[k] = mny[k] = mnz[k] = FLT_MAX;
+        mxx[k] = mxy[k] = mxz[k] = -FLT_MAX;
+        ch[k]                    = BVH_NONE;
+      }
+    }
+    w.pad[q] = make_uint4(0, 0, 0, 0);
+  }
+  out[it.wide] = w;
 }
 
 }  // namespace
@@ -386,8 +489,9 @@ __global__ void k_single_leaf(const float4* leafLo, const float4* leafHi, BvhNod
 
 // Builds TriRec[numTris] (leaf order) and BvhNode[max(1,numTris-1)] into caller-allocated device memory.
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, BvhNode* dNodesOut, char* err, size_t errLen)
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen)
 {
+  *numWideOut = 0;
   if(numTris == 0)
     return 0;
   const uint32_t n          = numTris;
@@ -396,6 +500,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   const uint32_t G          = (n + B - 1) / B;
 
   TriRec*   dUnsorted = nullptr;
+  AlphaRec* dAlphaUnsorted = nullptr;
   float4 *  dCen = nullptr, *dLeafLo = nullptr, *dLeafHi = nullptr, *dNodeLo = nullptr, *dNodeHi = nullptr;
   uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr, *dHist = nullptr, *dBounds = nullptr;
   uint32_t *dChildL = nullptr, *dChildR = nullptr, *dParI = nullptr, *dParL = nullptr;
@@ -403,6 +508,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   uint32_t  initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
 
   HIPCHK(hipMalloc(&dUnsorted, sizeof(TriRec) * size_t(n)));
+  HIPCHK(hipMalloc(&dAlphaUnsorted, sizeof(AlphaRec) * size_t(n)));
   HIPCHK(hipMalloc(&dCen, sizeof(float4) * size_t(n)));
   HIPCHK(hipMalloc(&dLeafLo, sizeof(float4) * size_t(n)));
   HIPCHK(hipMalloc(&dLeafHi, sizeof(float4) * size_t(n)));
@@ -422,7 +528,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   HIPCHK(hipMemcpyAsync(dBounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream));
 
-  k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dCen, dBounds);
+  k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
   k_morton<<<G, B, 0, stream>>>(n, dCen, dBounds, dKeysA, dValsA);
   {
     uint32_t *kin = dKeysA, *kout = dKeysB, *vin = dValsA, *vout = dValsB;
@@ -437,29 +543,59 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     }
     // after 4 passes the sorted data is back in A
   }
-  k_gather<<<G, B, 0, stream>>>(n, dValsA, dUnsorted, dTrisOut, dLeafLo, dLeafHi);
+  k_gather<<<G, B, 0, stream>>>(n, dValsA, dUnsorted, dTrisOut, dAlphaUnsorted, dAlphaOut, dLeafLo, dLeafHi);
   if(n == 1)
   {
-    k_single_leaf<<<1, 1, 0, stream>>>(dLeafLo, dLeafHi, dNodesOut);
+    k_single_leaf<<<1, 1, 0, stream>>>(dLeafLo, dLeafHi, dTrisOut, dNodesOut);
   }
   else
   {
     k_hierarchy<<<G, B, 0, stream>>>(int(n), dKeysA, dChildL, dChildR, dParI, dParL);
     k_refit<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
-    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dNodesOut);
+    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(stream));
 
+  // ---- collapse to the wide layout, one BVH level per launch (the queue sizes come back to the host between levels;
+  // the build is not on the timed path)
   {
-    void* all[] = {dUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
+    CollapseItem* dQ[2] = {nullptr, nullptr};
+    uint32_t*     dCnt  = nullptr;
+    HIPCHK(hipMalloc(&dQ[0], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(hipMalloc(&dQ[1], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(hipMalloc(&dCnt, 8));
+    CollapseItem first{0u, 0u};
+    uint32_t     cnt[2] = {0u, 1u};  // next-queue size, wide nodes allocated (root = 0)
+    HIPCHK(hipMemcpyAsync(dQ[0], &first, sizeof(first), hipMemcpyHostToDevice, stream));
+    uint32_t nIn = 1;
+    int      cur = 0;
+    bool     ok  = true;
+    while(nIn && ok)
+    {
+      HIPCHK(hipMemcpyAsync(dCnt, cnt, 8, hipMemcpyHostToDevice, stream));
+      k_collapse<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, dWideOut);
+      HIPCHK(hipMemcpyAsync(cnt, dCnt, 8, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      nIn    = cnt[0];
+      cnt[0] = 0;
+      cur ^= 1;
+    }
+    *numWideOut = cnt[1];
+    (void)hipFree(dQ[0]);
+    (void)hipFree(dQ[1]);
+    (void)hipFree(dCnt);
+  }
+
+  {
+    void* all[] = {dUnsorted, dAlphaUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
     for(void* p : all)
       (void)hipFree(p);
   }
   return 0;
 fail:
 {
-  void* all[] = {dUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
+  void* all[] = {dUnsorted, dAlphaUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
   for(void* p : all)
     if(p)
       (void)hipFree(p);

@@ -30,8 +30,8 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
-  DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dTris, dEnv, dEnvAccel;
-  uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0;
+  DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dEnv, dEnvAccel;
+  uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0;
   bool     haveScene = false, haveAccel = false, haveEnv = false;
   DeviceScene scene{};
 
@@ -164,7 +164,10 @@ void refresh_scene_ptrs(pt_context* c)
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
   s.texels       = (const uint32_t*)c->dTexels.p;
   s.bvh          = (const BvhNode*)c->dBvh.p;
+  s.wide         = (const WideNode*)c->dWide.p;
   s.tris         = (const TriRec*)c->dTris.p;
+  s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
+  s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.env          = (const float4*)c->dEnv.p;
   s.envAccel     = (const pt_EnvAccel*)c->dEnvAccel.p;
   s.numTris      = c->numTris;
@@ -303,7 +306,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dTris, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dEnv,
                    &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -444,6 +447,26 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     for(uint32_t t = 0; t < d->numTextures; ++t)
       HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + recs[t].offset, d->textures[t].rgba8, size_t(recs[t].w) * recs[t].h * 4, hipMemcpyHostToDevice));
     if((rc = upload(c, c->dTexRecs, recs.data(), sizeof(TexRec) * recs.size())) != PT_OK) return rc;
+    // compact alpha view of every material (what the any-hit evaluation reads)
+    std::vector<AlphaMat> am(d->numMaterials);
+    for(uint32_t m = 0; m < d->numMaterials; ++m)
+    {
+      const pt_GltfShadeMaterial& mt = d->materials[m];
+      AlphaMat&                   a  = am[m];
+      std::memset(&a, 0, sizeof(a));
+      a.factorA = mt.pbrBaseColorFactor[3];
+      a.cutoff  = mt.alphaCutoff;
+      a.mode    = mt.alphaMode;
+      a.tex     = mt.pbrBaseColorTexture;
+      for(int k = 0; k < 8; ++k)
+        a.m[k] = mt.uvTransform[k];
+      if(mt.pbrBaseColorTexture > -1)
+      {
+        const TexRec& tr = recs[mt.pbrBaseColorTexture];
+        a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8);
+      }
+    }
+    if((rc = upload(c, c->dAlphaMats, am.data(), sizeof(AlphaMat) * am.size())) != PT_OK) return rc;
   }
   c->numInstances = d->numNodes;
   c->numTris      = uint32_t(triTotal);
@@ -462,11 +485,13 @@ int pt_build_accel(pt_context* c)
   int rc;
   c->numBvhNodes = c->numTris > 1 ? c->numTris - 1 : 1;
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dBvh, sizeof(BvhNode) * size_t(c->numBvhNodes))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dWide, sizeof(WideNode) * size_t(c->numBvhNodes))) != PT_OK) return rc;
   auto t0 = std::chrono::steady_clock::now();
   char msg[256];
   if(pt_accel_build(c->stream, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
-                    (TriRec*)c->dTris.p, (BvhNode*)c->dBvh.p, msg, sizeof(msg)) != 0)
+                    (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p, (BvhNode*)c->dBvh.p, (WideNode*)c->dWide.p, &c->numWideNodes, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
   HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -784,10 +809,10 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.msAccumulate = c->timers.ms[4];
   s.launchesTraceClosest = c->timers.launchesClosest;
   s.numTriangles = c->numTris;
-  s.numBvhNodes  = c->numBvhNodes;
+  s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;
   s.msBuildAccel = c->msBuild;
   uint64_t bytes = 0;
-  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dTris, &c->dEnv, &c->dEnvAccel};
+  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dEnv, &c->dEnvAccel};
   for(const DevBuf* b : sb)
     bytes += b->bytes;
   s.bytesScene = bytes;

@@ -24,7 +24,42 @@ struct BvhNode {
   uint4  d;  // left, right (bit31 set: leaf -> TriRec slot), 0, 0
 };
 #define BVH_LEAF 0x80000000u
+#define BVH_ALPHA 0x40000000u  // leaf reference: the triangle is non-opaque (its AlphaRec is fetched together with its TriRec)
+#define BVH_SLOT_MASK 0x3fffffffu
 #define BVH_NONE 0xffffffffu
+
+// Any-hit inputs of a triangle, in leaf order: what the reference's HitTest gathers through
+// InstanceData -> indices -> 3 x VertexAttributes (shaders/traceray_rq.glsl:62-79), flattened to one 32-byte record
+// so that an opacity evaluation is 3 dependent loads deep instead of 5.
+struct AlphaRec {
+  float    uv0[2], uv1[2], uv2[2];  // raw texcoords (handedness bit left in place, Appendix C-8)
+  uint32_t material;
+  uint32_t _pad;
+};
+// The alpha-relevant part of a material + its base-colour texture descriptor (64 B, one per material, cache resident).
+struct AlphaMat {
+  float    factorA, cutoff;
+  int32_t  mode, tex;             // alphaMode, pbrBaseColorTexture (-1: none)
+  float    m[8];                  // uvTransform columns 0 and 1 (the two the (u,v) result needs)
+  uint32_t texOffset;
+  int32_t  texW, texH, texMag;    // wrap modes packed: wrapS | wrapT << 8 in texWrap
+  int32_t  texWrap;
+  uint32_t _pad;
+};
+
+// Wide node (PT_BVH_WIDTH = 4 or 8 children), collapsed on device from the binary LBVH by surface area.  The
+// traversal is bound by dependent memory round trips, not ALU, so fewer / fatter steps win: one node fetch
+// (W/4 * 7 aligned 16-byte loads, all in flight together) decides W children.  SoA inside the node.
+#ifndef PT_BVH_WIDTH
+#define PT_BVH_WIDTH 4
+#endif
+#define PT_WIDE_Q (PT_BVH_WIDTH / 4)
+struct WideNode {
+  float4 minx[PT_WIDE_Q], miny[PT_WIDE_Q], minz[PT_WIDE_Q];
+  float4 maxx[PT_WIDE_Q], maxy[PT_WIDE_Q], maxz[PT_WIDE_Q];
+  uint4  child[PT_WIDE_Q];   // bit31: leaf -> TriRec slot; BVH_NONE: empty slot (its box is inverted)
+  uint4  pad[PT_WIDE_Q];     // pads the node to 128 B (W=4) / 256 B (W=8)
+};
 
 // ---- scene records -------------------------------------------------------------------------------
 // One per TLAS instance (glTF node): what the reference reads through gl_InstanceCustomIndex ->
@@ -58,8 +93,11 @@ struct DeviceScene {
   const pt_Light*             lights;
   const TexRec*               texRecs;
   const uint32_t*             texels;  // RGBA8 pool
-  const BvhNode*              bvh;
+  const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
+  const WideNode*             wide;  // collapsed wide BVH
   const TriRec*               tris;
+  const AlphaRec*             alphaRecs;  // leaf order, parallel to tris
+  const AlphaMat*             alphaMats;  // one per material
   const float4*               env;  // RGBA32F lat-long
   const pt_EnvAccel*          envAccel;
   int32_t                     envW, envH;

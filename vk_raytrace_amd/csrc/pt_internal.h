@@ -7,7 +7,7 @@
 
 // pt_accel.hip
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, BvhNode* dNodesOut, char* err, size_t errLen);
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen);
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
 // Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):

@@ -61,6 +61,22 @@ PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
 template <bool SHADOW>
 PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters)
 {
+#if PT_BVH_WIDTH != 2
+  const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
+  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.o, L.idir, lim, [&](uint32_t c) {
+    if(L.sp < STACK_LDS)
+      lds[L.sp++ * TRACE_BLOCK] = c;
+    else if(L.sp < STACK_LDS + STACK_SPILL)
+      spill[L.sp++ - STACK_LDS] = c;
+    else
+      atomicAdd(&counters->stackOverflow, 1u);
+  });
+  if(nxt != BVH_NONE)
+    L.cur = nxt;
+  else
+    lane_pop(L, lds, spill);
+}
+#else
   const BvhNode* np = S.bvh + L.cur;
   const float4   a = np->a, b = np->b, c = np->c;
   const uint4    ch = np->d;
@@ -98,13 +114,17 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   else
     lane_pop(L, lds, spill);
 }
+#endif
 
 // One leaf (triangle) visit; same candidate rules as traverse<TM_CLOSEST / TM_SHADOW / TM_COUNT>.
 template <bool SHADOW>
 PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill)
 {
-  const uint32_t slot  = L.cur & ~BVH_LEAF;
+  const uint32_t slot  = L.cur & BVH_SLOT_MASK;
   const TriRec   tr    = S.tris[slot];
+  AlphaRec       ar;
+  if(L.cur & BVH_ALPHA)
+    ar = S.alphaRecs[slot];
   const uint32_t wbits = __float_as_uint(tr.p0w.w);
   const uint32_t flags = wbits >> 29;
   const bool     opq   = (flags & TRI_OPAQUE) != 0;
@@ -118,7 +138,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
       {
         if(key_less(t, w, L.tmax, L.wLimit))
         {
-          const float op = hit_opacity(S, tr, u, v);
+          const float op = opacity_from(S, ar, u, v);
           if(op <= 0.0f)
             L.cnt++;
           else if(op < 1.0f)
@@ -136,7 +156,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
         bool certain = opq;
         if(!opq)
         {
-          const float op = hit_opacity(S, tr, u, v);
+          const float op = opacity_from(S, ar, u, v);
           certain        = op >= 1.0f;
           if(!certain)
           {

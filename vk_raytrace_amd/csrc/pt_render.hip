@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_x(DeviceScene S, Render
       if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
         break;
       atomicAdd(&rb.counters->alphaTests, 1ull);
-      if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+      if(alpha_test(S, h.slot, h.u, h.v, seed))
         break;
       tPrev = h.t;
       wPrev = h.w & TRI_INDEX_MASK;
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_x(DeviceScene S, RenderB
         if(h.slot == BVH_NONE)
           break;
         atomicAdd(&rb.counters->alphaTests, 1ull);
-        if(alpha_test(S, S.tris[h.slot], h.u, h.v, seed))
+        if(alpha_test(S, h.slot, h.u, h.v, seed))
         {
           inShadow = true;
           break;

@@ -37,22 +37,22 @@ PT_DEV f4 texel_bytes(const uint32_t* pool, const TexRec& tr, int ix, int iy)
 
 // RGBA8 texels are filtered as 0..255 floats and scaled by 1/255 once (the numerical contract both
 // sides of the parity tests use; Vulkan leaves filter precision to the implementation).
-PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv)
+PT_DEV f4 sample_rgba8_rec(const uint32_t* texels, const TexRec& tr, f2 uv)
 {
-  const TexRec tr   = S.texRecs[id];
   const float  s255 = 1.0f / 255.0f;
   float        x = uv.x * float(tr.w), y = uv.y * float(tr.h);
   if(tr.mag == PT_FILTER_NEAREST)
-    return texel_bytes(S.texels, tr, (int)floorf(x), (int)floorf(y)) * s255;
+    return texel_bytes(texels, tr, (int)floorf(x), (int)floorf(y)) * s255;
   x -= 0.5f;
   y -= 0.5f;
   float fx = floorf(x), fy = floorf(y);
   float a = x - fx, b = y - fy;
   int   x0 = (int)fx, y0 = (int)fy;
-  f4    top = texel_bytes(S.texels, tr, x0, y0) * (1.0f - a) + texel_bytes(S.texels, tr, x0 + 1, y0) * a;
-  f4    bot = texel_bytes(S.texels, tr, x0, y0 + 1) * (1.0f - a) + texel_bytes(S.texels, tr, x0 + 1, y0 + 1) * a;
+  f4    top = texel_bytes(texels, tr, x0, y0) * (1.0f - a) + texel_bytes(texels, tr, x0 + 1, y0) * a;
+  f4    bot = texel_bytes(texels, tr, x0, y0 + 1) * (1.0f - a) + texel_bytes(texels, tr, x0 + 1, y0 + 1) * a;
   return (top * (1.0f - b) + bot * b) * s255;
 }
+PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv) { return sample_rgba8_rec(S.texels, S.texRecs[id], uv); }
 
 // Environment: RGBA32F, LINEAR, U repeat / V clamp (reference: src/hdr_sampling.cpp:68-77)
 PT_DEV f3 sample_env(const DeviceScene& S, f2 uv)
@@ -139,31 +139,30 @@ PT_DEV void make_frame(f3 N, f3& T, f3& B)
 }
 
 // Opacity of a non-opaque candidate at barycentrics (bu,bv): baseColorFactor.a x texture alpha, thresholded
-// for ALPHA_MASK (reference: shaders/traceray_rq.glsl:32-94).
-PT_DEV float hit_opacity(const DeviceScene& S, const TriRec& tr, float bu, float bv)
+// for ALPHA_MASK (reference: shaders/traceray_rq.glsl:32-94).  Reads the flattened AlphaRec / AlphaMat records;
+// the arithmetic is the reference's (interpolate raw uvs, row-vector uvTransform, bilinear tap).
+PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, float bv)
 {
-  const InstanceRec&          I   = S.instances[__float_as_uint(tr.e1n.w)];
-  const pt_GltfShadeMaterial& mat = S.materials[I.materialIndex < 0 ? 0 : I.materialIndex];
-  float                       a   = mat.pbrBaseColorFactor[3];
-  if(mat.pbrBaseColorTexture > -1)
+  const AlphaMat am = S.alphaMats[ar.material];
+  float          a  = am.factorA;
+  if(am.tex > -1)
   {
-    const VertexTriple v  = fetch_triangle(S, I, __float_as_uint(tr.e2p.w));
-    const float        b0 = 1.0f - bu - bv;
-    // the handedness bit in the LSB of v is left in place here (reference quirk, Appendix C-8)
-    f2 uv = f2{v.b0.x, v.b0.y} * b0 + f2{v.b1.x, v.b1.y} * bu + f2{v.b2.x, v.b2.y} * bv;
-    // (vec4(uv,1,1) * uvTransform).xy : component i = dot(vec4, column i)
-    const float* m = mat.uvTransform;
-    f2           tuv = f2{((uv.x * m[0] + uv.y * m[1]) + 1.0f * m[2]) + 1.0f * m[3], ((uv.x * m[4] + uv.y * m[5]) + 1.0f * m[6]) + 1.0f * m[7]};
-    a *= sample_rgba8(S, mat.pbrBaseColorTexture, tuv).w;
+    const float b0 = 1.0f - bu - bv;
+    f2          uv = f2{ar.uv0[0], ar.uv0[1]} * b0 + f2{ar.uv1[0], ar.uv1[1]} * bu + f2{ar.uv2[0], ar.uv2[1]} * bv;
+    f2          tuv = f2{((uv.x * am.m[0] + uv.y * am.m[1]) + 1.0f * am.m[2]) + 1.0f * am.m[3], ((uv.x * am.m[4] + uv.y * am.m[5]) + 1.0f * am.m[6]) + 1.0f * am.m[7]};
+    TexRec      tr;
+    tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = am.texWrap >> 8;
+    a *= sample_rgba8_rec(S.texels, tr, tuv).w;
   }
-  return (mat.alphaMode == PT_ALPHA_MASK) ? (a > mat.alphaCutoff ? 1.0f : 0.0f) : a;
+  return (am.mode == PT_ALPHA_MASK) ? (a > am.cutoff ? 1.0f : 0.0f) : a;
 }
+PT_DEV float hit_opacity(const DeviceScene& S, uint32_t slot, float bu, float bv) { return opacity_from(S, S.alphaRecs[slot], bu, bv); }
 
 // Stochastic alpha (any-hit): returns true when the candidate is kept.  Draws exactly one random number
 // (reference: shaders/traceray_rq.glsl:96-101).
-PT_DEV bool alpha_test(const DeviceScene& S, const TriRec& tr, float bu, float bv, uint32_t& seed)
+PT_DEV bool alpha_test(const DeviceScene& S, uint32_t slot, float bu, float bv, uint32_t& seed)
 {
-  float opacity = hit_opacity(S, tr, bu, bv);
+  float opacity = hit_opacity(S, slot, bu, bv);
   return !(rng_next(seed) > opacity);
 }
 

@@ -89,6 +89,70 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
   return true;
 }
 
+#if PT_BVH_WIDTH != 2
+// One wide-node visit: slab-tests the W child boxes against [0, lim], pushes the hit children far-to-near through
+// `push` and returns the nearest one (BVH_NONE when nothing is hit).  (bound - o) * idir keeps NaN confined to the
+// degenerate 0*inf case, which fminf/fmaxf (IEEE minNum/maxNum) ignore -> conservative; the 1 +- 4e-7 factors keep
+// the box test conservative with respect to the triangle test (the boxes themselves are padded at build time).
+template <class Push>
+PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node, f3 o, f3 idir, float lim, Push&& push)
+{
+  const WideNode* np = nodes + node;
+  float           tn[PT_BVH_WIDTH];
+  uint32_t        cid[PT_BVH_WIDTH];
+  int             nh = 0;
+#pragma unroll
+  for(int q = 0; q < PT_WIDE_Q; ++q)
+  {
+    const float4 mnx = np->minx[q], mny = np->miny[q], mnz = np->minz[q];
+    const float4 mxx = np->maxx[q], mxy = np->maxy[q], mxz = np->maxz[q];
+    const uint4  ch  = np->child[q];
+    const float  ax[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ay[4] = {mny.x, mny.y, mny.z, mny.w}, az[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+    const float  bx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, by[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+    const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
+    {
+      float x0 = (ax[k] - o.x) * idir.x, x1 = (bx[k] - o.x) * idir.x;
+      float y0 = (ay[k] - o.y) * idir.y, y1 = (by[k] - o.y) * idir.y;
+      float z0 = (az[k] - o.z) * idir.z, z1 = (bz[k] - o.z) * idir.z;
+      float nr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f)) * 0.9999996f;
+      float fr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim)) * 1.0000004f;
+      bool  h  = (nr <= fr) && (cc[k] != BVH_NONE);
+      tn[q * 4 + k]  = h ? nr : 3.0e38f;
+      cid[q * 4 + k] = cc[k];
+      nh += h ? 1 : 0;
+    }
+  }
+  if(nh == 0)
+    return BVH_NONE;
+  // push all but the nearest, farthest first
+  for(int p = 0; p < PT_BVH_WIDTH - 1 && nh > 1; ++p, --nh)
+  {
+    float    mt  = -1.0f;
+    uint32_t mid = 0;
+    int      ms  = 0;
+#pragma unroll
+    for(int i = 0; i < PT_BVH_WIDTH; ++i)
+    {
+      bool g = tn[i] < 3.0e38f && tn[i] >= mt;
+      mt     = g ? tn[i] : mt;
+      mid    = g ? cid[i] : mid;
+      ms     = g ? i : ms;
+    }
+    push(mid);
+#pragma unroll
+    for(int i = 0; i < PT_BVH_WIDTH; ++i)
+      tn[i] = (i == ms) ? 3.0e38f : tn[i];
+  }
+  uint32_t nearest = BVH_NONE;
+#pragma unroll
+  for(int i = 0; i < PT_BVH_WIDTH; ++i)
+    nearest = tn[i] < 3.0e38f ? cid[i] : nearest;
+  return nearest;
+}
+#endif
+
 // tPrev/wPrev: exclusive lower key (TM_RAW_*); wLimit: with tmax the exclusive upper key (TM_COUNT).
 // `opaqueHit` is only meaningful for TM_SHADOW.
 template <int MODE>
@@ -119,12 +183,27 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   {
     if(!(cur & BVH_LEAF))
     {
-      const BvhNode* np = S.bvh + cur;
-      const float4   a = np->a, b = np->b, c = np->c;
-      const uint4    ch = np->d;
 #ifdef PT_STATS
       ++nNodes;
 #endif
+#if PT_BVH_WIDTH != 2
+      const uint32_t nxt = wide_node_step(S.wide, cur, o, idir, PT_TLIMIT, [&](uint32_t c) {
+        if(sp < STACK_LDS)
+          ldsStack[sp++ * TRACE_BLOCK] = c;
+        else if(sp < STACK_LDS + STACK_SPILL)
+          spill[sp++ - STACK_LDS] = c;
+        else
+          atomicAdd(&counters->stackOverflow, 1u);  // child dropped (flagged; pt_get_stats reports it)
+      });
+      if(nxt != BVH_NONE)
+      {
+        cur = nxt;
+        continue;
+      }
+#else
+      const BvhNode* np = S.bvh + cur;
+      const float4   a = np->a, b = np->b, c = np->c;
+      const uint4    ch = np->d;
       // slab test of both children; (bound - o) * idir keeps NaN confined to the degenerate 0*inf case,
       // which fminf/fmaxf (IEEE minNum/maxNum) then ignore -> conservative
       float lx0 = (a.x - o.x) * idir.x, lx1 = (a.w - o.x) * idir.x;
@@ -160,11 +239,15 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
         cur = hl ? ch.x : ch.y;
         continue;
       }
+#endif
     }
     else
     {
-      const uint32_t slot  = cur & ~BVH_LEAF;
+      const uint32_t slot  = cur & BVH_SLOT_MASK;
       const TriRec   tr    = S.tris[slot];
+      AlphaRec       ar;
+      if(cur & BVH_ALPHA)  // non-opaque triangle: its any-hit inputs travel with the triangle (one round trip)
+        ar = S.alphaRecs[slot];
       const uint32_t wbits = __float_as_uint(tr.p0w.w);
       const uint32_t flags = wbits >> 29;
       const bool     opq   = (flags & TRI_OPAQUE) != 0;
@@ -190,7 +273,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
           {
             if(t > 0.0f && key_less(t, w, tmax, wLimit))
             {
-              const float op = hit_opacity(S, tr, u, v);
+              const float op = opacity_from(S, ar, u, v);
               if(op <= 0.0f)
                 best.count++;
               else if(op < 1.0f)
@@ -213,7 +296,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
               bool certain = opq;
               if(!opq)
               {
-                const float op = hit_opacity(S, tr, u, v);
+                const float op = opacity_from(S, ar, u, v);
                 certain        = op >= 1.0f;
                 if(!certain)
                 {
