@@ -270,6 +270,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
+    if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
   }
   pt_context* c = new pt_context();
@@ -429,13 +430,14 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
       recs[t].mag    = td.magFilter;
       recs[t].wrapS  = td.wrapS;
       recs[t].wrapT  = td.wrapT;
+      recs[t].pot    = ((td.width & (td.width - 1)) == 0 ? 1 : 0) | ((td.height & (td.height - 1)) == 0 ? 2 : 0);
       texels += size_t(td.width) * td.height;
       if(texels > 0xffffffffull)
         return c->fail(PT_ERR_INVALID, "texture pool exceeds 2^32 texels");
     }
     if(d->numTextures == 0)
     {  // a 1x1 white default like src/scene.cpp:513-519
-      recs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, {0, 0}};
+      recs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, 3, 0};
       texels  = 1;
     }
     if((rc = dev_alloc(c, c->dTexels, texels * 4)) != PT_OK) return rc;
@@ -463,7 +465,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
       if(mt.pbrBaseColorTexture > -1)
       {
         const TexRec& tr = recs[mt.pbrBaseColorTexture];
-        a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8);
+        a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8) | (tr.pot << 16);
       }
     }
     if((rc = upload(c, c->dAlphaMats, am.data(), sizeof(AlphaMat) * am.size())) != PT_OK) return rc;

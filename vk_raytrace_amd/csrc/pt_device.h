@@ -42,7 +42,7 @@ struct AlphaMat {
   int32_t  mode, tex;             // alphaMode, pbrBaseColorTexture (-1: none)
   float    m[8];                  // uvTransform columns 0 and 1 (the two the (u,v) result needs)
   uint32_t texOffset;
-  int32_t  texW, texH, texMag;    // wrap modes packed: wrapS | wrapT << 8 in texWrap
+  int32_t  texW, texH, texMag;    // texWrap = wrapS | wrapT << 8 | pot << 16
   int32_t  texWrap;
   uint32_t _pad;
 };
@@ -82,7 +82,8 @@ struct TexRec {
   uint32_t offset;  // texel offset into the RGBA8 pool
   int32_t  w, h;
   int32_t  mag, wrapS, wrapT;
-  int32_t  _pad[2];
+  int32_t  pot;  // bit0: w is a power of two, bit1: h is
+  int32_t  _pad;
 };
 
 struct DeviceScene {

@@ -40,6 +40,7 @@ struct PtTuning {
   int simpleClosestBounces = 9999;   // bounces whose closest-hit stage uses the lock-step kernel (coherent rays)
   int simpleShadowBounces  = 9999;
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;
+  int chunk                = 64;   // rays a persistent wave reserves per queue atomic
   int framesInFlight       = 7;    // independent frames overlapped on separate streams (accumulate stays ordered)
 };
 extern PtTuning g_tuning;

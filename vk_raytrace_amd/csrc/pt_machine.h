@@ -13,7 +13,6 @@
 #pragma once
 #include "pt_trace.h"
 
-#define PT_CHUNK 256        // rays a wave reserves per queue atomic
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)
 
 struct TraceLane {
@@ -182,6 +181,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
 // its idle lanes.  Returns the queue index for this lane or 0xffffffff.
 struct RaySupply {
   uint32_t pos = 0, end = 0;
+  uint32_t chunk = 64;  // rays a wave reserves per queue atomic
   bool     more = true;
 };
 PT_DEV uint32_t supply_next(RaySupply& rs, uint32_t* chunkCounter, uint32_t count, bool wants)
@@ -197,14 +197,14 @@ PT_DEV uint32_t supply_next(RaySupply& rs, uint32_t* chunkCounter, uint32_t coun
       if(lane == 0)
         c = atomicAdd(chunkCounter, 1u);
       c                       = __builtin_amdgcn_readfirstlane(c);
-      const unsigned long long base = (unsigned long long)c * PT_CHUNK;
+      const unsigned long long base = (unsigned long long)c * rs.chunk;
       if(base >= count)
       {
         rs.more = false;
         break;
       }
       rs.pos = uint32_t(base);
-      rs.end = (base + PT_CHUNK < count) ? uint32_t(base + PT_CHUNK) : count;
+      rs.end = (base + rs.chunk < count) ? uint32_t(base + rs.chunk) : count;
     }
     const uint32_t avail = rs.end - rs.pos;
     const uint32_t want  = (uint32_t)__popcll(need);

@@ -156,7 +156,7 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
 }
 
 // Persistent wavefronts: pass A / pass B of the exact stochastic alpha scheme on the trace machine.
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int refillBelow)
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int refillBelow, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
+  rs.chunk = uint32_t(chunk);
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -583,7 +584,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuff
 {
   uint32_t*      C     = rb.counts + depth * CNT_STRIDE;
   const uint32_t count = C[CNT_IN];
-  for(uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x; i < count; i += gridDim.x * SHADE_BLOCK)
+  // one path per lane, no loop: a grid-stride loop around shade_path costs ~120 extra VGPRs (256 vs 136)
+  const uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+  if(i < count)
     shade_path(S, rb, fp, queueIn[i], queueOut, C, depth);
 }
 
@@ -614,7 +617,7 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int refillBelow)
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int refillBelow, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
@@ -623,6 +626,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
+  rs.chunk = uint32_t(chunk);
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -945,7 +949,6 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
   const uint32_t gridAll   = (n + 255) / 256;
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
   const uint32_t gridTrace = wavesAll < PT_PERSISTENT_WAVES ? wavesAll : PT_PERSISTENT_WAVES;  // 256 CUs x 20 resident waves
-  const uint32_t gridShade = wavesAll < 256u * 12u ? wavesAll : 256u * 12u;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
@@ -963,17 +966,17 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
       if(depth < g_tuning.simpleClosestBounces)
         k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
       else
-        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow);
+        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk);
       k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
-      k_shade<<<gridShade, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
+      k_shade<<<wavesAll, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
       pt_timers_end(tm, stream, 2);
       pt_timers_begin(tm, stream, 3);
       if(depth < g_tuning.simpleShadowBounces)
         k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
       else
-        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow);
+        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk);
       k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
       pt_timers_end(tm, stream, 3);
       std::swap(qIn, qOut);

@@ -11,27 +11,31 @@
 #include "pt_device.h"
 
 // ---- textures -------------------------------------------------------------------------------------
-PT_DEV int wrap_index(int i, int n, int mode)
+// Integer texel coordinate -> [0, n) per the Vulkan address modes.  AMD GPUs have no integer divide (each `%` is
+// ~40 instructions), so power-of-two sizes -- flagged per texture -- wrap by masking (identical result, two's complement).
+PT_DEV int wrap_index(int i, int n, int mode, bool pot)
 {
   if(mode == PT_WRAP_CLAMP_TO_EDGE)
     return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
   if(mode == PT_WRAP_MIRRORED_REPEAT)
   {
     int p = 2 * n;
-    int m = i % p;
+    int m = pot ? (i & (p - 1)) : (i % p);
     if(m < 0)
       m += p;
     m -= n;
     int mir = m >= 0 ? m : -(1 + m);
     return (n - 1) - mir;
   }
+  if(pot)
+    return i & (n - 1);
   int m = i % n;
   return m < 0 ? m + n : m;
 }
 
 PT_DEV f4 texel_bytes(const uint32_t* pool, const TexRec& tr, int ix, int iy)
 {
-  uint32_t p = pool[tr.offset + uint32_t(wrap_index(iy, tr.h, tr.wrapT)) * uint32_t(tr.w) + uint32_t(wrap_index(ix, tr.w, tr.wrapS))];
+  uint32_t p = pool[tr.offset + uint32_t(wrap_index(iy, tr.h, tr.wrapT, (tr.pot & 2) != 0)) * uint32_t(tr.w) + uint32_t(wrap_index(ix, tr.w, tr.wrapS, (tr.pot & 1) != 0))];
   return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)};
 }
 
@@ -61,8 +65,9 @@ PT_DEV f3 sample_env(const DeviceScene& S, f2 uv)
   float fx = floorf(x), fy = floorf(y);
   float a = x - fx, b = y - fy;
   int   x0 = (int)fx, y0 = (int)fy;
-  int   xa = wrap_index(x0, S.envW, PT_WRAP_REPEAT), xb = wrap_index(x0 + 1, S.envW, PT_WRAP_REPEAT);
-  int   ya = wrap_index(y0, S.envH, PT_WRAP_CLAMP_TO_EDGE), yb = wrap_index(y0 + 1, S.envH, PT_WRAP_CLAMP_TO_EDGE);
+  const bool wpot = (S.envW & (S.envW - 1)) == 0;
+  int   xa = wrap_index(x0, S.envW, PT_WRAP_REPEAT, wpot), xb = wrap_index(x0 + 1, S.envW, PT_WRAP_REPEAT, wpot);
+  int   ya = wrap_index(y0, S.envH, PT_WRAP_CLAMP_TO_EDGE, false), yb = wrap_index(y0 + 1, S.envH, PT_WRAP_CLAMP_TO_EDGE, false);
   f3    t00 = xyz(S.env[size_t(ya) * S.envW + xa]), t10 = xyz(S.env[size_t(ya) * S.envW + xb]);
   f3    t01 = xyz(S.env[size_t(yb) * S.envW + xa]), t11 = xyz(S.env[size_t(yb) * S.envW + xb]);
   f3    top = t00 * (1.0f - a) + t10 * a;
@@ -151,7 +156,7 @@ PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, fl
     f2          uv = f2{ar.uv0[0], ar.uv0[1]} * b0 + f2{ar.uv1[0], ar.uv1[1]} * bu + f2{ar.uv2[0], ar.uv2[1]} * bv;
     f2          tuv = f2{((uv.x * am.m[0] + uv.y * am.m[1]) + 1.0f * am.m[2]) + 1.0f * am.m[3], ((uv.x * am.m[4] + uv.y * am.m[5]) + 1.0f * am.m[6]) + 1.0f * am.m[7]};
     TexRec      tr;
-    tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = am.texWrap >> 8;
+    tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = (am.texWrap >> 8) & 0xff; tr.pot = am.texWrap >> 16;
     a *= sample_rgba8_rec(S.texels, tr, tuv).w;
   }
   return (am.mode == PT_ALPHA_MASK) ? (a > am.cutoff ? 1.0f : 0.0f) : a;

@@ -325,8 +325,11 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   }
 #undef PT_TLIMIT
 #ifdef PT_STATS
-  atomicAdd(&counters->nodesVisited, (unsigned long long)nNodes);
-  atomicAdd(&counters->trisTested, (unsigned long long)nTris);
+  if(PT_STATS == 0 || (PT_STATS == 1 && MODE == TM_SHADOW) || (PT_STATS == 2 && MODE == TM_CLOSEST) || (PT_STATS == 3 && MODE == TM_COUNT))
+  {
+    atomicAdd(&counters->nodesVisited, (unsigned long long)nNodes);
+    atomicAdd(&counters->trisTested, (unsigned long long)nTris);
+  }
 #endif
 }
 
