@@ -56,7 +56,13 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"  # exercise the torch.distributed / RCCL plumbing with one rank
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -124,7 +130,7 @@ def main():
 
     # the one collective of the path (untimed, reported)
     t0 = time.perf_counter()
-    img = shard.gather_framebuffer(r, rank, world, f"cuda:{local_rank}" if world > 1 else None)
+    img = shard.gather_framebuffer(r, rank, world, f"cuda:{local_rank}" if dist is not None else None, force=force_dist)
     gather_ms = (time.perf_counter() - t0) * 1e3
 
     if dist is not None:

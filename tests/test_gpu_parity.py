@@ -9,6 +9,7 @@ Bars
    radiance; the converged-image bar of BASELINE.md (L2 <= 1e-3) is asserted on the many-frame case.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -18,6 +19,7 @@ from tests.common import Config, render_hip, render_oracle, l2, mismatch_fractio
 from vk_raytrace_amd import capi, host_device as hd, synth, shard, workloads
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -241,3 +243,31 @@ def test_sample_example_orchestrator(env_small):
     assert mismatch_fraction(img, o) <= 2e-3
     assert app.drawPost().shape == (64, 96, 4)
     app.destroy()
+
+
+def test_shard_gather_plumbing_single_rank():
+    """The RCCL-gather plumbing on one rank: zero-copy torch view of pt_local_shard, dist.gather over "nccl",
+    pt_scatter_shards, read-back -- must reproduce pt_read_accum bit for bit.  Runs in a fresh process (torch /
+    RCCL initialisation order must not depend on what the rest of the suite did to the HIP runtime)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, socket
+sys.path.insert(0, %r)
+import numpy as np
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+import torch, torch.distributed as dist
+from tests.common import Config, render_hip
+from vk_raytrace_amd import synth, shard
+cfg = Config(synth.feature_box(tex_size=32), synth.procedural_sky(128, 64), 100, 70)
+h, r = render_hip(cfg, 2, return_obj=True)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+img = shard.gather_framebuffer(r, 0, 1, "cuda:0", force=True)
+dist.destroy_process_group()
+assert np.array_equal(img, h)
+print("GATHER_OK")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

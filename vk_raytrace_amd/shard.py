@@ -44,11 +44,11 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
-def gather_framebuffer(renderer, rank, nranks, device):
+def gather_framebuffer(renderer, rank, nranks, device, force=False):
     """The single collective of the path: gathers every rank's shard on rank 0 and lets libptmi place
     the tiles (pt_scatter_shards).  Returns the full RGBA32F image on rank 0, None elsewhere."""
     renderer.synchronize()
-    if nranks == 1:
+    if nranks == 1 and not force:
         return renderer.read_accum()
     import torch
     import torch.distributed as dist
