@@ -13,7 +13,8 @@ from . import host_device as hd
 
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptmi.so")
+# PT_LIB: developer override used to compare builds of the same HIP library (tools/build_variants.sh); never a fallback
+LIB_PATH = os.environ.get("PT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptmi.so")
 
 # every symbol include/pt_api.h declares: (name, restype, argtypes)
 _P = C.c_void_p

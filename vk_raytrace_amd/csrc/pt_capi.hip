@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 #include "../../include/pt_api.h"
@@ -30,7 +32,7 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
-  DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dEnv, dEnvAccel;
+  DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0;
   bool     haveScene = false, haveAccel = false, haveEnv = false;
   DeviceScene scene{};
@@ -51,6 +53,11 @@ struct pt_context {
   };
   FrameSlot slots[PT_MAX_INFLIGHT];
   int       inflight     = 1;
+  // frames handed to pt_render_frame but not launched yet: consecutive frames with identical state are traced as one
+  // batch (flushed when full and by every call that reads results or changes inputs)
+  pt_RtxState pendState{};
+  int         pendCount = 0;
+  int         batchMax  = 1;
   uint64_t  frameCounter = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
@@ -83,6 +90,7 @@ struct pt_context {
       return (ctx)->fail(e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
   } while(0)
 
+int flush_pending(pt_context* c);  // defined next to pt_render_frame
 namespace {
 
 int dev_alloc(pt_context* c, DevBuf& b, size_t bytes)
@@ -142,6 +150,8 @@ bool affine_inverse(const float* m, double inv[12], double& det3)
 
 hipError_t sync_all(pt_context* c)
 {
+  if(flush_pending(c) != PT_OK)
+    return hipErrorUnknown;
   for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
     if(c->slots[i].stream)
     {
@@ -168,6 +178,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
+  s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
   s.env          = (const float4*)c->dEnv.p;
   s.envAccel     = (const pt_EnvAccel*)c->dEnvAccel.p;
   s.numTris      = c->numTris;
@@ -270,7 +281,9 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
+    if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) g_tuning.persistentWaves = v;
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
+    if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
   }
   pt_context* c = new pt_context();
@@ -307,7 +320,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv,
                    &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -333,6 +346,87 @@ int pt_destroy(pt_context* c)
   (void)hipStreamDestroy(c->stream);
   delete c;
   return PT_OK;
+}
+
+// Opacity maps (pt_device.h): for every non-opaque material whose base-colour texture takes the fast tap, classify each
+// ALPHA_MAP_BLOCK^2 block of base texels + one texel of apron on every side (a bilinear tap based in the block blends
+// texels of that window only).  A state is assigned only when every texel of the window decides the same way with a
+// 1e-5 relative margin -- two orders above the fp32 filtering error -- so the map never changes a result.
+static void build_opacity_maps(const pt_SceneDesc* d, std::vector<AlphaMat>& am, std::vector<uint32_t>& words)
+{
+  struct Key {
+    int   tex, mode;
+    float factor, cutoff;
+    bool  operator<(const Key& o) const { return std::tie(tex, mode, factor, cutoff) < std::tie(o.tex, o.mode, o.factor, o.cutoff); }
+  };
+  std::map<Key, uint32_t> done;
+  words.assign(1, 0u);  // never empty (word 0 is unused padding)
+  for(size_t m = 0; m < am.size(); ++m)
+  {
+    AlphaMat& a = am[m];
+    if(a.mode == PT_ALPHA_OPAQUE || a.tex < 0 || !(a.texWrap & ALPHA_FAST_TAP) || a.texW < ALPHA_MAP_BLOCK || a.texH < ALPHA_MAP_BLOCK)
+      continue;
+    if(!(a.factorA >= 0.0f && a.factorA <= 3.0e38f) || !(std::fabs(a.cutoff) <= 3.0e38f))
+      continue;
+    const Key key{a.tex, a.mode, a.factorA, a.cutoff};
+    auto      it = done.find(key);
+    if(it != done.end())
+    {
+      a.mapOffset = it->second;
+      continue;
+    }
+    const int      W = a.texW, H = a.texH, bw = W >> ALPHA_MAP_SHIFT, bh = H >> ALPHA_MAP_SHIFT;
+    const uint8_t* px = (const uint8_t*)d->textures[a.tex].rgba8;
+    // separable min / max of the alpha byte over [b*B - 1, b*B + B] (wrapped)
+    std::vector<uint8_t> rmin(size_t(bw) * H), rmax(size_t(bw) * H);
+    for(int y = 0; y < H; ++y)
+      for(int bx = 0; bx < bw; ++bx)
+      {
+        uint8_t lo = 255, hi = 0;
+        for(int k = -1; k <= ALPHA_MAP_BLOCK; ++k)
+        {
+          const uint8_t v = px[(size_t(y) * W + ((bx * ALPHA_MAP_BLOCK + k) & (W - 1))) * 4 + 3];
+          lo = v < lo ? v : lo;
+          hi = v > hi ? v : hi;
+        }
+        rmin[size_t(y) * bw + bx] = lo;
+        rmax[size_t(y) * bw + bx] = hi;
+      }
+    const uint32_t off = uint32_t(words.size());
+    words.resize(words.size() + (size_t(bw) * bh + 15) / 16, 0u);
+    const double f = a.factorA, cut = a.cutoff;
+    for(int by = 0; by < bh; ++by)
+      for(int bx = 0; bx < bw; ++bx)
+      {
+        uint8_t lo = 255, hi = 0;
+        for(int k = -1; k <= ALPHA_MAP_BLOCK; ++k)
+        {
+          const int y = (by * ALPHA_MAP_BLOCK + k) & (H - 1);
+          lo = rmin[size_t(y) * bw + bx] < lo ? rmin[size_t(y) * bw + bx] : lo;
+          hi = rmax[size_t(y) * bw + bx] > hi ? rmax[size_t(y) * bw + bx] : hi;
+        }
+        const double vmin = f * lo / 255.0, vmax = f * hi / 255.0;
+        uint32_t     st = ALPHA_ST_UNKNOWN;
+        if(a.mode == PT_ALPHA_MASK)
+        {
+          if(vmin > cut + 1e-5 * std::fmax(std::fabs(cut), vmin))
+            st = ALPHA_ST_ONE;
+          else if((hi == 0 && cut >= 0.0) || vmax < cut - 1e-5 * std::fmax(std::fabs(cut), vmax))
+            st = ALPHA_ST_ZERO;
+        }
+        else  // BLEND: opacity = factor x filtered alpha
+        {
+          if(hi == 0 || f == 0.0)
+            st = ALPHA_ST_ZERO;
+          else if(vmin >= 1.0 + 1e-5)
+            st = ALPHA_ST_ONE;
+        }
+        const uint32_t bidx = uint32_t(by) * uint32_t(bw) + uint32_t(bx);
+        words[off + (bidx >> 4)] |= st << ((bidx & 15u) * 2u);
+      }
+    a.mapOffset = off;
+    done[key]   = off;
+  }
 }
 
 int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
@@ -462,12 +556,18 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
       a.tex     = mt.pbrBaseColorTexture;
       for(int k = 0; k < 8; ++k)
         a.m[k] = mt.uvTransform[k];
+      a.mapOffset = ALPHA_NO_MAP;
       if(mt.pbrBaseColorTexture > -1)
       {
         const TexRec& tr = recs[mt.pbrBaseColorTexture];
         a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8) | (tr.pot << 16);
+        if(tr.wrapS == PT_WRAP_REPEAT && tr.wrapT == PT_WRAP_REPEAT && tr.pot == 3)
+          a.texWrap |= ALPHA_FAST_TAP;
       }
     }
+    std::vector<uint32_t> maps;
+    build_opacity_maps(d, am, maps);
+    if((rc = upload(c, c->dAlphaMaps, maps.data(), 4 * maps.size())) != PT_OK) return rc;
     if((rc = upload(c, c->dAlphaMats, am.data(), sizeof(AlphaMat) * am.size())) != PT_OK) return rc;
   }
   c->numInstances = d->numNodes;
@@ -507,6 +607,9 @@ int pt_set_camera(pt_context* c, const pt_SceneCamera* cam)
   CTX_CHECK(c);
   if(!cam)
     return c->fail(PT_ERR_INVALID, "pt_set_camera: null");
+  int rc = flush_pending(c);  // frames already handed over keep the camera they were given
+  if(rc != PT_OK)
+    return rc;
   c->scene.camera = *cam;
   return PT_OK;
 }
@@ -516,6 +619,9 @@ int pt_set_sunsky(pt_context* c, const pt_SunAndSky* ss)
   CTX_CHECK(c);
   if(!ss)
     return c->fail(PT_ERR_INVALID, "pt_set_sunsky: null");
+  int rc = flush_pending(c);
+  if(rc != PT_OK)
+    return rc;
   c->scene.sunsky = *ss;
   return PT_OK;
 }
@@ -586,8 +692,10 @@ int pt_resize(pt_context* c, int width, int height)
     c->maxTilesPerRank = v > c->maxTilesPerRank ? v : c->maxTilesPerRank;
   c->numSlots = c->numLocalTiles * 1024u;
 
-  int          rc;
-  const size_t n = c->numSlots ? c->numSlots : 1;
+  int rc;
+  // frames per batch: the tuning value, bounded so that one frame slot's path state stays below 2^26 paths (~11 GB)
+  c->batchMax = std::max(1, std::min(g_tuning.batch, int((1u << 26) / (c->numSlots ? c->numSlots : 1u))));
+  const size_t n = size_t(c->numSlots ? c->numSlots : 1) * size_t(c->batchMax);
   for(int i = 0; i < c->inflight; ++i)
   {
     pt_context::FrameSlot& fs = c->slots[i];
@@ -650,8 +758,30 @@ int pt_render_frame(pt_context* c, const pt_RtxState* st)
   HIP_TRY(c, hipSetDevice(c->device));
   if(c->numSlots == 0)
     return PT_OK;
+  pt_RtxState a = *st, b = c->pendState;
+  a.frame = b.frame = 0;
+  const bool joins = c->pendCount > 0 && c->pendCount < c->batchMax && std::memcmp(&a, &b, sizeof(a)) == 0 && st->frame == c->pendState.frame + c->pendCount;
+  int rc;
+  if(!joins && (rc = flush_pending(c)) != PT_OK)
+    return rc;
+  if(c->pendCount == 0)
+    c->pendState = *st;
+  c->pendCount++;
+  c->haveFull = false;
+  c->stats.samples += uint64_t(st->maxSamples) * c->localPixels;
+  if(c->pendCount >= c->batchMax)
+    return flush_pending(c);
+  return PT_OK;
+}
+
+// Launches the pending batch of frames on the next frame slot's stream.
+}  // extern "C"
+int flush_pending(pt_context* c)
+{
+  if(c->pendCount == 0)
+    return PT_OK;
   FrameParams fp{};
-  fp.st            = *st;
+  fp.st            = c->pendState;
   fp.width         = c->width;
   fp.height        = c->height;
   fp.tilesX        = c->tilesX;
@@ -660,17 +790,16 @@ int pt_render_frame(pt_context* c, const pt_RtxState* st)
   fp.nranks        = c->nranks;
   fp.numLocalTiles = c->numLocalTiles;
   fp.numSlots      = c->numSlots;
+  fp.batch         = uint32_t(c->pendCount);
   fp.sample        = 0;
-  {
-    pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
-    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
-    c->lastAccum = fs.accumDone;
-  }
+  c->pendCount     = 0;
+  pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
+  pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
+  c->lastAccum = fs.accumDone;
   HIP_TRY(c, hipGetLastError());
-  c->haveFull = false;
-  c->stats.samples += uint64_t(st->maxSamples) * c->localPixels;
   return PT_OK;
 }
+extern "C" {
 
 int pt_synchronize(pt_context* c)
 {
@@ -682,6 +811,9 @@ int pt_synchronize(pt_context* c)
 
 static int untile_to_rowmajor(pt_context* c)
 {
+  int rc = flush_pending(c);
+  if(rc != PT_OK)
+    return rc;
   // frames run on their own streams; the last accumulate (itself ordered after all earlier ones) gates the readback
   if(c->lastAccum)
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lastAccum, 0));
@@ -747,6 +879,9 @@ int pt_local_shard(pt_context* c, void** device_ptr, size_t* bytes, int* num_loc
   CTX_CHECK(c);
   if(c->width == 0)
     return c->fail(PT_ERR_STATE, "pt_local_shard before pt_resize");
+  int rc = flush_pending(c);
+  if(rc != PT_OK)
+    return rc;
   if(device_ptr) *device_ptr = c->dFrame.p;
   if(bytes) *bytes = sizeof(float4) * size_t(c->maxTilesPerRank) * 1024u;
   if(num_local_tiles) *num_local_tiles = int(c->numLocalTiles);
@@ -814,7 +949,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;
   s.msBuildAccel = c->msBuild;
   uint64_t bytes = 0;
-  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dEnv, &c->dEnvAccel};
+  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel};
   for(const DevBuf* b : sb)
     bytes += b->bytes;
   s.bytesScene = bytes;

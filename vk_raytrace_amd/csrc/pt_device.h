@@ -42,10 +42,22 @@ struct AlphaMat {
   int32_t  mode, tex;             // alphaMode, pbrBaseColorTexture (-1: none)
   float    m[8];                  // uvTransform columns 0 and 1 (the two the (u,v) result needs)
   uint32_t texOffset;
-  int32_t  texW, texH, texMag;    // texWrap = wrapS | wrapT << 8 | pot << 16
+  int32_t  texW, texH, texMag;    // texWrap = wrapS | wrapT << 8 | pot << 16 | ALPHA_FAST_TAP (REPEAT x REPEAT, both sizes 2^k)
   int32_t  texWrap;
-  uint32_t _pad;
+  uint32_t mapOffset;             // first word of this material's opacity map in DeviceScene::alphaMaps, ALPHA_NO_MAP: none
 };
+#define ALPHA_FAST_TAP (1 << 24)
+#define ALPHA_NO_MAP 0xffffffffu
+// Opacity map: a conservative 2-bit classification of every ALPHA_MAP_BLOCK^2 block of base texels (+ a one-texel
+// apron, so that it bounds every bilinear tap whose base texel lies in the block) under the material's factor /
+// cutoff / mode: the any-hit evaluation of most candidates is then one word fetch instead of four texel taps.
+// Exactness: a block is classified only when every texel it can blend decides the same way with a 1e-5 relative
+// margin (fp32 filtering error is < 1e-6); everything else is ALPHA_ST_UNKNOWN and evaluated in full.
+#define ALPHA_MAP_SHIFT 2
+#define ALPHA_MAP_BLOCK (1 << ALPHA_MAP_SHIFT)
+#define ALPHA_ST_UNKNOWN 0u
+#define ALPHA_ST_ZERO 1u    // opacity <= 0 everywhere
+#define ALPHA_ST_ONE 2u     // opacity >= 1 everywhere
 
 // Wide node (PT_BVH_WIDTH = 4 or 8 children), collapsed on device from the binary LBVH by surface area.  The
 // traversal is bound by dependent memory round trips, not ALU, so fewer / fatter steps win: one node fetch
@@ -99,6 +111,7 @@ struct DeviceScene {
   const TriRec*               tris;
   const AlphaRec*             alphaRecs;  // leaf order, parallel to tris
   const AlphaMat*             alphaMats;  // one per material
+  const uint32_t*             alphaMaps;  // opacity maps, 16 blocks per word
   const float4*               env;  // RGBA32F lat-long
   const pt_EnvAccel*          envAccel;
   int32_t                     envW, envH;
@@ -132,6 +145,7 @@ struct FrameParams {
   int32_t     tilesX, tilesY;
   int32_t     rank, nranks;
   uint32_t    numLocalTiles;
-  uint32_t    numSlots;  // numLocalTiles * 1024
+  uint32_t    numSlots;  // numLocalTiles * 1024 (path slots of ONE frame)
+  uint32_t    batch;     // consecutive frames (st.frame, st.frame + 1, ...) traced together: path slot = f * numSlots + pixel slot
   int32_t     sample;    // index of the sample inside this frame
 };

@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "pt_device.h"
-#define PT_REFILL_BELOW_DEFAULT 16
+#define PT_REFILL_BELOW_DEFAULT 48
+#define PT_MIN_GENERATIONS 4  // persistent kernels: rays per lane below which a launch uses fewer waves
 
 // pt_accel.hip
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
@@ -37,11 +38,13 @@ struct RenderBuffers {
 // Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
 // the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
 struct PtTuning {
-  int simpleClosestBounces = 9999;   // bounces whose closest-hit stage uses the lock-step kernel (coherent rays)
-  int simpleShadowBounces  = 9999;
-  int refillBelow          = PT_REFILL_BELOW_DEFAULT;
+  int simpleClosestBounces = 1;   // bounces whose closest-hit stage uses the lock-step kernel (coherent primary rays: 82 % lane utilisation)
+  int simpleShadowBounces  = 0;   // shadow rays differ 10x in length: always on the refilling machine
+  int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
+  int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
-  int framesInFlight       = 7;    // independent frames overlapped on separate streams (accumulate stays ordered)
+  int framesInFlight       = 3;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
+  int batch                = 8;    // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
 extern PtTuning g_tuning;
 struct StageTimers;  // pt_capi.hip

@@ -137,7 +137,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
       {
         if(key_less(t, w, L.tmax, L.wLimit))
         {
-          const float op = opacity_from(S, ar, u, v);
+          const float op = opacity_class(S, ar, u, v);
           if(op <= 0.0f)
             L.cnt++;
           else if(op < 1.0f)
@@ -155,7 +155,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
         bool certain = opq;
         if(!opq)
         {
-          const float op = opacity_from(S, ar, u, v);
+          const float op = opacity_class(S, ar, u, v);
           certain        = op >= 1.0f;
           if(!certain)
           {

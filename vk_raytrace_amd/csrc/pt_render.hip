@@ -93,13 +93,15 @@ PT_DEV f3 offset_ray(f3 p, f3 n)
 __global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
 {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if(slot >= fp.numSlots)
+  if(slot >= fp.numSlots * fp.batch)
     return;
-  int px, py;
-  if(!slot_pixel(fp, rb.slotTile, slot, px, py))
+  const uint32_t fb = slot / fp.numSlots;  // frame of the batch
+  int            px, py;
+  if(!slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py))
     return;
-  const pt_RtxState& st = fp.st;
-  uint32_t           seed;
+  pt_RtxState st = fp.st;
+  st.frame += int(fb);
+  uint32_t seed;
   if(fp.sample == 0)
     seed = rng_tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(st.frame * st.maxSamples));
   else
@@ -155,13 +157,21 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
     rb.ps.hit[slot] = make_float4(t, __uint_as_float(bslot), u, v);
 }
 
-// Persistent wavefronts: pass A / pass B of the exact stochastic alpha scheme on the trace machine.
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int refillBelow, int chunk)
+// Persistent wavefronts on the trace machine (pt_machine.h).  The loop alternates between
+//   service: lanes whose ray has finished settle it (pass A -> pass B transition, RNG draws, hit record) and every
+//            idle lane pulls the next ray from the queue;
+//   run:     the traversal steps, executed until fewer than `minRun` lanes are still traversing (or, once the
+//            queue is empty, until all are done).
+// Settling rays outside the run loop keeps the hot loop to the node step and the triangle test; a finished lane
+// waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
+__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[CNT_IN];
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
+    return;  // small queue: fewer waves, so that each still refills its lanes a few times
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
@@ -169,8 +179,41 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
+  L.cur                     = 0;
+#ifdef PT_HIST
+  unsigned long long hIter = 0, hInner = 0, hLeaf = 0, hService = 0, hBoth = 0, hInnerIt = 0, hLeafIt = 0;
+#endif
   for(;;)
   {
+    // ---- service
+    if(alive && L.done)
+    {
+      bool fallback = (L.flags & TF_SAW_FRAC) != 0;
+      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
+        lane_begin_count(L);  // stay alive: pass B runs in the same loop
+      else
+      {
+        if(!fallback)
+        {
+          uint32_t nDraw = L.cnt;  // pass A's count when it is final, else pass B's
+          if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
+            ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
+          uint32_t s2 = seed;
+          if(consume_rejected_draws(s2, nDraw))
+          {
+            store_hit(rb, pslot, L.bslot, L.bt, L.bu, L.bv);
+            if(nDraw)
+              rb.ps.rayD[pslot].w = __uint_as_float(s2);
+            nAlpha += nDraw;
+          }
+          else
+            fallback = true;
+        }
+        if(fallback)
+          enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
+        alive = false;
+      }
+    }
     const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_CLOSEST], count, !alive);
     if(qi != 0xffffffffu)
     {
@@ -183,48 +226,33 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
     }
     if(!__ballot(alive))
       break;
-    for(;;)
+    // ---- run
+    const int target = rs.more ? minRun : 1;
+#ifdef PT_HIST
+    ++hService;
+#endif
+    while(__popcll(__ballot(!L.done)) >= target)
     {
-      if(alive && !L.done && !(L.cur & BVH_LEAF))
+#ifdef PT_HIST
+      const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
+#endif
+      if(!L.done && !(L.cur & BVH_LEAF))
         lane_inner<false>(S, L, lds, spill, rb.counters);
-      if(alive && !L.done && (L.cur & BVH_LEAF))
+#ifdef PT_HIST
+      const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
+      ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
+#endif
+      if(!L.done && (L.cur & BVH_LEAF))
         lane_leaf<false>(S, L, lds, spill);
-      if(alive && L.done)
-      {
-        bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-        if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
-        {
-          lane_begin_count(L);  // stay alive: pass B runs in the same loop
-          L.done = S.numTris == 0;
-        }
-        else
-        {
-          if(!fallback)
-          {
-            uint32_t nDraw = L.cnt;  // pass A's count when it is final, else pass B's
-            if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
-              ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
-            uint32_t s2 = seed;
-            if(consume_rejected_draws(s2, nDraw))
-            {
-              store_hit(rb, pslot, L.bslot, L.bt, L.bu, L.bv);
-              if(nDraw)
-                rb.ps.rayD[pslot].w = __uint_as_float(s2);
-              nAlpha += nDraw;
-            }
-            else
-              fallback = true;
-          }
-          if(fallback)
-            enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
-          alive = false;
-        }
-      }
-      const unsigned long long run = __ballot(alive);
-      if(!run || (rs.more && __popcll(run) < refillBelow))
-        break;
     }
   }
+#ifdef PT_HIST
+  if((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&g_hist[5][0], hIter); atomicAdd(&g_hist[5][1], hInner); atomicAdd(&g_hist[5][2], hLeaf); atomicAdd(&g_hist[5][3], hService);
+    atomicAdd(&g_hist[5][4], hBoth); atomicAdd(&g_hist[5][5], hInnerIt); atomicAdd(&g_hist[5][6], hLeafIt);
+  }
+#endif
   wave_add(&rb.counters->closestRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
 }
@@ -617,12 +645,14 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int refillBelow, int chunk)
+__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[CNT_SHADOW];
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
+    return;  // small queue: fewer waves, so that each still refills its lanes a few times
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
@@ -630,8 +660,43 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
+  L.cur                     = 0;
+#ifdef PT_HIST
+  unsigned long long hIter = 0, hInner = 0, hLeaf = 0, hService = 0, hBoth = 0, hInnerIt = 0, hLeafIt = 0;
+#endif
   for(;;)
   {
+    // ---- service (see k_closest_p)
+    if(alive && L.done)
+    {
+      bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
+      if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
+        lane_begin_count(L);
+      else
+      {
+        bool inShadow = L.opaqueHit;  // an opaque occluder ends the ray without a draw (trace contract T6)
+        if(!fallback && !L.opaqueHit)
+        {
+          uint32_t nDraw = L.cnt;
+          if(L.bslot != BVH_NONE)
+            ++nDraw;
+          uint32_t s2 = seed;
+          if(consume_rejected_draws(s2, nDraw))
+          {
+            seed     = s2;
+            inShadow = L.bslot != BVH_NONE;
+            nAlpha += nDraw;
+          }
+          else
+            fallback = true;
+        }
+        if(fallback)
+          enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
+        else
+          finish_bounce(rb, pslot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+        alive = false;
+      }
+    }
     const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_SHADOW], count, !alive);
     if(qi != 0xffffffffu)
     {
@@ -643,50 +708,33 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
     }
     if(!__ballot(alive))
       break;
-    for(;;)
+    // ---- run
+    const int target = rs.more ? minRun : 1;
+#ifdef PT_HIST
+    ++hService;
+#endif
+    while(__popcll(__ballot(!L.done)) >= target)
     {
-      if(alive && !L.done && !(L.cur & BVH_LEAF))
+#ifdef PT_HIST
+      const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
+#endif
+      if(!L.done && !(L.cur & BVH_LEAF))
         lane_inner<true>(S, L, lds, spill, rb.counters);
-      if(alive && !L.done && (L.cur & BVH_LEAF))
+#ifdef PT_HIST
+      const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
+      ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
+#endif
+      if(!L.done && (L.cur & BVH_LEAF))
         lane_leaf<true>(S, L, lds, spill);
-      if(alive && L.done)
-      {
-        bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
-        if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
-        {
-          lane_begin_count(L);
-          L.done = S.numTris == 0;
-        }
-        else
-        {
-          bool inShadow = L.opaqueHit;  // an opaque occluder ends the ray without a draw (trace contract T6)
-          if(!fallback && !L.opaqueHit)
-          {
-            uint32_t nDraw = L.cnt;
-            if(L.bslot != BVH_NONE)
-              ++nDraw;
-            uint32_t s2 = seed;
-            if(consume_rejected_draws(s2, nDraw))
-            {
-              seed     = s2;
-              inShadow = L.bslot != BVH_NONE;
-              nAlpha += nDraw;
-            }
-            else
-              fallback = true;
-          }
-          if(fallback)
-            enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
-          else
-            finish_bounce(rb, pslot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
-          alive = false;
-        }
-      }
-      const unsigned long long run = __ballot(alive);
-      if(!run || (rs.more && __popcll(run) < refillBelow))
-        break;
     }
   }
+#ifdef PT_HIST
+  if((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&g_hist[6][0], hIter); atomicAdd(&g_hist[6][1], hInner); atomicAdd(&g_hist[6][2], hLeaf); atomicAdd(&g_hist[6][3], hService);
+    atomicAdd(&g_hist[6][4], hBoth); atomicAdd(&g_hist[6][5], hInnerIt); atomicAdd(&g_hist[6][6], hLeafIt);
+  }
+#endif
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
 }
@@ -786,34 +834,36 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_x(DeviceScene S, RenderB
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParams fp)
 {
-  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if(slot >= fp.numSlots)
+  uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
+  if(pslot >= fp.numSlots)
     return;
   int px, py;
-  if(!slot_pixel(fp, rb.slotTile, slot, px, py))
+  if(!slot_pixel(fp, rb.slotTile, pslot, px, py))
     return;
   const pt_RtxState& st = fp.st;
-  f3                 r  = xyz(rb.ps.rad[slot]);
-  float              lum = dot3(r, f3{0.212671f, 0.715160f, 0.072169f});
-  if(lum > st.fireflyClampThreshold)
-    r *= st.fireflyClampThreshold / lum;
+  // the frames of the batch fold into the running mean in frame order (one thread per pixel: exact sequence)
+  f3 acc = xyz(rb.frame[pslot]);
+  for(uint32_t fb = 0; fb < fp.batch; ++fb)
+  {
+    const uint32_t slot = fb * fp.numSlots + pslot;
+    f3             r    = xyz(rb.ps.rad[slot]);
+    float          lum  = dot3(r, f3{0.212671f, 0.715160f, 0.072169f});
+    if(lum > st.fireflyClampThreshold)
+      r *= st.fireflyClampThreshold / lum;
 
-  f3 sum = (fp.sample == 0) ? splat3(0.0f) : xyz(rb.ps.sum[slot]);
-  sum += r;
-  if(fp.sample + 1 < st.maxSamples)
-  {
-    rb.ps.sum[slot] = make_float4(sum.x, sum.y, sum.z, 0.f);
-    return;
+    f3 sum = (fp.sample == 0) ? splat3(0.0f) : xyz(rb.ps.sum[slot]);
+    sum += r;
+    if(fp.sample + 1 < st.maxSamples)
+    {
+      rb.ps.sum[slot] = make_float4(sum.x, sum.y, sum.z, 0.f);
+      continue;
+    }
+    const f3  pixel = sum / float(st.maxSamples);
+    const int frame = st.frame + int(fb);
+    acc             = frame > 0 ? lerp(acc, pixel, 1.0f / float(frame + 1)) : pixel;
   }
-  f3 pixel = sum / float(st.maxSamples);
-  if(st.frame > 0)
-  {
-    f3 old         = xyz(rb.frame[slot]);
-    f3 nw          = lerp(old, pixel, 1.0f / float(st.frame + 1));
-    rb.frame[slot] = make_float4(nw.x, nw.y, nw.z, 1.f);
-  }
-  else
-    rb.frame[slot] = make_float4(pixel.x, pixel.y, pixel.z, 1.f);
+  if(fp.sample + 1 == st.maxSamples)
+    rb.frame[pslot] = make_float4(acc.x, acc.y, acc.z, 1.f);
 }
 
 // ---- framebuffer plumbing ---------------------------------------------------------------------------------------
@@ -945,10 +995,11 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
                      hipEvent_t recordAfterAccum)
 {
   FrameParams    fp        = fpIn;
-  const uint32_t n         = fp.numSlots;
+  const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
   const uint32_t gridAll   = (n + 255) / 256;
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-  const uint32_t gridTrace = wavesAll < PT_PERSISTENT_WAVES ? wavesAll : PT_PERSISTENT_WAVES;  // 256 CUs x 20 resident waves
+  const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
+  const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
@@ -985,7 +1036,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     if(waitBeforeAccum && s == 0)
       (void)hipStreamWaitEvent(stream, waitBeforeAccum, 0);
     pt_timers_begin(tm, stream, 4);
-    k_accumulate<<<gridAll, 256, 0, stream>>>(rb, fp);
+    k_accumulate<<<(fp.numSlots + 255) / 256, 256, 0, stream>>>(rb, fp);
     pt_timers_end(tm, stream, 4);
     if(recordAfterAccum && s == fp.st.maxSamples - 1)
       (void)hipEventRecord(recordAfterAccum, stream);
@@ -1015,3 +1066,20 @@ void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double
   (void)hipMemsetAsync(out3, 0, 3 * sizeof(double), stream);
   k_mean<<<256, 256, 0, stream>>>(rowMajor, n, out3);
 }
+
+#ifdef PT_HIST
+// measurement build only: copies (and optionally clears) the traversal histograms of pt_trace.h
+extern "C" int pt_debug_hist(unsigned long long* out, int reset)
+{
+  if(hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(g_hist)) != hipSuccess)
+    return -1;
+  if(reset)
+  {
+    static unsigned long long zero[8][40];
+    if(hipMemcpyToSymbol(HIP_SYMBOL(g_hist), zero, sizeof(zero)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+

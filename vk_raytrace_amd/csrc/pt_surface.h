@@ -146,7 +146,10 @@ PT_DEV void make_frame(f3 N, f3& T, f3& B)
 // Opacity of a non-opaque candidate at barycentrics (bu,bv): baseColorFactor.a x texture alpha, thresholded
 // for ALPHA_MASK (reference: shaders/traceray_rq.glsl:32-94).  Reads the flattened AlphaRec / AlphaMat records;
 // the arithmetic is the reference's (interpolate raw uvs, row-vector uvTransform, bilinear tap).
-PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, float bv)
+// `useMap`: let the material's opacity map (pt_device.h) answer when it can -- the traversal only asks whether the
+// opacity is <= 0, >= 1 or in between, so a classified block returns exactly 0 or 1 without touching the texels.
+template <bool useMap>
+PT_DEV float opacity_eval(const DeviceScene& S, const AlphaRec& ar, float bu, float bv)
 {
   const AlphaMat am = S.alphaMats[ar.material];
   float          a  = am.factorA;
@@ -155,12 +158,60 @@ PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, fl
     const float b0 = 1.0f - bu - bv;
     f2          uv = f2{ar.uv0[0], ar.uv0[1]} * b0 + f2{ar.uv1[0], ar.uv1[1]} * bu + f2{ar.uv2[0], ar.uv2[1]} * bv;
     f2          tuv = f2{((uv.x * am.m[0] + uv.y * am.m[1]) + 1.0f * am.m[2]) + 1.0f * am.m[3], ((uv.x * am.m[4] + uv.y * am.m[5]) + 1.0f * am.m[6]) + 1.0f * am.m[7]};
-    TexRec      tr;
-    tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = (am.texWrap >> 8) & 0xff; tr.pot = am.texWrap >> 16;
-    a *= sample_rgba8_rec(S.texels, tr, tuv).w;
+    if(am.texWrap & ALPHA_FAST_TAP)
+    {
+      // REPEAT x REPEAT on power-of-two sizes: the arithmetic of sample_rgba8_rec on the alpha channel alone
+      const bool linear = am.texMag != PT_FILTER_NEAREST;
+      float      x = tuv.x * float(am.texW), y = tuv.y * float(am.texH);
+      if(linear)
+      {
+        x -= 0.5f;
+        y -= 0.5f;
+      }
+      const float fx = floorf(x), fy = floorf(y);
+      const int   x0 = (int)fx, y0 = (int)fy;
+      const int   mx = am.texW - 1, my = am.texH - 1;
+      const int   xa = x0 & mx, ya = y0 & my;
+      if(useMap && am.mapOffset != ALPHA_NO_MAP && fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f)
+      {
+        const uint32_t bidx = (uint32_t(ya) >> ALPHA_MAP_SHIFT) * (uint32_t(am.texW) >> ALPHA_MAP_SHIFT) + (uint32_t(xa) >> ALPHA_MAP_SHIFT);
+        const uint32_t st   = (S.alphaMaps[am.mapOffset + (bidx >> 4)] >> ((bidx & 15u) * 2u)) & 3u;
+        if(st != ALPHA_ST_UNKNOWN)
+          return st == ALPHA_ST_ONE ? 1.0f : 0.0f;
+      }
+      const uint32_t* tp = S.texels + am.texOffset;
+      float           ta;
+      if(!linear)
+        ta = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xa)] >> 24);
+      else
+      {
+        const int   xb = (x0 + 1) & mx, yb = (y0 + 1) & my;
+        const float t00 = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xa)] >> 24), t10 = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xb)] >> 24);
+        const float t01 = float(tp[uint32_t(yb) * uint32_t(am.texW) + uint32_t(xa)] >> 24), t11 = float(tp[uint32_t(yb) * uint32_t(am.texW) + uint32_t(xb)] >> 24);
+        const float fa = x - fx, fb = y - fy;
+        const float top = t00 * (1.0f - fa) + t10 * fa;
+        const float bot = t01 * (1.0f - fa) + t11 * fa;
+        ta              = top * (1.0f - fb) + bot * fb;
+      }
+      a *= ta * (1.0f / 255.0f);
+    }
+    else
+    {
+      TexRec tr;
+      tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = (am.texWrap >> 8) & 0xff; tr.pot = (am.texWrap >> 16) & 3;
+      a *= sample_rgba8_rec(S.texels, tr, tuv).w;
+    }
   }
   return (am.mode == PT_ALPHA_MASK) ? (a > am.cutoff ? 1.0f : 0.0f) : a;
 }
+// exact value (the stochastic test of the key-ordered fallback compares a draw with it)
+PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<false>(S, ar, bu, bv); }
+// <= 0, >= 1 or the exact value in between (all the two-pass traversal needs)
+#ifdef PT_NO_ALPHA_MAP  // (measurement only)
+PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<false>(S, ar, bu, bv); }
+#else
+PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<true>(S, ar, bu, bv); }
+#endif
 PT_DEV float hit_opacity(const DeviceScene& S, uint32_t slot, float bu, float bv) { return opacity_from(S, S.alphaRecs[slot], bu, bv); }
 
 // Stochastic alpha (any-hit): returns true when the candidate is kept.  Draws exactly one random number

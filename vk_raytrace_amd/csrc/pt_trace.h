@@ -153,6 +153,13 @@ PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node
 }
 #endif
 
+#ifdef PT_HIST
+// measurement build only (tools/gpu_hist.py): per traversal mode, the distribution of per-ray loop iterations
+// ([0..31]: floor(log2)+1 buckets) and the wave-level lane utilisation ([32] sum of iterations, [33] sum over waves
+// of max x 64, [34] rays, [35] waves, [36] sum over waves of max)
+__device__ unsigned long long g_hist[8][40];  // rows 5 / 6: persistent closest / shadow kernels (see pt_render.hip)
+#endif
+
 // tPrev/wPrev: exclusive lower key (TM_RAW_*); wLimit: with tmax the exclusive upper key (TM_COUNT).
 // `opaqueHit` is only meaningful for TM_SHADOW.
 template <int MODE>
@@ -178,9 +185,15 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
 #ifdef PT_STATS
   uint32_t nNodes = 0, nTris = 0;
 #endif
+#ifdef PT_HIST
+  uint32_t nIter = 0;
+#endif
 
   for(;;)
   {
+#ifdef PT_HIST
+    ++nIter;
+#endif
     if(!(cur & BVH_LEAF))
     {
 #ifdef PT_STATS
@@ -273,7 +286,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
           {
             if(t > 0.0f && key_less(t, w, tmax, wLimit))
             {
-              const float op = opacity_from(S, ar, u, v);
+              const float op = opacity_class(S, ar, u, v);
               if(op <= 0.0f)
                 best.count++;
               else if(op < 1.0f)
@@ -296,7 +309,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
               bool certain = opq;
               if(!opq)
               {
-                const float op = opacity_from(S, ar, u, v);
+                const float op = opacity_class(S, ar, u, v);
                 certain        = op >= 1.0f;
                 if(!certain)
                 {
@@ -324,6 +337,31 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
     cur = sp < STACK_LDS ? ldsStack[sp * TRACE_BLOCK] : spill[sp - STACK_LDS];
   }
 #undef PT_TLIMIT
+#ifdef PT_HIST
+  {
+    atomicAdd(&g_hist[MODE][nIter ? 32 - __clz(nIter) : 0], 1ull);
+    unsigned long long m = __ballot(1);
+    const int          first = __ffsll(m) - 1;
+    uint32_t           wmax = 0, wsum = 0, wn = 0;
+    while(m)
+    {
+      const int      l = __ffsll(m) - 1;
+      const uint32_t x = __builtin_amdgcn_readlane(nIter, l);
+      wmax = x > wmax ? x : wmax;
+      wsum += x;
+      ++wn;
+      m &= m - 1;
+    }
+    if(int(threadIdx.x & 63) == first)
+    {
+      atomicAdd(&g_hist[MODE][32], (unsigned long long)wsum);
+      atomicAdd(&g_hist[MODE][33], (unsigned long long)wmax * 64ull);
+      atomicAdd(&g_hist[MODE][34], (unsigned long long)wn);
+      atomicAdd(&g_hist[MODE][35], 1ull);
+      atomicAdd(&g_hist[MODE][36], (unsigned long long)wmax);
+    }
+  }
+#endif
 #ifdef PT_STATS
   if(PT_STATS == 0 || (PT_STATS == 1 && MODE == TM_SHADOW) || (PT_STATS == 2 && MODE == TM_CLOSEST) || (PT_STATS == 3 && MODE == TM_COUNT))
   {
