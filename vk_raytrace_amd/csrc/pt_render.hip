@@ -31,7 +31,9 @@
 
 namespace {
 
-constexpr int SHADE_BLOCK = 64;
+constexpr int SHADE_BLOCK = 256;
+enum { SHADE_DONE = 0, SHADE_TO_SHADOW = 1, SHADE_TO_NEXT = 2 };
+enum { EV_MISS = 1u, EV_HIT = 2u, EV_NEE = 4u };
 
 // ---- wave-aggregated helpers ---------------------------------------------------------------------------
 PT_DEV void count_event(unsigned long long* ctr)
@@ -51,6 +53,29 @@ PT_DEV void enqueue(uint32_t* queue, uint32_t* count, uint32_t slot)
     base = atomicAdd(count, (uint32_t)__popcll(m));
   base                   = __shfl(base, leader);
   queue[base + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+
+// Block-wide variant for kernels whose lanes all reach the call (no early return): one atomic per workgroup.
+// `valid` lanes append `slot`.  Same-address atomics that return a value are latency-serialised per address, so a
+// launch of a few 100 k waves must not issue one per wave.
+PT_DEV void enqueue_block(uint32_t* queue, uint32_t* count, uint32_t slot, bool valid)
+{
+  __shared__ uint32_t sBase, sCount;
+  if(threadIdx.x == 0)
+    sCount = 0;
+  __syncthreads();
+  const unsigned long long m    = __ballot(valid);
+  const int                lane = threadIdx.x & 63;
+  uint32_t                 wbase = 0;
+  if(lane == 0 && m)
+    wbase = atomicAdd(&sCount, (uint32_t)__popcll(m));  // LDS atomic
+  wbase = __shfl(wbase, 0);
+  __syncthreads();
+  if(threadIdx.x == 0 && sCount)
+    sBase = atomicAdd(count, sCount);
+  __syncthreads();
+  if(valid)
+    queue[sBase + wbase + __popcll(m & ((1ull << lane) - 1ull))] = slot;
 }
 
 // Path slot -> pixel.  A local tile is 32x32 pixels = 16 waves of 8x8 pixels, so that the 64 lanes of a
@@ -90,14 +115,15 @@ PT_DEV f3 offset_ray(f3 p, f3 n)
 }
 
 // ---- k_generate -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
+__global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
 {
-  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if(slot >= fp.numSlots * fp.batch)
-    return;
-  const uint32_t fb = slot / fp.numSlots;  // frame of the batch
-  int            px, py;
-  if(!slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py))
+  uint32_t       slot  = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     inRange = slot < fp.numSlots * fp.batch;
+  const uint32_t fb    = inRange ? slot / fp.numSlots : 0u;  // frame of the batch
+  int            px = 0, py = 0;
+  const bool     valid = inRange && slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py);
+  enqueue_block(rb.queueA, &rb.counts[CNT_IN], slot, valid);  // bounce 0 reads queueA
+  if(!valid)
     return;
   pt_RtxState st = fp.st;
   st.frame += int(fb);
@@ -137,7 +163,6 @@ __global__ void __launch_bounds__(256) k_generate(DeviceScene S, RenderBuffers r
   rb.ps.thr[slot]    = make_float4(1.f, 1.f, 1.f, 1.f);
   rb.ps.rad[slot]    = make_float4(0.f, 0.f, 0.f, 0.f);
   rb.ps.absorb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-  enqueue(rb.queueA, &rb.counts[CNT_IN], slot);  // bounce 0 reads queueA
 }
 
 // ---- closest hit ----------------------------------------------------------------------------------------------
@@ -175,7 +200,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
-  rs.chunk = uint32_t(chunk);
+  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -264,44 +290,49 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_s(DeviceScene S, Render
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  if(i >= C[CNT_IN])
-    return;
-  const uint32_t slot = queueIn[i];
-  const f3       o    = xyz(rb.ps.rayO[slot]);
-  const float4   dw   = rb.ps.rayD[slot];
-  const f3       d    = xyz(dw);
-  const uint32_t seed = __float_as_uint(dw.w);
-  count_event(&rb.counters->closestRays);
-  RayHit h;
-  bool   dummy;
-  traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-  bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
-  uint32_t nDraw    = h.count;
-  if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
+  const bool          valid = i < C[CNT_IN];
+  uint32_t            slot = 0, nAlpha = 0;
+  bool                fallback = false;
+  if(valid)
   {
-    RayHit c;
-    traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
-                       rb.counters);
-    fallback = (c.flags & TF_SAW_FRAC) != 0;
-    nDraw    = c.count;
-  }
-  if(!fallback)
-  {
-    if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
-      ++nDraw;
-    uint32_t s2 = seed;
-    if(consume_rejected_draws(s2, nDraw))
+    slot                = queueIn[i];
+    const f3       o    = xyz(rb.ps.rayO[slot]);
+    const float4   dw   = rb.ps.rayD[slot];
+    const f3       d    = xyz(dw);
+    const uint32_t seed = __float_as_uint(dw.w);
+    RayHit         h;
+    bool           dummy;
+    traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+    fallback       = (h.flags & TF_SAW_FRAC) != 0;
+    uint32_t nDraw = h.count;
+    if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
     {
-      store_hit(rb, slot, h.slot, h.t, h.u, h.v);
-      if(nDraw)
+      RayHit c;
+      traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                         rb.counters);
+      fallback = (c.flags & TF_SAW_FRAC) != 0;
+      nDraw    = c.count;
+    }
+    if(!fallback)
+    {
+      if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+        ++nDraw;
+      uint32_t s2 = seed;
+      if(consume_rejected_draws(s2, nDraw))
       {
-        rb.ps.rayD[slot].w = __uint_as_float(s2);
-        atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
+        store_hit(rb, slot, h.slot, h.t, h.u, h.v);
+        if(nDraw)
+          rb.ps.rayD[slot].w = __uint_as_float(s2);
+        nAlpha = nDraw;
       }
-      return;
+      else
+        fallback = true;
     }
   }
-  enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
+  wave_add(&rb.counters->closestRays, valid ? 1u : 0u);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+  if(fallback)
+    enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
 }
 
 // Exact fallback: one ray per lane, key-ordered stochastic alpha (trace contract T5).  Runs on the rays the
@@ -398,7 +429,8 @@ PT_DEV f3 bsdf_sample(int pbrMode, const Surface& s, f3 V, f3 N, f3& L, float& p
 
 // ---- k_shade ----------------------------------------------------------------------------------------------
 // One path: everything between the closest-hit trace and the shadow trace of a bounce.
-PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, uint32_t* __restrict__ queueOut, uint32_t* C, int depth)
+// Returns where the path goes next (SHADE_*) and ORs the events it counted into `events` (EV_*).
+PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, int depth, uint32_t& events)
 {
   const pt_RtxState& st   = fp.st;
   const float4       dw   = rb.ps.rayD[slot];
@@ -430,16 +462,16 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
     }
     if(!done)
     {
-      count_event(&rb.counters->misses);
+      events |= EV_MISS;
       f3 env = (S.sunsky.in_use == 1) ? sun_and_sky(S.sunsky, rdir) : sample_env(S, spherical_uv(rdir));
       result = radiance + (env * st.hdrMultiplier * throughput);
     }
     rb.ps.rad[slot] = make_float4(result.x, result.y, result.z, 0.f);
-    return;
+    return SHADE_DONE;
   }
 
   // ---- hit ----
-  count_event(&rb.counters->shadedHits);
+  events |= EV_HIT;
   const TriRec       tr = S.tris[__float_as_uint(hit.y)];
   const InstanceRec& I  = S.instances[__float_as_uint(tr.e1n.w)];
   Surface            sf;
@@ -465,13 +497,13 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
       case PT_DEBUG_TANGENT: r = (sf.tangent + splat3(1.0f)) * .5f; break;
     }
     rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
-    return;
+    return SHADE_DONE;
   }
   if(sf.unlit)  // KHR_materials_unlit
   {
     f3 r            = radiance + sf.albedo * throughput;
     rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
-    return;
+    return SHADE_DONE;
   }
 
   f3 absorption = xyz(rb.ps.absorb[slot]);
@@ -527,7 +559,7 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
     else
     {
       float a = rng_next(seed), b = rng_next(seed), c = rng_next(seed);
-      count_event(&rb.counters->neeLookups);
+      events |= EV_NEE;
       lightContrib = env_importance_sample(S, f3{a, b, c}, lightDir, lightPdf);
       lightContrib *= st.hdrMultiplier;
     }
@@ -558,7 +590,7 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
   {  // `break`: the path ends before its shadow ray
     rb.ps.rad[slot]    = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
     rb.ps.rayD[slot].w = __uint_as_float(seed);
-    return;
+    return SHADE_DONE;
   }
 
   if(dbg != PT_DEBUG_NONE && depth == st.maxDepth - 1)
@@ -576,7 +608,7 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
     if(ret)
     {
       rb.ps.rad[slot] = make_float4(r.x, r.y, r.z, 0.f);
-      return;
+      return SHADE_DONE;
     }
   }
 
@@ -594,33 +626,71 @@ PT_DEV void shade_path(const DeviceScene& S, const RenderBuffers& rb, const Fram
   {
     rb.ps.neeDir[slot] = make_float4(lightDir.x, lightDir.y, lightDir.z, 1.f);
     rb.ps.neeRad[slot] = make_float4(neeRadiance.x, neeRadiance.y, neeRadiance.z, 0.f);
-    enqueue(rb.queueS, &C[CNT_SHADOW], slot);
-    return;
+    return SHADE_TO_SHADOW;
   }
   // no shadow ray for this bounce: the Russian-roulette draw follows the BSDF draws directly (pathtrace.glsl:333-338)
   const bool die     = rng_next(seed) >= rrPcont;
   rb.ps.rayD[slot].w = __uint_as_float(seed);
   if(die)
-    return;
+    return SHADE_DONE;
   throughput /= rrPcont;
   rb.ps.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
-  if(depth != st.maxDepth - 1)
-    enqueue(queueOut, &C[CNT_STRIDE + CNT_IN], slot);
+  return depth != st.maxDepth - 1 ? SHADE_TO_NEXT : SHADE_DONE;
 }
 
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
 {
+  __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups
   uint32_t*      C     = rb.counts + depth * CNT_STRIDE;
   const uint32_t count = C[CNT_IN];
+  if(threadIdx.x < 5)
+    sCnt[threadIdx.x] = 0;
+  __syncthreads();
   // one path per lane, no loop: a grid-stride loop around shade_path costs ~120 extra VGPRs (256 vs 136)
-  const uint32_t i = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+  const uint32_t i    = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+  uint32_t       slot = 0, events = 0;
+  int            to   = SHADE_DONE;
   if(i < count)
-    shade_path(S, rb, fp, queueIn[i], queueOut, C, depth);
+  {
+    slot = queueIn[i];
+    to   = shade_path(S, rb, fp, slot, depth, events);
+  }
+  // queue appends and statistics: wave totals into LDS, one global atomic per workgroup and counter (a returning
+  // atomic per wave on one address costs ~11 ns each, serialised: 2.9 ms for the 260 k waves of a bounce-0 batch)
+  const int                lane = threadIdx.x & 63;
+  const unsigned long long mS = __ballot(to == SHADE_TO_SHADOW), mN = __ballot(to == SHADE_TO_NEXT);
+  const unsigned long long e0 = __ballot(events & EV_MISS), e1 = __ballot(events & EV_HIT), e2 = __ballot(events & EV_NEE);
+  uint32_t                 wS = 0, wN = 0;
+  if(lane == 0)
+  {
+    if(mS) wS = atomicAdd(&sCnt[0], (uint32_t)__popcll(mS));
+    if(mN) wN = atomicAdd(&sCnt[1], (uint32_t)__popcll(mN));
+    if(e0) atomicAdd(&sCnt[2], (uint32_t)__popcll(e0));
+    if(e1) atomicAdd(&sCnt[3], (uint32_t)__popcll(e1));
+    if(e2) atomicAdd(&sCnt[4], (uint32_t)__popcll(e2));
+  }
+  wS = __shfl(wS, 0);
+  wN = __shfl(wN, 0);
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    if(sCnt[0]) sBase[0] = atomicAdd(&C[CNT_SHADOW], sCnt[0]);
+    if(sCnt[1]) sBase[1] = atomicAdd(&C[CNT_STRIDE + CNT_IN], sCnt[1]);
+    if(sCnt[2]) atomicAdd(&rb.counters->misses, (unsigned long long)sCnt[2]);
+    if(sCnt[3]) atomicAdd(&rb.counters->shadedHits, (unsigned long long)sCnt[3]);
+    if(sCnt[4]) atomicAdd(&rb.counters->neeLookups, (unsigned long long)sCnt[4]);
+  }
+  __syncthreads();
+  if(to == SHADE_TO_SHADOW)
+    rb.queueS[sBase[0] + wS + __popcll(mS & ((1ull << lane) - 1ull))] = slot;
+  else if(to == SHADE_TO_NEXT)
+    queueOut[sBase[1] + wN + __popcll(mN & ((1ull << lane) - 1ull))] = slot;
 }
 
 // ---- shadow + Russian roulette ---------------------------------------------------------------------------------
 // NEE contribution if unoccluded, then Russian roulette (pathtrace.glsl:327-338); survivors go to the next bounce.
-PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t seed, uint32_t* __restrict__ queueOut, uint32_t* nextCount, bool lastBounce)
+// Returns true when the path survives the roulette (the caller queues it for the next bounce).
+PT_DEV bool finish_bounce_core(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t seed)
 {
   if(!inShadow)
   {
@@ -636,18 +706,52 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
   const bool  die = rng_next(seed) >= pc;
   rb.ps.rayD[slot].w = __uint_as_float(seed);
   if(die)
-    return;
+    return false;
   t.x /= pc;
   t.y /= pc;
   t.z /= pc;
   rb.ps.thr[slot] = t;
-  if(!lastBounce)
+  return true;
+}
+PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t seed, uint32_t* __restrict__ queueOut, uint32_t* nextCount, bool lastBounce)
+{
+  if(finish_bounce_core(rb, slot, inShadow, seed) && !lastBounce)
     enqueue(queueOut, nextCount, slot);
+}
+
+// Wave-private staging of queue appends in LDS (persistent kernels): one global atomic per ~200 entries instead of
+// one per service round.  `n` is wave-uniform.
+#define STAGE_CAP 256
+PT_DEV void stage_flush(uint32_t* stage, uint32_t& n, uint32_t* __restrict__ queue, uint32_t* count)
+{
+  if(n == 0)
+    return;
+  const int lane = threadIdx.x & 63;
+  uint32_t  base = 0;
+  if(lane == 0)
+    base = atomicAdd(count, n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for(uint32_t k = lane; k < n; k += 64)
+    queue[base + k] = stage[k];
+  n = 0;
+}
+PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, uint32_t* __restrict__ queue, uint32_t* count)
+{
+  const unsigned long long m = __ballot(valid);
+  if(!m)
+    return;
+  if(n + 64 > STAGE_CAP)
+    stage_flush(stage, n, queue, count);
+  if(valid)
+    stage[n + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = slot;
+  n += (uint32_t)__popcll(m);
 }
 
 __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stage[STAGE_CAP];
+  uint32_t            nStage = 0;
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[CNT_SHADOW];
@@ -656,7 +760,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
-  rs.chunk = uint32_t(chunk);
+  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -667,6 +772,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
   for(;;)
   {
     // ---- service (see k_closest_p)
+    bool survivor = false;
     if(alive && L.done)
     {
       bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
@@ -693,10 +799,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
         if(fallback)
           enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
         else
-          finish_bounce(rb, pslot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+          survivor = finish_bounce_core(rb, pslot, inShadow, seed) && !lastBounce;
         alive = false;
       }
     }
+    stage_push(stage, nStage, survivor, pslot, queueOut, &C[CNT_STRIDE + CNT_IN]);
     const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_SHADOW], count, !alive);
     if(qi != 0xffffffffu)
     {
@@ -735,6 +842,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
     atomicAdd(&g_hist[6][4], hBoth); atomicAdd(&g_hist[6][5], hInnerIt); atomicAdd(&g_hist[6][6], hLeafIt);
   }
 #endif
+  stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
 }
@@ -745,51 +853,53 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_s(DeviceScene S, RenderB
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  if(i >= C[CNT_SHADOW])
-    return;
-  const uint32_t slot    = rb.queueS[i];
-  uint32_t       seed    = __float_as_uint(rb.ps.rayD[slot].w);
-  const f3       o       = xyz(rb.ps.rayO[slot]);
-  const f3       d       = xyz(rb.ps.neeDir[slot]);
-  const float    maxDist = rb.ps.absorb[slot].w;
-  count_event(&rb.counters->shadowRays);
-  bool   inShadow, dummy;
-  RayHit h;
-  traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
-  if(!inShadow)
+  const bool          valid = i < C[CNT_SHADOW];
+  uint32_t            slot = 0, nAlpha = 0, seed = 0;
+  bool                fallback = false, inShadow = false;
+  if(valid)
   {
-    bool     fallback = (h.flags & TF_SAW_FRAC) != 0;
-    uint32_t nDraw    = h.count;
-    if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
+    slot                   = rb.queueS[i];
+    seed                   = __float_as_uint(rb.ps.rayD[slot].w);
+    const f3       o       = xyz(rb.ps.rayO[slot]);
+    const f3       d       = xyz(rb.ps.neeDir[slot]);
+    const float    maxDist = rb.ps.absorb[slot].w;
+    bool           dummy;
+    RayHit         h;
+    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
+    if(!inShadow)
     {
-      RayHit c;
-      traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
-                         rb.counters);
-      fallback = (c.flags & TF_SAW_FRAC) != 0;
-      nDraw    = c.count;
-    }
-    if(!fallback)
-    {
-      if(h.slot != BVH_NONE)
-        ++nDraw;
-      uint32_t s2 = seed;
-      if(consume_rejected_draws(s2, nDraw))
+      fallback       = (h.flags & TF_SAW_FRAC) != 0;
+      uint32_t nDraw = h.count;
+      if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
       {
-        seed     = s2;
-        inShadow = h.slot != BVH_NONE;
-        if(nDraw)
-          atomicAdd(&rb.counters->alphaTests, (unsigned long long)nDraw);
+        RayHit c;
+        traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                           rb.counters);
+        fallback = (c.flags & TF_SAW_FRAC) != 0;
+        nDraw    = c.count;
       }
-      else
-        fallback = true;
-    }
-    if(fallback)
-    {
-      enqueue(rb.queueX2, &C[CNT_X_SHADOW], slot);
-      return;
+      if(!fallback)
+      {
+        if(h.slot != BVH_NONE)
+          ++nDraw;
+        uint32_t s2 = seed;
+        if(consume_rejected_draws(s2, nDraw))
+        {
+          seed     = s2;
+          inShadow = h.slot != BVH_NONE;
+          nAlpha   = nDraw;
+        }
+        else
+          fallback = true;
+      }
     }
   }
-  finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+  wave_add(&rb.counters->shadowRays, valid ? 1u : 0u);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+  if(fallback)
+    enqueue(rb.queueX2, &C[CNT_X_SHADOW], slot);
+  else if(valid)
+    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
@@ -1006,7 +1116,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     fp.sample = s;
     (void)hipMemsetAsync(rb.counts, 0, sizeof(uint32_t) * CNT_STRIDE * size_t(fp.st.maxDepth + 2), stream);
     pt_timers_begin(tm, stream, 0);
-    k_generate<<<gridAll, 256, 0, stream>>>(scene, rb, fp);
+    k_generate<<<(n + 1023) / 1024, 1024, 0, stream>>>(scene, rb, fp);
     pt_timers_end(tm, stream, 0);
     uint32_t* qIn  = rb.queueA;
     uint32_t* qOut = rb.queueB;
@@ -1021,7 +1131,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
       k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
-      k_shade<<<wavesAll, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
+      k_shade<<<(n + SHADE_BLOCK - 1) / SHADE_BLOCK, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
       pt_timers_end(tm, stream, 2);
       pt_timers_begin(tm, stream, 3);
       if(depth < g_tuning.simpleShadowBounces)
