@@ -12,6 +12,7 @@
 //
 // Everything runs on the caller's stream; temporaries are freed before returning.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <cfloat>
 #include <cstdio>
 #include "pt_device.h"
@@ -505,6 +506,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr, *dHist = nullptr, *dBounds = nullptr;
   uint32_t *dChildL = nullptr, *dChildR = nullptr, *dParI = nullptr, *dParL = nullptr;
   unsigned* dArrive = nullptr;
+  bool      sah     = false;
   uint32_t  initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
 
   HIPCHK(hipMalloc(&dUnsorted, sizeof(TriRec) * size_t(n)));
@@ -529,8 +531,25 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   HIPCHK(hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream));
 
   k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
-  k_morton<<<G, B, 0, stream>>>(n, dCen, dBounds, dKeysA, dValsA);
+  sah = g_tuning.sahBuild != 0 && n >= 2;
+  if(sah)
   {
+    // fast-trace build: SAH topology on the host from the world-space triangles (pt_sah.hip); boxes stay on the device
+    std::vector<TriRec>   hTris(n);
+    std::vector<uint32_t> hVals(n), hL(n), hR(n), hPI(n), hPL(n);
+    HIPCHK(hipMemcpyAsync(hTris.data(), dUnsorted, sizeof(TriRec) * size_t(n), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    pt_sah_topology(n, hTris.data(), hVals.data(), hL.data(), hR.data(), hPI.data(), hPL.data());
+    HIPCHK(hipMemcpyAsync(dValsA, hVals.data(), 4 * size_t(n), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dChildL, hL.data(), 4 * size_t(n), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dChildR, hR.data(), 4 * size_t(n), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dParI, hPI.data(), 4 * size_t(n), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dParL, hPL.data(), 4 * size_t(n), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // the host vectors die at the end of this scope
+  }
+  else
+  {
+    k_morton<<<G, B, 0, stream>>>(n, dCen, dBounds, dKeysA, dValsA);
     uint32_t *kin = dKeysA, *kout = dKeysB, *vin = dValsA, *vout = dValsB;
     for(int pass = 0; pass < 4; ++pass)
     {
@@ -550,7 +569,8 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   }
   else
   {
-    k_hierarchy<<<G, B, 0, stream>>>(int(n), dKeysA, dChildL, dChildR, dParI, dParL);
+    if(!sah)
+      k_hierarchy<<<G, B, 0, stream>>>(int(n), dKeysA, dChildL, dChildR, dParI, dParL);
     k_refit<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
     k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut);
   }

@@ -283,6 +283,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
     if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) g_tuning.persistentWaves = v;
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
+    if(strstr(tune, "build=lbvh")) g_tuning.sahBuild = 0;
+    if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
   }
