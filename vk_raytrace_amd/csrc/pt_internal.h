@@ -45,7 +45,7 @@ struct PtTuning {
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
   int framesInFlight       = 3;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
   int sahBuild             = 1;    // 1: host SAH topology (fast trace, the default), 0: device LBVH (fast build)
-  int batch                = 16;   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
+  int batch                = 32;   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
 extern PtTuning g_tuning;
 void pt_sah_topology(uint32_t n, const struct TriRec* tris, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);  // pt_sah.hip

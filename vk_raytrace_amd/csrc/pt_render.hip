@@ -31,6 +31,10 @@
 
 namespace {
 
+// resident waves per SIMD the trace kernels are compiled for (bounds their VGPR budget: 512 / waves)
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 6  // 80 VGPRs: 1029 vs 995 Msamples/s against 5; 7 and 8 spill and lose (r01)
+#endif
 constexpr int SHADE_BLOCK = 256;
 enum { SHADE_DONE = 0, SHADE_TO_SHADOW = 1, SHADE_TO_NEXT = 2 };
 enum { EV_MISS = 1u, EV_HIT = 2u, EV_NEE = 4u };
@@ -189,7 +193,7 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
 //            queue is empty, until all are done).
 // Settling rays outside the run loop keeps the hot loop to the node step and the triangle test; a finished lane
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_p(DeviceScene S, Render
 
 // Simple variant: one ray per lane for the lifetime of the wave (lock-step traversal: for coherent rays every
 // node fetch is a broadcast), pass A + pass B inline, exact fallback through queueX.
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_closest_s(DeviceScene S, Render
 
 // Exact fallback: one ray per lane, key-ordered stochastic alpha (trace contract T5).  Runs on the rays the
 // machine could not settle (fractional opacity in front of the hit, or a rejected-candidate draw of exactly 0.0).
-__global__ void __launch_bounds__(TRACE_BLOCK) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   const uint32_t      count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
@@ -747,7 +751,7 @@ PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, 
   n += (uint32_t)__popcll(m);
 }
 
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -848,7 +852,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_p(DeviceScene S, RenderB
 }
 
 // Simple variant of the shadow stage (one ray per lane).
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
@@ -903,7 +907,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_s(DeviceScene S, RenderB
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
-__global__ void __launch_bounds__(TRACE_BLOCK) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
