@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tris", type=int, default=262_267)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"], help="BASELINE.json configuration (stand-in scene); c3 is the bench line, the others are for the results table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (roofline fields become null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
@@ -73,7 +74,12 @@ def main():
     from vk_raytrace_amd import shard
 
     t_setup = time.time()
-    wl = workloads.c3_sponza(args.width, args.height, args.steps, tex_size=args.tex_size, target_tris=args.tris)
+    if args.workload == "c3":
+        wl = workloads.c3_sponza(args.width, args.height, args.steps, tex_size=args.tex_size, target_tris=args.tris)
+    else:
+        wl = {"c2": workloads.c2_helmet, "c4": workloads.c4_sponza_4k, "c5": workloads.c5_bistro}[args.workload]()
+        wl.name = wl.name.replace(f"{wl.spp}spp", f"{args.steps}spp")
+        args.no_cpu_baseline = True  # the CPU leg and its algorithmic-byte model are sized for the bench line only
     wl.scene.finalize(capi.pack_vertices)
     W, H = wl.width, wl.height
 

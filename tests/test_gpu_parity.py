@@ -271,3 +271,75 @@ print("GATHER_OK")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _render_in_subprocess(tune, frames=5, max_samples=1, scene="feature"):
+    """Renders in a fresh process with PT_TUNE set (the launch-policy knobs are read once at pt_create) and returns
+    the accumulation buffer."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from tests.common import Config, render_hip
+from vk_raytrace_amd import synth
+if %r == "feature":
+    cfg = Config(synth.feature_box(tex_size=32), synth.procedural_sky(128, 64), 160, 96, depth=6, max_samples=%d)
+else:
+    cfg = Config(synth.sponza_like(target_tris=30000, tex_size=64), synth.procedural_sky(128, 64), 192, 108, depth=6, max_samples=%d)
+frames = %d
+if %r != "camswitch":
+    np.save(sys.argv[1], render_hip(cfg, frames))
+else:
+    # the camera moves in the middle of an accumulation: frames handed over before the move keep the old camera
+    from vk_raytrace_amd.renderer import HipRenderer
+    from vk_raytrace_amd import capi
+    r = HipRenderer(); r.setup(0); r.set_scene(cfg.scene); integral, _ = r.set_env(cfg.env)
+    r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky); r.create((cfg.width, cfg.height))
+    st = cfg.state(integral)
+    for f in range(2 * frames):
+        if f == frames:
+            cam = cfg.scene.camera
+            cam.eye = [cam.eye[0] + 0.3, cam.eye[1] + 0.1, cam.eye[2]]
+            r.set_camera(capi.camera_lookat(cam, cfg.width / cfg.height, nb_lights=len(cfg.scene.lights)))
+        st.frame = f
+        r.setPushContants(st)
+        r.run()
+    np.save(sys.argv[1], r.read_accum())
+""" % (ROOT, scene.replace("camswitch", "feature"), max_samples, max_samples, frames, scene)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "acc.npy")
+        env = dict(os.environ)
+        env["PT_TUNE"] = tune
+        out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return np.load(path)
+
+
+def test_launch_policy_never_changes_results():
+    """Frame batches, frames in flight, the persistent / lock-step kernels and the BVH builder are performance policy:
+    every combination must produce bit-identical accumulation buffers (5 frames: a full batch, a partial one and the
+    single-frame path all occur)."""
+    ref = _render_in_subprocess("batch=1,inflight=1,simpleClosest=9999,simpleShadow=9999,build=lbvh")
+    assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+    for tune in ["batch=2,inflight=2", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64"]:
+        got = _render_in_subprocess(tune)
+        assert np.array_equal(got, ref), tune
+
+
+def test_launch_policy_sponza_like_and_samples_per_frame():
+    """Same on the alpha-heavy scene, with maxSamples > 1 (the per-frame sample loop inside a batch)."""
+    ref = _render_in_subprocess("batch=1,inflight=1,simpleClosest=9999,simpleShadow=9999,build=lbvh", frames=3, max_samples=2, scene="sponza")
+    got = _render_in_subprocess("batch=2,inflight=2,build=sah", frames=3, max_samples=2, scene="sponza")
+    assert np.array_equal(got, ref)
+
+
+def test_camera_change_flushes_pending_frames():
+    ref = _render_in_subprocess("batch=1,inflight=1", frames=3, scene="camswitch")
+    got = _render_in_subprocess("batch=32,inflight=3", frames=3, scene="camswitch")
+    assert np.array_equal(got, ref)
+    still = _render_in_subprocess("batch=32,inflight=3", frames=6, scene="feature")
+    assert not np.array_equal(still, got)  # (the move is visible)
+
