@@ -16,7 +16,12 @@
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)
 
 struct TraceLane {
-  f3       o, d, idir;
+  f3       o, d;
+#if PT_BVH_WIDTH != 2
+  RayBox   rbox;
+#else
+  f3       idir;
+#endif
   float    tmax;           // exclusive upper bound on t (pass B: the limit key's t, inclusive for ties)
   float    bt, bu, bv;     // best CERTAIN hit
   uint32_t bslot, bw;
@@ -31,7 +36,12 @@ struct TraceLane {
 
 PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
 {
-  L.o = o; L.d = d; L.idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  L.o = o; L.d = d;
+#if PT_BVH_WIDTH != 2
+  L.rbox = make_raybox(o, d);
+#else
+  L.idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+#endif
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
   L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f;
 }
@@ -62,7 +72,7 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 {
 #if PT_BVH_WIDTH != 2
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
-  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.o, L.idir, lim, [&](uint32_t c) {
+  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.rbox, lim, [&](uint32_t c) {
     if(L.sp < STACK_LDS)
       lds[L.sp++ * TRACE_BLOCK] = c;
     else if(L.sp < STACK_LDS + STACK_SPILL)

@@ -33,7 +33,10 @@ namespace {
 
 // resident waves per SIMD the trace kernels are compiled for (bounds their VGPR budget: 512 / waves)
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 6  // 80 VGPRs: 1029 vs 995 Msamples/s against 5; 7 and 8 spill and lose (r01)
+#define PT_TRACE_WAVES 5  // 96 VGPRs; 6 (80 VGPRs) spills once the fused slab test's per-ray constants are live: 996 vs 1070 Msamples/s (r01)
+#endif
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 3
 #endif
 constexpr int SHADE_BLOCK = 256;
 enum { SHADE_DONE = 0, SHADE_TO_SHADOW = 1, SHADE_TO_NEXT = 2 };
@@ -642,7 +645,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   return depth != st.maxDepth - 1 ? SHADE_TO_NEXT : SHADE_DONE;
 }
 
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
+__global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
 {
   __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups
   uint32_t*      C     = rb.counts + depth * CNT_STRIDE;

@@ -90,39 +90,64 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
 }
 
 #if PT_BVH_WIDTH != 2
-// One wide-node visit: slab-tests the W child boxes against [0, lim], pushes the hit children far-to-near through
-// `push` and returns the nearest one (BVH_NONE when nothing is hit).  (bound - o) * idir keeps NaN confined to the
-// degenerate 0*inf case, which fminf/fmaxf (IEEE minNum/maxNum) ignore -> conservative; the 1 +- 4e-7 factors keep
-// the box test conservative with respect to the triangle test (the boxes themselves are padded at build time).
-template <class Push>
-PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node, f3 o, f3 idir, float lim, Push&& push)
+// Per-ray constants of the slab test.  The test runs in the fused form t = plane * idir + n with n = -(o * idir):
+// one FMA per plane instead of a subtract and a multiply, and -- because the sign of idir says which plane of a slab
+// is the near one -- no per-axis min / max: the near and far planes are fetched from sign-dependent offsets inside
+// the node.  The box test is not part of the bit-exact contract (results are BVH independent), it only has to be
+// conservative: the fused form adds an absolute error of |o * idir| * 2^-24 per axis (cancellation), absorbed by
+// biasing n by E = |o * idir| * 2^-21 towards "hit" (nlo for near planes, nhi for far planes); the relative part
+// stays covered by the (1 -+ 4e-7) factors.  |d| components below 1e-18 are clamped so that idir stays finite
+// (a ray moves < 1 ulp along such an axis over any representable distance).
+struct RayBox {
+  f3       idir, nlo, nhi;
+  uint32_t nearOff[3];  // byte offset of the near-plane quadruple of each axis inside a WideNode (far = the other one)
+};
+PT_DEV RayBox make_raybox(f3 o, f3 d)
 {
-  const WideNode* np = nodes + node;
-  float           tn[PT_BVH_WIDTH];
-  uint32_t        cid[PT_BVH_WIDTH];
-  int             nh = 0;
+  RayBox      rb;
+  const float dx = copysignf(fmaxf(fabsf(d.x), 1.0e-18f), d.x), dy = copysignf(fmaxf(fabsf(d.y), 1.0e-18f), d.y), dz = copysignf(fmaxf(fabsf(d.z), 1.0e-18f), d.z);
+  rb.idir        = f3{1.0f / dx, 1.0f / dy, 1.0f / dz};
+  const f3 oi    = f3{o.x * rb.idir.x, o.y * rb.idir.y, o.z * rb.idir.z};
+  const f3 e     = f3{fabsf(oi.x) * 4.76837158e-7f, fabsf(oi.y) * 4.76837158e-7f, fabsf(oi.z) * 4.76837158e-7f};
+  rb.nlo         = f3{-oi.x - e.x, -oi.y - e.y, -oi.z - e.z};
+  rb.nhi         = f3{-oi.x + e.x, -oi.y + e.y, -oi.z + e.z};
+  rb.nearOff[0]  = rb.idir.x < 0.0f ? 48u : 0u;
+  rb.nearOff[1]  = rb.idir.y < 0.0f ? 48u : 0u;
+  rb.nearOff[2]  = rb.idir.z < 0.0f ? 48u : 0u;
+  return rb;
+}
+
+// One wide-node visit: slab-tests the 4 child boxes against [0, lim], pushes the hit children far-to-near through
+// `push` and returns the nearest one (BVH_NONE when nothing is hit).  Empty slots carry inverted infinite boxes.
+template <class Push>
+PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, Push&& push)
+{
+  static_assert(PT_BVH_WIDTH == 4, "the fused slab test is written for 4-wide nodes");
+  const char*    nb = reinterpret_cast<const char*>(nodes);
+  const uint32_t at = node << 7;  // sizeof(WideNode) == 128; 32-bit byte offsets (the node array is < 4 GB)
+  const float4   px = *reinterpret_cast<const float4*>(nb + (at + rb.nearOff[0])), qx = *reinterpret_cast<const float4*>(nb + (at + 48u - rb.nearOff[0]));
+  const float4   py = *reinterpret_cast<const float4*>(nb + (at + 16u + rb.nearOff[1])), qy = *reinterpret_cast<const float4*>(nb + (at + 64u - rb.nearOff[1]));
+  const float4   pz = *reinterpret_cast<const float4*>(nb + (at + 32u + rb.nearOff[2])), qz = *reinterpret_cast<const float4*>(nb + (at + 80u - rb.nearOff[2]));
+  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 96u));
+  const float    nx[4] = {__builtin_fmaf(px.x, rb.idir.x, rb.nlo.x), __builtin_fmaf(px.y, rb.idir.x, rb.nlo.x), __builtin_fmaf(px.z, rb.idir.x, rb.nlo.x), __builtin_fmaf(px.w, rb.idir.x, rb.nlo.x)};
+  const float    fx[4] = {__builtin_fmaf(qx.x, rb.idir.x, rb.nhi.x), __builtin_fmaf(qx.y, rb.idir.x, rb.nhi.x), __builtin_fmaf(qx.z, rb.idir.x, rb.nhi.x), __builtin_fmaf(qx.w, rb.idir.x, rb.nhi.x)};
+  const float    ny[4] = {__builtin_fmaf(py.x, rb.idir.y, rb.nlo.y), __builtin_fmaf(py.y, rb.idir.y, rb.nlo.y), __builtin_fmaf(py.z, rb.idir.y, rb.nlo.y), __builtin_fmaf(py.w, rb.idir.y, rb.nlo.y)};
+  const float    fy[4] = {__builtin_fmaf(qy.x, rb.idir.y, rb.nhi.y), __builtin_fmaf(qy.y, rb.idir.y, rb.nhi.y), __builtin_fmaf(qy.z, rb.idir.y, rb.nhi.y), __builtin_fmaf(qy.w, rb.idir.y, rb.nhi.y)};
+  const float    nz[4] = {__builtin_fmaf(pz.x, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.y, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.z, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.w, rb.idir.z, rb.nlo.z)};
+  const float    fz[4] = {__builtin_fmaf(qz.x, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.y, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.z, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.w, rb.idir.z, rb.nhi.z)};
+  const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
+  float          tn[4];
+  uint32_t       cid[4];
+  int            nh = 0;
 #pragma unroll
-  for(int q = 0; q < PT_WIDE_Q; ++q)
+  for(int k = 0; k < 4; ++k)
   {
-    const float4 mnx = np->minx[q], mny = np->miny[q], mnz = np->minz[q];
-    const float4 mxx = np->maxx[q], mxy = np->maxy[q], mxz = np->maxz[q];
-    const uint4  ch  = np->child[q];
-    const float  ax[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ay[4] = {mny.x, mny.y, mny.z, mny.w}, az[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
-    const float  bx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, by[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-    const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
-#pragma unroll
-    for(int k = 0; k < 4; ++k)
-    {
-      float x0 = (ax[k] - o.x) * idir.x, x1 = (bx[k] - o.x) * idir.x;
-      float y0 = (ay[k] - o.y) * idir.y, y1 = (by[k] - o.y) * idir.y;
-      float z0 = (az[k] - o.z) * idir.z, z1 = (bz[k] - o.z) * idir.z;
-      float nr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f)) * 0.9999996f;
-      float fr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim)) * 1.0000004f;
-      bool  h  = (nr <= fr) && (cc[k] != BVH_NONE);
-      tn[q * 4 + k]  = h ? nr : 3.0e38f;
-      cid[q * 4 + k] = cc[k];
-      nh += h ? 1 : 0;
-    }
+    const float nr = fmaxf(fmaxf(nx[k], ny[k]), fmaxf(nz[k], 0.0f)) * 0.9999996f;
+    const float fr = fminf(fminf(fx[k], fy[k]), fminf(fz[k], lim)) * 1.0000004f;
+    const bool  h  = (nr <= fr) && (cc[k] != BVH_NONE);
+    tn[k]  = h ? nr : 3.0e38f;
+    cid[k] = cc[k];
+    nh += h ? 1 : 0;
   }
   if(nh == 0)
     return BVH_NONE;
@@ -176,7 +201,11 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   if(S.numTris == 0)
     return;
 
+#if PT_BVH_WIDTH != 2
+  const RayBox rbox = make_raybox(o, d);
+#else
   const f3 idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+#endif
   // TM_SHADOW must keep looking for opaque triangles behind the best alpha candidate; TM_COUNT has a fixed range
 #define PT_TLIMIT ((MODE == TM_SHADOW || MODE == TM_COUNT) ? tmax : best.t)
   uint32_t spill[STACK_SPILL];
@@ -200,7 +229,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       ++nNodes;
 #endif
 #if PT_BVH_WIDTH != 2
-      const uint32_t nxt = wide_node_step(S.wide, cur, o, idir, PT_TLIMIT, [&](uint32_t c) {
+      const uint32_t nxt = wide_node_step(S.wide, cur, rbox, PT_TLIMIT, [&](uint32_t c) {
         if(sp < STACK_LDS)
           ldsStack[sp++ * TRACE_BLOCK] = c;
         else if(sp < STACK_LDS + STACK_SPILL)
