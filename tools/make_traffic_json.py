@@ -16,7 +16,11 @@ res = {"units": "bytes per launch; FETCH_SIZE x2 (gfx950 half-count for 16-B/lan
 for k in names:
     if nf.get(k):
         res["kernels"][k] = {"launches": nf[k], "read_bytes_per_launch": f[k] * 2 * 1024 / nf[k], "write_bytes_per_launch": (w[k] * 1024 / nw[k]) if nw.get(k) else None}
-cl = res["kernels"].get("k_closest_s") or res["kernels"].get("k_closest_p")
-res["k_closest_bytes_per_launch"] = (cl["read_bytes_per_launch"] + (cl["write_bytes_per_launch"] or 0)) if cl else None
+# bench.py's "launch" of the closest-hit stage = one bounce of one frame batch: k_closest_s or k_closest_p, plus k_closest_x
+stage = [k for k in ("k_closest_s", "k_closest_p", "k_closest_x") if k in res["kernels"]]
+tot = sum(res["kernels"][k]["launches"] * (res["kernels"][k]["read_bytes_per_launch"] + (res["kernels"][k]["write_bytes_per_launch"] or 0)) for k in stage)
+launches = res["kernels"]["k_closest_x"]["launches"] if "k_closest_x" in res["kernels"] else None
+res["k_closest_stage_launches"] = launches
+res["k_closest_bytes_per_launch"] = tot / launches if launches else None
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
