@@ -255,7 +255,9 @@ __global__ void k_gather(uint32_t n, const uint32_t* __restrict__ vals, const Tr
   alphaOut[i] = alphaIn[vals[i]];
   f3 lo, hi;
   tri_box(r, lo, hi);
-  leafLo[i] = make_float4(lo.x, lo.y, lo.z, 0.f);
+  // .w of the lower corner: 1 when the subtree holds a non-opaque triangle (propagated by k_refit, becomes the
+  // BVH_ALPHA tag of child references: the alpha-only traversals skip everything else)
+  leafLo[i] = make_float4(lo.x, lo.y, lo.z, ((__float_as_uint(r.p0w.w) >> 29) & TRI_OPAQUE) ? 0.f : 1.f);
   leafHi[i] = make_float4(hi.x, hi.y, hi.z, 0.f);
 }
 
@@ -345,7 +347,7 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ childL, const uint32
     float4   lhi = (l & BVH_LEAF) ? leafHi[l & ~BVH_LEAF] : nodeHi[l];
     float4   rlo = (r & BVH_LEAF) ? leafLo[r & ~BVH_LEAF] : nodeLo[r];
     float4   rhi = (r & BVH_LEAF) ? leafHi[r & ~BVH_LEAF] : nodeHi[r];
-    nodeLo[cur]  = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.f);
+    nodeLo[cur]  = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), fmaxf(llo.w, rlo.w));
     nodeHi[cur]  = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.f);
     cur          = parentOfInner[cur];
   }
@@ -374,7 +376,7 @@ __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const 
   nd.a   = make_float4(llo.x, llo.y, llo.z, lhi.x);
   nd.b   = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
   nd.c   = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
-  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : l, (r & BVH_LEAF) ? leaf_ref(tris, r) : r, 0u, 0u);
+  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : (l | (llo.w > 0.f ? BVH_ALPHA : 0u)), (r & BVH_LEAF) ? leaf_ref(tris, r) : (r | (rlo.w > 0.f ? BVH_ALPHA : 0u)), 0u, 0u);
   out[i] = nd;
 }
 
@@ -411,7 +413,7 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
   float4             lo[PT_BVH_WIDTH], hi[PT_BVH_WIDTH];
   int                n = 0;
   auto               push_children = [&](uint32_t node) {
-    const BvhNode nd = b2[node];
+    const BvhNode nd = b2[node & BVH_SLOT_MASK];
     id[n] = nd.d.x; lo[n] = make_float4(nd.a.x, nd.a.y, nd.a.z, 0.f); hi[n] = make_float4(nd.a.w, nd.b.x, nd.b.y, 0.f); ++n;
     if(nd.d.y != BVH_NONE)
     {
@@ -459,8 +461,8 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
         {
           uint32_t wid = atomicAdd(&counters[1], 1u);
           uint32_t qi  = atomicAdd(&counters[0], 1u);
-          qout[qi]     = CollapseItem{id[c], wid};
-          ch[k]        = wid;
+          qout[qi]     = CollapseItem{id[c] & BVH_SLOT_MASK, wid};
+          ch[k]        = wid | (id[c] & BVH_ALPHA);  // inner reference: wide node index + "subtree holds non-opaque triangles"
         }
       }
       else

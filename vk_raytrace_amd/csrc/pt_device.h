@@ -24,7 +24,7 @@ struct BvhNode {
   uint4  d;  // left, right (bit31 set: leaf -> TriRec slot), 0, 0
 };
 #define BVH_LEAF 0x80000000u
-#define BVH_ALPHA 0x40000000u  // leaf reference: the triangle is non-opaque (its AlphaRec is fetched together with its TriRec)
+#define BVH_ALPHA 0x40000000u  // leaf reference: the triangle is non-opaque; inner reference: the subtree holds non-opaque triangles
 #define BVH_SLOT_MASK 0x3fffffffu
 #define BVH_NONE 0xffffffffu
 

@@ -72,7 +72,7 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 {
 #if PT_BVH_WIDTH != 2
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
-  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.rbox, lim, [&](uint32_t c) {
+  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.rbox, lim, L.pass == 1, [&](uint32_t c) {
     if(L.sp < STACK_LDS)
       lds[L.sp++ * TRACE_BLOCK] = c;
     else if(L.sp < STACK_LDS + STACK_SPILL)
@@ -86,7 +86,7 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
     lane_pop(L, lds, spill);
 }
 #else
-  const BvhNode* np = S.bvh + L.cur;
+  const BvhNode* np = S.bvh + (L.cur & BVH_SLOT_MASK);
   const float4   a = np->a, b = np->b, c = np->c;
   const uint4    ch = np->d;
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;

@@ -119,12 +119,13 @@ PT_DEV RayBox make_raybox(f3 o, f3 d)
 
 // One wide-node visit: slab-tests the 4 child boxes against [0, lim], pushes the hit children far-to-near through
 // `push` and returns the nearest one (BVH_NONE when nothing is hit).  Empty slots carry inverted infinite boxes.
+// alphaOnly: visit only children tagged BVH_ALPHA (pass B and the non-opaque fallback never need an opaque subtree).
 template <class Push>
-PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, Push&& push)
+PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
 {
   static_assert(PT_BVH_WIDTH == 4, "the fused slab test is written for 4-wide nodes");
   const char*    nb = reinterpret_cast<const char*>(nodes);
-  const uint32_t at = node << 7;  // sizeof(WideNode) == 128; 32-bit byte offsets (the node array is < 4 GB)
+  const uint32_t at = (node & BVH_SLOT_MASK) << 7;  // sizeof(WideNode) == 128; 32-bit byte offsets (the node array is < 4 GB)
   const float4   px = *reinterpret_cast<const float4*>(nb + (at + rb.nearOff[0])), qx = *reinterpret_cast<const float4*>(nb + (at + 48u - rb.nearOff[0]));
   const float4   py = *reinterpret_cast<const float4*>(nb + (at + 16u + rb.nearOff[1])), qy = *reinterpret_cast<const float4*>(nb + (at + 64u - rb.nearOff[1]));
   const float4   pz = *reinterpret_cast<const float4*>(nb + (at + 32u + rb.nearOff[2])), qz = *reinterpret_cast<const float4*>(nb + (at + 80u - rb.nearOff[2]));
@@ -144,7 +145,7 @@ PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node
   {
     const float nr = fmaxf(fmaxf(nx[k], ny[k]), fmaxf(nz[k], 0.0f)) * 0.9999996f;
     const float fr = fminf(fminf(fx[k], fy[k]), fminf(fz[k], lim)) * 1.0000004f;
-    const bool  h  = (nr <= fr) && (cc[k] != BVH_NONE);
+    const bool  h  = (nr <= fr) && (cc[k] != BVH_NONE) && (!alphaOnly || (cc[k] & BVH_ALPHA));
     tn[k]  = h ? nr : 3.0e38f;
     cid[k] = cc[k];
     nh += h ? 1 : 0;
@@ -229,7 +230,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       ++nNodes;
 #endif
 #if PT_BVH_WIDTH != 2
-      const uint32_t nxt = wide_node_step(S.wide, cur, rbox, PT_TLIMIT, [&](uint32_t c) {
+      const uint32_t nxt = wide_node_step(S.wide, cur, rbox, PT_TLIMIT, MODE == TM_COUNT || MODE == TM_RAW_NONOPAQUE, [&](uint32_t c) {
         if(sp < STACK_LDS)
           ldsStack[sp++ * TRACE_BLOCK] = c;
         else if(sp < STACK_LDS + STACK_SPILL)
@@ -243,7 +244,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
         continue;
       }
 #else
-      const BvhNode* np = S.bvh + cur;
+      const BvhNode* np = S.bvh + (cur & BVH_SLOT_MASK);
       const float4   a = np->a, b = np->b, c = np->c;
       const uint4    ch = np->d;
       // slab test of both children; (bound - o) * idir keeps NaN confined to the degenerate 0*inf case,
