@@ -226,3 +226,21 @@ void pt_sah_topology(uint32_t n, const TriRec* tris, uint32_t* vals, uint32_t* c
   for(uint32_t i = 0; i < n; ++i)
     vals[i] = prims[i].id;
 }
+
+// Test hook (tests/test_sah_cpu.py; not part of include/pt_api.h): the topology builder on plain arrays, no GPU involved.
+// tri9: n x 9 floats (p0, e1, e2).
+extern "C" int pt_debug_sah_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL)
+{
+  if(n < 2 || !tri9)
+    return -1;
+  std::vector<TriRec> t(n);
+  for(uint32_t i = 0; i < n; ++i)
+  {
+    const float* p = tri9 + 9 * size_t(i);
+    t[i].p0w = make_float4(p[0], p[1], p[2], 0.f);
+    t[i].e1n = make_float4(p[3], p[4], p[5], 0.f);
+    t[i].e2p = make_float4(p[6], p[7], p[8], 0.f);
+  }
+  pt_sah_topology(n, t.data(), vals, childL, childR, parI, parL);
+  return 0;
+}
