@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--tris", type=int, default=262_267)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"], help="BASELINE.json configuration (stand-in scene); c3 is the bench line, the others are for the results table")
+    ap.add_argument("--emulate-shard", default="", help="R/N: render only rank R's tiles of an N-GPU run on this one GPU (scaling estimate; value = this shard's rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (roofline fields become null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
@@ -85,7 +86,12 @@ def main():
 
     r = HipRenderer()
     r.setup(local_rank)
-    r.set_shard(rank, world)
+    if args.emulate_shard:
+        er, en = (int(x) for x in args.emulate_shard.split("/"))
+        r.set_shard(er, en)
+        args.no_cpu_baseline = True
+    else:
+        r.set_shard(rank, world)
     r.set_scene(wl.scene)
     integral, _ = r.set_env(wl.env)
     cam = capi.camera_lookat(wl.scene.camera, W / H, nb_lights=len(wl.scene.lights))

@@ -695,8 +695,9 @@ int pt_resize(pt_context* c, int width, int height)
   c->numSlots = c->numLocalTiles * 1024u;
 
   int rc;
-  // frames per batch: the tuning value, bounded so that one frame slot's path state stays below 2^27 paths (~22 GB)
-  c->batchMax = std::max(1, std::min(g_tuning.batch, int((1u << 27) / (c->numSlots ? c->numSlots : 1u))));
+  // frames per batch: the tuning value, bounded so that one frame slot's path state stays below 2^26 paths (~11 GB):
+  // 32 frames of a full 1080p image, 64 of an 8-GPU shard (measured best for both, profiles/r01_scaling_estimate.txt)
+  c->batchMax = std::max(1, std::min(g_tuning.batch, int((1u << 26) / (c->numSlots ? c->numSlots : 1u))));
   const size_t n = size_t(c->numSlots ? c->numSlots : 1) * size_t(c->batchMax);
   for(int i = 0; i < c->inflight; ++i)
   {

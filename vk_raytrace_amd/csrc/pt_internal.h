@@ -43,9 +43,9 @@ struct PtTuning {
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
   int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
-  int framesInFlight       = 3;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
+  int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
   int sahBuild             = 1;    // 1: host SAH topology (fast trace, the default), 0: device LBVH (fast build)
-  int batch                = 32;   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
+  int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
 extern PtTuning g_tuning;
 void pt_sah_topology(uint32_t n, const struct TriRec* tris, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);  // pt_sah.hip
