@@ -343,3 +343,16 @@ def test_camera_change_flushes_pending_frames():
     still = _render_in_subprocess("batch=32,inflight=3", frames=6, scene="feature")
     assert not np.array_equal(still, got)  # (the move is visible)
 
+
+
+def test_gltf_round_trip_renders_identically(env_small, tmp_path):
+    """A scene written as .glb and read back through the importer renders bit-identically (same camera object)."""
+    from vk_raytrace_amd import gltf
+    sc = synth.feature_box(tex_size=32)
+    path = str(tmp_path / "box.glb")
+    gltf.save_gltf(sc, path)
+    back = gltf.load_gltf(path)
+    back.camera = sc.camera
+    a = render_hip(Config(sc, env_small, 160, 120, depth=6), 3)
+    b = render_hip(Config(back, env_small, 160, 120, depth=6), 3)
+    assert np.array_equal(a, b)

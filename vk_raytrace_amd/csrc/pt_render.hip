@@ -645,6 +645,9 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   return depth != st.maxDepth - 1 ? SHADE_TO_NEXT : SHADE_DONE;
 }
 
+#ifdef PT_SHADE_VGPRS
+__attribute__((amdgpu_num_vgpr(PT_SHADE_VGPRS)))
+#endif
 __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
 {
   __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups

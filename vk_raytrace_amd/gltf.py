@@ -1,0 +1,620 @@
+"""glTF 2.0 import / export for the host-side ``Scene`` container.
+
+The reference delegates glTF import to the un-vendored ``nvh::GltfScene`` (``src/scene.cpp:56-75``:
+``importMaterials`` + ``importDrawableNodes(Normal | Texcoord_0 | Tangent | Color_0)``) and only consumes its flat
+output: per-primitive vertex/index ranges de-duplicated by accessor key, one node per (scene-graph node, primitive) with
+its world matrix, materials with the KHR extensions that ``Scene::createMaterialBuffer`` copies (``src/scene.cpp:344-378``),
+punctual lights (``:304-333``), textures = (sampler, image) pairs converted by ``gltfSamplerToVulkan`` (``:447-482,561-571``),
+the first camera (``:281-298``).  This module produces exactly that flat form.  What the library does where the file leaves
+attributes out is **parity unpinned** (the library is not in the reference tree); the choices here follow the glTF 2.0
+specification and are stated next to the code: missing normals -> area-weighted vertex normals, missing tangents -> per-vertex
+tangents from the uv parameterisation (Gram-Schmidt, handedness in w), missing uv -> 0, missing colour -> 1.
+
+``save_gltf`` writes a ``Scene`` back as .gltf (+ .bin + PNG) or .glb.  It exists so that (i) the importer has round-trip
+tests on files with every feature the renderer consumes, and (ii) the synthetic stand-in scenes of ``synth.py`` can be
+rendered by the *reference itself* wherever Vulkan exists -- the cross-check BASELINE.md asks for.
+
+Image decoding (PNG / JPEG) uses Pillow when it is importable; without it only uncompressed sources fail, with a clear error.
+"""
+import base64
+import io
+import json
+import math
+import os
+import struct
+
+import numpy as np
+
+from . import capi, host_device as hd
+from .scene import Camera, Scene, default_tangents
+
+_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}
+_ALPHA = {"OPAQUE": hd.ALPHA_OPAQUE, "MASK": hd.ALPHA_MASK, "BLEND": hd.ALPHA_BLEND}
+_ALPHA_NAME = {v: k for k, v in _ALPHA.items()}
+
+
+class GltfError(ValueError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------ file container
+def _read_container(path):
+    """Returns (json dict, list of buffer bytes, base directory)."""
+    base = os.path.dirname(os.path.abspath(path))
+    with open(path, "rb") as f:
+        raw = f.read()
+    glb_bin = None
+    if raw[:4] == b"glTF":
+        magic, version, length = struct.unpack_from("<4sII", raw, 0)
+        if version != 2:
+            raise GltfError(f"GLB version {version} is not supported")
+        off, doc = 12, None
+        while off + 8 <= min(length, len(raw)):
+            clen, ctype = struct.unpack_from("<II", raw, off)
+            chunk = raw[off + 8: off + 8 + clen]
+            if ctype == 0x4E4F534A:
+                doc = json.loads(chunk.decode("utf-8"))
+            elif ctype == 0x004E4942 and glb_bin is None:
+                glb_bin = bytes(chunk)
+            off += 8 + clen + ((4 - clen % 4) % 4)
+        if doc is None:
+            raise GltfError("GLB without a JSON chunk")
+    else:
+        doc = json.loads(raw.decode("utf-8"))
+    if str(doc.get("asset", {}).get("version", "2.0")).split(".")[0] != "2":
+        raise GltfError("only glTF 2.x is supported")
+    buffers = []
+    for i, b in enumerate(doc.get("buffers", [])):
+        uri = b.get("uri")
+        if uri is None:
+            if glb_bin is None or i != 0:
+                raise GltfError(f"buffer {i} has no uri and there is no GLB binary chunk")
+            buffers.append(glb_bin)
+        else:
+            buffers.append(_read_uri(uri, base))
+    return doc, buffers, base
+
+
+def _read_uri(uri, base):
+    if uri.startswith("data:"):
+        head, _, payload = uri.partition(",")
+        if not head.endswith(";base64"):
+            raise GltfError("data: uris must be base64")
+        return base64.b64decode(payload)
+    from urllib.parse import unquote
+    with open(os.path.join(base, unquote(uri)), "rb") as f:
+        return f.read()
+
+
+class _Doc:
+    def __init__(self, doc, buffers, base):
+        self.doc, self.buffers, self.base = doc, buffers, base
+
+    def view(self, index):
+        v = self.doc["bufferViews"][index]
+        b = self.buffers[v["buffer"]]
+        o = v.get("byteOffset", 0)
+        return b[o: o + v["byteLength"]], v.get("byteStride", 0)
+
+    def accessor(self, index, as_float=True):
+        """Decoded accessor as an (count, ncomp) array; normalised integers become floats per the specification."""
+        a = self.doc["accessors"][index]
+        if "sparse" in a:
+            raise GltfError("sparse accessors are not supported")
+        dt, nc, count = np.dtype(_COMP[a["componentType"]]), _NCOMP[a["type"]], a["count"]
+        if "bufferView" not in a:
+            arr = np.zeros((count, nc), dt)
+        else:
+            data, stride = self.view(a["bufferView"])
+            off = a.get("byteOffset", 0)
+            elem = dt.itemsize * nc
+            if stride in (0, elem):
+                arr = np.frombuffer(data, dt, count * nc, off).reshape(count, nc)
+            else:
+                raw = np.frombuffer(data, np.uint8)
+                idx = off + stride * np.arange(count)[:, None] + np.arange(elem)[None, :]
+                arr = raw[idx].copy().view(dt).reshape(count, nc)
+        if not as_float:
+            return arr
+        if dt == np.float32:
+            return arr.astype(np.float32)
+        if a.get("normalized", False):
+            if dt.kind == "u":
+                return (arr.astype(np.float32) / np.float32(np.iinfo(dt).max)).astype(np.float32)
+            return np.maximum(arr.astype(np.float32) / np.float32(np.iinfo(dt).max), np.float32(-1.0)).astype(np.float32)
+        return arr.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ images / samplers
+def _decode_image(data, what):
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise GltfError(f"decoding {what} needs Pillow (PNG / JPEG)") from e
+    im = Image.open(io.BytesIO(data))
+    if im.mode in ("I;16", "I;16B", "I"):  # 16-bit PNG: keep the high byte like stb_image's 8-bit path
+        im = im.point(lambda v: v / 257).convert("L")
+    return np.ascontiguousarray(np.asarray(im.convert("RGBA"), np.uint8))
+
+
+def _sampler(doc, tex):
+    """(magFilter, minFilter, wrapS, wrapT) in pt enums through pt_sampler_from_gltf (== gltfSamplerToVulkan + the
+    LINEAR / REPEAT default of textures without a sampler, src/scene.cpp:561-571)."""
+    td = hd.TextureDesc()
+    s = tex.get("sampler", -1)
+    if s is None or s < 0:
+        capi.lib().pt_sampler_from_gltf(0, 0, 0, 0, 0, td)
+    else:
+        sm = doc.get("samplers", [])[s]
+        # tinygltf defaults: filters -1 (-> enum 0 = NEAREST through the reference's std::map lookup), wrap REPEAT
+        capi.lib().pt_sampler_from_gltf(1, sm.get("magFilter", -1), sm.get("minFilter", -1), sm.get("wrapS", 10497), sm.get("wrapT", 10497), td)
+    return td.magFilter, td.minFilter, td.wrapS, td.wrapT
+
+
+# ------------------------------------------------------------------------------------------------ materials
+def _tex_index(info):
+    return -1 if not info else int(info.get("index", -1))
+
+
+def _uv_transform(ext):
+    """KHR_texture_transform -> the mat4 the shader applies as a ROW vector: (u, v, 1, 1) * M (gltf_material.glsl:52-58).
+    uv' = T * R * S * uv per the extension's specification; M holds that matrix transposed."""
+    m = np.eye(4, dtype=np.float32)
+    if not ext:
+        return m
+    ox, oy = ext.get("offset", [0.0, 0.0])
+    sx, sy = ext.get("scale", [1.0, 1.0])
+    r = float(ext.get("rotation", 0.0))
+    c, s = math.cos(r), math.sin(r)
+    # T * R * S with R = [[c, s], [-s, c]] (the specification's counter-clockwise rotation in uv space)
+    a, b = c * sx, s * sy
+    d, e = -s * sx, c * sy
+    m[0, 0], m[0, 1], m[0, 2] = a, b, ox     # column 0 of the GLSL matrix = coefficients of u'
+    m[1, 0], m[1, 1], m[1, 2] = d, e, oy     # column 1 = coefficients of v'
+    return m
+
+
+def _material(m):
+    out = hd.default_material()
+    pbr = m.get("pbrMetallicRoughness", {})
+    out["pbrBaseColorFactor"] = pbr.get("baseColorFactor", [1, 1, 1, 1])
+    out["pbrBaseColorTexture"] = _tex_index(pbr.get("baseColorTexture"))
+    out["pbrMetallicFactor"] = pbr.get("metallicFactor", 1.0)
+    out["pbrRoughnessFactor"] = pbr.get("roughnessFactor", 1.0)
+    out["pbrMetallicRoughnessTexture"] = _tex_index(pbr.get("metallicRoughnessTexture"))
+    out["emissiveTexture"] = _tex_index(m.get("emissiveTexture"))
+    out["emissiveFactor"] = m.get("emissiveFactor", [0, 0, 0])
+    out["alphaMode"] = _ALPHA.get(m.get("alphaMode", "OPAQUE"), hd.ALPHA_OPAQUE)
+    out["alphaCutoff"] = m.get("alphaCutoff", 0.5)
+    out["doubleSided"] = 1 if m.get("doubleSided", False) else 0
+    nt = m.get("normalTexture")
+    out["normalTexture"] = _tex_index(nt)
+    out["normalTextureScale"] = (nt or {}).get("scale", 1.0)
+    bct = pbr.get("baseColorTexture") or {}
+    out["uvTransform"] = _uv_transform((bct.get("extensions") or {}).get("KHR_texture_transform")).reshape(16)  # G[c] = column c of the GLSL mat4
+    ext = m.get("extensions", {}) or {}
+    out["unlit"] = 1 if "KHR_materials_unlit" in ext else 0
+    tr = ext.get("KHR_materials_transmission", {})
+    out["transmissionFactor"] = tr.get("transmissionFactor", 0.0)
+    out["transmissionTexture"] = _tex_index(tr.get("transmissionTexture"))
+    out["ior"] = ext.get("KHR_materials_ior", {}).get("ior", 1.5)
+    an = ext.get("KHR_materials_anisotropy", {})
+    rot = float(an.get("anisotropyRotation", 0.0))
+    out["anisotropy"] = an.get("anisotropyStrength", 0.0)
+    out["anisotropyDirection"] = (np.float32(math.sin(rot)), np.float32(math.cos(rot)), 0.0)  # src/scene.cpp:366
+    vol = ext.get("KHR_materials_volume", {})
+    out["attenuationColor"] = vol.get("attenuationColor", [1, 1, 1])
+    out["thicknessFactor"] = vol.get("thicknessFactor", 0.0)
+    out["thicknessTexture"] = _tex_index(vol.get("thicknessTexture"))
+    out["attenuationDistance"] = np.float32(min(float(vol.get("attenuationDistance", 3.4028235e38)), 3.4028235e38))
+    cc = ext.get("KHR_materials_clearcoat", {})
+    out["clearcoatFactor"] = cc.get("clearcoatFactor", 0.0)
+    out["clearcoatRoughness"] = cc.get("clearcoatRoughnessFactor", 0.0)
+    out["clearcoatTexture"] = _tex_index(cc.get("clearcoatTexture"))
+    out["clearcoatRoughnessTexture"] = _tex_index(cc.get("clearcoatRoughnessTexture"))
+    sh = ext.get("KHR_materials_sheen", {})
+    col = list(sh.get("sheenColorFactor", [0, 0, 0])) + [sh.get("sheenRoughnessFactor", 0.0)]
+    out["sheen"] = pack_unorm4x8(col)  # glm::packUnorm4x8 (src/scene.cpp:376)
+    return out
+
+
+def pack_unorm4x8(v):
+    b = [int(np.rint(np.clip(np.float32(x), 0.0, 1.0) * np.float32(255.0))) for x in v]
+    return np.uint32(b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24))
+
+
+def unpack_unorm4x8(u):
+    u = int(u)
+    return [((u >> s) & 255) / 255.0 for s in (0, 8, 16, 24)]
+
+
+# ------------------------------------------------------------------------------------------------ geometry helpers
+def _local_matrix(n):
+    if "matrix" in n:
+        return np.array(n["matrix"], np.float64).reshape(4, 4).T  # column-major in the file
+    t = np.array(n.get("translation", [0, 0, 0]), np.float64)
+    q = np.array(n.get("rotation", [0, 0, 0, 1]), np.float64)
+    s = np.array(n.get("scale", [1, 1, 1]), np.float64)
+    x, y, z, w = q
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    m = np.eye(4)
+    m[:3, :3] = r * s[None, :]
+    m[:3, 3] = t
+    return m
+
+
+def synth_normals(pos, idx):
+    """Area-weighted vertex normals (files without NORMAL; the glTF specification asks for flat normals -- per-vertex
+    accumulation is what survives index sharing -- parity unpinned, see the module docstring)."""
+    tri = idx.reshape(-1, 3)
+    fn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]]).astype(np.float64)
+    n = np.zeros((len(pos), 3), np.float64)
+    for k in range(3):
+        np.add.at(n, tri[:, k], fn)
+    l = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(l > 0, n / np.maximum(l, 1e-300), np.array([[0.0, 0.0, 1.0]]))
+    return n.astype(np.float32)
+
+
+def synth_tangents(pos, nrm, uv, idx):
+    """Per-vertex tangents from the uv parameterisation (Lengyel): accumulate dP/du per triangle, orthogonalise against
+    the normal, handedness = sign of (N x T) . dP/dv.  Vertices without a usable parameterisation get the container's
+    default frame."""
+    tri = idx.reshape(-1, 3)
+    p0, p1, p2 = (pos[tri[:, k]].astype(np.float64) for k in range(3))
+    w0, w1, w2 = (uv[tri[:, k]].astype(np.float64) for k in range(3))
+    e1, e2 = p1 - p0, p2 - p0
+    d1, d2 = w1 - w0, w2 - w0
+    det = d1[:, 0] * d2[:, 1] - d2[:, 0] * d1[:, 1]
+    ok = np.abs(det) > 1e-20
+    r = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)[:, None]
+    tdir = (e1 * d2[:, 1:2] - e2 * d1[:, 1:2]) * r
+    bdir = (e2 * d1[:, 0:1] - e1 * d2[:, 0:1]) * r
+    tan, bit = np.zeros((len(pos), 3)), np.zeros((len(pos), 3))
+    for k in range(3):
+        np.add.at(tan, tri[:, k], tdir)
+        np.add.at(bit, tri[:, k], bdir)
+    n = nrm.astype(np.float64)
+    t = tan - n * np.sum(n * tan, axis=1, keepdims=True)
+    l = np.linalg.norm(t, axis=1, keepdims=True)
+    good = l[:, 0] > 1e-12
+    t = np.where(good[:, None], t / np.maximum(l, 1e-300), 0.0)
+    h = np.where(np.sum(np.cross(n, t) * bit, axis=1) < 0.0, -1.0, 1.0)
+    out = np.concatenate([t, h[:, None]], axis=1).astype(np.float32)
+    if not good.all():
+        out[~good] = default_tangents(nrm[~good])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ import
+def load_gltf(path, scene_index=None):
+    """Reads a .gltf / .glb file into a ``Scene`` (call ``finalize(capi.pack_vertices)`` before rendering)."""
+    D = _Doc(*_read_container(path))
+    doc = D.doc
+    sc = Scene(os.path.splitext(os.path.basename(path))[0])
+
+    # textures = (sampler, image) pairs; materials index TEXTURES (src/scene.cpp:552-575)
+    images = {}
+
+    def image(i):
+        if i not in images:
+            im = doc["images"][i]
+            if "bufferView" in im:
+                data, _ = D.view(im["bufferView"])
+            elif "uri" in im:
+                data = _read_uri(im["uri"], D.base)
+            else:
+                raise GltfError(f"image {i} has neither uri nor bufferView")
+            images[i] = _decode_image(data, f"image {i}")
+        return images[i]
+
+    white = np.full((1, 1, 4), 255, np.uint8)
+    for t in doc.get("textures", []):
+        src = t.get("source", -1)
+        if src is None or src < 0 or src >= len(doc.get("images", [])):
+            sc.add_texture(white)  # "Incorrect source image" -> dummy (src/scene.cpp:554-559)
+            continue
+        mag, mn, ws, wt = _sampler(doc, t)
+        sc.add_texture(image(src), magFilter=mag, minFilter=mn, wrapS=ws, wrapT=wt)
+
+    for m in doc.get("materials", []):
+        sc.materials.append(_material(m))
+    if not sc.materials:
+        sc.materials.append(hd.default_material())  # a model without materials renders with the default one
+    ntex = len(sc.textures)
+    for m in sc.materials:
+        for k in ("pbrBaseColorTexture", "pbrMetallicRoughnessTexture", "emissiveTexture", "normalTexture", "transmissionTexture", "thicknessTexture",
+                  "clearcoatTexture", "clearcoatRoughnessTexture"):
+            if int(m[k]) >= ntex:
+                raise GltfError(f"material references texture {int(m[k])} of {ntex}")
+
+    # drawable nodes: one Scene node per (graph node, triangle primitive); primitives de-duplicated by accessor key
+    prim_cache = {}
+
+    def prim_mesh(p):
+        if p.get("mode", 4) != 4:
+            return None  # only triangle lists reach the BLAS builder
+        at = p.get("attributes", {})
+        if "POSITION" not in at:
+            return None
+        key = (at.get("POSITION"), at.get("NORMAL"), at.get("TEXCOORD_0"), at.get("TANGENT"), at.get("COLOR_0"), p.get("indices"), p.get("material", -1))
+        if key in prim_cache:
+            return prim_cache[key]
+        pos = D.accessor(at["POSITION"])[:, :3]
+        n = len(pos)
+        idx = D.accessor(p["indices"], as_float=False).reshape(-1).astype(np.uint32) if p.get("indices") is not None else np.arange(n, dtype=np.uint32)
+        idx = idx[: len(idx) // 3 * 3]
+        if len(idx) and idx.max() >= n:
+            raise GltfError("primitive index out of range")
+        nrm = D.accessor(at["NORMAL"])[:, :3] if "NORMAL" in at else synth_normals(pos, idx)
+        uv = D.accessor(at["TEXCOORD_0"])[:, :2] if "TEXCOORD_0" in at else np.zeros((n, 2), np.float32)
+        if "TANGENT" in at:
+            tan = D.accessor(at["TANGENT"])
+            if tan.shape[1] == 3:
+                tan = np.concatenate([tan, np.ones((n, 1), np.float32)], axis=1)
+        else:
+            tan = synth_tangents(pos, nrm, uv, idx) if len(idx) else default_tangents(nrm)
+        if "COLOR_0" in at:
+            col = D.accessor(at["COLOR_0"])
+            if col.shape[1] == 3:
+                col = np.concatenate([col, np.ones((n, 1), np.float32)], axis=1)
+        else:
+            col = np.ones((n, 4), np.float32)
+        mat = p.get("material", -1)
+        mat = mat if mat is not None and 0 <= mat < len(sc.materials) else 0
+        pm = sc.add_prim_mesh(pos, nrm, uv, idx, mat, tangents=tan, colors=col)
+        prim_cache[key] = pm
+        return pm
+
+    cameras, lights_ext = [], (doc.get("extensions", {}) or {}).get("KHR_lights_punctual", {}).get("lights", [])
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+
+    def visit(ni, parent):
+        nonlocal lo, hi
+        n = doc["nodes"][ni]
+        world = parent @ _local_matrix(n)
+        if n.get("mesh") is not None:
+            for p in doc["meshes"][n["mesh"]].get("primitives", []):
+                pm = prim_mesh(p)
+                if pm is None:
+                    continue
+                sc.add_node(pm, world.astype(np.float32))
+                pts = sc._pos[pm]
+                c = np.array([[pts[:, k].min(), pts[:, k].max()] for k in range(3)])
+                corners = np.array([[c[0, i], c[1, j], c[2, k], 1.0] for i in (0, 1) for j in (0, 1) for k in (0, 1)])
+                w = (world @ corners.T).T[:, :3]
+                lo, hi = np.minimum(lo, w.min(0)), np.maximum(hi, w.max(0))
+        if n.get("camera") is not None:
+            cam = doc["cameras"][n["camera"]]
+            if cam.get("type", "perspective") == "perspective":
+                cameras.append((world, cam))
+        le = (n.get("extensions", {}) or {}).get("KHR_lights_punctual")
+        if le is not None and 0 <= le.get("light", -1) < len(lights_ext):
+            L = lights_ext[le["light"]]
+            spot = L.get("spot", {})
+            kind = {"point": hd.LightType_Point, "directional": hd.LightType_Directional, "spot": hd.LightType_Spot}.get(L.get("type"), hd.LightType_Point)
+            sc.add_light(position=(world @ np.array([0, 0, 0, 1.0]))[:3], direction=(world @ np.array([0, 0, -1.0, 0]))[:3], color=L.get("color", [1, 1, 1]),
+                         innerConeCos=math.cos(spot.get("innerConeAngle", 0.0)), outerConeCos=math.cos(spot.get("outerConeAngle", math.pi / 4)),
+                         range=L.get("range", 0.0), intensity=L.get("intensity", 1.0), type=kind)
+        for c in n.get("children", []):
+            visit(c, world)
+
+    scenes = doc.get("scenes", [])
+    si = doc.get("scene", 0) if scene_index is None else scene_index
+    roots = scenes[si].get("nodes", []) if scenes else list(range(len(doc.get("nodes", []))))
+    for r in roots:
+        visit(r, np.eye(4))
+
+    if cameras:
+        world, cam = cameras[0]
+        eye = (world @ np.array([0, 0, 0, 1.0]))[:3]
+        fwd = (world @ np.array([0, 0, -1.0, 0]))[:3]
+        up = (world @ np.array([0, 1.0, 0, 0]))[:3]
+        dist = float(np.linalg.norm(hi - lo)) if np.isfinite(lo).all() else 1.0
+        center = eye + fwd / max(np.linalg.norm(fwd), 1e-30) * (cam.get("extras", {}).get("pt_focus_distance") or max(dist * 0.5, 1e-3))
+        sc.camera = Camera(tuple(float(x) for x in eye), tuple(float(x) for x in center), tuple(float(x) for x in up),
+                           math.degrees(cam.get("perspective", {}).get("yfov", math.radians(60.0))))
+    elif np.isfinite(lo).all():
+        # no camera in the file: look at the bounding box from +z so that it fits the default 60 degree frustum
+        c, r = (lo + hi) * 0.5, float(np.linalg.norm(hi - lo)) * 0.5
+        sc.camera = Camera(tuple(float(x) for x in (c + np.array([0, 0, r / math.sin(math.radians(30.0))]))), tuple(float(x) for x in c), (0.0, 1.0, 0.0), 60.0)
+    sc.dimensions = (lo, hi)
+    return sc
+
+
+# ------------------------------------------------------------------------------------------------ export
+def _gl_filter(f):
+    return 9729 if f == hd.FILTER_LINEAR else 9728
+
+
+def _gl_wrap(w):
+    return {hd.WRAP_REPEAT: 10497, hd.WRAP_MIRRORED_REPEAT: 33648, hd.WRAP_CLAMP_TO_EDGE: 33071}[w]
+
+
+def _f(x):
+    return float(np.float32(x))  # the shortest decimal that round-trips the float32 value through a double
+
+
+def save_gltf(scene, path):
+    """Writes ``scene`` as glTF 2.0: ``*.glb`` (everything embedded) or ``*.gltf`` + ``*.bin`` + ``*_imgN.png``."""
+    from PIL import Image
+    glb = path.lower().endswith(".glb")
+    stem = os.path.splitext(os.path.basename(path))[0]
+    base = os.path.dirname(os.path.abspath(path))
+    blob = bytearray()
+    views, accessors = [], []
+
+    def add_view(data, target=None):
+        while len(blob) % 4:
+            blob.append(0)
+        v = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)}
+        if target:
+            v["target"] = target
+        blob.extend(data)
+        views.append(v)
+        return len(views) - 1
+
+    def add_accessor(arr, ctype, typ, target=None, minmax=False):
+        arr = np.ascontiguousarray(arr)
+        a = {"bufferView": add_view(arr.tobytes(), target), "componentType": ctype, "count": int(arr.shape[0]), "type": typ}
+        if minmax:
+            a["min"], a["max"] = [_f(x) for x in arr.min(0)], [_f(x) for x in arr.max(0)]
+        accessors.append(a)
+        return len(accessors) - 1
+
+    doc = {"asset": {"version": "2.0", "generator": "vk_raytrace_amd.gltf"}, "scene": 0}
+    meshes = []
+    for i, (vo, vc, fi, ic, mat) in enumerate(scene.prim_meshes):
+        at = {"POSITION": add_accessor(scene._pos[i], 5126, "VEC3", 34962, True), "NORMAL": add_accessor(scene._nrm[i], 5126, "VEC3", 34962),
+              "TEXCOORD_0": add_accessor(scene._uv[i], 5126, "VEC2", 34962), "TANGENT": add_accessor(scene._tan[i], 5126, "VEC4", 34962),
+              "COLOR_0": add_accessor(scene._col[i], 5126, "VEC4", 34962)}
+        meshes.append({"primitives": [{"attributes": at, "indices": add_accessor(scene._idx[i].reshape(-1, 1), 5125, "SCALAR", 34963), "material": int(mat), "mode": 4}]})
+    doc["meshes"] = meshes
+
+    nodes = [{"mesh": int(pm), "matrix": [_f(x) for x in np.asarray(m, np.float32).T.reshape(16)]} for m, pm in scene.nodes]
+
+    # textures: one (sampler, image) pair each
+    if scene.textures:
+        doc["images"], doc["samplers"], doc["textures"] = [], [], []
+        for i, t in enumerate(scene.textures):
+            buf = io.BytesIO()
+            Image.fromarray(t.rgba8, "RGBA").save(buf, format="PNG")
+            if glb:
+                doc["images"].append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png"})
+            else:
+                name = f"{stem}_img{i}.png"
+                with open(os.path.join(base, name), "wb") as f:
+                    f.write(buf.getvalue())
+                doc["images"].append({"uri": name})
+            doc["samplers"].append({"magFilter": _gl_filter(t.magFilter), "minFilter": _gl_filter(t.minFilter), "wrapS": _gl_wrap(t.wrapS), "wrapT": _gl_wrap(t.wrapT)})
+            doc["textures"].append({"sampler": i, "source": i})
+
+    used = set()
+    mats = []
+    for m in scene.materials:
+        def tex(key):
+            return {"index": int(m[key])} if int(m[key]) >= 0 else None
+        pbr = {"baseColorFactor": [_f(x) for x in m["pbrBaseColorFactor"]], "metallicFactor": _f(m["pbrMetallicFactor"]), "roughnessFactor": _f(m["pbrRoughnessFactor"])}
+        g = {"pbrMetallicRoughness": pbr, "emissiveFactor": [_f(x) for x in m["emissiveFactor"]], "alphaMode": _ALPHA_NAME[int(m["alphaMode"])],
+             "alphaCutoff": _f(m["alphaCutoff"]), "doubleSided": bool(int(m["doubleSided"]))}
+        if tex("pbrBaseColorTexture"):
+            pbr["baseColorTexture"] = tex("pbrBaseColorTexture")
+        if tex("pbrMetallicRoughnessTexture"):
+            pbr["metallicRoughnessTexture"] = tex("pbrMetallicRoughnessTexture")
+        if tex("emissiveTexture"):
+            g["emissiveTexture"] = tex("emissiveTexture")
+        if tex("normalTexture"):
+            g["normalTexture"] = dict(tex("normalTexture"), scale=_f(m["normalTextureScale"]))
+        M = np.asarray(m["uvTransform"], np.float32).reshape(4, 4)  # M[c] = column c of the GLSL mat4
+        if not np.array_equal(M, np.eye(4, dtype=np.float32)):
+            # (u, v, 1, 1) * M: entries 2 and 3 of a column both multiply 1
+            a, b, ox, d, e, oy = (float(x) for x in (M[0, 0], M[0, 1], M[0, 2] + M[0, 3], M[1, 0], M[1, 1], M[1, 2] + M[1, 3]))
+            sx, sy = math.hypot(a, d), math.hypot(b, e)
+            rot = math.atan2(-d, a) if sx > 0 else 0.0
+            chk = _uv_transform({"offset": [ox, oy], "scale": [sx, sy], "rotation": rot})
+            Mf = M.copy(); Mf[0, 2] += Mf[0, 3]; Mf[1, 2] += Mf[1, 3]; Mf[0, 3] = Mf[1, 3] = 0
+            if not np.allclose(chk, Mf, rtol=1e-5, atol=1e-6) or "baseColorTexture" not in pbr:
+                raise GltfError("uvTransform is not an offset / rotation / scale of the base-colour texture: not representable as KHR_texture_transform")
+            pbr["baseColorTexture"]["extensions"] = {"KHR_texture_transform": {"offset": [ox, oy], "scale": [sx, sy], "rotation": rot}}
+            used.add("KHR_texture_transform")
+        ext = {}
+        if int(m["unlit"]):
+            ext["KHR_materials_unlit"] = {}
+        if float(m["transmissionFactor"]) != 0.0 or tex("transmissionTexture"):
+            ext["KHR_materials_transmission"] = {"transmissionFactor": _f(m["transmissionFactor"])}
+            if tex("transmissionTexture"):
+                ext["KHR_materials_transmission"]["transmissionTexture"] = tex("transmissionTexture")
+        if _f(m["ior"]) != 1.5:
+            ext["KHR_materials_ior"] = {"ior": _f(m["ior"])}
+        if float(m["anisotropy"]) != 0.0 or not np.array_equal(np.asarray(m["anisotropyDirection"], np.float32), np.array([0, 1, 0], np.float32)):
+            d = m["anisotropyDirection"]
+            ext["KHR_materials_anisotropy"] = {"anisotropyStrength": _f(m["anisotropy"]), "anisotropyRotation": math.atan2(float(d[0]), float(d[1]))}
+        vol = {}
+        if not np.array_equal(np.asarray(m["attenuationColor"], np.float32), np.ones(3, np.float32)):
+            vol["attenuationColor"] = [_f(x) for x in m["attenuationColor"]]
+        if float(m["thicknessFactor"]) != 0.0:
+            vol["thicknessFactor"] = _f(m["thicknessFactor"])
+        if tex("thicknessTexture"):
+            vol["thicknessTexture"] = tex("thicknessTexture")
+        if float(m["attenuationDistance"]) < 3.0e38:
+            vol["attenuationDistance"] = _f(m["attenuationDistance"])
+        if vol:
+            ext["KHR_materials_volume"] = vol
+        if float(m["clearcoatFactor"]) != 0.0 or float(m["clearcoatRoughness"]) != 0.0 or tex("clearcoatTexture") or tex("clearcoatRoughnessTexture"):
+            cc = {"clearcoatFactor": _f(m["clearcoatFactor"]), "clearcoatRoughnessFactor": _f(m["clearcoatRoughness"])}
+            if tex("clearcoatTexture"):
+                cc["clearcoatTexture"] = tex("clearcoatTexture")
+            if tex("clearcoatRoughnessTexture"):
+                cc["clearcoatRoughnessTexture"] = tex("clearcoatRoughnessTexture")
+            ext["KHR_materials_clearcoat"] = cc
+        if int(m["sheen"]) != 0:
+            s = unpack_unorm4x8(m["sheen"])
+            ext["KHR_materials_sheen"] = {"sheenColorFactor": s[:3], "sheenRoughnessFactor": s[3]}
+        if ext:
+            g["extensions"] = ext
+            used.update(ext.keys())
+        mats.append(g)
+    doc["materials"] = mats
+
+    # camera: a node whose local frame is the look-at frame (-z forward, +y up)
+    cam = scene.camera
+    eye, center, up = (np.array(v, np.float64) for v in (cam.eye, cam.center, cam.up))
+    f = center - eye
+    dist = float(np.linalg.norm(f))
+    f = f / max(dist, 1e-30)
+    s = np.cross(f, up)
+    s /= max(np.linalg.norm(s), 1e-30)
+    u = np.cross(s, f)
+    cm = np.eye(4)
+    cm[:3, 0], cm[:3, 1], cm[:3, 2], cm[:3, 3] = s, u, -f, eye
+    doc["cameras"] = [{"type": "perspective", "perspective": {"yfov": math.radians(cam.fov), "znear": 0.001, "zfar": 100000.0, "aspectRatio": 1.0},
+                       "extras": {"pt_focus_distance": dist}}]
+    nodes.append({"camera": 0, "matrix": [float(x) for x in cm.T.reshape(16)]})
+
+    if scene.lights:
+        used.add("KHR_lights_punctual")
+        ls = []
+        for l in scene.lights:
+            kind = {hd.LightType_Point: "point", hd.LightType_Directional: "directional", hd.LightType_Spot: "spot"}[int(l["type"])]
+            e = {"type": kind, "color": [_f(x) for x in l["color"]], "intensity": _f(l["intensity"])}
+            if float(l["range"]) > 0:
+                e["range"] = _f(l["range"])
+            if kind == "spot":
+                e["spot"] = {"innerConeAngle": math.acos(min(1.0, float(l["innerConeCos"]))), "outerConeAngle": math.acos(min(1.0, float(l["outerConeCos"])))}
+            ls.append(e)
+            d = np.array(l["direction"], np.float64)
+            d = d / max(np.linalg.norm(d), 1e-30) if np.linalg.norm(d) > 0 else np.array([0, 0, -1.0])
+            a = np.array([0, 1.0, 0]) if abs(d[1]) < 0.99 else np.array([1.0, 0, 0])
+            sx = np.cross(d, a)
+            sx /= np.linalg.norm(sx)
+            uy = np.cross(sx, d)
+            lm = np.eye(4)
+            lm[:3, 0], lm[:3, 1], lm[:3, 2], lm[:3, 3] = sx, uy, -d, np.array(l["position"], np.float64)
+            nodes.append({"matrix": [float(x) for x in lm.T.reshape(16)], "extensions": {"KHR_lights_punctual": {"light": len(ls) - 1}}})
+        doc["extensions"] = {"KHR_lights_punctual": {"lights": ls}}
+
+    doc["nodes"] = nodes
+    doc["scenes"] = [{"nodes": list(range(len(nodes)))}]
+    if used:
+        doc["extensionsUsed"] = sorted(used)
+    doc["bufferViews"], doc["accessors"] = views, accessors
+    doc["buffers"] = [{"byteLength": len(blob)}]
+    if glb:
+        js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+        js += b" " * ((4 - len(js) % 4) % 4)
+        while len(blob) % 4:
+            blob.append(0)
+        with open(path, "wb") as f:
+            f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)))
+            f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+            f.write(struct.pack("<II", len(blob), 0x004E4942) + bytes(blob))
+    else:
+        doc["buffers"][0]["uri"] = stem + ".bin"
+        with open(os.path.join(base, stem + ".bin"), "wb") as f:
+            f.write(bytes(blob))
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
+    return path

@@ -320,7 +320,7 @@ def feature_box(tex_size=64, lights=False, seed=SEED_BASE + 100):
 
     uvt = np.eye(4, dtype=np.float32)
     uvt[0, 0], uvt[1, 1] = 2.0, 2.0
-    uvt[3, 0], uvt[3, 1] = 0.25, 0.5  # translation lives in the last COLUMN of the glm matrix == row-vector convention (Appendix C-16)
+    uvt[2, 0], uvt[2, 1] = 0.25, 0.5  # nvh builds KHR_texture_transform in row-vector convention: the offset multiplies the z = 1 of (u, v, 1, 1) (Appendix C-16)
 
     m_wall = sc.add_material(pbrBaseColorTexture=t_wall, normalTexture=t_wall_n, pbrMetallicFactor=0.0, pbrRoughnessFactor=0.9, normalTextureScale=1.0)
     m_floor = sc.add_material(pbrBaseColorTexture=t_floor, pbrMetallicFactor=0.0, pbrRoughnessFactor=0.6, uvTransform=uvt.T.reshape(16))

@@ -23,6 +23,22 @@ class Workload:
     note: str = ""
 
 
+def real_asset(name):
+    """A real glTF asset when the PT_ASSET_DIR environment variable points at a directory that holds it (SURVEY.md 8(d):
+    "real assets used instead if PT_ASSET_DIR provides them"); None otherwise.  `name`: e.g. "Sponza" -- looked up as
+    <dir>/<name>.gltf|.glb, <dir>/<name>/<name>.gltf and <dir>/<name>/glTF/<name>.gltf (the Khronos sample-model layout)."""
+    import os
+    root = os.environ.get("PT_ASSET_DIR")
+    if not root:
+        return None
+    for rel in (f"{name}.gltf", f"{name}.glb", f"{name}/{name}.gltf", f"{name}/glTF/{name}.gltf", f"{name}/glTF-Binary/{name}.glb"):
+        p = os.path.join(root, rel)
+        if os.path.exists(p):
+            from . import gltf
+            return gltf.load_gltf(p)
+    return None
+
+
 def c1_quad():
     return Workload("C1 quad 256x256 1spp", synth.quad_scene(), synth.constant_env(16, 8, 1.0), 256, 256, 1, 10, 0)
 
@@ -36,6 +52,10 @@ def c2_helmet(scale=1.0):
 
 
 def c3_sponza(width=1920, height=1080, spp=256, tex_size=1024, target_tris=262_267, env_w=2048):
+    real = real_asset("Sponza")
+    if real is not None:
+        return Workload(f"C3 Sponza (real asset from PT_ASSET_DIR, {real.num_triangles} tris) {width}x{height} {spp}spp depth8 Disney + HDR env",
+                        real, synth.procedural_sky(env_w, env_w // 2), width, height, spp, 8, 0)
     return Workload(f"C3 sponza-like (synthetic Crytek-Sponza stand-in, {target_tris} tris target) {width}x{height} {spp}spp depth8 Disney + HDR env",
                     synth.sponza_like(target_tris=target_tris, tex_size=tex_size), synth.procedural_sky(env_w, env_w // 2), width, height, spp, 8, 0)
 
