@@ -89,6 +89,16 @@ int pt_resize(pt_context* ctx, int width, int height);
  * the pixels are bit-identical to a 1-GPU render.  Default (0, 1).  Call before pt_resize. */
 int pt_set_shard(pt_context* ctx, int rank, int nranks);
 
+/* Selects which of the reference's two Renderer implementations the frames reproduce (SampleExample::RndMethod,
+ * src/sample_example.hpp:136-137).  PT_VARIANT_RAYQUERY (default): the compute / ray-query path [src/rayquery.cpp,
+ * shaders/pathtrace.comp].  PT_VARIANT_RTX: the ray-tracing-pipeline path [src/rtx_pipeline.cpp, shaders/pathtrace.rgen +
+ * .rchit / .rahit / .rmiss], which differs in two observable ways: the per-pixel seed is tea(y * W + x, frame) without the
+ * maxSamples factor (pathtrace.rgen:72 vs pathtrace.comp:97), and the stochastic alpha tests of a SHADOW ray draw from a copy
+ * of the path's seed, so they do not advance it (traceray_rtx.glsl:54-55 with pathtrace.rahit:44,112).  Everything else
+ * (samplePixel, PathTrace, the BSDFs) is the same pathtrace.glsl. */
+/* (enum PT_VARIANT_* lives in pt_types.h) */
+int pt_set_variant(pt_context* ctx, int variant);
+
 /* replaces Renderer::setPushContants(state) + Renderer::run(cmdBuf, size, profiler, descSets)
  * [src/renderer.h:38-45; src/rayquery.cpp:97-109 -> shaders/pathtrace.comp:87-134]: renders
  * state->maxSamples samples for every local pixel and folds them into the accumulation buffer with

@@ -185,6 +185,8 @@ typedef struct pt_Node {
 
 /* Sampler state as it reaches the shader (VkFilter / VkSamplerAddressMode numeric values;
  * reference: src/scene.cpp:447-482,561-571). Only the mag filter matters: every tap is LOD 0. */
+/* the reference's two Renderer implementations (src/sample_example.hpp:136-137), see pt_set_variant */
+enum { PT_VARIANT_RAYQUERY = 0, PT_VARIANT_RTX = 1 };
 enum { PT_FILTER_NEAREST = 0, PT_FILTER_LINEAR = 1 };
 enum { PT_WRAP_REPEAT = 0, PT_WRAP_MIRRORED_REPEAT = 1, PT_WRAP_CLAMP_TO_EDGE = 2 };
 

@@ -117,7 +117,9 @@ struct Tracer {
   PtPayload         prd;
   Stats             stats;
 
-  Tracer(const Scene& s, const pt_RtxState& r) : sc(s), st(r) {}
+  int               variant = 0;  // 0: ray-query / compute path, 1: RT-pipeline path (see below)
+
+  Tracer(const Scene& s, const pt_RtxState& r, int variant_ = 0) : sc(s), st(r), variant(variant_) {}
 
   static vec2 uv_of(const pt_VertexAttributes& a) { return vec2(a.texcoord[0], a.texcoord[1]); }
 
@@ -185,8 +187,20 @@ struct Tracer {
     }
   }
 
-  // ---- shaders/traceray_rq.glsl:153-185 on trace contract T6
+  // RT-pipeline variant (shaders/traceray_rtx.glsl:52-73): the shadow payload carries a COPY of the path's seed
+  // (`shadow_payload.seed = prd.seed`, :54-55) and pathtrace.rahit draws from the payload it is handed (:44,112), so the
+  // stochastic alpha tests of a shadow ray do not advance prd.seed.
   bool AnyHit(const Ray& r, float maxDist)
+  {
+    const uint32_t saved = prd.seed;
+    const bool     hit   = AnyHitRq(r, maxDist);
+    if(variant == 1)
+      prd.seed = saved;
+    return hit;
+  }
+
+  // ---- shaders/traceray_rq.glsl:153-185 on trace contract T6
+  bool AnyHitRq(const Ray& r, float maxDist)
   {
     stats.shadowRays++;
     const uint64_t n0 = stats.nodesVisited, t0 = stats.trisTested;
@@ -706,7 +720,8 @@ struct Tracer {
   // ---- shaders/pathtrace.comp:87-134 (heat-map debug mode is not reproduced: it is a wall-clock read)
   void render_pixel(int px, int py, float* rgba)
   {
-    prd.seed = tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(st.frame * st.maxSamples));
+    // pathtrace.comp:97 seeds with frame * maxSamples, pathtrace.rgen:72 (initRandom) with the frame alone
+    prd.seed = tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(variant == 1 ? st.frame : st.frame * st.maxSamples));
     vec3 pixelColor(0);
     for(int smpl = 0; smpl < st.maxSamples; ++smpl)
       pixelColor += samplePixel(px, py, st.size[0], st.size[1]);

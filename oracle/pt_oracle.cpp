@@ -65,6 +65,7 @@ struct orc_ctx {
   Scene       scene;
   Stats       stats;
   int         threads = 0;
+  int         variant = 0;  // 0: ray-query path, 1: RT-pipeline path (orc_path.h Tracer::variant)
   std::string err;
 };
 
@@ -83,6 +84,11 @@ int orc_set_threads(orc_ctx* c, int n)
 int orc_set_math_mode(int mode)
 {
   g_math_mode = mode;
+  return 0;
+}
+int orc_set_variant(orc_ctx* c, int variant)
+{
+  c->variant = variant ? 1 : 0;
   return 0;
 }
 int orc_set_use_bvh(orc_ctx* c, int use)
@@ -140,7 +146,7 @@ int orc_render_frame(orc_ctx* c, const pt_RtxState* state, float* accum, const u
   Stats     total;
 #pragma omp parallel num_threads(nthreads)
   {
-    Tracer tr(c->scene, *state);
+    Tracer tr(c->scene, *state, c->variant);
     if(pixel_ids)
     {
 #pragma omp for schedule(dynamic, 64)
@@ -298,7 +304,7 @@ void orc_trace_closest(orc_ctx* c, uint32_t n, const float* org, const float* di
   pt_RtxState st{};
 #pragma omp parallel
   {
-    Tracer tr(c->scene, st);
+    Tracer tr(c->scene, st, c->variant);
 #pragma omp for schedule(dynamic, 256)
     for(int64_t i = 0; i < (int64_t)n; ++i)
     {

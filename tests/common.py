@@ -9,7 +9,7 @@ from vk_raytrace_amd import capi, host_device as hd, synth
 
 
 class Config:
-    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0, firefly=None):
+    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0, firefly=None, variant=0):
         self.scene = scene
         if scene.vertices is None:
             scene.finalize(capi.pack_vertices)
@@ -19,6 +19,7 @@ class Config:
         self.sunsky = sunsky if sunsky is not None else hd.default_sun_and_sky()
         self.hdr_multiplier = hdr_multiplier
         self.firefly = firefly
+        self.variant = variant  # capi.PT_VARIANT_RAYQUERY / PT_VARIANT_RTX
         self.camera = capi.camera_lookat(scene.camera, width / height, nb_lights=len(scene.lights))
 
     def state(self, integral):
@@ -34,6 +35,7 @@ def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False, math_m
     orc.set_math_mode(math_mode)
     o = orc.Oracle(threads)
     o.set_use_bvh(use_bvh)
+    o.set_variant(cfg.variant)
     o.set_scene(cfg.scene)
     integral, _ = o.set_env(cfg.env)
     o.set_camera(cfg.camera)
@@ -56,6 +58,7 @@ def render_hip(cfg, frames, device=0, shard=None, return_obj=False):
     integral, _ = r.set_env(cfg.env)
     r.set_camera(cfg.camera)
     r.set_sunsky(cfg.sunsky)
+    r.set_variant(cfg.variant)
     r.create((cfg.width, cfg.height))
     st = cfg.state(integral)
     for f in range(frames):

@@ -38,6 +38,7 @@ def lib():
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_use_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_variant.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_math_mode.argtypes = [C.c_int]
         L.orc_set_scene.argtypes = [C.c_void_p, C.POINTER(hd.SceneDesc)]
         L.orc_set_env.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -112,6 +113,9 @@ class Oracle:
 
     def __del__(self):
         self.close()
+
+    def set_variant(self, variant):
+        self.L.orc_set_variant(self.ctx, int(variant))
 
     def set_use_bvh(self, use):
         self.L.orc_set_use_bvh(self.ctx, int(use))

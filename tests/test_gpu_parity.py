@@ -356,3 +356,17 @@ def test_gltf_round_trip_renders_identically(env_small, tmp_path):
     a = render_hip(Config(sc, env_small, 160, 120, depth=6), 3)
     b = render_hip(Config(back, env_small, 160, 120, depth=6), 3)
     assert np.array_equal(a, b)
+
+
+def test_rtx_pipeline_variant(env_small):
+    """The reference's RtxPipeline flavour (pt_set_variant): seed without the maxSamples factor, shadow-ray alpha tests on a
+    copy of the seed.  Parity against the oracle's restatement, and the two flavours must actually differ where they should."""
+    sc = synth.feature_box(tex_size=64)
+    rq = Config(sc, env_small, 200, 150, depth=6, max_samples=2)
+    rtx = Config(sc, env_small, 200, 150, depth=6, max_samples=2, variant=capi.PT_VARIANT_RTX)
+    h, o = check_frames(rtx, 3)
+    assert not np.array_equal(h, render_hip(rq, 3))
+    # first-hit AOVs do not depend on the flavour
+    a = Config(sc, env_small, 200, 150, debug=hd.eNormal, variant=capi.PT_VARIANT_RTX)
+    assert np.array_equal(render_hip(a, 1), render_oracle(a, 1))
+

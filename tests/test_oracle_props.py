@@ -187,3 +187,27 @@ def test_shard_helpers_partition_the_image():
         assert len(allp) == W * H and len(np.unique(allp)) == W * H
         sizes = [len(shard.tiles_of_rank(W, H, r, n)) for r in range(n)]
         assert max(sizes) - min(sizes) <= 3 and max(sizes) == shard.max_tiles_per_rank(W, H, n)
+
+
+def test_rtx_variant_seed_and_shadow_seed_copy():
+    """orc_set_variant(1): with maxSamples = 1 and no non-opaque geometry the two flavours are the same program (same seed,
+    no any-hit draws) and must agree bit for bit; with maxSamples = 2 the seed differs (frame vs frame * maxSamples) from
+    frame 1 on; with alpha-tested occluders the shadow rays' draws no longer advance the path's stream."""
+    from tests.common import Config, render_oracle
+    from vk_raytrace_amd import synth
+    env = synth.procedural_sky(64, 32)
+    opaque = synth.quad_scene()
+    a = render_oracle(Config(opaque, env, 48, 32, depth=4), 3)
+    b = render_oracle(Config(opaque, env, 48, 32, depth=4, variant=1), 3)
+    assert np.array_equal(a, b)
+    a2 = render_oracle(Config(opaque, env, 48, 32, depth=4, max_samples=2), 1)
+    b2 = render_oracle(Config(opaque, env, 48, 32, depth=4, max_samples=2, variant=1), 1)
+    assert np.array_equal(a2, b2)                       # frame 0: 0 * maxSamples == 0
+    a3 = render_oracle(Config(opaque, env, 48, 32, depth=4, max_samples=2), 2)
+    b3 = render_oracle(Config(opaque, env, 48, 32, depth=4, max_samples=2, variant=1), 2)
+    assert not np.array_equal(a3, b3)                   # frame 1: tea(., 2) vs tea(., 1)
+    box = synth.feature_box(tex_size=16)                # has MASK / BLEND materials
+    c = render_oracle(Config(box, env, 64, 48, depth=4), 2)
+    d = render_oracle(Config(box, env, 64, 48, depth=4, variant=1), 2)
+    assert not np.array_equal(c, d) and np.isfinite(d).all()
+

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import host_device as hd
 
+PT_VARIANT_RAYQUERY, PT_VARIANT_RTX = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
 
 # PT_LIB: developer override used to compare builds of the same HIP library (tools/build_variants.sh); never a fallback
@@ -30,6 +31,7 @@ API = [
     ("pt_set_sunsky", C.c_int, [_P, C.POINTER(hd.SunAndSky)]),
     ("pt_resize", C.c_int, [_P, C.c_int, C.c_int]),
     ("pt_set_shard", C.c_int, [_P, C.c_int, C.c_int]),
+    ("pt_set_variant", C.c_int, [_P, C.c_int]),
     ("pt_render_frame", C.c_int, [_P, C.POINTER(hd.RtxState)]),
     ("pt_synchronize", C.c_int, [_P]),
     ("pt_read_accum", C.c_int, [_P, _P]),

@@ -58,6 +58,7 @@ struct pt_context {
   pt_RtxState pendState{};
   int         pendCount = 0;
   int         batchMax  = 1;
+  int         variant   = PT_VARIANT_RAYQUERY;
   uint64_t  frameCounter = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
@@ -651,6 +652,18 @@ int pt_set_env(pt_context* c, const float* rgba, int w, int h, float* out_integr
   return PT_OK;
 }
 
+int pt_set_variant(pt_context* c, int variant)
+{
+  CTX_CHECK(c);
+  if(variant != PT_VARIANT_RAYQUERY && variant != PT_VARIANT_RTX)
+    return c->fail(PT_ERR_INVALID, "pt_set_variant: %d", variant);
+  int rc = flush_pending(c);  // frames already handed over keep the variant they were given
+  if(rc != PT_OK)
+    return rc;
+  c->variant = variant;
+  return PT_OK;
+}
+
 int pt_set_shard(pt_context* c, int rank, int nranks)
 {
   CTX_CHECK(c);
@@ -794,6 +807,7 @@ int flush_pending(pt_context* c)
   fp.numLocalTiles = c->numLocalTiles;
   fp.numSlots      = c->numSlots;
   fp.batch         = uint32_t(c->pendCount);
+  fp.variant       = c->variant;
   fp.sample        = 0;
   c->pendCount     = 0;
   pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];

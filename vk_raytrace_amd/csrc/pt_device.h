@@ -148,4 +148,5 @@ struct FrameParams {
   uint32_t    numSlots;  // numLocalTiles * 1024 (path slots of ONE frame)
   uint32_t    batch;     // consecutive frames (st.frame, st.frame + 1, ...) traced together: path slot = f * numSlots + pixel slot
   int32_t     sample;    // index of the sample inside this frame
+  int32_t     variant;   // PT_VARIANT_RAYQUERY / PT_VARIANT_RTX (include/pt_api.h)
 };

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers 
   st.frame += int(fb);
   uint32_t seed;
   if(fp.sample == 0)
-    seed = rng_tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(st.frame * st.maxSamples));
+    seed = rng_tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(fp.variant == PT_VARIANT_RTX ? st.frame : st.frame * st.maxSamples));
   else
     seed = __float_as_uint(rb.ps.rayD[slot].w);  // the stream continues across the samples of a frame (pathtrace.comp:97-105)
 
@@ -757,7 +757,7 @@ PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, 
   n += (uint32_t)__popcll(m);
 }
 
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
           uint32_t s2 = seed;
           if(consume_rejected_draws(s2, nDraw))
           {
-            seed     = s2;
+            seed     = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
             inShadow = L.bslot != BVH_NONE;
             nAlpha += nDraw;
           }
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
 }
 
 // Simple variant of the shadow stage (one ray per lane).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
@@ -895,7 +895,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
         uint32_t s2 = seed;
         if(consume_rejected_draws(s2, nDraw))
         {
-          seed     = s2;
+          seed     = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
           inShadow = h.slot != BVH_NONE;
           nAlpha   = nDraw;
         }
@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -922,6 +922,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(Device
   {
     const uint32_t slot    = rb.queueX2[i];
     uint32_t       seed    = __float_as_uint(rb.ps.rayD[slot].w);
+    const uint32_t seed0   = seed;
     const f3       o       = xyz(rb.ps.rayO[slot]);
     const f3       d       = xyz(rb.ps.neeDir[slot]);
     const float    maxDist = rb.ps.absorb[slot].w;
@@ -947,7 +948,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(Device
         wPrev = h.w & TRI_INDEX_MASK;
       }
     }
-    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+    finish_bounce(rb, slot, inShadow, variant == PT_VARIANT_RTX ? seed0 : seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
   }
 }
 
@@ -1145,10 +1146,10 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
       pt_timers_end(tm, stream, 2);
       pt_timers_begin(tm, stream, 3);
       if(depth < g_tuning.simpleShadowBounces)
-        k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
+        k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       else
-        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk);
-      k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last);
+        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
+      k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       pt_timers_end(tm, stream, 3);
       std::swap(qIn, qOut);
     }

@@ -116,6 +116,10 @@ class HipRenderer(Renderer):
     def set_sunsky(self, ss: hd.SunAndSky):
         self._check(self._lib.pt_set_sunsky(self._ctx, C.byref(ss)))
 
+    def set_variant(self, variant):
+        """capi.PT_VARIANT_RAYQUERY (the reference's RayQuery renderer, default) or capi.PT_VARIANT_RTX (its RtxPipeline)."""
+        self._check(self._lib.pt_set_variant(self._ctx, int(variant)))
+
     def set_shard(self, rank, nranks):
         self._check(self._lib.pt_set_shard(self._ctx, rank, nranks))
 
