@@ -57,6 +57,8 @@ public:
 
   // what the reference hands over through descriptor sets 2 and 3
   void setCamera(const pt_SceneCamera& c) { check(pt_set_camera(m_ctx, &c)); }
+  // PT_VARIANT_RAYQUERY (the reference's RayQuery renderer, default) or PT_VARIANT_RTX (its RtxPipeline)
+  void setVariant(int variant) { check(pt_set_variant(m_ctx, variant)); }
   void setSunAndSky(const pt_SunAndSky& s) { check(pt_set_sunsky(m_ctx, &s)); }
   void setEnvironment(const float* rgba32f, int w, int h, float* integral, float* average) { check(pt_set_env(m_ctx, rgba32f, w, h, integral, average)); }
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
