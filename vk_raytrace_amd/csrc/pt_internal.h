@@ -4,7 +4,10 @@
 #include <stddef.h>
 #include "pt_device.h"
 #define PT_REFILL_BELOW_DEFAULT 48
-#define PT_MIN_GENERATIONS 4  // persistent kernels: rays per lane below which a launch uses fewer waves
+#ifndef PT_MIN_GENERATIONS
+#define PT_MIN_GENERATIONS 1  // persistent kernels: rays per lane below which a launch uses fewer waves (1: only waves beyond the queue
+                              // exit; 2-32 measured slower: kernel latency matters more than the lane utilisation of small launches)
+#endif
 
 // pt_accel.hip
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
