@@ -257,6 +257,19 @@ def main():
                                "traffic": traffic, "alg_bytes_per_launch": bytes_closest / launches, "avg_launch_ms": ms_c / launches, "launches": launches}
         else:
             out["roofline"] = None
+    # ---- what actually bounds the path: VALU issue.  Instruction counts per sample are a property of the code and the workload
+    # (rocprofv3 PMC pass, profiles/valu_r1.json); the rate is this run's.  Peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per
+    # 4 cycles and SIMD, 2.4 GHz (MI355X_MICROARCH.md).
+    vpath = os.path.join(ROOT, "profiles", "valu_r1.json")
+    if args.workload == "c3" and os.path.exists(vpath):
+        try:
+            per_sample = json.load(open(vpath))["valu_wave_instr_per_sample"]
+            peak = 256 * 4 * 2.4e9 / 4
+            ach = per_sample * samples / elapsed / max(1, world)
+            out["issue_roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU", "frac": ach / peak,
+                                     "valu_wave_instr_per_sample": per_sample, "source": "profiles/valu_r1.json"}
+        except Exception:
+            pass
     out["stage_ms"] = {k: stats[k] for k in ("msGenerate", "msTraceClosest", "msShade", "msTraceShadow", "msAccumulate")}
     print(json.dumps(out))
     if dist is not None:
