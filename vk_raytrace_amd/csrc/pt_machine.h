@@ -28,7 +28,7 @@ struct TraceLane {
   uint32_t cur;
   int      sp;
   uint32_t flags, cnt, wLimit;
-  float    zeroMaxT;       // pass A: largest t among the zero-opacity candidates seen
+  float    zeroMaxT, zeroMaxT2, zeroMaxT3;  // pass A: the three largest t among the zero-opacity candidates seen
   int      pass;           // 0: pass A (nearest certain hit), 1: pass B (count zero-opacity candidates in front of it)
   bool     opaqueHit;      // shadow rays: an opaque occluder was found
   bool     done;
@@ -43,7 +43,7 @@ PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
   L.idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 #endif
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
-  L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f;
+  L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f; L.zeroMaxT2 = -1.0f; L.zeroMaxT3 = -1.0f;
 }
 // pass B over the candidates with key < (best hit | ray end)
 PT_DEV void lane_begin_count(TraceLane& L)
@@ -173,7 +173,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
             if(op <= 0.0f)
             {
               L.cnt++;
-              L.zeroMaxT = fmaxf(L.zeroMaxT, t);
+              note_zero_candidate(t, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3);
             }
           }
         }

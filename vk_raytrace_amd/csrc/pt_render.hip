@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
     if(alive && L.done)
     {
       bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
+      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
         lane_begin_count(L);  // stay alive: pass B runs in the same loop
       else
       {
@@ -311,8 +311,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(Devic
     bool           dummy;
     traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
     fallback       = (h.flags & TF_SAW_FRAC) != 0;
-    uint32_t nDraw = h.count;
-    if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
+    const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+    uint32_t   nDraw = h.count;
+    if(passB)
     {
       RayHit c;
       traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
@@ -786,7 +787,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
     if(alive && L.done)
     {
       bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
-      if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_count_is_final(L.bslot, L.bt, L.zeroMaxT))
+      if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
         lane_begin_count(L);
       else
       {
@@ -879,8 +880,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
     if(!inShadow)
     {
       fallback       = (h.flags & TF_SAW_FRAC) != 0;
-      uint32_t nDraw = h.count;
-      if(!fallback && (h.flags & TF_SAW_ZERO) && !pass_a_count_is_final(h))
+      const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+      uint32_t   nDraw = h.count;
+      if(passB)
       {
         RayHit c;
         traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,

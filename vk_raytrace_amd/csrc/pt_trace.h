@@ -51,13 +51,34 @@ struct RayHit {
   uint32_t flags;  // TF_*
   uint32_t count;  // TM_COUNT: zero-opacity candidates in range.  TM_CLOSEST / TM_SHADOW: zero-opacity candidates SEEN
   float    zeroMaxT;  // TM_CLOSEST / TM_SHADOW: largest t among the zero-opacity candidates seen (-1: none)
+  float    zeroMaxT2, zeroMaxT3;  //                        second and third largest
 };
 
 // After pass A: if every zero-opacity candidate that was evaluated lies strictly in front of the final certain hit
 // (or there is no hit and all of them are inside the ray range), `count` is already the number of draws they
-// consume and pass B is unnecessary.  Traversal is near-to-far, so this is the common case.
-PT_DEV bool pass_a_count_is_final(const RayHit& h) { return h.slot == BVH_NONE || h.zeroMaxT < h.t; }
-PT_DEV bool pass_a_count_is_final(uint32_t bslot, float bt, float zeroMaxT) { return bslot == BVH_NONE || zeroMaxT < bt; }
+// consume and pass B is unnecessary.  Traversal is near-to-far, so this is the common case; the next most common one
+// -- one or two candidates behind the hit -- is settled by tracking the three largest t values.
+PT_DEV bool pass_a_settles(uint32_t bslot, float bt, float z1, float z2, float z3, uint32_t& count)
+{
+  if(bslot == BVH_NONE || z1 < bt)
+    return true;
+  if(z3 < bt && z1 != bt && z2 != bt)
+  {  // every evaluated zero-opacity candidate behind the final hit (seen while the bound was still larger) is among
+     // the three largest: subtract them
+    count -= (z1 > bt ? 1u : 0u) + (z2 > bt ? 1u : 0u);
+    return true;
+  }
+  return false;  // more than two behind, or a tie in t with the hit (the key order decides): count again in pass B
+}
+// keeps z1 >= z2 >= z3, the three largest t seen
+PT_DEV void note_zero_candidate(float t, float& z1, float& z2, float& z3)
+{
+  const float a = fminf(z1, t);
+  z1            = fmaxf(z1, t);
+  const float b = fminf(z2, a);
+  z2            = fmaxf(z2, a);
+  z3            = fmaxf(z3, b);
+}
 
 
 PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta < tb || (ta == tb && wa < wb); }
@@ -198,6 +219,8 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
   best.flags    = 0;
   best.count    = 0;
   best.zeroMaxT = -1.0f;
+  best.zeroMaxT2 = -1.0f;
+  best.zeroMaxT3 = -1.0f;
   opaqueHit     = false;
   if(S.numTris == 0)
     return;
@@ -347,7 +370,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
                   if(op <= 0.0f)
                   {
                     best.count++;
-                    best.zeroMaxT = fmaxf(best.zeroMaxT, t);
+                    note_zero_candidate(t, best.zeroMaxT, best.zeroMaxT2, best.zeroMaxT3);
                   }
                 }
               }
