@@ -322,16 +322,16 @@ def test_launch_policy_never_changes_results():
     """Frame batches, frames in flight, the persistent / lock-step kernels and the BVH builder are performance policy:
     every combination must produce bit-identical accumulation buffers (5 frames: a full batch, a partial one and the
     single-frame path all occur)."""
-    ref = _render_in_subprocess("batch=1,inflight=1,simpleClosest=9999,simpleShadow=9999,build=lbvh")
+    ref = _render_in_subprocess("batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh")
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
-    for tune in ["batch=2,inflight=2", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64"]:
+    for tune in ["batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7", "packetClosest=0,simpleClosest=1", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64"]:
         got = _render_in_subprocess(tune)
         assert np.array_equal(got, ref), tune
 
 
 def test_launch_policy_sponza_like_and_samples_per_frame():
     """Same on the alpha-heavy scene, with maxSamples > 1 (the per-frame sample loop inside a batch)."""
-    ref = _render_in_subprocess("batch=1,inflight=1,simpleClosest=9999,simpleShadow=9999,build=lbvh", frames=3, max_samples=2, scene="sponza")
+    ref = _render_in_subprocess("batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh", frames=3, max_samples=2, scene="sponza")
     got = _render_in_subprocess("batch=2,inflight=2,build=sah", frames=3, max_samples=2, scene="sponza")
     assert np.array_equal(got, ref)
 

@@ -42,3 +42,5 @@ for row, nm in ((5, "closest_p"), (6, "shadow_p")):
     if it:
         print(f"{nm}: wave-iterations/frame {it / frames / 1e6:.3f}M  inner lanes/iter {int(h[row, 1]) / it:.1f}  leaf lanes/iter {int(h[row, 2]) / it:.1f}  "
               f"service rounds/frame {int(h[row, 3]) / frames / 1e3:.1f}k  iterations with inner {int(h[row, 5]) / it:.2f} leaf {int(h[row, 6]) / it:.2f} both {int(h[row, 4]) / it:.2f}")
+if int(h[7, 2]):
+    print(f"packet: waves/frame {int(h[7, 2]) / frames / 1e3:.1f}k  inner visits/wave {int(h[7, 0]) / int(h[7, 2]):.1f}  leaf visits/wave {int(h[7, 1]) / int(h[7, 2]):.1f}")

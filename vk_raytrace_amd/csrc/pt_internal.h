@@ -22,6 +22,8 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
 #define CNT_X_SHADOW 3       // rays handed to the exact shadow fallback
 #define CNT_CHUNK_CLOSEST 4  // ray-supply chunk counter of k_closest_p
 #define CNT_CHUNK_SHADOW 5   // ray-supply chunk counter of k_shadow_p
+#define CNT_REDO 6           // size of queueR
+#define CNT_CHUNK_REDO 7     // ray-supply chunk counter of k_closest_p on queueR
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
 #define PT_PERSISTENT_WAVES (256u * 20u)
@@ -33,6 +35,7 @@ struct RenderBuffers {
   uint32_t* queueS;    // paths with a shadow ray
   uint32_t* queueX;    // exact-fallback queues (normally empty)
   uint32_t* queueX2;
+  uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
@@ -42,6 +45,8 @@ struct RenderBuffers {
 // the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
 struct PtTuning {
   int simpleClosestBounces = 1;   // bounces whose closest-hit stage uses the lock-step kernel (coherent primary rays: 82 % lane utilisation)
+  int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
+  int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
   int simpleShadowBounces  = 0;   // shadow rays differ 10x in length: always on the refilling machine
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
   int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)

@@ -28,6 +28,7 @@
 #include "pt_internal.h"
 #include "pt_sky.h"
 #include "pt_machine.h"
+#include "pt_packet.h"
 
 namespace {
 
@@ -83,6 +84,34 @@ PT_DEV void enqueue_block(uint32_t* queue, uint32_t* count, uint32_t slot, bool 
   __syncthreads();
   if(valid)
     queue[sBase + wbase + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+
+// Wave-private staging of queue appends in LDS (persistent kernels): one global atomic per ~200 entries instead of
+// one per service round.  `n` is wave-uniform.
+#define STAGE_CAP 256
+PT_DEV void stage_flush(uint32_t* stage, uint32_t& n, uint32_t* __restrict__ queue, uint32_t* count)
+{
+  if(n == 0)
+    return;
+  const int lane = threadIdx.x & 63;
+  uint32_t  base = 0;
+  if(lane == 0)
+    base = atomicAdd(count, n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for(uint32_t k = lane; k < n; k += 64)
+    queue[base + k] = stage[k];
+  n = 0;
+}
+PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, uint32_t* __restrict__ queue, uint32_t* count)
+{
+  const unsigned long long m = __ballot(valid);
+  if(!m)
+    return;
+  if(n + 64 > STAGE_CAP)
+    stage_flush(stage, n, queue, count);
+  if(valid)
+    stage[n + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = slot;
+  n += (uint32_t)__popcll(m);
 }
 
 // Path slot -> pixel.  A local tile is 32x32 pixels = 16 waves of 8x8 pixels, so that the 64 lanes of a
@@ -196,12 +225,12 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
 //            queue is empty, until all are done).
 // Settling rays outside the run loop keeps the hot loop to the node step and the triangle test; a finished lane
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      count = C[CNT_IN];
+  const uint32_t      count = C[cntIn];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves, so that each still refills its lanes a few times
   uint32_t*           lds   = stack + threadIdx.x;
@@ -247,7 +276,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
         alive = false;
       }
     }
-    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_CLOSEST], count, !alive);
+    const uint32_t qi = supply_next(rs, &C[cntChunk], count, !alive);
     if(qi != 0xffffffffu)
     {
       pslot           = queueIn[qi];
@@ -341,6 +370,67 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(Devic
   wave_add(&rb.counters->alphaTests, nAlpha);
   if(fallback)
     enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
+}
+
+// Packet kernel for coherent rays (bounce 0, pt_packet.h): persistent wavefronts walk the queue 64 rays (one 8x8 pixel block)
+// at a time with ONE traversal per wave.  Rays it cannot settle on the spot -- packets whose lanes disagree on a direction
+// sign, rays that need pass B or the exact fallback -- are staged in LDS and appended to queueR, which the refilling trace
+// machine (k_closest_p) then redoes per lane.  Keeping those paths out of this kernel keeps it at ~64 VGPRs: the packet
+// traversal is a serial chain of scalar loads, so it lives on resident waves, not on instruction throughput.
+#ifndef PT_PACKET_WAVES
+#define PT_PACKET_WAVES 8
+#endif
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+{
+  __shared__ uint32_t wstack[PACKET_STACK];
+  __shared__ uint32_t stage[STAGE_CAP];
+  uint32_t            nStage = 0, nRays = 0, nAlpha = 0;
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_IN];
+#pragma unroll 1
+  for(uint32_t base = blockIdx.x * TRACE_BLOCK; base < count; base += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t i     = base + threadIdx.x;
+    const bool     valid = i < count;
+    uint32_t       slot = 0, seed = 0;
+    f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
+    if(valid)
+    {
+      slot            = queueIn[i];
+      o               = xyz(rb.ps.rayO[slot]);
+      const float4 dw = rb.ps.rayD[slot];
+      d               = xyz(dw);
+      seed            = __float_as_uint(dw.w);
+    }
+    RayHit     h;
+    const bool packet = traverse_packet_closest(S, valid, o, d, wstack, h, rb.counters);
+    bool       redo   = valid && !packet;
+    if(valid && packet)
+    {
+      redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
+      if(!redo)
+      {
+        uint32_t nDraw = h.count;
+        if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+          ++nDraw;
+        uint32_t s2 = seed;
+        if(consume_rejected_draws(s2, nDraw))
+        {
+          store_hit(rb, slot, h.slot, h.t, h.u, h.v);
+          if(nDraw)
+            rb.ps.rayD[slot].w = __uint_as_float(s2);
+          nAlpha += nDraw;
+          ++nRays;
+        }
+        else
+          redo = true;
+      }
+    }
+    stage_push(stage, nStage, redo, slot, rb.queueR, &C[CNT_REDO]);
+  }
+  stage_flush(stage, nStage, rb.queueR, &C[CNT_REDO]);
+  wave_add(&rb.counters->closestRays, nRays);
+  wave_add(&rb.counters->alphaTests, nAlpha);
 }
 
 // Exact fallback: one ray per lane, key-ordered stochastic alpha (trace contract T5).  Runs on the rays the
@@ -730,34 +820,6 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
-// Wave-private staging of queue appends in LDS (persistent kernels): one global atomic per ~200 entries instead of
-// one per service round.  `n` is wave-uniform.
-#define STAGE_CAP 256
-PT_DEV void stage_flush(uint32_t* stage, uint32_t& n, uint32_t* __restrict__ queue, uint32_t* count)
-{
-  if(n == 0)
-    return;
-  const int lane = threadIdx.x & 63;
-  uint32_t  base = 0;
-  if(lane == 0)
-    base = atomicAdd(count, n);
-  base = __builtin_amdgcn_readfirstlane(base);
-  for(uint32_t k = lane; k < n; k += 64)
-    queue[base + k] = stage[k];
-  n = 0;
-}
-PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, uint32_t* __restrict__ queue, uint32_t* count)
-{
-  const unsigned long long m = __ballot(valid);
-  if(!m)
-    return;
-  if(n + 64 > STAGE_CAP)
-    stage_flush(stage, n, queue, count);
-  if(valid)
-    stage[n + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = slot;
-  n += (uint32_t)__popcll(m);
-}
-
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
@@ -1137,10 +1199,16 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     {
       const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
       pt_timers_begin(tm, stream, 1);
-      if(depth < g_tuning.simpleClosestBounces)
+      if(depth < g_tuning.packetClosestBounces)
+      {
+        const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+        k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
+        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+      }
+      else if(depth < g_tuning.simpleClosestBounces)
         k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
       else
-        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk);
+        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
       k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
