@@ -46,7 +46,7 @@ struct pt_context {
   // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
   // running-mean accumulate is ordered across frames (events).
   struct FrameSlot {
-    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dCounts;
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dCounts;
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
@@ -281,6 +281,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     int v;
     if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) g_tuning.packetClosestBounces = v;
+    if(const char* p = strstr(tune, "packetShadow=")) if(sscanf(p, "packetShadow=%d", &v) == 1) g_tuning.packetShadowBounces = v;
+    if(const char* p = strstr(tune, "minPacket=")) if(sscanf(p, "minPacket=%d", &v) == 1) g_tuning.minPacket = v;
     if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) g_tuning.packetWaves = v;
     if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
@@ -334,7 +336,7 @@ int pt_destroy(pt_context* c)
   {
     for(DevBuf& b : fs.dState)
       dev_free(b);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dCounts};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dCounts};
     for(DevBuf* b : q)
       dev_free(*b);
     if(fs.accumDone)
@@ -719,7 +721,7 @@ int pt_resize(pt_context* c, int width, int height)
     pt_context::FrameSlot& fs = c->slots[i];
     for(DevBuf& bf : fs.dState)
       if((rc = dev_alloc(c, bf, sizeof(float4) * n)) != PT_OK) return rc;
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2};
     for(DevBuf* bf : q)
       if((rc = dev_alloc(c, *bf, 4 * n)) != PT_OK) return rc;
     if((rc = dev_alloc(c, fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2))) != PT_OK) return rc;
@@ -749,6 +751,7 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.queueX   = (uint32_t*)fs.dQueueX.p;
     fs.rb.queueX2  = (uint32_t*)fs.dQueueX2.p;
     fs.rb.queueR   = (uint32_t*)fs.dQueueR.p;
+    fs.rb.queueR2  = (uint32_t*)fs.dQueueR2.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;

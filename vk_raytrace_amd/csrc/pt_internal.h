@@ -15,7 +15,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
 // Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):
-#define CNT_STRIDE 8
+#define CNT_STRIDE 16
 #define CNT_IN 0             // size of the bounce's input queue (bounce b+1's lives at +CNT_STRIDE)
 #define CNT_SHADOW 1         // size of queueS (paths with a shadow ray)
 #define CNT_X_CLOSEST 2      // rays handed to the exact closest-hit fallback
@@ -24,6 +24,8 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
 #define CNT_CHUNK_SHADOW 5   // ray-supply chunk counter of k_shadow_p
 #define CNT_REDO 6           // size of queueR
 #define CNT_CHUNK_REDO 7     // ray-supply chunk counter of k_closest_p on queueR
+#define CNT_REDO_SHADOW 8         // size of queueR2 (shadow rays the packet kernel could not settle)
+#define CNT_CHUNK_REDO_SHADOW 9   // ray-supply chunk counter of k_shadow_p on queueR2
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
 #define PT_PERSISTENT_WAVES (256u * 20u)
@@ -36,6 +38,7 @@ struct RenderBuffers {
   uint32_t* queueX;    // exact-fallback queues (normally empty)
   uint32_t* queueX2;
   uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
+  uint32_t* queueR2;   // same for shadow rays
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
@@ -46,6 +49,9 @@ struct RenderBuffers {
 struct PtTuning {
   int simpleClosestBounces = 1;   // bounces whose closest-hit stage uses the lock-step kernel (coherent primary rays: 82 % lane utilisation)
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
+  int packetShadowBounces  = 0;    // bounces whose shadow rays first go through the packet kernel.  Off: measured slower on C3 (1173 vs 1287
+                                   // Msamples/s at 1, 851 at 2) -- unoccluded any-hit rays cannot prune, so a packet walks the union of 64 full-length rays
+  int minPacket            = 16;   // lanes that must share the majority direction signs for a shadow packet to be walked
   int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
   int simpleShadowBounces  = 0;   // shadow rays differ 10x in length: always on the refilling machine
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing

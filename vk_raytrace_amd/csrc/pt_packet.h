@@ -33,14 +33,18 @@ PT_DEV uint4 sloadu4(const void* base, uint32_t byteOff)
 
 // `valid`: the lane carries a ray.  wstack: PACKET_STACK dwords of LDS shared by the wave.  Returns false when the packet
 // is not sign-coherent (nothing was traversed; the caller runs the per-lane traversal instead).
-PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint32_t* wstack, RayHit& best, Counters* counters)
+// SHADOW: any-hit semantics of traverse<TM_SHADOW> -- an opaque hit inside (0, tmax) ends the lane (`opaqueHit`), the bound stays
+// tmax because an opaque occluder may lie behind the nearest non-opaque candidate.
+template <bool SHADOW>
+PT_DEV bool traverse_packet(const DeviceScene& S, bool valid, f3 o, f3 d, float tmax, uint32_t* wstack, RayHit& best, bool& opaqueHit, Counters* counters)
 {
   const RayBox rb = make_raybox(o, d);
+  opaqueHit       = false;
   const unsigned long long vm = __ballot(valid);
   const unsigned long long sx = __ballot(valid && rb.idir.x < 0.0f), sy = __ballot(valid && rb.idir.y < 0.0f), sz = __ballot(valid && rb.idir.z < 0.0f);
   if((sx != 0ull && sx != vm) || (sy != 0ull && sy != vm) || (sz != 0ull && sz != vm))
     return false;
-  best.slot = BVH_NONE; best.t = PT_INFINITY; best.w = 0xffffffffu; best.flags = 0; best.count = 0;
+  best.slot = BVH_NONE; best.t = tmax; best.w = 0xffffffffu; best.flags = 0; best.count = 0;
   best.zeroMaxT = best.zeroMaxT2 = best.zeroMaxT3 = -1.0f;
   best.u = best.v = 0.0f;
   if(S.numTris == 0 || vm == 0ull)
@@ -75,7 +79,7 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
       for(int k = 0; k < 4; ++k)
       {
         const float nr = fmaxf(fmaxf(__builtin_fmaf(pxs[k], rb.idir.x, rb.nlo.x), __builtin_fmaf(pys[k], rb.idir.y, rb.nlo.y)), fmaxf(__builtin_fmaf(pzs[k], rb.idir.z, rb.nlo.z), 0.0f)) * 0.9999996f;
-        const float fr = fminf(fminf(__builtin_fmaf(qxs[k], rb.idir.x, rb.nhi.x), __builtin_fmaf(qys[k], rb.idir.y, rb.nhi.y)), fminf(__builtin_fmaf(qzs[k], rb.idir.z, rb.nhi.z), best.t)) * 1.0000004f;
+        const float fr = fminf(fminf(__builtin_fmaf(qxs[k], rb.idir.x, rb.nhi.x), __builtin_fmaf(qys[k], rb.idir.y, rb.nhi.y)), fminf(__builtin_fmaf(qzs[k], rb.idir.z, rb.nhi.z), SHADOW ? tmax : best.t)) * 1.0000004f;
         const unsigned long long hm = (cc[k] != BVH_NONE) ? __ballot(valid && nr <= fr) : 0ull;
         if(hm)
         {
@@ -115,10 +119,15 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
       const uint32_t flags = wbits >> 29;
       const bool     opq   = (flags & TRI_OPAQUE) != 0;
       float          t, u, v;
-      if(valid && tri_test(tr, flags, o, d, t, u, v) && t > 0.0f)
+      if(valid && tri_test(tr, flags, o, d, t, u, v) && t > 0.0f && t < tmax)
       {
         const uint32_t w = wbits & TRI_INDEX_MASK;
-        if(best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK))
+        if(SHADOW && opq)
+        {
+          opaqueHit = true;
+          valid     = false;  // the lane leaves the packet
+        }
+        else if(best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK))
         {
           bool certain = opq;
           if(!opq)
@@ -142,7 +151,7 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
         }
       }
     }
-    if(sp == 0)
+    if(sp == 0 || (SHADOW && __ballot(valid) == 0ull))
       break;
     cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
   }
@@ -154,3 +163,10 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
 #endif
   return true;
 }
+
+PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint32_t* wstack, RayHit& best, Counters* counters)
+{
+  bool dummy;
+  return traverse_packet<false>(S, valid, o, d, PT_INFINITY, wstack, best, dummy, counters);
+}
+

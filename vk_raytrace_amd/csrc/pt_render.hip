@@ -820,14 +820,15 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant)
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
+                                                                             int cntIn, int cntChunk)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      count = C[CNT_SHADOW];
+  const uint32_t      count = C[cntIn];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves, so that each still refills its lanes a few times
   uint32_t*           lds   = stack + threadIdx.x;
@@ -877,10 +878,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
       }
     }
     stage_push(stage, nStage, survivor, pslot, queueOut, &C[CNT_STRIDE + CNT_IN]);
-    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_SHADOW], count, !alive);
+    const uint32_t qi = supply_next(rs, &C[cntChunk], count, !alive);
     if(qi != 0xffffffffu)
     {
-      pslot = rb.queueS[qi];
+      pslot = queueIn[qi];
       seed  = __float_as_uint(rb.ps.rayD[pslot].w);
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
       alive = true;
@@ -916,6 +917,85 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
   }
 #endif
   stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
+  wave_add(&rb.counters->shadowRays, nRays);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Packet kernel for shadow rays (pt_packet.h).  The next-event rays of one 8x8 pixel block start at neighbouring surface points
+// and -- whenever one bright light dominates the environment's alias table, i.e. any map with a sun -- nearly all point the same
+// way, so they walk the BVH together.  Per packet the lanes that share the majority's direction signs take the packet traversal;
+// the others, and every ray that needs pass B or the exact fallback, go to queueR2 and are settled per lane by k_shadow_p.
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_shadow_k(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant, int minPacket)
+{
+  __shared__ uint32_t wstack[PACKET_STACK];
+  __shared__ uint32_t stageR[STAGE_CAP], stageN[STAGE_CAP];
+  uint32_t            nR = 0, nN = 0, nRays = 0, nAlpha = 0;
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_SHADOW];
+#pragma unroll 1
+  for(uint32_t base = blockIdx.x * TRACE_BLOCK; base < count; base += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t i     = base + threadIdx.x;
+    const bool     valid = i < count;
+    uint32_t       slot = 0, seed = 0;
+    f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
+    float          maxDist = 0.f;
+    if(valid)
+    {
+      slot    = rb.queueS[i];
+      seed    = __float_as_uint(rb.ps.rayD[slot].w);
+      o       = xyz(rb.ps.rayO[slot]);
+      d       = xyz(rb.ps.neeDir[slot]);
+      maxDist = rb.ps.absorb[slot].w;
+    }
+    // the sign pattern most lanes share
+    const uint32_t           pat = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    unsigned long long       bestMask = 0ull;
+#pragma unroll
+    for(uint32_t q = 0; q < 8; ++q)
+    {
+      const unsigned long long m = __ballot(valid && pat == q);
+      if(__popcll(m) > __popcll(bestMask))
+        bestMask = m;
+    }
+    const bool inPacket = __popcll(bestMask) >= minPacket && ((bestMask >> (threadIdx.x & 63)) & 1ull);
+    RayHit     h;
+    bool       inShadow = false;
+    const bool packet   = traverse_packet<true>(S, inPacket, o, d, maxDist, wstack, h, inShadow, rb.counters);
+    bool       redo     = valid && !(inPacket && packet);
+    bool       survivor = false;
+    if(valid && !redo)
+    {
+      if(!inShadow)
+      {
+        redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
+        if(!redo)
+        {
+          uint32_t nDraw = h.count;
+          if(h.slot != BVH_NONE)
+            ++nDraw;
+          uint32_t s2 = seed;
+          if(consume_rejected_draws(s2, nDraw))
+          {
+            seed     = variant == PT_VARIANT_RTX ? seed : s2;
+            inShadow = h.slot != BVH_NONE;
+            nAlpha += nDraw;
+          }
+          else
+            redo = true;
+        }
+      }
+      if(!redo)
+      {
+        ++nRays;
+        survivor = finish_bounce_core(rb, slot, inShadow, seed) && !lastBounce;
+      }
+    }
+    stage_push(stageR, nR, redo, slot, rb.queueR2, &C[CNT_REDO_SHADOW]);
+    stage_push(stageN, nN, survivor, slot, queueOut, &C[CNT_STRIDE + CNT_IN]);
+  }
+  stage_flush(stageR, nR, rb.queueR2, &C[CNT_REDO_SHADOW]);
+  stage_flush(stageN, nN, queueOut, &C[CNT_STRIDE + CNT_IN]);
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
 }
@@ -1218,7 +1298,16 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
       if(depth < g_tuning.simpleShadowBounces)
         k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       else
-        k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
+      {
+        if(depth < g_tuning.packetShadowBounces)
+        {
+          const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+          k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
+          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+        }
+        else
+          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+      }
       k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       pt_timers_end(tm, stream, 3);
       std::swap(qIn, qOut);
