@@ -4,10 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vk_raytrace_amd import capi, workloads, host_device as hd
 from vk_raytrace_amd.renderer import HipRenderer
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-wl = workloads.c3_sponza(1920, 1080, 8, tex_size=256)
+wl = workloads.c3_sponza(1920, 1080, 8, tex_size=int(os.environ.get("PT_TEX", "1024")))
 if os.environ.get("PT_OPAQUE_FOLIAGE") == "1":   # experiment: how much does stochastic alpha cost?
     for m in wl.scene.materials:
         m["alphaMode"] = 0
+if os.environ.get("PT_NO_TEXTURES") == "1":     # experiment: what do the texture fetches of k_shade cost? (alpha textures kept)
+    for m in wl.scene.materials:
+        for k in ("pbrMetallicRoughnessTexture", "emissiveTexture", "normalTexture", "transmissionTexture", "thicknessTexture", "clearcoatTexture", "clearcoatRoughnessTexture"):
+            m[k] = -1
+        if int(m["alphaMode"]) == 0:
+            m["pbrBaseColorTexture"] = -1
 wl.scene.finalize(capi.pack_vertices)
 r = HipRenderer(); r.setup(0); r.set_scene(wl.scene); integ, _ = r.set_env(wl.env)
 r.set_camera(capi.camera_lookat(wl.scene.camera, 1920 / 1080)); r.set_sunsky(hd.default_sun_and_sky()); r.create((1920, 1080))

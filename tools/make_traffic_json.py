@@ -3,7 +3,7 @@ profiles/traffic_rNN.json: HBM bytes per launch for each kernel.  Corrections pe
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane reads -> x2."""
 import csv, collections, json, sys
 fetch_csv, write_csv, out = sys.argv[1:4]
-names = ["k_generate", "k_closest_s", "k_closest_p", "k_closest_x", "k_shade", "k_shadow_s", "k_shadow_p", "k_shadow_x", "k_accumulate"]
+names = ["k_generate", "k_closest_k", "k_closest_s", "k_closest_p", "k_closest_x", "k_shade", "k_shadow_s", "k_shadow_p", "k_shadow_x", "k_accumulate"]
 def agg(path, counter):
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(path)):
@@ -16,8 +16,9 @@ res = {"units": "bytes per launch; FETCH_SIZE x2 (gfx950 half-count for 16-B/lan
 for k in names:
     if nf.get(k):
         res["kernels"][k] = {"launches": nf[k], "read_bytes_per_launch": f[k] * 2 * 1024 / nf[k], "write_bytes_per_launch": (w[k] * 1024 / nw[k]) if nw.get(k) else None}
-# bench.py's "launch" of the closest-hit stage = one bounce of one frame batch: k_closest_s or k_closest_p, plus k_closest_x
-stage = [k for k in ("k_closest_s", "k_closest_p", "k_closest_x") if k in res["kernels"]]
+# bench.py's "launch" of the closest-hit stage = one bounce of one frame batch: k_closest_k (+ k_closest_p on its redo queue) at bounce 0,
+# k_closest_p afterwards (k_closest_s when selected), plus k_closest_x
+stage = [k for k in ("k_closest_k", "k_closest_s", "k_closest_p", "k_closest_x") if k in res["kernels"]]
 tot = sum(res["kernels"][k]["launches"] * (res["kernels"][k]["read_bytes_per_launch"] + (res["kernels"][k]["write_bytes_per_launch"] or 0)) for k in stage)
 launches = res["kernels"]["k_closest_x"]["launches"] if "k_closest_x" in res["kernels"] else None
 res["k_closest_stage_launches"] = launches
