@@ -111,6 +111,12 @@ int pt_synchronize(pt_context* ctx);
  * With nranks > 1 only locally owned pixels are valid unless pt_scatter_shards was called. */
 int pt_read_accum(pt_context* ctx, float* rgba32f_out);
 
+/* Checkpoint restore (no reference counterpart; SURVEY.md section 5 "Checkpoint / resume": the progressive state of the reference is the
+ * accumulation image plus RtxState.frame, src/sample_example.cpp:183-207).  Replaces the accumulation image by a row-major
+ * width*height*4 float image previously obtained from pt_read_accum; continuing with frame = N reproduces an uninterrupted run bit for bit
+ * (the running mean of pathtrace.comp:122-133 only needs the image and the frame index). */
+int pt_write_accum(pt_context* ctx, const float* rgba32f_in);
+
 /* replaces RenderOutput::run [src/render_output.cpp:174-182 -> shaders/post.frag:98-147]:
  * tonemaps the accumulation image into row-major RGBA8. */
 int pt_tonemap(pt_context* ctx, const pt_Tonemapper* tm, uint8_t* rgba8_out);

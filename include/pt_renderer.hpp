@@ -62,6 +62,7 @@ public:
   void setSunAndSky(const pt_SunAndSky& s) { check(pt_set_sunsky(m_ctx, &s)); }
   void setEnvironment(const float* rgba32f, int w, int h, float* integral, float* average) { check(pt_set_env(m_ctx, rgba32f, w, h, integral, average)); }
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
+  void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
 
   bool               ok() const { return m_status == PT_OK; }

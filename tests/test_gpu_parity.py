@@ -370,3 +370,30 @@ def test_rtx_pipeline_variant(env_small):
     a = Config(sc, env_small, 200, 150, debug=hd.eNormal, variant=capi.PT_VARIANT_RTX)
     assert np.array_equal(render_hip(a, 1), render_oracle(a, 1))
 
+
+def test_checkpoint_resume(env_small):
+    """pt_read_accum after N frames + pt_write_accum into a fresh context + frames N.. == an uninterrupted run, bit for bit
+    (also across a shard: only the rank's own pixels travel)."""
+    from vk_raytrace_amd.renderer import HipRenderer
+    cfg = Config(synth.feature_box(tex_size=32), env_small, 150, 100, depth=6)
+    full = render_hip(cfg, 6)
+
+    def run(first, last, start_img=None, shard=None):
+        r = HipRenderer(); r.setup(0)
+        if shard:
+            r.set_shard(*shard)
+        r.set_scene(cfg.scene); integral, _ = r.set_env(cfg.env); r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky)
+        r.create((cfg.width, cfg.height))
+        if start_img is not None:
+            r.write_accum(start_img)
+        st = cfg.state(integral)
+        for f in range(first, last):
+            st.frame = f; r.setPushContants(st); r.run()
+        img = r.read_accum(); r.destroy()
+        return img
+    half = run(0, 3)
+    assert np.array_equal(run(3, 6, half), full)
+    ids = shard.local_pixel_ids(cfg.width, cfg.height, 1, 2)
+    part = run(3, 6, run(0, 3, shard=(1, 2)), shard=(1, 2))
+    assert np.array_equal(part.reshape(-1, 4)[ids], full.reshape(-1, 4)[ids])
+

@@ -35,6 +35,7 @@ API = [
     ("pt_render_frame", C.c_int, [_P, C.POINTER(hd.RtxState)]),
     ("pt_synchronize", C.c_int, [_P]),
     ("pt_read_accum", C.c_int, [_P, _P]),
+    ("pt_write_accum", C.c_int, [_P, _P]),
     ("pt_tonemap", C.c_int, [_P, C.POINTER(hd.Tonemapper), _P]),
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),

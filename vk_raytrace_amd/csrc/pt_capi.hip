@@ -865,6 +865,23 @@ int pt_read_accum(pt_context* c, float* out)
   return PT_OK;
 }
 
+int pt_write_accum(pt_context* c, const float* in)
+{
+  CTX_CHECK(c);
+  if(!in)
+    return c->fail(PT_ERR_INVALID, "pt_write_accum: null");
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_write_accum before pt_resize");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));  // launches what is pending and waits: the restored image replaces everything rendered so far
+  HIP_TRY(c, hipMemcpyAsync(c->dRowMajor.p, in, sizeof(float4) * size_t(c->width) * c->height, hipMemcpyHostToDevice, c->stream));
+  pt_launch_retile(c->stream, (const float4*)c->dRowMajor.p, (const uint32_t*)c->dSlotTile.p, c->numLocalTiles, c->tilesX, c->width, c->height, (float4*)c->dFrame.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sync_all(c));
+  c->haveFull = false;
+  return PT_OK;
+}
+
 int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
 {
   CTX_CHECK(c);

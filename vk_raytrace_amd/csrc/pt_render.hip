@@ -1145,6 +1145,19 @@ __global__ void k_untile(const float4* __restrict__ tiles, const uint32_t* __res
     out[size_t(py) * width + px] = tiles[slot];
 }
 
+// inverse of k_untile: row-major image -> this rank's accumulation tiles (checkpoint restore)
+__global__ void k_retile(const float4* __restrict__ in, const uint32_t* __restrict__ slotTile, uint32_t numSlots, int tilesX, int width, int height, float4* __restrict__ tiles)
+{
+  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if(slot >= numSlots)
+    return;
+  uint32_t gt = slotTile[slot >> 10];
+  uint32_t in_ = slot & 1023u, blk = in_ >> 6, lane = in_ & 63u;
+  int      px = int(gt % uint32_t(tilesX)) * PT_TILE + int(blk & 3u) * 8 + int(lane & 7u);
+  int      py = int(gt / uint32_t(tilesX)) * PT_TILE + int(blk >> 2) * 8 + int(lane >> 3);
+  tiles[slot] = (px < width && py < height) ? in[size_t(py) * width + px] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // gathered: [nranks][maxTilesPerRank][1024] float4; rank r's j-th tile is the j-th global tile with (tx+ty)%nranks == r
 __global__ void k_scatter_tiles(const float4* __restrict__ gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* __restrict__ tileLocalIndex,
                                 float4* __restrict__ full)
@@ -1327,6 +1340,13 @@ void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32
 {
   uint32_t n = numLocalTiles * 1024u;
   k_untile<<<(n + 255) / 256, 256, 0, stream>>>(frameTiles, slotTile, n, tilesX, width, height, outRowMajor);
+}
+
+void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles)
+{
+  uint32_t n = numLocalTiles * 1024u;
+  if(n)
+    k_retile<<<(n + 255) / 256, 256, 0, stream>>>(rowMajor, slotTile, n, tilesX, width, height, frameTiles);
 }
 
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles)

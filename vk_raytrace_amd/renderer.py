@@ -133,6 +133,13 @@ class HipRenderer(Renderer):
         self._check(self._lib.pt_read_accum(self._ctx, out.ctypes.data))
         return out
 
+    def write_accum(self, img):
+        """Checkpoint restore: replaces the accumulation image (continue with RtxState.frame = frames already in it)."""
+        w, h = self.size
+        img = np.ascontiguousarray(img, np.float32)
+        assert img.shape == (h, w, 4)
+        self._check(self._lib.pt_write_accum(self._ctx, img.ctypes.data))
+
     def tonemap(self, tm: hd.Tonemapper):
         w, h = self.size
         out = np.empty((h, w, 4), np.uint8)
