@@ -44,3 +44,5 @@ for row, nm in ((5, "closest_p"), (6, "shadow_p")):
               f"service rounds/frame {int(h[row, 3]) / frames / 1e3:.1f}k  iterations with inner {int(h[row, 5]) / it:.2f} leaf {int(h[row, 6]) / it:.2f} both {int(h[row, 4]) / it:.2f}")
 if int(h[7, 2]):
     print(f"packet: waves/frame {int(h[7, 2]) / frames / 1e3:.1f}k  inner visits/wave {int(h[7, 0]) / int(h[7, 2]):.1f}  leaf visits/wave {int(h[7, 1]) / int(h[7, 2]):.1f}")
+if int(h[7, 6]):
+    print(f"shadow packet: waves/frame {int(h[7, 6]) / frames / 1e3:.1f}k  lanes in packet {int(h[7, 7]) / int(h[7, 6]):.1f}  inner visits/wave {int(h[7, 4]) / int(h[7, 6]):.1f}  leaf visits/wave {int(h[7, 5]) / int(h[7, 6]):.1f}")

@@ -158,7 +158,8 @@ PT_DEV bool traverse_packet(const DeviceScene& S, bool valid, f3 o, f3 d, float 
 #ifdef PT_HIST
   if((threadIdx.x & 63) == 0)
   {
-    atomicAdd(&g_hist[7][0], (unsigned long long)hInner); atomicAdd(&g_hist[7][1], (unsigned long long)hLeaf); atomicAdd(&g_hist[7][2], 1ull);
+    atomicAdd(&g_hist[7][SHADOW ? 4 : 0], (unsigned long long)hInner); atomicAdd(&g_hist[7][SHADOW ? 5 : 1], (unsigned long long)hLeaf); atomicAdd(&g_hist[7][SHADOW ? 6 : 2], 1ull);
+    atomicAdd(&g_hist[7][SHADOW ? 7 : 3], (unsigned long long)__popcll(vm));
   }
 #endif
   return true;
