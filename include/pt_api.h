@@ -161,6 +161,19 @@ int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel*
  * (has_sampler == 0: LINEAR / REPEAT; unknown filter code: NEAREST; unknown wrap: REPEAT). */
 int pt_sampler_from_gltf(int has_sampler, int gltf_mag, int gltf_min, int gltf_wrapS, int gltf_wrapT, pt_TextureDesc* io);
 
+/* ---- glTF import (host only, no GPU) ------------------------------------------------------------------------------------
+ * replaces Scene::load -> loadGltfScene (tinygltf) + nvh::GltfScene::importMaterials / importDrawableNodes + the create*Buffer
+ * packing [src/scene.cpp:56-155, 190-382, 488-580] for .gltf and .glb files: the result is the flat pt_SceneDesc pt_set_scene
+ * takes (textures are (sampler, image) pairs decoded to RGBA8; PNG and baseline JPEG), plus the first camera of the file or a
+ * fit to the bounding box [src/scene.cpp:281-298].  The scene owns every array the description points to until pt_gltf_free.
+ * On failure returns PT_ERR_INVALID and writes a message to `err` (may be NULL). */
+typedef struct pt_GltfScene pt_GltfScene;
+int                 pt_gltf_load(const char* path, pt_GltfScene** out_scene, char* err, size_t err_len);
+const pt_SceneDesc* pt_gltf_desc(const pt_GltfScene* scene);
+int                 pt_gltf_camera(const pt_GltfScene* scene, float eye[3], float center[3], float up[3], float* fov_degrees);
+int                 pt_gltf_bounds(const pt_GltfScene* scene, float bbox_min[3], float bbox_max[3]);
+void                pt_gltf_free(pt_GltfScene* scene);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,165 @@
+"""The C++ glTF importer (pt_gltf_load, vk_raytrace_amd/csrc/pt_gltf.cpp) against the Python one (vk_raytrace_amd/gltf.py): both must
+produce the same flat scene arrays -- bit for bit on files that carry all attributes (exporter round trips), to float tolerance where
+normals / tangents are synthesised or node transforms are composed -- plus PNG / JPEG decoder checks against Pillow."""
+import ctypes as C
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from vk_raytrace_amd import capi, gltf, host_device as hd, synth
+from tests.test_gltf import _tri_doc, _write
+
+
+class CppScene:
+    def __init__(self, path):
+        L = capi.lib()
+        self.L = L
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.pt_gltf_load(path.encode(), C.byref(self.h), err, 512)
+        if rc != capi.PT_OK:
+            raise ValueError(err.value.decode())
+        d = L.pt_gltf_desc(self.h).contents
+        self.vertices = np.ctypeslib.as_array(C.cast(d.vertices, C.POINTER(C.c_uint8)), (d.numVertices * 32,)).copy() if d.numVertices else np.zeros(0, np.uint8)
+        self.indices = np.ctypeslib.as_array(C.cast(d.indices, C.POINTER(C.c_uint32)), (d.numIndices,)).copy() if d.numIndices else np.zeros(0, np.uint32)
+        self.prim_meshes = np.frombuffer(C.string_at(d.primMeshes, d.numPrimMeshes * hd.primmesh_dtype.itemsize), hd.primmesh_dtype).copy()
+        self.nodes = np.frombuffer(C.string_at(d.nodes, d.numNodes * hd.node_dtype.itemsize), hd.node_dtype).copy()
+        self.materials = np.frombuffer(C.string_at(d.materials, d.numMaterials * hd.material_dtype.itemsize), hd.material_dtype).copy()
+        self.lights = np.frombuffer(C.string_at(d.lights, d.numLights * hd.light_dtype.itemsize), hd.light_dtype).copy() if d.numLights else np.zeros(0, hd.light_dtype)
+        self.textures = []
+        tex = C.cast(d.textures, C.POINTER(hd.TextureDesc))
+        for i in range(d.numTextures):
+            t = tex[i]
+            img = np.ctypeslib.as_array(C.cast(t.rgba8, C.POINTER(C.c_uint8)), (t.height, t.width, 4)).copy()
+            self.textures.append((img, t.magFilter, t.minFilter, t.wrapS, t.wrapT))
+        e, c, u = (np.zeros(3, np.float32) for _ in range(3))
+        f = C.c_float()
+        L.pt_gltf_camera(self.h, e.ctypes.data, c.ctypes.data, u.ctypes.data, C.byref(f))
+        self.camera = (e, c, u, f.value)
+
+    def close(self):
+        self.L.pt_gltf_free(self.h)
+
+
+def compare(py, cpp, exact=True):
+    py.finalize(capi.pack_vertices)
+    pv = py.vertices.view(np.uint8).reshape(-1)
+    if exact:
+        assert np.array_equal(pv, cpp.vertices)
+    else:
+        a = np.frombuffer(pv.tobytes(), hd.vertex_dtype); b = np.frombuffer(cpp.vertices.tobytes(), hd.vertex_dtype)
+        assert np.allclose(a["position"], b["position"]) and np.allclose(a["texcoord"], b["texcoord"], atol=1e-6)
+    assert np.array_equal(py.indices, cpp.indices)
+    assert [tuple(int(x) for x in t) for t in py.prim_meshes] == [tuple(int(x) for x in t) for t in cpp.prim_meshes.tolist()]
+    assert len(py.nodes) == len(cpp.nodes)
+    for (m, pm), nd in zip(py.nodes, cpp.nodes):
+        assert int(nd["primMesh"]) == pm
+        got = np.asarray(nd["worldMatrix"]).reshape(4, 4).T
+        assert np.array_equal(got, m) if exact else np.allclose(got, m, rtol=1e-6, atol=1e-6)
+    assert len(py.materials) == len(cpp.materials)
+    for x, y in zip(py.materials, cpp.materials):
+        assert x.tobytes() == y.tobytes()
+    assert len(py.textures) == len(cpp.textures)
+    for x, (img, mag, mn, ws, wt) in zip(py.textures, cpp.textures):
+        assert np.array_equal(x.rgba8, img) and (x.magFilter, x.minFilter, x.wrapS, x.wrapT) == (mag, mn, ws, wt)
+    assert len(py.lights) == len(cpp.lights)
+    for x, y in zip(py.lights, cpp.lights):
+        assert x.tobytes() == y.tobytes()
+    e, c, u, f = cpp.camera
+    assert np.allclose(py.camera.eye, e, atol=1e-6) and np.allclose(py.camera.center, c, atol=1e-5) and np.allclose(py.camera.up, u, atol=1e-6) and abs(py.camera.fov - f) < 1e-4
+
+
+@pytest.mark.parametrize("ext", ["gltf", "glb"])
+@pytest.mark.parametrize("make", [lambda: synth.feature_box(tex_size=16, lights=True), lambda: synth.quad_scene(), lambda: synth.sponza_like(target_tris=3000, tex_size=8)])
+def test_cpp_importer_matches_python_on_round_trips(tmp_path, make, ext):
+    path = str(tmp_path / f"scene.{ext}")
+    gltf.save_gltf(make(), path)
+    cpp = CppScene(path)
+    compare(gltf.load_gltf(path), cpp, exact=True)
+    cpp.close()
+
+
+def test_cpp_importer_synthesis_and_trs(tmp_path):
+    doc = _tri_doc()
+    doc["nodes"] = [{"children": [1, 2], "translation": [1, 2, 3]}, {"mesh": 0, "rotation": [0, 0, 0.70710678, 0.70710678], "scale": [2, 2, 2]}, {"mesh": 0}]
+    doc["scenes"] = [{"nodes": [0]}]
+    path = _write(tmp_path, doc)
+    cpp = CppScene(path)
+    py = gltf.load_gltf(path)
+    compare(py, cpp, exact=False)
+    a = np.frombuffer(cpp.vertices.tobytes(), hd.vertex_dtype)
+    py.finalize(capi.pack_vertices)
+    assert np.array_equal(a["normal"], py.vertices["normal"]) and np.array_equal(a["tangent"], py.vertices["tangent"])   # synthesised attributes, packed identically
+    cpp.close()
+
+
+def test_cpp_importer_errors(tmp_path):
+    with pytest.raises(ValueError):
+        CppScene(str(tmp_path / "missing.gltf"))
+    (tmp_path / "bad.gltf").write_text("{ not json")
+    with pytest.raises(ValueError):
+        CppScene(str(tmp_path / "bad.gltf"))
+    doc = _tri_doc()
+    doc["accessors"][0]["sparse"] = {"count": 1}
+    with pytest.raises(ValueError, match="sparse"):
+        CppScene(_write(tmp_path, doc))
+
+
+def _image_doc(tmp_path, data, name):
+    (tmp_path / name).write_bytes(data)
+    doc = _tri_doc()
+    doc["images"] = [{"uri": name}]
+    doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    return _write(tmp_path, doc, name + ".gltf")
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA", "P"])
+def test_png_decoder_against_pillow(tmp_path, mode):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    src = Image.fromarray(rng.integers(0, 256, (13, 21, 4), dtype=np.uint8), "RGBA").convert(mode)
+    b = io.BytesIO(); src.save(b, format="PNG")
+    cpp = CppScene(_image_doc(tmp_path, b.getvalue(), f"img_{mode}.png"))
+    assert np.array_equal(cpp.textures[0][0], np.asarray(src.convert("RGBA")))
+    cpp.close()
+
+
+@pytest.mark.parametrize("sub,gray,restart", [(0, False, 0), (2, False, 0), (0, True, 0), (1, False, 4)])
+def test_jpeg_decoder_against_pillow(tmp_path, sub, gray, restart):
+    """Baseline JPEG: within an LSB or two of libjpeg where no chroma upsampling is involved (decoders differ in IDCT rounding);
+    with subsampled chroma libjpeg interpolates and this decoder replicates, so only the mean error is bounded there."""
+    from PIL import Image
+    y, x = np.mgrid[0:40, 0:56]
+    img = np.stack([(x * 4) % 256, (y * 6) % 256, ((x + y) * 3) % 256], -1).astype(np.uint8)
+    src = Image.fromarray(img, "RGB").convert("L") if gray else Image.fromarray(img, "RGB")
+    b = io.BytesIO()
+    kw = {} if gray else {"subsampling": sub}
+    if restart:
+        kw["restart_marker_rows"] = restart
+    try:
+        src.save(b, format="JPEG", quality=92, **kw)
+    except TypeError:
+        kw.pop("restart_marker_rows", None)
+        src.save(b, format="JPEG", quality=92, **kw)
+    ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGBA")).astype(int)
+    cpp = CppScene(_image_doc(tmp_path, b.getvalue(), f"img_{sub}_{int(gray)}_{restart}.jpg"))
+    got = cpp.textures[0][0].astype(int)
+    cpp.close()
+    assert got.shape == ref.shape and (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3] - ref[..., :3])
+    if sub == 0 or gray:
+        assert d.max() <= 3, d.max()
+    else:
+        assert d.mean() < 4.0, d.mean()
+
+
+def test_progressive_jpeg_is_rejected_with_a_message(tmp_path):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(b, format="JPEG", progressive=True)
+    with pytest.raises(ValueError, match="baseline"):
+        CppScene(_image_doc(tmp_path, b.getvalue(), "prog.jpg"))

@@ -47,6 +47,11 @@ API = [
     ("pt_camera_lookat", C.c_int, [_P, _P, _P, C.c_float, C.c_float, C.POINTER(hd.SceneCamera)]),
     ("pt_build_env_accel", C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("pt_sampler_from_gltf", C.c_int, [C.c_int] * 5 + [C.POINTER(hd.TextureDesc)]),
+    ("pt_gltf_load", C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    ("pt_gltf_desc", C.POINTER(hd.SceneDesc), [_P]),
+    ("pt_gltf_camera", C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_float)]),
+    ("pt_gltf_bounds", C.c_int, [_P, _P, _P]),
+    ("pt_gltf_free", None, [_P]),
 ]
 
 _lib = None

@@ -38,8 +38,14 @@ struct Box {
   }
 };
 
-constexpr int      kBins        = 32;
-constexpr uint32_t kSweepBelow  = 12;      // ranges this small evaluate every split of every axis
+#ifndef PT_SAH_BINS
+#define PT_SAH_BINS 32
+#endif
+#ifndef PT_SAH_SWEEP
+#define PT_SAH_SWEEP 12
+#endif
+constexpr int      kBins        = PT_SAH_BINS;
+constexpr uint32_t kSweepBelow  = PT_SAH_SWEEP;  // ranges this small evaluate every split of every axis
 constexpr uint32_t kSpawnAbove  = 1u << 15;
 
 struct Builder {
