@@ -61,6 +61,30 @@ public:
   void setVariant(int variant) { check(pt_set_variant(m_ctx, variant)); }
   void setSunAndSky(const pt_SunAndSky& s) { check(pt_set_sunsky(m_ctx, &s)); }
   void setEnvironment(const float* rgba32f, int w, int h, float* integral, float* average) { check(pt_set_env(m_ctx, rgba32f, w, h, integral, average)); }
+  // Scene::load for a .gltf / .glb file (src/scene.cpp:56-118): imports, uploads, builds the acceleration structure and sets the
+  // file's first camera (or a fit to the bounding box) for the given aspect ratio.  Returns false and keeps lastError() on failure.
+  bool loadGltf(const char* path, float aspect)
+  {
+    pt_GltfScene* sc = nullptr;
+    char          msg[512];
+    if(pt_gltf_load(path, &sc, msg, sizeof(msg)) != PT_OK)
+    {
+      m_status = PT_ERR_INVALID;
+      m_error  = msg;
+      return false;
+    }
+    const pt_SceneDesc* d  = pt_gltf_desc(sc);
+    bool                ok = check(pt_set_scene(m_ctx, d)) && check(pt_build_accel(m_ctx));
+    float               eye[3], center[3], up[3], fov;
+    pt_SceneCamera      cam{};
+    if(ok && pt_gltf_camera(sc, eye, center, up, &fov) == PT_OK && check(pt_camera_lookat(eye, center, up, fov, aspect, &cam)))
+    {
+      cam.nbLights = int(d->numLights);
+      ok           = check(pt_set_camera(m_ctx, &cam));
+    }
+    pt_gltf_free(sc);  // pt_set_scene copied everything
+    return ok;
+  }
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
   void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }

@@ -6,7 +6,7 @@
 #include <vector>
 #include "pt_renderer.hpp"
 
-int main()
+int main(int argc, char** argv)
 {
   ptmi::HipPathTracer r;
   if(r.name() != "HIP")
@@ -53,6 +53,28 @@ int main()
     std::printf("ERROR %s\n", r.lastError().c_str());
     return 4;
   }
+  const bool first = std::fabs(img[0] - 1.f) < 1e-5f && img[(32 * 64 + 32) * 4] > 0.1f;
+  if(argc > 1)
+  {  // Scene::load path: the same quad as a .glb written by vk_raytrace_amd.gltf.save_gltf must render the same image
+    std::vector<float> ref = img;
+    if(!r.loadGltf(argv[1], 1.f))
+    {
+      std::printf("ERROR loadGltf: %s\n", r.lastError().c_str());
+      return 6;
+    }
+    r.create({64, 64});
+    r.setPushContants(st);
+    r.run({64, 64});
+    r.readAccum(img.data());
+    float worst = 0.f;
+    for(size_t i = 0; i < ref.size(); ++i)
+      worst = std::fmax(worst, std::fabs(ref[i] - img[i]));
+    if(!r.ok() || worst > 1e-5f)
+    {
+      std::printf("ERROR glTF render differs (%s)\n", r.lastError().c_str());
+      return 7;
+    }
+  }
   std::printf("OK corner=%.3f centre=%.3f\n", img[0], img[(32 * 64 + 32) * 4]);
-  return (std::fabs(img[0] - 1.f) < 1e-5f && img[(32 * 64 + 32) * 4] > 0.1f) ? 0 : 5;
+  return first ? 0 : 5;
 }

@@ -24,5 +24,8 @@ def test_cpp_shim_builds_and_fails_loudly_without_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_cpp_shim_renders_on_gpu(tmp_path):
-    out = subprocess.run([_build(tmp_path)], capture_output=True, text=True)
+    from vk_raytrace_amd import gltf, synth
+    glb = str(tmp_path / "quad.glb")
+    gltf.save_gltf(synth.quad_scene(), glb)     # the same quad through Scene::load's replacement (pt_gltf_load via HipPathTracer::loadGltf)
+    out = subprocess.run([_build(tmp_path), glb], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
