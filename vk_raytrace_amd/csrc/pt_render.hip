@@ -5,21 +5,28 @@
 // calls into stages that communicate through an SoA path state in HBM and compacted queues of path
 // slots, so that every stage runs with full 64-lane wavefronts of live paths:
 //
-//   k_generate      seed (pathtrace.comp:97), jitter + camera ray (pathtrace.glsl:348-372)      all local pixels
+//   k_generate      seed (pathtrace.comp:97), jitter + camera ray (pathtrace.glsl:348-372)      all paths of the frame batch
 //   per bounce:
-//   k_closest_p     ClosestHit incl. stochastic alpha (traceray_rq.glsl:108-147); persistent
-//                   wavefronts on the trace machine (pt_machine.h)                               queue[in]
+//   k_closest_k     bounce 0: ClosestHit incl. stochastic alpha (traceray_rq.glsl:108-147) as one packet traversal per
+//                   wavefront (pt_packet.h); rays it cannot settle go to queueR                     queue[in] -> queueR
+//   k_closest_p     bounce >= 1 and queueR: the same per lane, persistent wavefronts on the refilling
+//                   trace machine (pt_machine.h)                                                   queue[in] | queueR
 //   k_shade         miss/env, GetShadeState, material, emission, absorption, DirectLight,
 //                   BSDF sample, throughput, next ray (pathtrace.glsl:201-325); Russian roulette
 //                   right away for paths without a shadow ray                                    queue[in] -> queueS | queue[out]
 //   k_shadow_p      AnyHit for the deferred NEE contribution, then Russian roulette
-//                   (pathtrace.glsl:327-338); persistent wavefronts                              queueS -> queue[out]
-//   k_closest_x / k_shadow_x   the simple one-ray-per-lane kernels, run on the (normally empty) queues of rays
-//                   that need the exact key-ordered alpha loop
-//   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean (pathtrace.comp:122-133)
+//                   (pathtrace.glsl:327-338); trace machine                                       queueS -> queue[out]
+//   k_closest_x / k_shadow_x   one ray per lane, exact key-ordered alpha loop, on the (normally almost empty) queues of
+//                   rays the two-pass scheme cannot settle
+//   k_closest_s / k_shadow_s / k_shadow_k   lock-step and packet variants selectable through PT_TUNE (bit-identical results)
+//   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean over the frames of the batch, in frame order
+//                   (pathtrace.comp:122-133)
 //
-// Queue sizes live on the device in a per-bounce counter block (8 words per bounce, zeroed once per frame), so a
-// frame is enqueued without any host synchronisation.
+// A "frame batch" is up to 64 consecutive frames traced as one wavefront (path slot = frame x pixel slot); queue sizes live
+// on the device in a per-bounce counter block (16 words per bounce, zeroed once per sample pass), so a batch is enqueued
+// without any host synchronisation.  Queue appends never issue one returning atomic per wave on a shared counter (~11 ns each,
+// serialised): they are aggregated per workgroup through LDS (k_generate, k_shade) or staged in LDS and flushed every ~200
+// entries (persistent kernels).
 //
 // Random numbers are drawn in the reference's order from one PCG state per
 // path that travels with the path state.  Queue order never influences a pixel's value.
