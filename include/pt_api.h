@@ -161,6 +161,12 @@ int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel*
  * (has_sampler == 0: LINEAR / REPEAT; unknown filter code: NEAREST; unknown wrap: REPEAT). */
 int pt_sampler_from_gltf(int has_sampler, int gltf_mag, int gltf_min, int gltf_wrapS, int gltf_wrapT, pt_TextureDesc* io);
 
+/* replaces the ray picker of SampleExample::screenPicking [src/sample_example.cpp:468-511 -> nvvk::RayPickerKHR]: shoots one ray through
+ * the normalised window position (pick_x, pick_y in [0,1], origin top-left like the reference's cursor position) with the given inverse view
+ * and inverse projection matrices (column-major, as in pt_SceneCamera) and returns the nearest triangle -- every triangle counts, without
+ * face culling or alpha test, like the picker's flag-less traceRayEXT.  Synchronous. */
+int pt_pick(pt_context* ctx, float pick_x, float pick_y, const float view_inverse[16], const float proj_inverse[16], pt_PickResult* out);
+
 /* ---- glTF import (host only, no GPU) ------------------------------------------------------------------------------------
  * replaces Scene::load -> loadGltfScene (tinygltf) + nvh::GltfScene::importMaterials / importDrawableNodes + the create*Buffer
  * packing [src/scene.cpp:56-155, 190-382, 488-580] for .gltf and .glb files: the result is the flat pt_SceneDesc pt_set_scene

@@ -85,6 +85,8 @@ public:
     pt_gltf_free(sc);  // pt_set_scene copied everything
     return ok;
   }
+  // SampleExample::screenPicking (src/sample_example.cpp:468-511)
+  bool pick(float x, float y, const pt_SceneCamera& cam, pt_PickResult* out) { return check(pt_pick(m_ctx, x, y, cam.viewInverse, cam.projInverse, out)); }
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
   void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }

@@ -217,6 +217,17 @@ typedef struct pt_SceneDesc {
   uint32_t                    numTextures;
 } pt_SceneDesc;
 
+/* Result of pt_pick: the fields of nvvk::RayPickerKHR::PickResult the reference consumes (src/sample_example.cpp:493-510). */
+typedef struct pt_PickResult {
+  float    worldRayOrigin[3];
+  float    hitT;               /* distance along the ray; undefined when nothing is hit */
+  float    worldRayDirection[3];
+  int32_t  primitiveID;        /* triangle inside the prim-mesh */
+  uint32_t instanceID;         /* node (TLAS instance) index, 0xffffffff: nothing hit */
+  int32_t  instanceCustomIndex;/* prim-mesh index */
+  float    baryCoord[3];       /* (1 - u - v, u, v) */
+} pt_PickResult;
+
 /* Counters the measurement contract needs; all totals since pt_reset_stats. */
 typedef struct pt_Stats {
   uint64_t samples;          /* pixel-samples rendered */

@@ -39,6 +39,7 @@ API = [
     ("pt_tonemap", C.c_int, [_P, C.POINTER(hd.Tonemapper), _P]),
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
+    ("pt_pick", C.c_int, [_P, C.c_float, C.c_float, _P, _P, C.POINTER(hd.PickResult)]),
     ("pt_set_profiling", C.c_int, [_P, C.c_int]),
     ("pt_get_stats", C.c_int, [_P, C.POINTER(hd.Stats)]),
     ("pt_reset_stats", C.c_int, [_P]),

@@ -62,6 +62,7 @@ struct pt_context {
   uint64_t  frameCounter = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
+  DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
   StageTimers timers;
@@ -327,7 +328,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -879,6 +880,24 @@ int pt_write_accum(pt_context* c, const float* in)
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sync_all(c));
   c->haveFull = false;
+  return PT_OK;
+}
+
+int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse, const float* proj_inverse, pt_PickResult* out)
+{
+  CTX_CHECK(c);
+  if(!view_inverse || !proj_inverse || !out)
+    return c->fail(PT_ERR_INVALID, "pt_pick: null");
+  if(!c->haveScene || !c->haveAccel)
+    return c->fail(PT_ERR_STATE, "pt_pick before pt_set_scene / pt_build_accel");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if((rc = dev_alloc(c, c->dPick, sizeof(pt_PickResult))) != PT_OK)
+    return rc;
+  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->dPick.p, sizeof(pt_PickResult), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PT_OK;
 }
 

@@ -31,6 +31,7 @@
 // Random numbers are drawn in the reference's order from one PCG state per
 // path that travels with the path state.  Queue order never influences a pixel's value.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "pt_bsdf.h"
 #include "pt_internal.h"
 #include "pt_sky.h"
@@ -1138,6 +1139,57 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
     rb.frame[pslot] = make_float4(acc.x, acc.y, acc.z, 1.f);
 }
 
+// ---- ray picker (src/sample_example.cpp:468-511; nvvk::RayPickerKHR shoots a flag-less ray: no culling, no any-hit) ------------------
+__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out)
+{
+  const f2 d         = f2{pickX * 2.0f - 1.0f, pickY * 2.0f - 1.0f};
+  const f4 origin    = mat4_mul(cam.viewInverse, f4{0, 0, 0, 1});
+  const f4 target    = mat4_mul(cam.projInverse, f4{d.x, d.y, 1, 1});
+  const f3 tn        = unit(xyz(target));
+  const f4 direction = mat4_mul(cam.viewInverse, f4{tn.x, tn.y, tn.z, 0});
+  const f3 o = xyz(origin), dir = xyz(direction);
+  // nearest triangle in key order (t, world index), no culling: one ray against every triangle record, 64 lanes in parallel
+  // (a pick is a rare, latency-insensitive query; the BVH is not worth a second traversal flavour for it)
+  float    bt = PT_INFINITY, bu = 0.f, bv = 0.f;
+  uint32_t bw = 0xffffffffu, bs = BVH_NONE;
+  for(uint32_t i = threadIdx.x; i < S.numTris; i += 64u)
+  {
+    const TriRec   tr    = S.tris[i];
+    const uint32_t wbits = __float_as_uint(tr.p0w.w);
+    float          t, u, v;
+    if(tri_test(tr, (wbits >> 29) | TRI_NOCULL, o, dir, t, u, v) && t > 0.0f && (bs == BVH_NONE || key_less(t, wbits & TRI_INDEX_MASK, bt, bw)))
+    {
+      bt = t; bu = u; bv = v; bw = wbits & TRI_INDEX_MASK; bs = i;
+    }
+  }
+  for(int off = 32; off > 0; off >>= 1)
+  {
+    const float    ot = __shfl_xor(bt, off), ou = __shfl_xor(bu, off), ov = __shfl_xor(bv, off);
+    const uint32_t ow = __shfl_xor(bw, off), os = __shfl_xor(bs, off);
+    if(os != BVH_NONE && (bs == BVH_NONE || key_less(ot, ow, bt, bw)))
+    {
+      bt = ot; bu = ou; bv = ov; bw = ow; bs = os;
+    }
+  }
+  if(threadIdx.x != 0)
+    return;
+  pt_PickResult r;
+  r.worldRayOrigin[0] = o.x; r.worldRayOrigin[1] = o.y; r.worldRayOrigin[2] = o.z;
+  r.worldRayDirection[0] = dir.x; r.worldRayDirection[1] = dir.y; r.worldRayDirection[2] = dir.z;
+  r.hitT = 0.f; r.primitiveID = -1; r.instanceID = 0xffffffffu; r.instanceCustomIndex = -1;
+  r.baryCoord[0] = r.baryCoord[1] = r.baryCoord[2] = 0.f;
+  if(bs != BVH_NONE)
+  {
+    const TriRec tr = S.tris[bs];
+    r.hitT                = bt;
+    r.instanceID          = __float_as_uint(tr.e1n.w);
+    r.primitiveID         = int(__float_as_uint(tr.e2p.w));
+    r.instanceCustomIndex = S.instances[r.instanceID].primMesh;
+    r.baryCoord[0] = 1.0f - bu - bv; r.baryCoord[1] = bu; r.baryCoord[2] = bv;
+  }
+  *out = r;
+}
+
 // ---- framebuffer plumbing ---------------------------------------------------------------------------------------
 __global__ void k_untile(const float4* __restrict__ tiles, const uint32_t* __restrict__ slotTile, uint32_t numSlots, int tilesX, int width, int height, float4* __restrict__ out)
 {
@@ -1341,6 +1393,14 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     if(recordAfterAccum && s == fp.st.maxSamples - 1)
       (void)hipEventRecord(recordAfterAccum, stream);
   }
+}
+
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut)
+{
+  pt_SceneCamera cam = scene.camera;
+  std::memcpy(cam.viewInverse, viewInv, sizeof(cam.viewInverse));
+  std::memcpy(cam.projInverse, projInv, sizeof(cam.projInverse));
+  k_pick<<<1, 64, 0, stream>>>(scene, px, py, cam, dOut);
 }
 
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor)

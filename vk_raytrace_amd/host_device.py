@@ -99,6 +99,11 @@ class SceneDesc(C.Structure):
                 ("textures", C.c_void_p), ("numTextures", C.c_uint32)]
 
 
+class PickResult(C.Structure):
+    _fields_ = [("worldRayOrigin", C.c_float * 3), ("hitT", C.c_float), ("worldRayDirection", C.c_float * 3), ("primitiveID", C.c_int32),
+                ("instanceID", C.c_uint32), ("instanceCustomIndex", C.c_int32), ("baryCoord", C.c_float * 3)]
+
+
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closestRays", C.c_uint64), ("shadowRays", C.c_uint64),
                 ("shadedHits", C.c_uint64), ("misses", C.c_uint64), ("alphaTests", C.c_uint64),

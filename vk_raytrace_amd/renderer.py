@@ -140,6 +140,14 @@ class HipRenderer(Renderer):
         assert img.shape == (h, w, 4)
         self._check(self._lib.pt_write_accum(self._ctx, img.ctypes.data))
 
+    def pick(self, x, y, cam: hd.SceneCamera):
+        """SampleExample::screenPicking (src/sample_example.cpp:468-511): nearest triangle under the normalised window position."""
+        out = hd.PickResult()
+        vi = (C.c_float * 16)(*cam.viewInverse)
+        pi = (C.c_float * 16)(*cam.projInverse)
+        self._check(self._lib.pt_pick(self._ctx, float(x), float(y), vi, pi, C.byref(out)))
+        return out
+
     def tonemap(self, tm: hd.Tonemapper):
         w, h = self.size
         out = np.empty((h, w, 4), np.uint8)
