@@ -252,9 +252,9 @@ def main():
             except Exception:
                 traffic = None
         if ms_c > 0:
-            achieved = bytes_closest / (ms_c * 1e-3) / 1e9
+            achieved = bytes_closest / max(1, world) / (ms_c * 1e-3) / 1e9  # per GPU: whole-job bytes / ranks over the mean per-rank stage time
             out["roofline"] = {"bound": "hbm", "kernel": "k_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": traffic, "alg_bytes_per_launch": bytes_closest / launches, "avg_launch_ms": ms_c / launches, "launches": launches,
+                               "traffic": traffic, "alg_bytes_per_launch": bytes_closest / max(1, world) / launches, "avg_launch_ms": ms_c / launches, "launches": launches,
                                "note": "algorithmic bytes (reference-layout BVH2 visits x 32 B + triangle tests x 36 B of this stage's rays) are served from L2 / Infinity Cache: "
                                        "`traffic` is the measured HBM bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE passes), so `frac` can exceed 1; "
                                        "the binding resource is VALU issue -- see issue_roofline"}
