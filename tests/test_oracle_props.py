@@ -211,3 +211,27 @@ def test_rtx_variant_seed_and_shadow_seed_copy():
     d = render_oracle(Config(box, env, 64, 48, depth=4, variant=1), 2)
     assert not np.array_equal(c, d) and np.isfinite(d).all()
 
+
+
+@pytest.mark.parametrize("pbr,lo,hi", [(1, 1.15, 1.27), (0, 1.22, 1.42)])
+def test_white_furnace(pbr, lo, hi):
+    """SURVEY.md 8(c)(iii), adapted to what the reference's estimator actually computes.  A white, rough, non-metallic convex object in a
+    constant environment of radiance 1: every path is hit -> (light sample) -> BSDF sample -> escape.  The reference weights the LIGHT sample
+    with the power heuristic but adds the escaped BSDF sample at full weight (pathtrace.glsl:204-228 vs :150-186), so the expectation is not 1
+    but 1 + E[w_light f cos / p_light]; for a Lambertian lobe and a uniform light pdf 1/(4 pi) that is 1 + ln(17)/16 = 1.177.  The glTF BSDF
+    at roughness 1 is that lobe plus a 4 % specular one (measured 1.21); Disney's diffuse lobe adds its retro-reflection term (measured 1.33).
+    An analytic anchor for the estimator's scale that does not compare the restatement with itself -- and a record of the reference's bias."""
+    from vk_raytrace_amd.scene import Scene, Camera
+    assert abs(1.0 + np.log(17.0) / 16.0 - 1.177) < 1e-3
+    sc = Scene("furnace")
+    m = sc.add_material(pbrBaseColorFactor=(1.0, 1.0, 1.0, 1.0), pbrMetallicFactor=0.0, pbrRoughnessFactor=1.0)
+    pos, nrm, uv, idx, tan = synth.uv_sphere(1.0, 48, 24)
+    pm = sc.add_prim_mesh(pos, nrm, uv, idx, m, tangents=tan)
+    sc.add_node(pm)
+    sc.camera = Camera(eye=(0.0, 0.0, 4.0), center=(0, 0, 0), up=(0, 1, 0), fov=20.0)     # the sphere fills the frame
+    cfg = Config(sc, synth.constant_env(16, 8, 1.0), 48, 48, depth=40, pbr=pbr, firefly=1e9)
+    img = render_oracle(cfg, 24)
+    yy, xx = np.mgrid[0:48, 0:48]
+    inside = (xx - 23.5) ** 2 + (yy - 23.5) ** 2 < 14 ** 2
+    mean = float(img[inside][:, :3].mean())
+    assert lo <= mean <= hi, mean
