@@ -24,6 +24,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* libptmi.so is built with -fvisibility=hidden: exactly these entry points are exported */
+#endif
 
 typedef struct pt_context pt_context;
 
@@ -180,6 +183,9 @@ int                 pt_gltf_camera(const pt_GltfScene* scene, float eye[3], floa
 int                 pt_gltf_bounds(const pt_GltfScene* scene, float bbox_min[3], float bbox_max[3]);
 void                pt_gltf_free(pt_GltfScene* scene);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

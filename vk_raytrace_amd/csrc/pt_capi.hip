@@ -92,7 +92,7 @@ struct pt_context {
       return (ctx)->fail(e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
   } while(0)
 
-int flush_pending(pt_context* c);  // defined next to pt_render_frame
+__attribute__((visibility("hidden"))) int flush_pending(pt_context* c);  // defined next to pt_render_frame (internal: not part of the ABI)
 namespace {
 
 int dev_alloc(pt_context* c, DevBuf& b, size_t bytes)

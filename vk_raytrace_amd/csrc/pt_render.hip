@@ -1436,7 +1436,7 @@ void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double
 
 #ifdef PT_HIST
 // measurement build only: copies (and optionally clears) the traversal histograms of pt_trace.h
-extern "C" int pt_debug_hist(unsigned long long* out, int reset)
+extern "C" __attribute__((visibility("default"))) int pt_debug_hist(unsigned long long* out, int reset)
 {
   if(hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(g_hist)) != hipSuccess)
     return -1;

@@ -235,7 +235,7 @@ void pt_sah_topology(uint32_t n, const TriRec* tris, uint32_t* vals, uint32_t* c
 
 // Test hook (tests/test_sah_cpu.py; not part of include/pt_api.h): the topology builder on plain arrays, no GPU involved.
 // tri9: n x 9 floats (p0, e1, e2).
-extern "C" int pt_debug_sah_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL)
+extern "C" __attribute__((visibility("default"))) int pt_debug_sah_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL)
 {
   if(n < 2 || !tri9)
     return -1;
