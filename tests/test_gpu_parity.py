@@ -324,7 +324,7 @@ def test_launch_policy_never_changes_results():
     single-frame path all occur)."""
     ref = _render_in_subprocess("batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh")
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
-    for tune in ["batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7,packetShadow=2,minPacket=4", "packetClosest=0,simpleClosest=1", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64"]:
+    for tune in ["batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7,packetShadow=2,minPacket=4", "packetClosest=0,simpleClosest=1", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=4,inflight=4,splitFull=2", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64"]:
         got = _render_in_subprocess(tune)
         assert np.array_equal(got, ref), tune
 

@@ -50,6 +50,7 @@ struct pt_context {
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
+    bool          launched  = false;  // a launch sequence was enqueued on this slot since the last synchronisation
   };
   FrameSlot slots[PT_MAX_INFLIGHT];
   int       inflight     = 1;
@@ -162,6 +163,8 @@ hipError_t sync_all(pt_context* c)
         return e;
     }
   c->lastAccum = nullptr;
+  for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+    c->slots[i].launched = false;
   return hipStreamSynchronize(c->stream);
 }
 
@@ -291,6 +294,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
     if(strstr(tune, "build=lbvh")) g_tuning.sahBuild = 0;
     if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
+    if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
   }
@@ -813,13 +817,41 @@ int flush_pending(pt_context* c)
   fp.nranks        = c->nranks;
   fp.numLocalTiles = c->numLocalTiles;
   fp.numSlots      = c->numSlots;
-  fp.batch         = uint32_t(c->pendCount);
   fp.variant       = c->variant;
   fp.sample        = 0;
-  c->pendCount     = 0;
-  pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
-  pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
-  c->lastAccum = fs.accumDone;
+  // A batch is cut into as many pieces as there are idle frame slots (separate streams), so that a short run of frames -- or the first
+  // batch of a long one -- has several launch sequences overlapping instead of one chain of dependent kernels.  In the steady state of a
+  // long run every slot is busy and a full batch goes out as one sequence.
+  int       parts = 1;
+  const int total = c->pendCount;
+  if(total >= 4)
+  {
+    int busy = 0;  // launch sequences still running (their accumulate has not completed)
+    for(int i = 0; i < c->inflight; ++i)
+      if(c->slots[i].launched && hipEventQuery(c->slots[i].accumDone) == hipErrorNotReady)
+        ++busy;
+      else
+        c->slots[i].launched = false;
+    (void)hipGetLastError();  // hipErrorNotReady is not an error
+    const int freeSlots = c->inflight - busy;
+    // a partial flush (the caller is waiting) is cut fine; a full batch only when the GPU is idle (the first batch of a run) -- later ones
+    // find busy slots and go out whole, so the steady state of a long run works on full batches
+    const int minPart = total < c->batchMax ? 2 : ((g_tuning.splitFull > 0 && busy == 0) ? g_tuning.splitFull : total);
+    parts = std::max(1, std::min(freeSlots, total / minPart));
+  }
+  c->pendCount = 0;
+  int done     = 0;
+  for(int p = 0; p < parts; ++p)
+  {
+    const int n = (total - done) / (parts - p);
+    fp.st.frame = c->pendState.frame + done;
+    fp.batch    = uint32_t(n);
+    done += n;
+    pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
+    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
+    c->lastAccum = fs.accumDone;
+    fs.launched  = true;
+  }
   HIP_TRY(c, hipGetLastError());
   return PT_OK;
 }

@@ -58,6 +58,8 @@ struct PtTuning {
   int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
+  int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of
+                                   // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
   int sahBuild             = 1;    // 1: host SAH topology (fast trace, the default), 0: device LBVH (fast build)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
