@@ -130,7 +130,11 @@ def test_strided_normalised_accessors_and_texture_transform(tmp_path):
 
 def test_rejects_what_it_cannot_represent(tmp_path):
     doc = _tri_doc()
-    doc["accessors"][0]["sparse"] = {"count": 1}
+    doc["accessors"][0]["sparse"] = {"count": 1, "indices": {"bufferView": 1, "componentType": 5123}, "values": {"bufferView": 0}}
+    doc["accessors"][0]["sparse"]["indices"]["byteOffset"] = 10      # index 3 (u16 at offset 10 of the index view) is fine ...
+    gltf.load_gltf(_write(tmp_path, doc))
+    doc["accessors"][0]["count"] = 3                                  # ... but not for a 3-element accessor
+    doc["meshes"][0]["primitives"][0].pop("indices")
     with pytest.raises(gltf.GltfError):
         gltf.load_gltf(_write(tmp_path, doc))
     doc = _tri_doc()
@@ -140,3 +144,27 @@ def test_rejects_what_it_cannot_represent(tmp_path):
     doc = _tri_doc()
     doc["meshes"][0]["primitives"][0]["mode"] = 1           # lines: not drawable, silently skipped like the reference
     assert gltf.load_gltf(_write(tmp_path, doc)).nodes == []
+
+
+def sparse_doc():
+    """The quad of _tri_doc with vertex 2 moved by a sparse accessor, and an accessor without bufferView (zeros) + sparse values as uv."""
+    import struct
+    doc = _tri_doc()
+    raw = base64.b64decode(doc["buffers"][0]["uri"].split(",")[1])
+    extra = struct.pack("<I", 2) + struct.pack("<3f", 5.0, 6.0, 7.0) + struct.pack("<HH", 1, 3) + struct.pack("<4f", 0.25, 0.5, 0.75, 1.0)
+    blob = raw + extra
+    doc["buffers"][0] = {"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}
+    doc["bufferViews"] += [{"buffer": 0, "byteOffset": 60, "byteLength": 4}, {"buffer": 0, "byteOffset": 64, "byteLength": 12},
+                           {"buffer": 0, "byteOffset": 76, "byteLength": 4}, {"buffer": 0, "byteOffset": 80, "byteLength": 16}]
+    doc["accessors"][0]["sparse"] = {"count": 1, "indices": {"bufferView": 2, "componentType": 5125}, "values": {"bufferView": 3}}
+    doc["accessors"].append({"componentType": 5126, "count": 4, "type": "VEC2",
+                             "sparse": {"count": 2, "indices": {"bufferView": 4, "componentType": 5123}, "values": {"bufferView": 5}}})
+    doc["meshes"][0]["primitives"][0]["attributes"]["TEXCOORD_0"] = 2
+    return doc
+
+
+def test_sparse_accessors(tmp_path):
+    sc = gltf.load_gltf(_write(tmp_path, sparse_doc()))
+    assert np.array_equal(sc._pos[0], [[0, 0, 0], [1, 0, 0], [5, 6, 7], [1, 1, 0]])
+    assert np.array_equal(sc._uv[0], [[0, 0], [0.25, 0.5], [0, 0], [0.75, 1.0]])
+

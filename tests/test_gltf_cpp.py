@@ -108,6 +108,16 @@ def test_cpp_importer_errors(tmp_path):
         CppScene(_write(tmp_path, doc))
 
 
+def test_cpp_importer_sparse_accessors(tmp_path):
+    from tests.test_gltf import sparse_doc
+    path = _write(tmp_path, sparse_doc())
+    cpp = CppScene(path)
+    compare(gltf.load_gltf(path), cpp, exact=False)
+    v = np.frombuffer(cpp.vertices.tobytes(), hd.vertex_dtype)
+    assert np.array_equal(v["position"][2], [5, 6, 7]) and np.allclose(v["texcoord"][3], [0.75, 1.0], atol=1e-6)
+    cpp.close()
+
+
 def _image_doc(tmp_path, data, name):
     (tmp_path / name).write_bytes(data)
     doc = _tri_doc()

@@ -754,8 +754,6 @@ struct Importer {
     if(index < 0 || size_t(index) >= accs.size())
       fail("accessor %d out of range", index);
     const JVal& a = accs[size_t(index)];
-    if(a.has("sparse"))
-      fail("sparse accessors are not supported");
     const int         ct = a.integer("componentType", 5126);
     const std::string ty = a.string("type", "SCALAR");
     ncomp                = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : ty == "MAT2" ? 4 : ty == "MAT3" ? 9 : 16;
@@ -798,6 +796,50 @@ struct Importer {
         }
         if(f) (*f)[i * size_t(ncomp) + size_t(k)] = float(v);
         if(u) (*u)[i * size_t(ncomp) + size_t(k)] = iv;
+      }
+    }
+    if(const JVal* sp = a.get("sparse"))
+    {  // substituted elements on top of the (possibly absent = zero) base data
+      const size_t n  = size_t(sp->number("count", 0));
+      const JVal*  si = sp->get("indices");
+      const JVal*  sv = sp->get("values");
+      if(!si || !sv)
+        fail("accessor %d: incomplete sparse block", index);
+      const uint8_t *ip, *vp;
+      size_t         il, vl, st;
+      view(si->integer("bufferView", -1), ip, il, st);
+      view(sv->integer("bufferView", -1), vp, vl, st);
+      const size_t ioff = size_t(si->number("byteOffset", 0)), voff = size_t(sv->number("byteOffset", 0));
+      const int    ict  = si->integer("componentType", 5125);
+      const size_t isz  = ict == 5121 ? 1 : ict == 5123 ? 2 : 4;
+      if(ioff + isz * n > il || voff + elem * n > vl)
+        fail("accessor %d: sparse data exceeds its bufferView", index);
+      long long prev = -1;
+      for(size_t j = 0; j < n; ++j)
+      {
+        uint32_t ix = 0;
+        memcpy(&ix, ip + ioff + isz * j, isz);
+        if((long long)ix <= prev || ix >= count)
+          fail("sparse accessor indices must be strictly increasing and below count");
+        prev = ix;
+        const uint8_t* e = vp + voff + elem * j;
+        for(int k = 0; k < ncomp; ++k)
+        {
+          const uint8_t* c = e + csize * size_t(k);
+          double         v;
+          uint32_t       iv = 0;
+          switch(ct)
+          {
+            case 5120: { int8_t x; memcpy(&x, c, 1); v = x; iv = uint32_t(x); if(norm) v = std::max(double(float(x) / 127.0f), -1.0); break; }
+            case 5121: { uint8_t x = *c; v = x; iv = x; if(norm) v = double(float(x) / 255.0f); break; }
+            case 5122: { int16_t x; memcpy(&x, c, 2); v = x; iv = uint32_t(x); if(norm) v = std::max(double(float(x) / 32767.0f), -1.0); break; }
+            case 5123: { uint16_t x; memcpy(&x, c, 2); v = x; iv = x; if(norm) v = double(float(x) / 65535.0f); break; }
+            case 5125: { uint32_t x; memcpy(&x, c, 4); v = x; iv = x; break; }
+            default: { float x; memcpy(&x, c, 4); v = x; iv = uint32_t(x); break; }
+          }
+          if(f) (*f)[size_t(ix) * size_t(ncomp) + size_t(k)] = float(v);
+          if(u) (*u)[size_t(ix) * size_t(ncomp) + size_t(k)] = iv;
+        }
       }
     }
   }

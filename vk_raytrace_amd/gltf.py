@@ -100,8 +100,6 @@ class _Doc:
     def accessor(self, index, as_float=True):
         """Decoded accessor as an (count, ncomp) array; normalised integers become floats per the specification."""
         a = self.doc["accessors"][index]
-        if "sparse" in a:
-            raise GltfError("sparse accessors are not supported")
         dt, nc, count = np.dtype(_COMP[a["componentType"]]), _NCOMP[a["type"]], a["count"]
         if "bufferView" not in a:
             arr = np.zeros((count, nc), dt)
@@ -115,6 +113,17 @@ class _Doc:
                 raw = np.frombuffer(data, np.uint8)
                 idx = off + stride * np.arange(count)[:, None] + np.arange(elem)[None, :]
                 arr = raw[idx].copy().view(dt).reshape(count, nc)
+        if "sparse" in a:  # substituted elements on top of the (possibly absent = zero) base data
+            sp = a["sparse"]
+            n = sp["count"]
+            idat, _ = self.view(sp["indices"]["bufferView"])
+            ind = np.frombuffer(idat, np.dtype(_COMP[sp["indices"]["componentType"]]), n, sp["indices"].get("byteOffset", 0)).astype(np.int64)
+            vdat, _ = self.view(sp["values"]["bufferView"])
+            val = np.frombuffer(vdat, dt, n * nc, sp["values"].get("byteOffset", 0)).reshape(n, nc)
+            if n and (ind.max() >= count or (np.diff(ind) <= 0).any()):
+                raise GltfError("sparse accessor indices must be strictly increasing and below count")
+            arr = arr.copy()
+            arr[ind] = val
         if not as_float:
             return arr
         if dt == np.float32:
