@@ -173,7 +173,7 @@ int pt_pick(pt_context* ctx, float pick_x, float pick_y, const float view_invers
 /* ---- glTF import (host only, no GPU) ------------------------------------------------------------------------------------
  * replaces Scene::load -> loadGltfScene (tinygltf) + nvh::GltfScene::importMaterials / importDrawableNodes + the create*Buffer
  * packing [src/scene.cpp:56-155, 190-382, 488-580] for .gltf and .glb files: the result is the flat pt_SceneDesc pt_set_scene
- * takes (textures are (sampler, image) pairs decoded to RGBA8; PNG and baseline JPEG), plus the first camera of the file or a
+ * takes (textures are (sampler, image) pairs decoded to RGBA8; PNG and Huffman-coded JPEG, sequential or progressive), plus the first camera of the file or a
  * fit to the bounding box [src/scene.cpp:281-298].  The scene owns every array the description points to until pt_gltf_free.
  * On failure returns PT_ERR_INVALID and writes a message to `err` (may be NULL). */
 typedef struct pt_GltfScene pt_GltfScene;

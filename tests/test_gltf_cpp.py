@@ -167,9 +167,27 @@ def test_jpeg_decoder_against_pillow(tmp_path, sub, gray, restart):
         assert d.mean() < 4.0, d.mean()
 
 
-def test_progressive_jpeg_is_rejected_with_a_message(tmp_path):
+@pytest.mark.parametrize("sub", [0, 2])
+def test_progressive_jpeg_against_pillow(tmp_path, sub):
     from PIL import Image
+    rng = np.random.default_rng(9)
+    y, x = np.mgrid[0:45, 0:70]
+    img = np.stack([(x * 3 + rng.integers(0, 9, x.shape)) % 256, (y * 5) % 256, ((x * y) // 7) % 256], -1).astype(np.uint8)
     b = io.BytesIO()
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(b, format="JPEG", progressive=True)
-    with pytest.raises(ValueError, match="baseline"):
-        CppScene(_image_doc(tmp_path, b.getvalue(), "prog.jpg"))
+    Image.fromarray(img, "RGB").save(b, format="JPEG", quality=88, progressive=True, subsampling=sub)
+    assert b"\xff\xc2" in b.getvalue()                      # really SOF2
+    ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGBA")).astype(int)
+    cpp = CppScene(_image_doc(tmp_path, b.getvalue(), f"prog_{sub}.jpg"))
+    got = cpp.textures[0][0].astype(int)
+    cpp.close()
+    d = np.abs(got[..., :3] - ref[..., :3])
+    if sub == 0:
+        assert d.max() <= 3, d.max()
+    else:
+        assert d.mean() < 4.0, d.mean()
+
+
+def test_arithmetic_or_garbage_jpeg_is_rejected_with_a_message(tmp_path):
+    data = b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00\xff\xd9"      # SOF9: arithmetic coding
+    with pytest.raises(ValueError, match="not supported"):
+        CppScene(_image_doc(tmp_path, data, "arith.jpg"))

@@ -261,6 +261,8 @@ Image decode_png(const Bytes& d)
     const uint8_t* body = &d[off + 8];
     if(!memcmp(type, "IHDR", 4))
     {
+      if(len < 13)
+        fail("PNG: short IHDR");
       w = int(be32(body)); h = int(be32(body + 4)); depth = body[8]; ctype = body[9]; interlace = body[12];
     }
     else if(!memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
@@ -339,17 +341,19 @@ Image decode_png(const Bytes& d)
   return im;
 }
 
-// Baseline (SOF0 / SOF1, Huffman, 8 bit) JPEG.  Chroma is upsampled by replication; the IDCT is the separable float one --
-// decoders legitimately differ by an LSB or so (JPEG decode is unpinned).
+// Huffman-coded 8-bit JPEG: baseline / extended sequential (SOF0, SOF1) and progressive (SOF2), interleaved or not, restart intervals.
+// Every scan decodes into per-component coefficient planes; dequantisation, IDCT and colour conversion run once at the end.  Chroma is
+// upsampled by replication and the IDCT is the separable float one -- decoders legitimately differ by an LSB or so (SURVEY.md 8(c):
+// JPEG decode is unpinned).
 struct Jpeg {
   const uint8_t* p;
   const uint8_t* end;
   struct Huff {
-    uint8_t  bits[17] = {0};
-    uint8_t  vals[256] = {0};
-    int      mincode[17], maxcode[18], valptr[17];
-    bool     set = false;
-    void     build()
+    uint8_t bits[17] = {0};
+    uint8_t vals[256] = {0};
+    int     mincode[17], maxcode[18], valptr[17];
+    bool    set = false;
+    void    build()
     {
       int code = 0, k = 0;
       for(int l = 1; l <= 16; ++l)
@@ -366,11 +370,19 @@ struct Jpeg {
     }
   } dc[4], ac[4];
   uint16_t qt[4][64] = {{0}};
-  struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; std::vector<uint8_t> plane; int pw = 0, ph = 0; } comp[3];
-  int      ncomp = 0, W = 0, H = 0, restart = 0;
+  struct Comp {
+    int                  id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+    int                  bw = 0, bh = 0;  // blocks per row / column, padded to whole MCUs
+    int                  cw = 0, ch = 0;  // blocks that cover the component (non-interleaved scans visit only these)
+    std::vector<int16_t> coef;            // bw * bh * 64, natural (de-zigzagged) order
+    std::vector<uint8_t> plane;
+  } comp[3];
+  int      ncomp = 0, W = 0, H = 0, restart = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+  bool     progressive = false, haveFrame = false;
   uint32_t bitbuf = 0;
   int      bitcnt = 0;
   bool     hitMarker = false;
+  int      eobrun = 0;
 
   int getbit()
   {
@@ -384,7 +396,7 @@ struct Jpeg {
         {
           int c2 = p < end ? *p : 0;
           if(c2 == 0) ++p;
-          else { hitMarker = true; --p; c = 0; }  // a marker: feed zeros until the restart logic consumes it
+          else { hitMarker = true; --p; c = 0; }  // a marker: feed zeros until the caller consumes it
         }
       }
       bitbuf = uint32_t(c);
@@ -394,13 +406,17 @@ struct Jpeg {
   }
   int getbits(int n)
   {
-    int v = 0;
+    if(n < 0 || n > 16)
+      fail("JPEG: bad bit count");
+    unsigned v = 0;
     while(n--)
-      v = (v << 1) | getbit();
-    return v;
+      v = (v << 1) | unsigned(getbit());
+    return int(v);
   }
   int decode(const Huff& h)
   {
+    if(!h.set)
+      fail("JPEG: missing Huffman table");
     int code = 0;
     for(int l = 1; l <= 16; ++l)
     {
@@ -410,7 +426,14 @@ struct Jpeg {
     }
     fail("JPEG: bad Huffman code");
   }
-  static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+  static int extend(int v, int t) { return (t > 0 && v < (1 << (t - 1))) ? v - (1 << t) + 1 : v; }
+
+  static const uint8_t* zigzag()
+  {
+    static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return zz;
+  }
 
   static void idct8x8(const float* in, uint8_t* out, int stride)
   {
@@ -443,52 +466,254 @@ struct Jpeg {
       }
   }
 
+  // ---- one 8x8 block of a scan
+  void block_sequential(Comp& c, int16_t* co)
+  {
+    const uint8_t* zz = zigzag();
+    const int      t  = decode(dc[c.td & 3]);
+    if(t > 15)
+      fail("JPEG: bad DC size");
+    c.pred += t ? extend(getbits(t), t) : 0;
+    co[0] = int16_t(c.pred);
+    for(int k = 1; k < 64;)
+    {
+      const int rs = decode(ac[c.ta & 3]), r = rs >> 4, sz = rs & 15;
+      if(sz == 0)
+      {
+        if(r != 15) break;
+        k += 16;
+        continue;
+      }
+      k += r;
+      if(k > 63)
+        fail("JPEG: bad coefficient index");
+      co[zz[k]] = int16_t(extend(getbits(sz), sz));
+      ++k;
+    }
+  }
+  void block_dc_progressive(Comp& c, int16_t* co, int ah, int al)
+  {
+    if(ah == 0)
+    {
+      const int t = decode(dc[c.td & 3]);
+      if(t > 15)
+        fail("JPEG: bad DC size");
+      c.pred += t ? extend(getbits(t), t) : 0;
+      co[0] = int16_t(c.pred * (1 << al));
+    }
+    else if(getbit())
+      co[0] = int16_t(co[0] | (1 << al));
+  }
+  void block_ac_progressive(Comp& c, int16_t* co, int ss, int se, int ah, int al)
+  {
+    const uint8_t* zz = zigzag();
+    if(ah == 0)
+    {
+      if(eobrun > 0) { --eobrun; return; }
+      for(int k = ss; k <= se;)
+      {
+        const int rs = decode(ac[c.ta & 3]), r = rs >> 4, sz = rs & 15;
+        if(sz == 0)
+        {
+          if(r < 15)
+          {
+            eobrun = (1 << r) - 1;
+            if(r) eobrun += getbits(r);
+            break;
+          }
+          k += 16;
+        }
+        else
+        {
+          k += r;
+          if(k > 63)
+            fail("JPEG: bad coefficient index");
+          co[zz[k]] = int16_t(extend(getbits(sz), sz) * (1 << al));
+          ++k;
+        }
+      }
+      return;
+    }
+    const int bit = 1 << al;
+    auto      refine = [&](int16_t& v) {
+      if(getbit() && (v & bit) == 0)
+        v = int16_t(v > 0 ? v + bit : v - bit);
+    };
+    if(eobrun > 0)
+    {
+      --eobrun;
+      for(int k = ss; k <= se; ++k)
+        if(co[zz[k]] != 0)
+          refine(co[zz[k]]);
+      return;
+    }
+    int k = ss;
+    while(k <= se)
+    {
+      const int rs = decode(ac[c.ta & 3]);
+      int       r = rs >> 4, sz = rs & 15, val = 0;
+      if(sz == 0)
+      {
+        if(r < 15)
+        {
+          eobrun = (1 << r) - 1;
+          if(r) eobrun += getbits(r);
+          r = 64;  // the rest of the band is refinement only
+        }
+      }
+      else
+      {
+        if(sz != 1)
+          fail("JPEG: bad refinement code");
+        val = getbit() ? bit : -bit;
+      }
+      while(k <= se)
+      {
+        int16_t& v = co[zz[k++]];
+        if(v != 0)
+          refine(v);
+        else
+        {
+          if(r == 0)
+          {
+            if(val) v = int16_t(val);
+            break;
+          }
+          --r;
+        }
+      }
+    }
+  }
+
+  void restart_marker()
+  {
+    bitcnt    = 0;
+    hitMarker = false;
+    while(p + 1 < end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
+    if(p + 1 < end) p += 2;
+    for(int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+    eobrun = 0;
+  }
+
+  void scan(int ns, const int* ci, int ss, int se, int ah, int al)
+  {
+    bitcnt = 0; hitMarker = false; eobrun = 0;
+    for(int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+    auto one = [&](Comp& c, int bx, int by) {
+      int16_t* co = &c.coef[(size_t(by) * c.bw + bx) * 64];
+      if(!progressive) block_sequential(c, co);
+      else if(ss == 0) block_dc_progressive(c, co, ah, al);
+      else block_ac_progressive(c, co, ss, se, ah, al);
+    };
+    int count = 0;
+    if(ns == 1)
+    {  // non-interleaved: the blocks that cover the component, in raster order
+      Comp& c = comp[ci[0]];
+      for(int by = 0; by < c.ch; ++by)
+        for(int bx = 0; bx < c.cw; ++bx)
+        {
+          if(restart && count && count % restart == 0) restart_marker();
+          ++count;
+          one(c, bx, by);
+        }
+    }
+    else
+    {
+      if(progressive && ss != 0)
+        fail("JPEG: progressive AC scans must not be interleaved");
+      for(int my = 0; my < mcuy; ++my)
+        for(int mx = 0; mx < mcux; ++mx)
+        {
+          if(restart && count && count % restart == 0) restart_marker();
+          ++count;
+          for(int i = 0; i < ns; ++i)
+          {
+            Comp& c = comp[ci[i]];
+            for(int by = 0; by < c.v; ++by)
+              for(int bx = 0; bx < c.h; ++bx)
+                one(c, mx * c.h + bx, my * c.v + by);
+          }
+        }
+    }
+    // position on the next marker
+    bitcnt = 0;
+    while(p + 1 < end && !(p[0] == 0xFF && p[1] != 0 && !(p[1] >= 0xD0 && p[1] <= 0xD7))) ++p;
+    hitMarker = false;
+  }
+
   Image run()
   {
-    static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    const uint8_t* zz = zigzag();
     if(end - p < 2 || p[0] != 0xFF || p[1] != 0xD8)
       fail("JPEG: no SOI");
     p += 2;
-    bool sos = false;
-    while(!sos)
+    bool scanned = false;
+    for(;;)
     {
-      if(end - p < 4 || p[0] != 0xFF)
+      if(end - p < 2)
+        break;  // tolerate a missing EOI
+      if(p[0] != 0xFF)
         fail("JPEG: marker expected");
       while(p < end && *p == 0xFF) ++p;
+      if(p >= end)
+        break;
       const int m = *p++;
       if(m == 0xD9)
-        fail("JPEG: no scan");
+        break;
+      if(end - p < 2)
+        fail("JPEG: truncated segment");
       const int      len = (p[0] << 8) | p[1];
       const uint8_t* s   = p + 2;
       const uint8_t* se  = p + len;
-      if(se > end)
+      if(se > end || len < 2)
         fail("JPEG: truncated segment");
+      p = se;
       if(m == 0xDB)
         while(s < se)
         {
           const int pq = *s >> 4, tq = *s & 15;
           ++s;
+          if(se - s < (pq ? 128 : 64))
+            fail("JPEG: truncated quantisation table");
           for(int i = 0; i < 64; ++i)
           {
             qt[tq & 3][zz[i]] = pq ? uint16_t((s[0] << 8) | s[1]) : *s;
             s += pq ? 2 : 1;
           }
         }
-      else if(m == 0xC0 || m == 0xC1)
+      else if(m == 0xC0 || m == 0xC1 || m == 0xC2)
       {
+        progressive = m == 0xC2;
+        if(se - s < 6 || se - s < 6 + 3 * s[5])
+          fail("JPEG: truncated frame header");
+        if(haveFrame)
+          fail("JPEG: more than one frame");
         if(s[0] != 8)
           fail("JPEG: only 8-bit samples are supported");
         H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4]; ncomp = s[5];
         if(ncomp != 1 && ncomp != 3)
           fail("JPEG: %d components are not supported", ncomp);
+        if(W <= 0 || H <= 0)
+          fail("JPEG: empty frame");
         for(int i = 0; i < ncomp; ++i)
         {
           comp[i].id = s[6 + i * 3]; comp[i].h = s[7 + i * 3] >> 4; comp[i].v = s[7 + i * 3] & 15; comp[i].tq = s[8 + i * 3] & 3;
+          if(comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4)
+            fail("JPEG: bad sampling factors");
+          hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v);
         }
+        mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+        for(int i = 0; i < ncomp; ++i)
+        {
+          Comp& c = comp[i];
+          c.bw = mcux * c.h; c.bh = mcuy * c.v;
+          c.cw = ((W * c.h + hmax - 1) / hmax + 7) / 8; c.ch = ((H * c.v + vmax - 1) / vmax + 7) / 8;
+          c.coef.assign(size_t(c.bw) * c.bh * 64, 0);
+        }
+        haveFrame = true;
       }
-      else if(m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC))
-        fail("JPEG: only baseline (sequential Huffman) files are supported, this one is SOF%d", m - 0xC0);
+      else if(m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)
+        fail("JPEG: lossless / arithmetic-coded files are not supported (SOF%d)", m - 0xC0);
       else if(m == 0xC4)
         while(s < se)
         {
@@ -496,94 +721,75 @@ struct Jpeg {
           ++s;
           Huff& h = tc ? ac[th] : dc[th];
           int   n = 0;
+          if(se - s < 16)
+            fail("JPEG: truncated Huffman table");
           for(int l = 1; l <= 16; ++l) { h.bits[l] = s[l - 1]; n += h.bits[l]; }
           s += 16;
-          if(n > 256)
+          if(n > 256 || se - s < n)
             fail("JPEG: bad DHT");
           memcpy(h.vals, s, size_t(n));
           s += n;
           h.build();
         }
       else if(m == 0xDD)
+      {
+        if(se - s < 2)
+          fail("JPEG: truncated DRI");
         restart = (s[0] << 8) | s[1];
+      }
       else if(m == 0xDA)
       {
+        if(!haveFrame)
+          fail("JPEG: scan before the frame header");
+        if(se - s < 1)
+          fail("JPEG: truncated scan header");
         const int ns = s[0];
-        if(ns != ncomp)
-          fail("JPEG: non-interleaved scans are not supported");
+        if(ns < 1 || ns > ncomp || se - s < 1 + ns * 2)
+          fail("JPEG: bad scan header");
+        int ci[3] = {0, 0, 0};
         for(int i = 0; i < ns; ++i)
-          for(int k = 0; k < ncomp; ++k)
-            if(comp[k].id == s[1 + i * 2])
-            {
-              comp[k].td = s[2 + i * 2] >> 4;
-              comp[k].ta = s[2 + i * 2] & 15;
-            }
-        sos = true;
+        {
+          int k = 0;
+          while(k < ncomp && comp[k].id != s[1 + i * 2]) ++k;
+          if(k == ncomp)
+            fail("JPEG: scan references an unknown component");
+          comp[k].td = s[2 + i * 2] >> 4;
+          comp[k].ta = s[2 + i * 2] & 15;
+          ci[i]      = k;
+        }
+        if(se - s < 4 + ns * 2)
+          fail("JPEG: truncated scan header");
+        const int ss = s[1 + ns * 2], sen = s[2 + ns * 2], ah = s[3 + ns * 2] >> 4, al = s[3 + ns * 2] & 15;
+        if(progressive && (ss > sen || sen > 63 || al > 13 || ah > 13))
+          fail("JPEG: bad spectral selection");
+        scan(ns, ci, progressive ? ss : 0, progressive ? sen : 63, progressive ? ah : 0, progressive ? al : 0);
+        scanned = true;
       }
-      p = se;
     }
-    if(W <= 0 || H <= 0)
-      fail("JPEG: no frame header");
-    int hmax = 1, vmax = 1;
-    for(int i = 0; i < ncomp; ++i) { hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v); }
-    const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+    if(!haveFrame || !scanned)
+      fail("JPEG: no image data");
+    float blk[64];
     for(int i = 0; i < ncomp; ++i)
     {
-      comp[i].pw = mcux * comp[i].h * 8;
-      comp[i].ph = mcuy * comp[i].v * 8;
-      comp[i].plane.assign(size_t(comp[i].pw) * comp[i].ph, 0);
-      if(!dc[comp[i].td & 3].set || !ac[comp[i].ta & 3].set)
-        fail("JPEG: missing Huffman table");
-    }
-    int   count = 0;
-    float blk[64];
-    for(int my = 0; my < mcuy; ++my)
-      for(int mx = 0; mx < mcux; ++mx)
-      {
-        if(restart && count && count % restart == 0)
-        {  // RSTn: byte-align, skip the marker, reset predictions
-          bitcnt = 0;
-          hitMarker = false;
-          while(p + 1 < end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
-          if(p + 1 < end) p += 2;
-          for(int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+      Comp& c = comp[i];
+      c.plane.assign(size_t(c.bw) * 8 * size_t(c.bh) * 8, 0);
+      const uint16_t* q = qt[c.tq];
+      for(int by = 0; by < c.bh; ++by)
+        for(int bx = 0; bx < c.bw; ++bx)
+        {
+          const int16_t* co = &c.coef[(size_t(by) * c.bw + bx) * 64];
+          for(int k = 0; k < 64; ++k)
+            blk[k] = float(int(co[k]) * int(q[k]));
+          idct8x8(blk, &c.plane[size_t(by) * 8 * (size_t(c.bw) * 8) + size_t(bx) * 8], c.bw * 8);
         }
-        ++count;
-        for(int i = 0; i < ncomp; ++i)
-          for(int by = 0; by < comp[i].v; ++by)
-            for(int bx = 0; bx < comp[i].h; ++bx)
-            {
-              std::fill(blk, blk + 64, 0.0f);
-              const uint16_t* q = qt[comp[i].tq];
-              int             t = decode(dc[comp[i].td & 3]);
-              int             diff = t ? extend(getbits(t), t) : 0;
-              comp[i].pred += diff;
-              blk[0] = float(comp[i].pred * q[0]);
-              for(int k = 1; k < 64;)
-              {
-                const int rs = decode(ac[comp[i].ta & 3]), r = rs >> 4, sz = rs & 15;
-                if(sz == 0)
-                {
-                  if(r != 15) break;
-                  k += 16;
-                  continue;
-                }
-                k += r;
-                if(k > 63)
-                  fail("JPEG: bad coefficient index");
-                blk[zz[k]] = float(extend(getbits(sz), sz) * q[zz[k]]);
-                ++k;
-              }
-              idct8x8(blk, &comp[i].plane[size_t((my * comp[i].v + by) * 8) * comp[i].pw + (mx * comp[i].h + bx) * 8], comp[i].pw);
-            }
-      }
+    }
     Image im;
     im.w = W; im.h = H;
     im.rgba.resize(size_t(W) * H * 4);
     for(int y = 0; y < H; ++y)
       for(int x = 0; x < W; ++x)
       {
-        auto at = [&](int i) { return int(comp[i].plane[size_t(y * comp[i].v / vmax) * comp[i].pw + x * comp[i].h / hmax]); };
+        auto at = [&](int i) { return int(comp[i].plane[size_t(y * comp[i].v / vmax) * (size_t(comp[i].bw) * 8) + size_t(x * comp[i].h / hmax)]); };
         int  r, g, b;
         if(ncomp == 1)
           r = g = b = at(0);
