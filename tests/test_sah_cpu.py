@@ -92,6 +92,16 @@ def test_coincident_and_degenerate():
     check_tree(n, *build(tri9))
 
 
+def test_non_finite_vertices_do_not_break_the_builder():
+    rng = np.random.default_rng(2)
+    n = 500
+    tri9 = np.concatenate([rng.uniform(-5, 5, (n, 3)), rng.normal(0, 0.3, (n, 6))], 1).astype(np.float32)
+    tri9[::7, 0] = np.nan
+    tri9[3::11, 4] = np.inf
+    tri9[5::13, 8] = -np.inf
+    check_tree(n, *build(tri9))
+
+
 def test_surface_area_quality():
     rng = np.random.default_rng(1)
     n = 4096

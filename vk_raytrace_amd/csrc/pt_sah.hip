@@ -222,7 +222,9 @@ void pt_sah_topology(uint32_t n, const TriRec* tris, uint32_t* vals, uint32_t* c
     {
       p.lo[a] = std::fmin(p0[a], std::fmin(p1[a], p2[a]));
       p.hi[a] = std::fmax(p0[a], std::fmax(p1[a], p2[a]));
-      p.c[a]  = 0.5f * (p.lo[a] + p.hi[a]);
+      if(!std::isfinite(p.lo[a]) || !std::isfinite(p.hi[a]))
+        p.lo[a] = p.hi[a] = 0.0f;  // non-finite input must not reach the comparators (strict weak ordering); the triangle can never be hit anyway
+      p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
     }
     p.id = i;
   }
