@@ -138,6 +138,27 @@ def test_png_decoder_against_pillow(tmp_path, mode):
     cpp.close()
 
 
+def test_interlaced_png_against_pillow(tmp_path):
+    """Adam7.  Pillow cannot write interlaced PNGs, so the file is assembled here: seven reduced images, filter 0, one zlib stream."""
+    import struct, zlib
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    w, h = 19, 13
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    raw = b""
+    for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        sub = img[y0::dy, x0::dx]
+        if sub.size:
+            raw += b"".join(b"\x00" + sub[r].tobytes() for r in range(sub.shape[0]))
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")), img)       # Pillow reads it back as the source image
+    cpp = CppScene(_image_doc(tmp_path, data, "adam7.png"))
+    assert np.array_equal(cpp.textures[0][0], img)
+    cpp.close()
+
+
 @pytest.mark.parametrize("sub,gray,restart", [(0, False, 0), (2, False, 0), (0, True, 0), (1, False, 4)])
 def test_jpeg_decoder_against_pillow(tmp_path, sub, gray, restart):
     """Baseline JPEG: within an LSB or two of libjpeg where no chroma upsampling is involved (decoders differ in IDCT rounding);

@@ -273,70 +273,98 @@ Image decode_png(const Bytes& d)
   }
   if(w <= 0 || h <= 0)
     fail("PNG: no IHDR");
-  if(interlace)
-    fail("PNG: interlaced images are not supported");
+  if(interlace > 1)
+    fail("PNG: unknown interlace method %d", interlace);
   const int ch  = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if(!ch || (depth != 8 && depth != 16 && !(depth < 8 && (ctype == 0 || ctype == 3))))
     fail("PNG: unsupported colour type %d / depth %d", ctype, depth);
-  const size_t bpp    = std::max<size_t>(1, size_t(ch) * depth / 8);       // bytes per complete pixel for filtering
-  const size_t stride = (size_t(w) * ch * depth + 7) / 8;
-  Bytes        raw((stride + 1) * size_t(h));
-  uLongf       rawLen = uLongf(raw.size());
+  const size_t bpp = std::max<size_t>(1, size_t(ch) * depth / 8);  // bytes per complete pixel for filtering
+  // (x0, y0, dx, dy) of the passes: one for a plain image, Adam7's seven for an interlaced one
+  static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const int plain[1][4] = {{0, 0, 1, 1}};
+  const int(*passes)[4]        = interlace ? adam7 : plain;
+  const int npass              = interlace ? 7 : 1;
+  auto      pass_dim = [&](int k, int& pw, int& ph) {
+    pw = (w - passes[k][0] + passes[k][2] - 1) / passes[k][2];
+    ph = (h - passes[k][1] + passes[k][3] - 1) / passes[k][3];
+    if(pw < 0) pw = 0;
+    if(ph < 0) ph = 0;
+  };
+  size_t total = 0;
+  for(int k = 0; k < npass; ++k)
+  {
+    int pw, ph;
+    pass_dim(k, pw, ph);
+    if(pw && ph)
+      total += ((size_t(pw) * ch * depth + 7) / 8 + 1) * size_t(ph);
+  }
+  Bytes  raw(total);
+  uLongf rawLen = uLongf(raw.size());
   if(uncompress(raw.data(), &rawLen, idat.data(), uLong(idat.size())) != Z_OK || rawLen != raw.size())
     fail("PNG: inflate failed");
-  Bytes prev(stride, 0), cur(stride);
   Image im;
   im.w = w; im.h = h;
   im.rgba.resize(size_t(w) * h * 4);
-  for(int y = 0; y < h; ++y)
+  size_t rawOff = 0;
+  for(int k = 0; k < npass; ++k)
   {
-    const uint8_t* row = &raw[(stride + 1) * size_t(y)];
-    const int      ft  = row[0];
-    for(size_t i = 0; i < stride; ++i)
+    int pw, ph;
+    pass_dim(k, pw, ph);
+    if(!pw || !ph)
+      continue;
+    const size_t stride = (size_t(pw) * ch * depth + 7) / 8;
+    Bytes        prev(stride, 0), cur(stride);
+    for(int y = 0; y < ph; ++y)
     {
-      const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-      int       x = row[1 + i];
-      switch(ft)
+      const uint8_t* row = &raw[rawOff + (stride + 1) * size_t(y)];
+      const int      ft  = row[0];
+      for(size_t i = 0; i < stride; ++i)
       {
-        case 0: break;
-        case 1: x += a; break;
-        case 2: x += b; break;
-        case 3: x += (a + b) >> 1; break;
-        case 4: {
-          int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-          x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          break;
+        const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+        int       x = row[1 + i];
+        switch(ft)
+        {
+          case 0: break;
+          case 1: x += a; break;
+          case 2: x += b; break;
+          case 3: x += (a + b) >> 1; break;
+          case 4: {
+            int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+            x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            break;
+          }
+          default: fail("PNG: bad filter %d", ft);
         }
-        default: fail("PNG: bad filter %d", ft);
+        cur[i] = uint8_t(x);
       }
-      cur[i] = uint8_t(x);
-    }
-    uint8_t* o = &im.rgba[size_t(y) * w * 4];
-    for(int x = 0; x < w; ++x)
-    {
-      auto sample = [&](int k) -> int {  // k-th channel of pixel x as 8 bit
-        if(depth == 8) return cur[size_t(x) * ch + k];
-        if(depth == 16) return cur[(size_t(x) * ch + k) * 2];  // high byte
-        const int per = 8 / depth, idx = x, byte = idx / per, sh = (per - 1 - idx % per) * depth;
-        const int v = (cur[byte] >> sh) & ((1 << depth) - 1);
-        return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
-      };
-      int r, g, b, a = 255;
-      if(ctype == 0) { r = g = b = sample(0); if(trns.size() >= 2 && depth == 8 && r == trns[1]) a = 0; }
-      else if(ctype == 2) { r = sample(0); g = sample(1); b = sample(2); if(trns.size() >= 6 && depth == 8 && r == trns[1] && g == trns[3] && b == trns[5]) a = 0; }
-      else if(ctype == 3)
+      for(int x = 0; x < pw; ++x)
       {
-        const int i = sample(0);
-        if(size_t(i) * 3 + 2 >= plte.size())
-          fail("PNG: palette index out of range");
-        r = plte[i * 3]; g = plte[i * 3 + 1]; b = plte[i * 3 + 2];
-        a = size_t(i) < trns.size() ? trns[i] : 255;
+        auto sample = [&](int q) -> int {  // q-th channel of pixel x as 8 bit
+          if(depth == 8) return cur[size_t(x) * ch + q];
+          if(depth == 16) return cur[(size_t(x) * ch + q) * 2];  // high byte
+          const int per = 8 / depth, byte = x / per, sh = (per - 1 - x % per) * depth;
+          const int v = (cur[byte] >> sh) & ((1 << depth) - 1);
+          return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+        };
+        int r, g, b, a = 255;
+        if(ctype == 0) { r = g = b = sample(0); if(trns.size() >= 2 && depth == 8 && r == trns[1]) a = 0; }
+        else if(ctype == 2) { r = sample(0); g = sample(1); b = sample(2); if(trns.size() >= 6 && depth == 8 && r == trns[1] && g == trns[3] && b == trns[5]) a = 0; }
+        else if(ctype == 3)
+        {
+          const int i = sample(0);
+          if(size_t(i) * 3 + 2 >= plte.size())
+            fail("PNG: palette index out of range");
+          r = plte[i * 3]; g = plte[i * 3 + 1]; b = plte[i * 3 + 2];
+          a = size_t(i) < trns.size() ? trns[i] : 255;
+        }
+        else if(ctype == 4) { r = g = b = sample(0); a = sample(1); }
+        else { r = sample(0); g = sample(1); b = sample(2); a = sample(3); }
+        uint8_t* o = &im.rgba[(size_t(passes[k][1] + y * passes[k][3]) * w + size_t(passes[k][0] + x * passes[k][2])) * 4];
+        o[0] = uint8_t(r); o[1] = uint8_t(g); o[2] = uint8_t(b); o[3] = uint8_t(a);
       }
-      else if(ctype == 4) { r = g = b = sample(0); a = sample(1); }
-      else { r = sample(0); g = sample(1); b = sample(2); a = sample(3); }
-      o[x * 4] = uint8_t(r); o[x * 4 + 1] = uint8_t(g); o[x * 4 + 2] = uint8_t(b); o[x * 4 + 3] = uint8_t(a);
+      prev.swap(cur);
     }
-    prev.swap(cur);
+    rawOff += (stride + 1) * size_t(ph);
   }
   return im;
 }
