@@ -170,6 +170,12 @@ int pt_sampler_from_gltf(int has_sampler, int gltf_mag, int gltf_min, int gltf_w
  * face culling or alpha test, like the picker's flag-less traceRayEXT.  Synchronous. */
 int pt_pick(pt_context* ctx, float pick_x, float pick_y, const float view_inverse[16], const float proj_inverse[16], pt_PickResult* out);
 
+/* Evaluates one function of the fp32 transcendental contract (include/pt_fpmath.h; enum PT_FN_* in pt_types.h) on the device for n
+ * arguments (b is the second argument of atan2(a, b) / pow(a, b), otherwise ignored and may be NULL).  No reference counterpart: GLSL
+ * leaves these functions' accuracy to the driver; the contract fixes one IEEE operation sequence and this entry point lets a test hold
+ * the gfx950 evaluation bit for bit to the host evaluation of the same header.  Synchronous. */
+int pt_fpmath_eval(pt_context* ctx, int fn, uint64_t n, const float* a, const float* b, float* out);
+
 /* ---- glTF import (host only, no GPU) ------------------------------------------------------------------------------------
  * replaces Scene::load -> loadGltfScene (tinygltf) + nvh::GltfScene::importMaterials / importDrawableNodes + the create*Buffer
  * packing [src/scene.cpp:56-155, 190-382, 488-580] for .gltf and .glb files: the result is the flat pt_SceneDesc pt_set_scene

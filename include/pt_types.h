@@ -187,6 +187,8 @@ typedef struct pt_Node {
  * reference: src/scene.cpp:447-482,561-571). Only the mag filter matters: every tap is LOD 0. */
 /* the reference's two Renderer implementations (src/sample_example.hpp:136-137), see pt_set_variant */
 enum { PT_VARIANT_RAYQUERY = 0, PT_VARIANT_RTX = 1 };
+/* functions of the fp32 transcendental contract (pt_fpmath.h), for pt_fpmath_eval */
+enum { PT_FN_SIN = 0, PT_FN_COS, PT_FN_TAN, PT_FN_ASIN, PT_FN_ACOS, PT_FN_ATAN2, PT_FN_EXP, PT_FN_LOG, PT_FN_POW };
 enum { PT_FILTER_NEAREST = 0, PT_FILTER_LINEAR = 1 };
 enum { PT_WRAP_REPEAT = 0, PT_WRAP_MIRRORED_REPEAT = 1, PT_WRAP_CLAMP_TO_EDGE = 2 };
 

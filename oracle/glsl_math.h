@@ -16,17 +16,19 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include "../include/pt_fpmath.h"  // the fp32 transcendental contract (one fixed IEEE operation sequence per function)
 
 namespace orc {
 
-// Transcendental functions go through these wrappers.  Mode 0 (default): the fp32 libm functions.  Mode 1:
-// the double-precision function rounded to fp32 (correctly rounded).  Rendering the same input in two modes
-// measures how sensitive an image is to ~1-ulp differences in sin/cos/pow/..., which is exactly what separates
-// the CPU's libm from the GPU's ocml; tests use it as the noise floor.
+// Transcendental functions go through these wrappers.  Mode 0 (default): the fp32 transcendental contract of
+// include/pt_fpmath.h -- GLSL leaves the accuracy of these functions to the implementation, the contract fixes
+// one legal implementation as a sequence of IEEE operations, and the HIP kernels run the same sequence, so
+// path-traced frames of the oracle and of the product are comparable bit for bit.  Mode 1: the double-precision
+// libm function rounded to fp32 (practically correctly rounded).  Mode 2: that result moved by one ulp in ~30 %
+// of the calls (deterministic hash of the argument).  Modes 1/2 are calibration tools: rendering the same input
+// in two modes measures how sensitive an image is to ~1-ulp differences in sin/cos/pow/... (what a driver with
+// a different libm would produce); no parity test depends on them any more.
 extern int g_math_mode;
-// Mode 2: the correctly rounded result moved by one ulp in ~30 % of the calls (deterministic hash of the
-// argument).  This models a libm that is accurate to ~1.5 ulp but correctly rounded only 60-90 % of the time,
-// which is what tools/math_ulps.hip measures for the GPU's ocml (profiles/r01_ocml_ulps.txt).
 inline float perturb_ulp(float r, float x)
 {
   uint32_t h;
@@ -39,7 +41,7 @@ inline float perturb_ulp(float r, float x)
 #define ORC_MATH1(name, fn)                                                                                         \
   inline float name(float x)                                                                                        \
   {                                                                                                                 \
-    if(g_math_mode == 0) return ::fn##f(x);                                                                         \
+    if(g_math_mode == 0) return ::pt_##fn(x);                                                                       \
     float r = (float)::fn((double)x);                                                                               \
     return g_math_mode == 2 ? perturb_ulp(r, x) : r;                                                                \
   }
@@ -52,13 +54,13 @@ ORC_MATH1(mexp, exp)
 ORC_MATH1(mlog, log)
 inline float mpow(float x, float y)
 {
-  if(g_math_mode == 0) return ::powf(x, y);
+  if(g_math_mode == 0) return ::pt_pow(x, y);
   float r = (float)::pow((double)x, (double)y);
   return g_math_mode == 2 ? perturb_ulp(r, x + y) : r;
 }
 inline float matan2(float y, float x)
 {
-  if(g_math_mode == 0) return ::atan2f(y, x);
+  if(g_math_mode == 0) return ::pt_atan2(y, x);
   float r = (float)::atan2((double)y, (double)x);
   return g_math_mode == 2 ? perturb_ulp(r, x - y) : r;
 }

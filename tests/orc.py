@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_ROOT, "oracle", "liborc.so")
 def build(force=False):
     src = os.path.join(_ROOT, "oracle")
     newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".h", ".cpp", "Makefile")))
-    newest = max(newest, os.path.getmtime(os.path.join(_ROOT, "include", "pt_types.h")))
+    newest = max(newest, os.path.getmtime(os.path.join(_ROOT, "include", "pt_types.h")), os.path.getmtime(os.path.join(_ROOT, "include", "pt_fpmath.h")))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", src, "-s"])
     return _LIB_PATH

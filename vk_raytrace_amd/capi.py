@@ -12,6 +12,7 @@ import numpy as np
 from . import host_device as hd
 
 PT_VARIANT_RAYQUERY, PT_VARIANT_RTX = 0, 1
+PT_FN = {"sin": 0, "cos": 1, "tan": 2, "asin": 3, "acos": 4, "atan2": 5, "exp": 6, "log": 7, "pow": 8}
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
 
 # PT_LIB: developer override used to compare builds of the same HIP library (tools/build_variants.sh); never a fallback
@@ -40,6 +41,7 @@ API = [
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
     ("pt_pick", C.c_int, [_P, C.c_float, C.c_float, _P, _P, C.POINTER(hd.PickResult)]),
+    ("pt_fpmath_eval", C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
     ("pt_set_profiling", C.c_int, [_P, C.c_int]),
     ("pt_get_stats", C.c_int, [_P, C.POINTER(hd.Stats)]),
     ("pt_reset_stats", C.c_int, [_P]),

@@ -34,7 +34,7 @@ PT_DEV float gtr1(float NdotH, float a)
     return PT_1_OVER_PI;
   float a2 = a * a;
   float t  = 1.0f + (a2 - 1.0f) * NdotH * NdotH;
-  return (a2 - 1.0f) / (PT_PI * logf(a2) * t);
+  return (a2 - 1.0f) / (PT_PI * pt_log(a2) * t);
 }
 PT_DEV float gtr2(float NdotH, float a)
 {
@@ -67,8 +67,8 @@ PT_DEV f3 sample_cosine_hemisphere(float r1, float r2)
   float r   = sqrtf(r1);
   float phi = PT_TWO_PI * r2;
   f3    d;
-  d.x = r * cosf(phi);
-  d.y = r * sinf(phi);
+  d.x = r * pt_cos(phi);
+  d.y = r * pt_sin(phi);
   d.z = sqrtf(fmax2(0.0f, 1.0f - d.x * d.x - d.y * d.y));
   return d;
 }
@@ -76,7 +76,7 @@ PT_DEV f3 sample_uniform_hemisphere(float r1, float r2)
 {
   float r   = sqrtf(fmax2(0.0f, 1.0f - r1 * r1));
   float phi = PT_TWO_PI * r2;
-  return f3{r * cosf(phi), r * sinf(phi), r1};
+  return f3{r * pt_cos(phi), r * pt_sin(phi), r1};
 }
 PT_DEV float power_heuristic(float a, float b)
 {
@@ -88,15 +88,15 @@ PT_DEV f3 sample_gtr1(float rgh, float r1)
   float a        = fmax2(0.001f, rgh);
   float a2       = a * a;
   float phi      = r1 * PT_TWO_PI;
-  float cosTheta = sqrtf((1.0f - powf(a2, 1.0f - r1)) / (1.0f - a2));
+  float cosTheta = sqrtf((1.0f - pt_pow(a2, 1.0f - r1)) / (1.0f - a2));
   float sinTheta = clampf(sqrtf(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  return f3{sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta};
+  return f3{sinTheta * pt_cos(phi), sinTheta * pt_sin(phi), cosTheta};
 }
 PT_DEV f3 sample_gtr2_aniso(float ax, float ay, float r1, float r2)
 {
   float phi      = r1 * PT_TWO_PI;
-  float sinPhi   = ay * sinf(phi);
-  float cosPhi   = ax * cosf(phi);
+  float sinPhi   = ay * pt_sin(phi);
+  float cosPhi   = ax * pt_cos(phi);
   float tanTheta = sqrtf(r2 / (1 - r2));
   return f3{tanTheta * cosPhi, tanTheta * sinPhi, 1.0f};
 }
@@ -106,7 +106,7 @@ PT_DEV f3 sample_gtr2(float rgh, float r1, float r2)
   float phi      = r1 * PT_TWO_PI;
   float cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
   float sinTheta = clampf(sqrtf(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  return f3{sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta};
+  return f3{sinTheta * pt_cos(phi), sinTheta * pt_sin(phi), cosTheta};
 }
 
 // ======================================= Disney ========================================================
@@ -319,7 +319,7 @@ PT_DEV f3 disney_eval(const Surface& s, f3 V, f3 N, f3 L, float& pdf)
 }
 
 // ======================================== glTF ==========================================================
-PT_DEV float schlick_pow5(float VdotH) { return powf(clampf(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
+PT_DEV float schlick_pow5(float VdotH) { return pt_pow(clampf(1.0f - VdotH, 0.0f, 1.0f), 5.0f); }
 PT_DEV f3 gltf_fresnel(f3 f0, f3 f90, float VdotH) { return f0 + (f90 - f0) * schlick_pow5(VdotH); }
 PT_DEV float gltf_fresnel(float f0, float f90, float VdotH) { return f0 + (f90 - f0) * schlick_pow5(VdotH); }
 PT_DEV float gltf_vis_ggx(float NdotL, float NdotV, float alphaRoughness)
@@ -355,7 +355,7 @@ PT_DEV f3 gltf_ggx_halfvector(float alpha, float r1, float r2)
   float phi      = r1 * 2.0f * PT_PI;
   float cosTheta = sqrtf((1.0f - r2) / (1.0f + (alpha * alpha - 1.0f) * r2));
   float sinTheta = clampf(sqrtf(1.0f - (cosTheta * cosTheta)), 0.0f, 1.0f);
-  return f3{sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta};
+  return f3{sinTheta * pt_cos(phi), sinTheta * pt_sin(phi), cosTheta};
 }
 PT_DEV f3 gltf_diffuse(const Surface& s, f3 V, f3 N, f3 L, float& pdf)
 {

@@ -933,6 +933,51 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
   return PT_OK;
 }
 
+// The fp32 transcendental contract evaluated on the device (include/pt_fpmath.h); tests hold it bit for bit to the host evaluation.
+__global__ void k_fpmath(int fn, uint64_t n, const float* a, const float* b, float* out)
+{
+  uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  float x = a[i], y = b ? b[i] : 0.0f, r;
+  switch(fn)
+  {
+    case PT_FN_SIN: r = pt_sin(x); break;
+    case PT_FN_COS: r = pt_cos(x); break;
+    case PT_FN_TAN: r = pt_tan(x); break;
+    case PT_FN_ASIN: r = pt_asin(x); break;
+    case PT_FN_ACOS: r = pt_acos(x); break;
+    case PT_FN_ATAN2: r = pt_atan2(x, y); break;
+    case PT_FN_EXP: r = pt_exp(x); break;
+    case PT_FN_LOG: r = pt_log(x); break;
+    default: r = pt_pow(x, y); break;
+  }
+  out[i] = r;
+}
+int pt_fpmath_eval(pt_context* c, int fn, uint64_t n, const float* a, const float* b, float* out)
+{
+  CTX_CHECK(c);
+  if(fn < PT_FN_SIN || fn > PT_FN_POW || !a || !out || ((fn == PT_FN_ATAN2 || fn == PT_FN_POW) && !b))
+    return c->fail(PT_ERR_INVALID, "pt_fpmath_eval: bad arguments");
+  if(n == 0)
+    return PT_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  float *dA = nullptr, *dB = nullptr, *dO = nullptr;
+  int    rc = PT_OK;
+  auto   done = [&](int r) {
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);
+    return r;
+  };
+  if(hipMalloc(&dA, n * 4) != hipSuccess || hipMalloc(&dO, n * 4) != hipSuccess || (b && hipMalloc(&dB, n * 4) != hipSuccess))
+    return done(c->fail(PT_ERR_OOM, "pt_fpmath_eval: out of device memory"));
+  if(hipMemcpy(dA, a, n * 4, hipMemcpyHostToDevice) != hipSuccess || (b && hipMemcpy(dB, b, n * 4, hipMemcpyHostToDevice) != hipSuccess))
+    return done(c->fail(PT_ERR_HIP, "pt_fpmath_eval: upload failed"));
+  k_fpmath<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(fn, n, dA, dB, dO);
+  if(hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, dO, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(c->fail(PT_ERR_HIP, "pt_fpmath_eval: kernel failed"));
+  return done(rc);
+}
+
 int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
 {
   CTX_CHECK(c);

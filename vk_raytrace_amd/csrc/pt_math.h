@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/pt_fpmath.h"  // the fp32 transcendental contract: one fixed IEEE operation sequence per function, same bits on host and device
 
 #define PT_DEV __device__ __forceinline__
 
@@ -68,9 +69,9 @@ PT_DEV f3 unit(f3 a)
   return a * inv;
 }
 PT_DEV f3 lerp(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
-PT_DEV f3 pow3(f3 a, float e) { return f3{powf(a.x, e), powf(a.y, e), powf(a.z, e)}; }
-PT_DEV f3 exp3(f3 a) { return f3{expf(a.x), expf(a.y), expf(a.z)}; }
-PT_DEV f3 log3(f3 a) { return f3{logf(a.x), logf(a.y), logf(a.z)}; }
+PT_DEV f3 pow3(f3 a, float e) { return f3{pt_pow(a.x, e), pt_pow(a.y, e), pt_pow(a.z, e)}; }
+PT_DEV f3 exp3(f3 a) { return f3{pt_exp(a.x), pt_exp(a.y), pt_exp(a.z)}; }
+PT_DEV f3 log3(f3 a) { return f3{pt_log(a.x), pt_log(a.y), pt_log(a.z)}; }
 PT_DEV f3 sqrt3(f3 a) { return f3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
 PT_DEV f3 mirror(f3 I, f3 N) { return I - N * (2.0f * dot3(N, I)); }  // GLSL reflect
 PT_DEV f3 bend(f3 I, f3 N, float eta)                                   // GLSL refract

@@ -143,8 +143,8 @@ PT_DEV f4 mat4_mul(const float* m, f4 v)
 // shaders/common.glsl:67-74
 PT_DEV f2 spherical_uv(f3 v)
 {
-  float gamma = asinf(-v.y);
-  float theta = atan2f(v.z, v.x);
+  float gamma = pt_asin(-v.y);
+  float theta = pt_atan2(v.z, v.x);
   return f2{theta * PT_1_OVER_PI * 0.5f + 0.5f, gamma * PT_1_OVER_PI + 0.5f};
 }
 // shaders/common.glsl:98-113 (Ray Tracing Gems ch. 6)
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers 
   float cam_r2     = rng_next(seed) * cam.aperture;
   f4    cam_right  = mat4_mul(cam.viewInverse, f4{1, 0, 0, 0});
   f4    cam_up     = mat4_mul(cam.viewInverse, f4{0, 1, 0, 0});
-  f3    lens       = (xyz(cam_right) * cosf(cam_r1) + xyz(cam_up) * sinf(cam_r1)) * sqrtf(cam_r2);
+  f3    lens       = (xyz(cam_right) * pt_cos(cam_r1) + xyz(cam_up) * pt_sin(cam_r1)) * sqrtf(cam_r2);
   f3    dir        = unit(focalPoint - lens);
   f3    org        = xyz(origin) + lens;
 
@@ -498,12 +498,12 @@ PT_DEV f3 env_importance_sample(const DeviceScene& S, f3 xi, f3& toLight, float&
   const uint32_t px = envIdx % width, py = envIdx / width;
   const float    u        = (float(px) + xi.y) / float(width);
   const float    phi      = u * (2.0f * PT_PI) - PT_PI;
-  const float    sin_phi  = sinf(phi), cos_phi = cosf(phi);
+  const float    sin_phi  = pt_sin(phi), cos_phi = pt_cos(phi);
   const float    step     = PT_PI / float(height);
   const float    theta0   = float(py) * step;
-  const float    cosTheta = cosf(theta0) * (1.0f - xi.z) + cosf(theta0 + step) * xi.z;
-  const float    theta    = acosf(cosTheta);
-  const float    sinTheta = sinf(theta);
+  const float    cosTheta = pt_cos(theta0) * (1.0f - xi.z) + pt_cos(theta0 + step) * xi.z;
+  const float    theta    = pt_acos(cosTheta);
+  const float    sinTheta = pt_sin(theta);
   const float    v        = theta * PT_1_OVER_PI;
   toLight                 = f3{cos_phi * sinTheta, cosTheta, sin_phi * sinTheta};
   return sample_env(S, f2{u, v});
@@ -513,7 +513,7 @@ PT_DEV float range_attenuation(float range, float distance)  // shaders/punctual
 {
   if(range <= 0.0f)
     return 1.0f;
-  return fmax2(fmin2(1.0f - powf(distance / range, 4.0f), 1.0f), 0.0f) / powf(distance, 2.0f);
+  return fmax2(fmin2(1.0f - pt_pow(distance / range, 4.0f), 1.0f), 0.0f) / pt_pow(distance, 2.0f);
 }
 PT_DEV float spot_attenuation(f3 pointToLight, f3 spotDir, float outerCos, float innerCos)  // shaders/punctual.glsl:39-51
 {

@@ -63,7 +63,7 @@ PT_DEV f3 sky_sun_color(f3 sun_dir, float turbidity)  // calc_sun_color :138-161
     const f3 ko     = f3{12.0f, 8.5f, 0.9f};
     const f3 wl     = f3{0.610f, 0.550f, 0.470f};
     const f3 solRad = f3{1.0f * 127500 / 0.9878f, 0.992f * 127500 / 0.9878f, 0.911f * 127500 / 0.9878f};
-    float    m      = (1.0f / (sun_dir.z + 0.15f * powf(93.885f - acosf(sun_dir.z) * 180 / SKY_PI, -1.253f)));
+    float    m      = (1.0f / (sun_dir.z + 0.15f * pt_pow(93.885f - pt_acos(sun_dir.z) * 180 / SKY_PI, -1.253f)));
     float    beta   = 0.04608f * turbidity - 0.04586f;
     f3       ta     = exp3(pow3(wl, -1.3f) * (-m * beta));
     f3       to     = exp3(ko * (-m) * 0.0035f);
@@ -75,8 +75,8 @@ PT_DEV f3 sky_sun_color(f3 sun_dir, float turbidity)  // calc_sun_color :138-161
 
 PT_DEV float sky_perez(float A, float B, float C, float D, float E, float cos_theta, float gamma, float cos_gamma, float theta_sun, float cos_theta_sun)
 {
-  return (((1 + A * expf(B / cos_theta)) * (1 + C * expf(D * gamma) + E * cos_gamma * cos_gamma))
-          / ((1 + A * expf(B / 1.0f)) * (1 + C * expf(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
+  return (((1 + A * pt_exp(B / cos_theta)) * (1 + C * pt_exp(D * gamma) + E * cos_gamma * cos_gamma))
+          / ((1 + A * pt_exp(B / 1.0f)) * (1 + C * pt_exp(D * theta_sun) + E * cos_theta_sun * cos_theta_sun)));
 }
 
 PT_DEV f3 sky_color_xyz(f3 dir, f3 sun, float T, float lum)  // :164-219
@@ -84,9 +84,9 @@ PT_DEV f3 sky_color_xyz(f3 dir, f3 sun, float T, float lum)  // :164-219
   float cos_gamma = dot3(sun, dir);
   if(cos_gamma > 1.0f)
     cos_gamma = 2.0f - cos_gamma;
-  float gamma = acosf(cos_gamma);
+  float gamma = pt_acos(cos_gamma);
   float ct = dir.z, cts = sun.z;
-  float ts  = acosf(cts);
+  float ts  = pt_acos(cts);
   float t2  = T * T;
   float ts2 = ts * ts;
   float ts3 = ts2 * ts;
@@ -94,7 +94,7 @@ PT_DEV f3 sky_color_xyz(f3 dir, f3 sun, float T, float lum)  // :164-219
               + (+0.116936f * ts3 - 0.211960f * ts2 + 0.060523f * ts + 0.258852f));
   float zy  = ((+0.002759f * ts3 - 0.006105f * ts2 + 0.003162f * ts + 0) * t2 + (-0.042149f * ts3 + 0.089701f * ts2 - 0.041536f * ts + 0.005158f) * T
               + (+0.153467f * ts3 - 0.267568f * ts2 + 0.066698f * ts + 0.266881f));
-  float A = -0.019257f * T - (0.29f - powf(cts, 0.5f) * 0.09f);
+  float A = -0.019257f * T - (0.29f - pt_pow(cts, 0.5f) * 0.09f);
   float B = -0.066513f * T + 0.000818f;
   float C = -0.000417f * T + 0.212479f;
   float D = -0.064097f * T - 0.898875f;
@@ -123,8 +123,8 @@ PT_DEV float sky_luminance(f3 dir, f3 sun, float T)  // :222-250
     cos_gamma = 0.0f;
   if(cos_gamma > 1.0f)
     cos_gamma = 2.0f - cos_gamma;
-  float gamma = acosf(cos_gamma);
-  float ts    = acosf(sun.z);
+  float gamma = pt_acos(cos_gamma);
+  float ts    = pt_acos(sun.z);
   float A     = 0.178721f * T - 1.463037f;
   float B     = -0.355402f * T + 0.427494f;
   float C     = -0.022669f * T + 5.325056f;
@@ -135,9 +135,9 @@ PT_DEV float sky_luminance(f3 dir, f3 sun, float T)  // :222-250
 
 PT_DEV f3 sky_env_color(f3 sun, f3 dir, float T)  // calc_env_color :253-267
 {
-  float ts  = acosf(sun.z);
+  float ts  = pt_acos(sun.z);
   float chi = (4.0f / 9.0f - T / 120.0f) * (SKY_PI - 2 * ts);
-  float lum = 1000.0f * ((4.0453f * T - 4.9710f) * tanf(chi) - 0.2155f * T + 2.4192f);
+  float lum = 1000.0f * ((4.0453f * T - 4.9710f) * pt_tan(chi) - 0.2155f * T + 2.4192f);
   lum *= sky_luminance(dir, sun, T);
   f3 X = sky_color_xyz(dir, sun, T, lum);
   f3 c = f3{3.241f * X.x - 1.537f * X.y - 0.499f * X.z, -0.969f * X.x + 1.876f * X.y + 0.042f * X.z, 0.056f * X.x - 0.204f * X.y + 1.057f * X.z};
@@ -154,8 +154,8 @@ PT_DEV f3 sky_irradiance(f3 sun, float haze)  // calc_irrad :269-289
     for(float v = 1.f / 10.f; v < 1.f; v += 1.f / 5.f)
     {
       f2    rp = sky_square_to_disk(u, v);
-      float x  = rp.x * cosf(rp.y);
-      float y  = rp.x * sinf(rp.y);
+      float x  = rp.x * pt_cos(rp.y);
+      float y  = rp.x * pt_sin(rp.y);
       float z2 = 1.0f - x * x - y * y;
       float z  = z2 > 0.0f ? sqrtf(z2) : 0.0f;
       acc += sky_env_color(sun, sky_frame_dir(up, x, y, z), haze);
@@ -183,7 +183,7 @@ PT_DEV f2 sky_physical_scale(float disk_scale, float glow_intensity, float disk_
   float disk_radius   = 0.00465f * disk_scale;
   float glow_radius   = disk_radius * 10.0f;
   float glow_integral = glow_intensity
-                        * ((4.f * SKY_PI) - (24.f * SKY_PI) / (glow_radius * glow_radius) + (24.f * SKY_PI) * sinf(glow_radius) / (glow_radius * glow_radius * glow_radius));
+                        * ((4.f * SKY_PI) - (24.f * SKY_PI) / (glow_radius * glow_radius) + (24.f * SKY_PI) * pt_sin(glow_radius) / (glow_radius * glow_radius * glow_radius));
   float target       = disk_intensity * SKY_PI;
   float glow_scale   = 1.0f;
   float max_glow     = 0.5f * target;
@@ -196,7 +196,7 @@ PT_DEV f2 sky_physical_scale(float disk_scale, float glow_intensity, float disk_
   {
     target -= glow_integral;
   }
-  float area             = 2 * SKY_PI * (1 - cosf(disk_radius));
+  float area             = 2 * SKY_PI * (1 - pt_cos(disk_radius));
   float target_intensity = target / area;
   float actual_integral  = 1.0f * area;
   float actual_intensity = disk_intensity * 100.0f * actual_integral / area;
@@ -215,7 +215,7 @@ PT_DEV f3 sun_and_sky(const pt_SunAndSky& ss, f3 in_direction)  // :453-599
   // tweak_saturation :292-309
   float saturation = 1.f;
   {
-    float lowsat = powf(ss.saturation, 3.0f);
+    float lowsat = pt_pow(ss.saturation, 3.0f);
     if(ss.saturation <= 1.0f)
     {
       float h = haze;
@@ -225,7 +225,7 @@ PT_DEV f3 sun_and_sky(const pt_SunAndSky& ss, f3 in_direction)  // :453-599
         h = 0.0f;
       if(h > 1.0f)
         h = 1.0f;
-      h          = powf(h, 3.0f);
+      h          = pt_pow(h, 3.0f);
       saturation = ((ss.saturation * (1.0f - h)) + lowsat * h);
     }
   }
@@ -278,7 +278,7 @@ PT_DEV f3 sun_and_sky(const pt_SunAndSky& ss, f3 in_direction)  // :453-599
   f3 sun_color = sky_sun_color(sun, downness > 0 ? haze : 2.0f);
   if(ss.sun_disk_intensity > 0.0f && ss.sun_disk_scale > 0.0f)
   {
-    float sun_angle  = acosf(dot3(real_dir, real_sun));
+    float sun_angle  = pt_acos(dot3(real_dir, real_sun));
     float sun_radius = 0.00465f * ss.sun_disk_scale * 10.0f;
     if(sun_angle < sun_radius)
     {
@@ -290,7 +290,7 @@ PT_DEV f3 sun_and_sky(const pt_SunAndSky& ss, f3 in_direction)  // :453-599
         glow_scale = rv.y;
       }
       float sf = (1.0f - sun_angle / sun_radius) * 10.0f;
-      sf       = (powf(sf / 10.0f, 3.0f) * 2.0f * ss.sun_glow_intensity * glow_scale + smooth(8.5f, 9.5f + (haze / 50.0f), sf) * 100.0f * ss.sun_disk_intensity * disk_scale);
+      sf       = (pt_pow(sf / 10.0f, 3.0f) * 2.0f * ss.sun_glow_intensity * glow_scale + smooth(8.5f, 9.5f + (haze / 50.0f), sf) * 100.0f * ss.sun_disk_intensity * disk_scale);
       tint += sun_color * sf;
     }
   }
