@@ -297,6 +297,97 @@ void orc_sample_texture(orc_ctx* c, int id, float u, float v, float* out)
   out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
 }
 
+// ---- the "driver" side of oracle/_ref (oracle/ref_glue/ref_driver.h RefHooks): the reference's shader code compiled from its own
+// sources calls back here for what the Vulkan driver would supply -- triangle candidates in the order of the trace contract
+// (T1-T6), the instance matrices, the Appendix-F samplers.  `user` is the orc_ctx.
+int orc_hook_query(void* user, const float* o, const float* d, float tmax, float tPrev, uint32_t wPrev, int want, float* t, float* u, float* v, uint32_t* w)
+{
+  const Scene& sc = static_cast<orc_ctx*>(user)->scene;
+  Candidate    c  = sc.query(vec3(o[0], o[1], o[2]), vec3(d[0], d[1], d[2]), tmax, tPrev, wPrev, want, nullptr);
+  if(!c.found)
+    return 0;
+  *t = c.t; *u = c.u; *v = c.v; *w = c.w;
+  return 1;
+}
+void orc_hook_tri_info(void* user, uint32_t w, int* node, int* prim, int* custom, int* opaque)
+{
+  const Scene&    sc = static_cast<orc_ctx*>(user)->scene;
+  const WorldTri& tr = sc.tris[w];
+  *node   = (int)tr.node;
+  *prim   = (int)tr.prim;
+  *custom = sc.nodes[tr.node].primMesh;
+  *opaque = (tr.flags & TRI_OPAQUE) ? 1 : 0;
+}
+void orc_hook_instance(void* user, int node, float* o2w12, float* w2o12)
+{
+  const Scene& sc = static_cast<orc_ctx*>(user)->scene;
+  for(int c = 0; c < 4; ++c)
+    for(int k = 0; k < 3; ++k)
+    {
+      o2w12[3 * c + k] = sc.objectToWorld[node].c[c][k];
+      w2o12[3 * c + k] = sc.worldToObject[node].c[c][k];
+    }
+}
+void orc_hook_sample_texture(void* user, int id, float u, float v, float* out)
+{
+  vec4 t = static_cast<orc_ctx*>(user)->scene.sample_texture(id, vec2(u, v), nullptr);
+  out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+void orc_hook_sample_env(void* user, float u, float v, float* out)
+{
+  vec3 t = static_cast<orc_ctx*>(user)->scene.sample_env(vec2(u, v));
+  out[0] = t.x; out[1] = t.y; out[2] = t.z;
+}
+const pt_EnvAccel* orc_env_accel(orc_ctx* c) { return c->scene.envAccel.data(); }
+
+// ---- function-level probes with the signatures of oracle/ref_glue/ref_comp.cpp (compared bit for bit in tests/test_oracle_vs_ref.py)
+void orc_spherical_uv(const float* d, float* o)
+{
+  vec2 r = GetSphericalUv(vec3(d[0], d[1], d[2]));
+  o[0] = r.x; o[1] = r.y;
+}
+void orc_coordinate_system(const float* n, float* t, float* b)
+{
+  vec3 T, B;
+  CreateCoordinateSystem(vec3(n[0], n[1], n[2]), T, B);
+  t[0] = T.x; t[1] = T.y; t[2] = T.z; b[0] = B.x; b[1] = B.y; b[2] = B.z;
+}
+float orc_range_attenuation(float range, float dist) { return Tracer::getRangeAttenuation(range, dist); }
+float orc_spot_attenuation(const float* p2l, const float* dir, float outerCos, float innerCos)
+{
+  return Tracer::getSpotAttenuation(vec3(p2l[0], p2l[1], p2l[2]), vec3(dir[0], dir[1], dir[2]), outerCos, innerCos);
+}
+static void orc_fill_state(State& st, const float* m, const float* N, const float* T, const float* B, float eta, int thin)
+{
+  st.depth = 0; st.eta = eta;
+  st.position = vec3(0); st.normal = vec3(N[0], N[1], N[2]); st.ffnormal = st.normal;
+  st.tangent = vec3(T[0], T[1], T[2]); st.bitangent = vec3(B[0], B[1], B[2]); st.texCoord = vec2(0, 0);
+  Material& a = st.mat;
+  a.albedo = vec3(m[0], m[1], m[2]); a.specular = m[3]; a.emission = vec3(0); a.anisotropy = m[4]; a.metallic = m[5]; a.roughness = m[6];
+  a.subsurface = m[7]; a.specularTint = m[8]; a.sheen = m[9]; a.sheenTint = vec3(m[10], m[11], m[12]); a.clearcoat = m[13];
+  a.clearcoatRoughness = m[14]; a.transmission = m[15]; a.ior = m[16]; a.attenuationColor = vec3(1); a.attenuationDistance = 1;
+  a.ax = m[17]; a.ay = m[18]; a.f0 = vec3(m[19], m[20], m[21]); a.alpha = 1; a.unlit = false; a.thinwalled = thin != 0;
+}
+void orc_bsdf_eval(int pbrMode, const float* m, const float* N, const float* T, const float* B, float eta, int thin, const float* V, const float* L, float* f, float* pdf)
+{
+  State st;
+  orc_fill_state(st, m, N, T, B, eta, thin);
+  float p = 0.0f;
+  vec3  v(V[0], V[1], V[2]), l(L[0], L[1], L[2]);
+  vec3  r = pbrMode == 0 ? DisneyEval(st, v, st.ffnormal, l, p) : PbrEval(st, v, st.ffnormal, l, p);
+  f[0] = r.x; f[1] = r.y; f[2] = r.z; *pdf = p;
+}
+void orc_bsdf_sample(int pbrMode, const float* m, const float* N, const float* T, const float* B, float eta, int thin, const float* V, uint32_t* seed, float* L, float* f,
+                     float* pdf)
+{
+  State st;
+  orc_fill_state(st, m, N, T, B, eta, thin);
+  float p = 0.0f;
+  vec3  v(V[0], V[1], V[2]), l(0);
+  vec3  r = pbrMode == 0 ? DisneySample(st, v, st.ffnormal, l, p, *seed) : PbrSample(st, v, st.ffnormal, l, p, *seed);
+  L[0] = l.x; L[1] = l.y; L[2] = l.z; f[0] = r.x; f[1] = r.y; f[2] = r.z; *pdf = p;
+}
+
 // Closest-hit known answers: n rays -> (t, node, prim, u, v); seeds are per-ray RNG states (in/out)
 void orc_trace_closest(orc_ctx* c, uint32_t n, const float* org, const float* dir, uint32_t* seeds, float* out_t, int32_t* out_node,
                        int32_t* out_prim, float* out_uv)
