@@ -349,9 +349,11 @@ inline vec4 operator*(const vec3& v, const mat4x3& m) { return vec4(dot(v, m.c[0
 }  // namespace glslc
 
 // <cmath> macros that collide with identifiers of the shaders (globals.glsl declares `const float M_PI`, `#define INFINITY`)
+#ifndef GLSLC_KEEP_MATH_DEFINES
 #undef M_PI
 #undef M_PI_2
 #undef M_PI_4
 #undef M_1_PI
 #undef M_2_PI
 #undef INFINITY
+#endif

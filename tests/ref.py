@@ -63,6 +63,15 @@ def lib():
         L.ref_spot_attenuation.restype = C.c_float
         L.ref_bsdf_eval.argtypes = [C.c_int, P, P, P, P, C.c_float, C.c_int, P, P, P, P]
         L.ref_bsdf_sample.argtypes = [C.c_int, P, P, P, P, C.c_float, C.c_int, P, P, P, P, P]
+        L.ref_host_compress_unit_vec.argtypes = [P]
+        L.ref_host_compress_unit_vec.restype = C.c_uint32
+        L.ref_host_pack_unorm4x8.argtypes = [P]
+        L.ref_host_pack_unorm4x8.restype = C.c_uint32
+        L.ref_host_round_even.argtypes = [C.c_float]
+        L.ref_host_round_even.restype = C.c_float
+        L.ref_env_accel.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ref_mip_chain.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_tonemap.argtypes = [C.POINTER(hd.Tonemapper), P, C.c_int, C.c_int, P]
         _lib = L
     return _lib
 

@@ -591,3 +591,46 @@ def bistro_like(target_tris=3_800_000, tex_size=512, seed=SEED_BASE + 5, distinc
         i += 1
     sc.camera = Camera(eye=(-40, 6, 30), center=(10, 1, -10), up=(0, 1, 0), fov=55.0)
     return sc
+
+
+def fuzz_scene(seed):
+    """Random geometry chosen to stress the traversal: axis-aligned boxes on an integer lattice (rays parallel to faces, origins
+    on box planes), slivers, tiny and huge triangles, coincident triangles (ties in t), mirrored / scaled instances, a mix of
+    opaque, MASK and BLEND materials with NEAREST / LINEAR, REPEAT / MIRROR / CLAMP textures of non-power-of-two size."""
+    from .scene import Scene, Camera, translate, scale, rotate_y
+    from . import host_device as hd
+    rng = np.random.default_rng(seed)
+    sc = Scene(f"fuzz{seed}")
+    texs = []
+    for k in range(4):
+        w, h = [(16, 16), (12, 20), (7, 5), (32, 8)][k]
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img[..., 3] = np.where(rng.random((h, w)) < 0.4, 0, np.where(rng.random((h, w)) < 0.5, 255, img[..., 3]))
+        texs.append(sc.add_texture(img, magFilter=int(rng.integers(0, 2)), wrapS=int(rng.integers(0, 3)), wrapT=int(rng.integers(0, 3))))
+    mats = [sc.add_material(pbrBaseColorFactor=(0.8, 0.7, 0.6, 1.0), pbrMetallicFactor=0.0, pbrRoughnessFactor=0.8),
+            sc.add_material(pbrBaseColorFactor=(0.5, 0.6, 0.9, 1.0), pbrMetallicFactor=0.3, pbrRoughnessFactor=0.4, doubleSided=1)]
+    for k in range(4):
+        mats.append(sc.add_material(pbrBaseColorTexture=texs[k], alphaMode=hd.ALPHA_MASK if k % 2 == 0 else hd.ALPHA_BLEND, alphaCutoff=float(rng.choice([0.0, 0.3, 0.5])),
+                                    pbrBaseColorFactor=(1.0, 1.0, 1.0, float(rng.choice([1.0, 0.7]))), doubleSided=int(k < 2), pbrMetallicFactor=0.0))
+    # lattice of unit boxes (shared planes -> ties, rays along faces)
+    bpos, bnrm, buv, bidx, btan = box((1, 1, 1))
+    bm = sc.add_prim_mesh(bpos, bnrm, buv, bidx, mats[0], tangents=btan)
+    for _ in range(12):
+        c = rng.integers(-3, 4, 3).astype(np.float32)
+        sc.add_node(bm, translate(*c))
+    sc.add_node(bm, translate(0, -5.5, 0) @ scale(40.0, 1.0, 40.0))                      # huge floor
+    sc.add_node(bm, translate(2, 0, 2) @ scale(-1.0, 1.0, 1.0))                          # mirrored
+    sc.add_node(bm, translate(-2, 1, 1) @ rotate_y(0.3) @ scale(0.01, 3.0, 0.01))        # sliver-like column
+    # random soup with alpha materials, incl. duplicated (coincident) triangles
+    for mi in range(1, len(mats)):
+        n = 60
+        p = rng.uniform(-4, 4, (n, 1, 3)) + rng.normal(0, 0.8, (n, 3, 3))
+        p = np.concatenate([p, p[:6]], 0).reshape(-1, 3).astype(np.float32)            # 6 coincident copies
+        tri = np.arange(len(p), dtype=np.uint32)
+        nn = np.cross(p[1::3] - p[0::3], p[2::3] - p[0::3]); nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-20)
+        pm = sc.add_prim_mesh(p, np.repeat(nn, 3, 0), rng.uniform(-2, 3, (len(p), 2)).astype(np.float32), tri, mats[mi])
+        sc.add_node(pm)
+    eye = rng.integers(-3, 4, 3).astype(np.float32) + np.float32(0.5) * (seed % 2)     # sometimes exactly on lattice planes
+    eye[2] = 9.0
+    sc.camera = Camera(eye=tuple(eye), center=(float(eye[0]), float(eye[1]), 0.0) if seed % 3 == 0 else (0.0, 0.0, 0.0), up=(0, 1, 0), fov=50.0)
+    return sc
