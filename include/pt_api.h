@@ -120,9 +120,17 @@ int pt_read_accum(pt_context* ctx, float* rgba32f_out);
  * (the running mean of pathtrace.comp:122-133 only needs the image and the frame index). */
 int pt_write_accum(pt_context* ctx, const float* rgba32f_in);
 
-/* replaces RenderOutput::run [src/render_output.cpp:174-182 -> shaders/post.frag:98-147]:
- * tonemaps the accumulation image into row-major RGBA8. */
+/* replaces RenderOutput::genMipmap + RenderOutput::run [src/render_output.cpp:174-193 -> shaders/post.frag:98-147]: tonemaps the
+ * accumulation image into row-major RGBA8.  Tonemapper.autoExposure bit 0 takes the image average from the 1x1 level of the
+ * vkCmdBlitImage(LINEAR) mip chain the reference generates, bit 1 selects toneLocalExposure (post.frag:72-96) on that chain. */
 int pt_tonemap(pt_context* ctx, const pt_Tonemapper* tm, uint8_t* rgba8_out);
+
+/* The display pass while the viewer de-scales [src/sample_example.cpp:378,410-413; shaders/post.frag:101]: the reference renders
+ * (W / level) x (H / level) pixels into the top-left corner of its W x H offscreen image and magnifies them with Tonemapper.zoom =
+ * 1 / level (NEAREST sampler).  Here the context is resized to the reduced size and this call produces the disp_width x disp_height
+ * RGBA8 viewport from it (texels of the offscreen image outside the rendered corner count as zero; the reference keeps stale data
+ * there).  With disp == accumulation size and zoom == 1 it is pt_tonemap. */
+int pt_tonemap_zoom(pt_context* ctx, const pt_Tonemapper* tm, int disp_width, int disp_height, uint8_t* rgba8_out);
 
 /* Device-side view of the local shard for the RCCL gather: pointer to [maxTilesPerRank][PT_TILE*PT_TILE][4]
  * floats (owned tiles first, in increasing global tile id; padding zero). */

@@ -90,6 +90,8 @@ public:
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
   void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
+  // while SampleExample de-scales (m_descaling, src/sample_example.cpp:410-413): viewport of dispW x dispH from the reduced-size render
+  void tonemapZoom(const pt_Tonemapper& tm, int dispW, int dispH, uint8_t* rgba8) { check(pt_tonemap_zoom(m_ctx, &tm, dispW, dispH, rgba8)); }
 
   bool               ok() const { return m_status == PT_OK; }
   int                status() const { return m_status; }

@@ -190,36 +190,136 @@ int orc_reset_stats(orc_ctx* c)
 }
 uint32_t orc_num_triangles(orc_ctx* c) { return (uint32_t)c->scene.tris.size(); }
 
-// shaders/post.frag:98-147 with TONEMAP_UNCHARTED.  zoom must be 1 (the viewer's de-scaling preview
-// is out of scope); auto-exposure bit 0 uses the mean of the image in place of the 1x1 mip; the
-// local-exposure variant (bit 1) is not reproduced.
-int orc_tonemap(const pt_Tonemapper* tm, const float* accum, int W, int H, uint8_t* out)
+// ---- the offscreen image as post.frag sees it ---------------------------------------------------------------------------------
+// RenderOutput::genMipmap (src/render_output.cpp:188-193 -> nvvk::cmdGenerateMipmaps): level i = vkCmdBlitImage(VK_FILTER_LINEAR) of
+// level i-1, extent max(1, e/2), floor(log2(max(w,h))) + 1 levels.  Blit per Vulkan 1.3 "Image Copies with Scaling": the centre of the
+// dst texel scaled into src space, unnormalised linear filtering, clamp-to-edge; horizontal lerps first, then the vertical one.
+static void blit_linear(const float* src, int sw, int sh, float* dst, int dw, int dh)
 {
-  vec3 avg(0);
-  if(tm->autoExposure & 1)
-  {
-    double s[3] = {0, 0, 0};
-    for(size_t i = 0; i < size_t(W) * H; ++i)
-      for(int k = 0; k < 3; ++k)
-        s[k] += accum[i * 4 + k];
-    avg = vec3(float(s[0] / (double(W) * H)), float(s[1] / (double(W) * H)), float(s[2] / (double(W) * H)));
-  }
-#pragma omp parallel for schedule(static)
-  for(int y = 0; y < H; ++y)
-  {
-    for(int x = 0; x < W; ++x)
+  const float su = float(sw) / float(dw), sv = float(sh) / float(dh);
+#pragma omp parallel for schedule(static) if(dw * dh > 4096)
+  for(int y = 0; y < dh; ++y)
+    for(int x = 0; x < dw; ++x)
     {
-      const float* p = accum + (size_t(y) * W + x) * 4;
-      vec3         hdr(p[0], p[1], p[2]);
-      if(tm->autoExposure & 1)
+      float u = (float(x) + 0.5f) * su - 0.5f, v = (float(y) + 0.5f) * sv - 0.5f;
+      float fu = std::floor(u), fv = std::floor(v);
+      float a = u - fu, b = v - fv;
+      int   x0 = std::min(std::max((int)fu, 0), sw - 1), x1 = std::min(std::max((int)fu + 1, 0), sw - 1);
+      int   y0 = std::min(std::max((int)fv, 0), sh - 1), y1 = std::min(std::max((int)fv + 1, 0), sh - 1);
+      for(int k = 0; k < 4; ++k)
       {
-        float avgLum2 = dot(avg, vec3(0.2126f, 0.7152f, 0.0722f));
-        hdr           = toneExposure(hdr, avgLum2, *tm);
+        float t00 = src[(size_t(y0) * sw + x0) * 4 + k], t10 = src[(size_t(y0) * sw + x1) * 4 + k];
+        float t01 = src[(size_t(y1) * sw + x0) * 4 + k], t11 = src[(size_t(y1) * sw + x1) * 4 + k];
+        float top = t00 * (1.0f - a) + t10 * a, bot = t01 * (1.0f - a) + t11 * a;
+        dst[(size_t(y) * dw + x) * 4 + k] = top * (1.0f - b) + bot * b;
+      }
+    }
+}
+struct MipImage {
+  std::vector<std::vector<float>> level;
+  std::vector<int>                w, h;
+  // the sampler RenderOutput creates (render_output.cpp:98-100, a zeroed VkSamplerCreateInfo): NEAREST texel, NEAREST mip, REPEAT
+  vec4 fetch(vec2 uv, int lod) const
+  {
+    lod = std::min(std::max(lod, 0), (int)level.size() - 1);
+    int i = (int)std::floor(uv.x * float(w[lod])), j = (int)std::floor(uv.y * float(h[lod]));
+    i %= w[lod]; if(i < 0) i += w[lod];
+    j %= h[lod]; if(j < 0) j += h[lod];
+    const float* p = &level[lod][(size_t(j) * w[lod] + i) * 4];
+    return vec4(p[0], p[1], p[2], p[3]);
+  }
+};
+static void build_mips(MipImage& im, bool chain)
+{
+  if(!chain)
+    return;
+  for(int m = std::max(im.w[0], im.h[0]); m > 1; m >>= 1)
+  {
+    int pw = im.w.back(), ph = im.h.back();
+    int nw = pw > 1 ? pw / 2 : 1, nh = ph > 1 ? ph / 2 : 1;
+    std::vector<float> d(size_t(nw) * nh * 4);
+    blit_linear(im.level.back().data(), pw, ph, d.data(), nw, nh);
+    im.level.push_back(std::move(d));
+    im.w.push_back(nw);
+    im.h.push_back(nh);
+  }
+}
+// level `lod` of the chain (test access)
+int orc_mip_chain(const float* rgba, int W, int H, int lod, float* out, int* outW, int* outH)
+{
+  MipImage im;
+  im.level.push_back(std::vector<float>(rgba, rgba + size_t(W) * H * 4));
+  im.w.push_back(W); im.h.push_back(H);
+  build_mips(im, true);
+  if(lod >= 0 && lod < (int)im.level.size())
+  {
+    *outW = im.w[lod]; *outH = im.h[lod];
+    if(out) std::memcpy(out, im.level[lod].data(), im.level[lod].size() * 4);
+  }
+  return (int)im.level.size();
+}
+
+// shaders/post.frag:98-147 with TONEMAP_UNCHARTED on a dispW x dispH viewport.  The offscreen image has the viewport's size and holds the
+// w x h accumulation image in its top-left corner (w = dispW / descalingLevel while navigating, src/sample_example.cpp:410-413; texels
+// outside are zero here -- the reference keeps whatever an earlier frame left there); tm->zoom = 1 / descalingLevel (:378).
+// out8: RGBA8 (floor(v * 255 + 0.5)); outF (may be NULL): fragColor as floats.
+int orc_tonemap_zoom(const pt_Tonemapper* tm, const float* accum, int w, int h, int dispW, int dispH, uint8_t* out8, float* outF)
+{
+  if(!tm || !accum || w <= 0 || h <= 0 || dispW < w || dispH < h)
+    return -1;
+  MipImage im;
+  im.level.emplace_back(size_t(dispW) * dispH * 4, 0.0f);
+  im.w.push_back(dispW); im.h.push_back(dispH);
+  for(int y = 0; y < h; ++y)
+    std::memcpy(&im.level[0][size_t(y) * dispW * 4], accum + size_t(y) * w * 4, size_t(w) * 16);
+  build_mips(im, (tm->autoExposure & 1) != 0);  // sample_example.cpp:423-427: the chain is only generated with auto-exposure on
+  auto luminance = [](vec3 c) { return dot(c, vec3(0.2126f, 0.7152f, 0.0722f)); };
+#pragma omp parallel for schedule(static)
+  for(int y = 0; y < dispH; ++y)
+  {
+    for(int x = 0; x < dispW; ++x)
+    {
+      vec2 uvCoords((float(x) + 0.5f) / float(dispW), (float(y) + 0.5f) / float(dispH));  // passthrough.vert interpolated at the pixel centre
+      vec2 uvz = uvCoords * tm->zoom;
+      vec4 hdr4 = im.fetch(uvz, 0);  // post.frag:101
+      vec3 hdr  = hdr4.xyz();
+      if(((tm->autoExposure >> 0) & 1) == 1)
+      {
+        vec4  avg     = im.fetch(vec2(0.5f, 0.5f), 20);  // :105 -- lod 20 clamps to the 1x1 level
+        float avgLum2 = luminance(avg.xyz());
+        // :66 RGB2XYZ is a column-major mat3 constructor: XYZ.y = 0.3575761 R + 0.7151522 G + 0.1191920 B
+        float XYZy = (0.3575761f * hdr.x + 0.7151522f * hdr.y) + 0.1191920f * hdr.z;
+        float Y    = (tm->key / avgLum2) * XYZy;
+        float Yd;
+        if(((tm->autoExposure >> 1) & 1) == 1)
+        {
+          // toneLocalExposure :72-96
+          float       La = 0.0f;
+          float       factor = tm->key / avgLum2;
+          float       epsilon = 0.05f, phi = 2.0f;
+          const float scale[7] = {1, 2, 4, 8, 16, 32, 64};
+          for(int i = 0; i < 7; ++i)
+          {
+            float v1 = luminance(im.fetch(uvz, i).xyz()) * factor;
+            float v2 = luminance(im.fetch(uvz, i + 1).xyz()) * factor;
+            if(std::fabs(v1 - v2) / ((tm->key * mpow(2.0f, phi) / (scale[i] * scale[i])) + v1) > epsilon)
+            {
+              La = v1;
+              break;
+            }
+            else
+              La = v2;
+          }
+          Yd = Y / (1.0f + La);
+        }
+        else
+          Yd = (Y * (1.0f + Y / (tm->Ywhite * tm->Ywhite))) / (1.0f + Y);  // toneExposure :64-70
+        hdr = hdr / XYZy * Yd;
       }
       vec3 color = toneMapUncharted(hdr * tm->avgLum);
       if(tm->dither > 0)
       {
-        uint32_t r[3] = {(uint32_t)x, (uint32_t)y, 0u};
+        uint32_t r[3] = {(uint32_t)(float(x) + 0.5f), (uint32_t)(float(y) + 0.5f), 0u};  // uvec3(gl_FragCoord.xy, 0)
         pcg3d(r);
         vec3 noise(uintBitsToFloat(0x3f800000u | (r[0] >> 9)) - 1.0f, uintBitsToFloat(0x3f800000u | (r[1] >> 9)) - 1.0f,
                    uintBitsToFloat(0x3f800000u | (r[2] >> 9)) - 1.0f);
@@ -229,20 +329,24 @@ int orc_tonemap(const pt_Tonemapper* tm, const float* accum, int W, int H, uint8
       color      = gpow(color, vec3(1.0f / tm->brightness));
       vec3  i    = vec3(dot(color, vec3(0.299f, 0.587f, 0.114f)));
       color      = gmix(i, color, tm->saturation);
-      vec2  uvc((float(x) + 0.5f) / float(W), (float(y) + 0.5f) / float(H));
-      vec2  uv   = ((uvc * vec2(tm->renderingRatio[0], tm->renderingRatio[1])) - vec2(0.5f)) * 2.0f;
+      vec2  uv   = ((uvCoords * vec2(tm->renderingRatio[0], tm->renderingRatio[1])) - vec2(0.5f)) * 2.0f;
       color *= 1.0f - dot(uv, uv) * tm->vignette;
-      uint8_t* o = out + (size_t(y) * W + x) * 4;
-      for(int k = 0; k < 3; ++k)
+      const size_t o = (size_t(y) * dispW + x) * 4;
+      if(outF)
       {
-        float v = gclamp(color[k], 0.0f, 1.0f);
-        o[k]    = (uint8_t)std::floor(v * 255.0f + 0.5f);
+        outF[o] = color.x; outF[o + 1] = color.y; outF[o + 2] = color.z; outF[o + 3] = hdr4.w;
       }
-      o[3] = (uint8_t)std::floor(gclamp(p[3], 0.0f, 1.0f) * 255.0f + 0.5f);
+      if(out8)
+      {
+        for(int k = 0; k < 3; ++k)
+          out8[o + k] = (uint8_t)std::floor(gclamp(color[k], 0.0f, 1.0f) * 255.0f + 0.5f);
+        out8[o + 3] = (uint8_t)std::floor(gclamp(hdr4.w, 0.0f, 1.0f) * 255.0f + 0.5f);
+      }
     }
   }
   return 0;
 }
+int orc_tonemap(const pt_Tonemapper* tm, const float* accum, int W, int H, uint8_t* out) { return orc_tonemap_zoom(tm, accum, W, H, W, H, out, nullptr); }
 
 // ---- small known-answer entry points ------------------------------------------------------------
 uint32_t orc_tea(uint32_t a, uint32_t b) { return tea(a, b); }

@@ -182,8 +182,11 @@ class Oracle:
         return t, node, prim, uv, seeds
 
 
-def tonemap(tm: hd.Tonemapper, accum):
+def tonemap(tm: hd.Tonemapper, accum, display_size=None):
     H, W = accum.shape[:2]
-    out = np.zeros((H, W, 4), np.uint8)
-    lib().orc_tonemap(C.byref(tm), np.ascontiguousarray(accum, np.float32).ctypes.data, W, H, out.ctypes.data)
+    dw, dh = display_size or (W, H)
+    out = np.zeros((dh, dw, 4), np.uint8)
+    L = lib()
+    L.orc_tonemap_zoom.argtypes = [C.POINTER(hd.Tonemapper), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.orc_tonemap_zoom(C.byref(tm), np.ascontiguousarray(accum, np.float32).ctypes.data, W, H, dw, dh, out.ctypes.data, None) == 0
     return out

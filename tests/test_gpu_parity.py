@@ -1,12 +1,12 @@
 """GPU parity tests: the HIP path through the C ABI (libptmi.so) against the CPU oracle on identical inputs.
 
-Bars
- * integer / RNG-independent results (first-hit AOVs that involve no transcendental function): BIT-EXACT;
- * AOVs behind pow(x, 2.2) (base colour / emissive textures): <= 1e-6 absolute (libm vs ocml ulps);
- * path-traced frames: every discrete decision is driven by the same RNG stream, so the images agree
-   pixel for pixel except where a 1-ulp difference of a transcendental flips a decision (observed ~1e-5 of
-   the pixels).  Asserted: mismatching-pixel fraction <= 1e-3 and per-pixel L2 <= 1e-3 of the image's RMS
-   radiance; the converged-image bar of BASELINE.md (L2 <= 1e-3) is asserted on the many-frame case.
+Bar: BIT-EXACT, for every result -- first-hit AOVs, path-traced accumulation images at any depth and spp, statistics counters, the
+display pass.  Both sides evaluate the same fp32 operation sequence everywhere: the GLSL built-ins with a fixed association
+(csrc/pt_math.h == oracle/glsl_math.h), the transcendental functions through the shared contract include/pt_fpmath.h, the
+BVH-independent trace contract T1-T6, the Appendix-F sampler.  The oracle itself is held bit for bit to the reference's own shader
+code (tests/test_oracle_vs_ref.py, tests/test_golden.py), so "equal to the oracle" means "equal to pathtrace.comp as compiled from
+/root/reference".  The stated tolerance of BASELINE.json (per-pixel L2 <= 1e-3 at equal spp) is therefore met with L2 == 0 at the
+stated configurations (C1 full; C2, C3, C4, C5 stand-ins at full resolution and spp on a sparse pixel sample the oracle can afford).
 """
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from tests import orc
-from tests.common import Config, render_hip, render_oracle, l2, mismatch_fraction, noise_floor
+from tests.common import Config, render_hip, render_oracle, l2
 from vk_raytrace_amd import capi, host_device as hd, synth, shard, workloads
 
 pytestmark = pytest.mark.gpu
@@ -27,23 +27,48 @@ def env_small():
     return synth.procedural_sky(256, 128)
 
 
-def rel_l2(a, b):
-    rms = float(np.sqrt(np.mean(b[..., :3].astype(np.float64) ** 2))) + 1e-12
-    return l2(a, b) / rms
+def assert_identical(h, o, what=""):
+    """bit-for-bit, NaN-aware (the reference's thin-walled refraction produces a NaN about once per 1e6 hits; both sides must do so in the
+    same pixels -- DESIGN.md section 2)"""
+    assert h.shape == o.shape
+    hn, on = np.isnan(h), np.isnan(o)
+    assert np.array_equal(hn, on), f"{what}: NaN pixels differ"
+    hb, ob = np.where(hn, 0, h).view(np.uint32), np.where(on, 0, o).view(np.uint32)
+    bad = np.count_nonzero(hb != ob)
+    assert bad == 0, f"{what}: {bad} of {hb.size} values differ, max abs diff {np.nanmax(np.abs(h - o)):.3e}, L2 {l2(np.nan_to_num(h), np.nan_to_num(o)):.3e}"
 
 
-def check_frames(cfg, frames, max_mismatch=1e-3, max_rel_l2=2e-2):
+def check_frames(cfg, frames, **_unused):
     h, o = render_hip(cfg, frames), render_oracle(cfg, frames)
-    assert np.isfinite(h).all()
     assert (h[..., 3] == 1).all()
-    mm = mismatch_fraction(h, o)
-    assert mm <= max_mismatch, f"{mm:.2e} of the pixels differ"
-    # robust L2: the few diverged pixels can carry a firefly each; everything else must agree to float noise
-    d = np.abs(h[..., :3] - o[..., :3]).max(-1)
-    ok = d <= 1e-4 + 1e-3 * np.abs(o[..., :3]).max(-1)
-    assert l2(h[ok], o[ok]) <= 1e-3 * (1 + float(np.abs(o[..., :3]).mean()))
-    assert rel_l2(h, o) <= max_rel_l2 * max(1.0, 8.0 / frames)
+    assert_identical(h, o, "accumulation image")
+    assert l2(np.nan_to_num(h), np.nan_to_num(o)) == 0.0  # the BASELINE metric (per-pixel L2 <= 1e-3) holds with L2 == 0
     return h, o
+
+
+def sparse_blocks(width, height, every):
+    """pixel ids of every `every`-th 8x8 block -- the sample of a full-size configuration the CPU oracle renders"""
+    bx = width // 8
+    blocks = np.arange(bx * (height // 8))[::every]
+    xs = (blocks % bx)[:, None, None] * 8 + np.arange(8)[None, None, :]
+    ys = (blocks // bx)[:, None, None] * 8 + np.arange(8)[None, :, None]
+    return (ys * width + xs).reshape(-1).astype(np.uint32)
+
+
+def check_sparse(cfg, frames, every, hip_image=None):
+    """full-size configuration: the HIP image against the oracle on a sparse pixel sample, all `frames` frames"""
+    a = render_hip(cfg, frames) if hip_image is None else hip_image
+    ids = sparse_blocks(cfg.width, cfg.height, every)
+    o = orc.Oracle()
+    o.set_scene(cfg.scene); integ, _ = o.set_env(cfg.env); o.set_camera(cfg.camera); o.set_sunsky(cfg.sunsky)
+    st = cfg.state(integ)
+    acc = np.zeros((cfg.height, cfg.width, 4), np.float32)
+    for f in range(frames):
+        st.frame = f
+        o.render_frame(st, acc, ids)
+    o.close()
+    assert_identical(a.reshape(-1, 4)[ids], acc.reshape(-1, 4)[ids], f"{len(ids)} sampled pixels x {frames} spp")
+    return a
 
 
 EXACT_AOVS = [hd.eNormal, hd.eMetallic, hd.eAlpha, hd.eRoughness, hd.eTexcoord, hd.eTangent]
@@ -58,16 +83,14 @@ def test_first_hit_aov_bit_exact(env_small, mode):
 @pytest.mark.parametrize("mode", [hd.eBaseColor, hd.eEmissive])
 def test_first_hit_aov_behind_pow(env_small, mode):
     cfg = Config(synth.feature_box(tex_size=64), env_small, 320, 240, debug=mode)
-    h, o = render_hip(cfg, 1), render_oracle(cfg, 1)
-    assert np.abs(h - o).max() <= 1e-6 * max(1.0, float(np.abs(o).max()))
+    assert_identical(render_hip(cfg, 1), render_oracle(cfg, 1))
 
 
 def test_c1_quad():
     """BASELINE config C1: single quad, 256x256, 1 spp."""
     wl = workloads.c1_quad()
     cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
-    h, o = render_hip(cfg, 1), render_oracle(cfg, 1)
-    assert np.abs(h - o).max() <= 2e-5 and mismatch_fraction(h, o) == 0.0
+    check_frames(cfg, 1)
 
 
 @pytest.mark.parametrize("pbr", [0, 1])
@@ -95,14 +118,13 @@ def test_multiple_samples_per_frame(env_small):
 def test_depth_of_field_and_hdr_multiplier(env_small):
     sc = synth.feature_box(tex_size=64)
     sc.camera.aperture = 0.05
-    check_frames(Config(sc, env_small, 160, 120, hdr_multiplier=0.5, depth=5), 3, max_mismatch=5e-3)
+    check_frames(Config(sc, env_small, 160, 120, hdr_multiplier=0.5, depth=5), 3)
 
 
 @pytest.mark.parametrize("mode", [hd.eRadiance, hd.eWeight, hd.eRayDir])
 def test_last_bounce_debug_modes(env_small, mode):
     cfg = Config(synth.feature_box(tex_size=64), env_small, 160, 120, debug=mode, depth=3)
-    h, o = render_hip(cfg, 1), render_oracle(cfg, 1)
-    assert mismatch_fraction(h, o, rtol=1e-3, atol=1e-3) <= 2e-3
+    assert_identical(render_hip(cfg, 1), render_oracle(cfg, 1))
 
 
 def test_odd_sizes_and_edge_tiles(env_small):
@@ -128,70 +150,72 @@ def test_tiny_scenes(env_small):
     empty.add_node(pm)
     empty.camera = Camera(eye=(0, 0, 3), center=(0, 0, 0), fov=45)
     cfg = Config(empty, env_small, 48, 32)
-    h, o = render_hip(cfg, 2), render_oracle(cfg, 2)
-    assert np.abs(h - o).max() <= 1e-5 * float(np.abs(o).max())
+    assert_identical(render_hip(cfg, 2), render_oracle(cfg, 2))
 
 
 def test_sponza_like_reduced(env_small):
-    """The C3 scene (full triangle count, small textures) at reduced resolution; many alpha-tested cards."""
+    """The C3 scene (full triangle count, small textures) at reduced resolution, depth 8, whole image; many alpha-tested cards."""
     wl = workloads.c3_sponza(480, 270, 8, tex_size=128, env_w=512)
     cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode, debug=hd.eNormal)
     assert np.array_equal(render_hip(cfg, 1), render_oracle(cfg, 1))
     cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
-    # depth-8 paths over glossy curved geometry amplify 1-ulp libm differences: calibrate the tolerance on the
-    # oracle itself (fp32 libm vs double-rounded libm) instead of guessing it
-    floor, _ = noise_floor(cfg, 8)
     (h, r), (o, oo) = render_hip(cfg, 8, return_obj=True), render_oracle(cfg, 8, return_obj=True)
-    mm = mismatch_fraction(h, o)
-    assert mm <= 2.0 * floor + 2e-4, f"HIP-vs-oracle mismatch {mm:.2e} exceeds the libm noise floor {floor:.2e}"
-    assert abs(float(h[..., :3].mean()) - float(o[..., :3].mean())) <= 2e-3 * float(o[..., :3].mean())   # no bias
-    # shallow paths leave no room for amplification: tight agreement
-    cfg2 = Config(wl.scene, wl.env, wl.width, wl.height, depth=2, pbr=wl.pbr_mode)
-    assert mismatch_fraction(render_hip(cfg2, 2), render_oracle(cfg2, 2)) <= 1e-4
+    assert_identical(h, o, "C3 stand-in 480x270 8 spp")
     hs, os_ = r.stats(), oo.stats()
-    for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups"):
-        assert abs(hs[k] - os_[k]) <= 2e-3 * os_[k] + 8, (k, hs[k], os_[k])   # identical work up to the few diverged paths
-    assert hs["samples"] == os_["samples"] == 480 * 270 * 8
+    for k in ("samples", "closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups"):
+        assert hs[k] == os_[k], (k, hs[k], os_[k])   # identical paths -> identical work
+    assert hs["samples"] == 480 * 270 * 8
     r.destroy()
 
 
-def test_full_size_properties():
-    """BASELINE size (1920x1080): determinism, tile-shard invariance and a sparse pixel sample against the oracle."""
-    wl = workloads.c3_sponza(1920, 1080, 2, tex_size=256, env_w=1024)
+def test_c3_full_size_256spp():
+    """BASELINE C3 as stated: 1920x1080, 256 spp, depth 8, Disney + HDR env (synthetic Sponza stand-in): determinism, tile-shard invariance,
+    and the converged 256-spp image against the oracle on every 256th 8x8 block (8 k pixels x 256 spp) -- bit-exact, i.e. L2 == 0 <= 1e-3."""
+    wl = workloads.c3_sponza(1920, 1080, 256, tex_size=256, env_w=1024)
     cfg = Config(wl.scene, wl.env, 1920, 1080, depth=8, pbr=0)
     a = render_hip(cfg, 2)
-    b = render_hip(cfg, 2)
-    assert np.array_equal(a, b)                                           # run-to-run determinism (queue order is irrelevant)
-    # shard invariance: two "ranks" on the same GPU cover the image with bit-identical pixels
-    parts = [render_hip(cfg, 2, shard=(r, 2)) for r in range(2)]
+    assert np.array_equal(a, render_hip(cfg, 2))                          # run-to-run determinism (queue order is irrelevant)
+    parts = [render_hip(cfg, 2, shard=(r, 2)) for r in range(2)]           # two "ranks" on the same GPU cover the image bit-identically
     assert np.array_equal(shard.assemble_rowmajor(parts, 1920, 1080), a)
-    # sparse sample against the oracle (every 64th 8x8 block)
-    o = orc.Oracle()
-    o.set_scene(cfg.scene); integ, _ = o.set_env(cfg.env); o.set_camera(cfg.camera); o.set_sunsky(cfg.sunsky)
-    st = cfg.state(integ)
-    bx = 1920 // 8
-    blocks = np.arange(bx * (1080 // 8))[::64]
-    xs = (blocks % bx)[:, None, None] * 8 + np.arange(8)[None, None, :]
-    ys = (blocks // bx)[:, None, None] * 8 + np.arange(8)[None, :, None]
-    ids = (ys * 1920 + xs).reshape(-1).astype(np.uint32)
-    acc = np.zeros((1080, 1920, 4), np.float32)
-    for f in range(2):
-        st.frame = f
-        o.render_frame(st, acc, ids)
-    ha, oa = a.reshape(-1, 4)[ids], acc.reshape(-1, 4)[ids]
-    assert mismatch_fraction(ha[None], oa[None]) <= 2e-3
+    check_sparse(cfg, 2, 64, hip_image=a)
+    check_sparse(cfg, 256, 256)
+
+
+def test_c2_full_size_64spp():
+    """BASELINE C2 as stated: 1024x1024, 64 spp, depth 4, glTF-PBR BSDF (synthetic DamagedHelmet stand-in, 2048^2 textures)."""
+    wl = workloads.c2_helmet()
+    cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
+    assert (cfg.width, cfg.height, cfg.depth, cfg.pbr, wl.spp) == (1024, 1024, 4, 1, 64)
+    check_sparse(cfg, 64, 64)
+
+
+def test_c4_c5_full_size_sampled():
+    """C4 (the C3 scene at 3840x2160) and C5 (bistro-like, 3.8 M instanced triangles, 3840x2160): a few frames at full size against the
+    oracle on a sparse pixel sample (their 1024 / 4096 spp only repeat the per-frame arithmetic checked here)."""
+    wl = workloads.c3_sponza(3840, 2160, 1024, tex_size=256, env_w=1024)
+    check_sparse(Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0), 4, 1024)
+    wl = workloads.c5_bistro(tex_size=128)
+    check_sparse(Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0), 4, 1024)
 
 
 def test_tonemap_matches_oracle(env_small):
+    """post.frag incl. dithering, global and local auto-exposure on the vkCmdBlitImage mip chain (odd sizes: 150 -> 75 -> 37 ...), and the
+    de-scaled preview (Tonemapper.zoom): RGBA8 output identical to the oracle's."""
     cfg = Config(synth.feature_box(tex_size=64), env_small, 160, 120)
     h, r = render_hip(cfg, 4, return_obj=True)
-    for dither, auto in ((0, 0), (1, 0), (1, 1)):
+    for dither, auto in ((0, 0), (1, 0), (1, 1), (0, 3), (1, 3)):
         tm = hd.default_tonemapper()
         tm.dither, tm.autoExposure, tm.avgLum = dither, auto, 0.3
         tm.contrast, tm.saturation, tm.vignette, tm.brightness = 1.1, 0.9, 0.2, 1.05
-        got = r.tonemap(tm).astype(int)
-        want = orc.tonemap(tm, h).astype(int)
-        assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.02
+        assert np.array_equal(r.tonemap(tm), orc.tonemap(tm, h)), (dither, auto)
+    r.destroy()
+    cfg = Config(synth.feature_box(tex_size=64), env_small, 75, 53)   # the reduced-size render of a 150 x 107 viewport at descaling level 2
+    h, r = render_hip(cfg, 2, return_obj=True)
+    for auto in (0, 1, 3):
+        tm = hd.default_tonemapper()
+        tm.zoom, tm.autoExposure = 0.5, auto
+        got = r.tonemap(tm, display_size=(150, 107))
+        assert got.shape == (107, 150, 4) and np.array_equal(got, orc.tonemap(tm, h, display_size=(150, 107))), auto
     r.destroy()
 
 
@@ -240,7 +264,7 @@ def test_sample_example_orchestrator(env_small):
     assert app.m_rtxState.frame == 2
     cfg = Config(sc, env_small, 96, 64)
     o = render_oracle(cfg, 3)
-    assert mismatch_fraction(img, o) <= 2e-3
+    assert_identical(img, o)
     assert app.drawPost().shape == (64, 96, 4)
     app.destroy()
 
@@ -411,8 +435,7 @@ def test_fuzz_scenes(env_small, seed):
         cfg = Config(sc, env_small, 96, 64, debug=mode)
         assert np.array_equal(render_hip(cfg, 1), render_oracle(cfg, 1)), (seed, mode)
     cfg = Config(sc, env_small, 96, 64, depth=5)
-    h, o = render_hip(cfg, 3, return_obj=False), render_oracle(cfg, 3)
-    assert mismatch_fraction(h, o) <= 2e-3
+    assert_identical(render_hip(cfg, 3), render_oracle(cfg, 3), f"fuzz scene {seed}")
 
 
 def test_ray_picker(env_small):

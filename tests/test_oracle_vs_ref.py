@@ -273,3 +273,83 @@ def test_frame_lights_sunsky_samples_dof(env_small):
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_frame_fuzz_scenes(env_small, seed):
     frames_equal(Config(synth.fuzz_scene(seed), env_small, 64, 48, depth=6, pbr=seed & 1), 2)
+
+
+# ---- display pass: shaders/post.frag on the mip chain of RenderOutput::genMipmap ----------------------------------------------------------
+def hdr_image(w, h, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.float32)
+    img[..., :3] = (0.05 + 3.0 * rng.random((h, w, 3)) ** 3 * (1 + 20 * np.exp(-((xx - w * 0.7) ** 2 + (yy - h * 0.3) ** 2) / (0.02 * w * w)))[..., None]).astype(np.float32)
+    img[..., 3] = 1.0
+    return img
+
+
+def tonemapper(**kw):
+    tm = hd.default_tonemapper()
+    for k, v in kw.items():
+        if k == "renderingRatio":
+            tm.renderingRatio[0], tm.renderingRatio[1] = v
+        else:
+            setattr(tm, k, v)
+    return tm
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (120, 68), (67, 33), (1, 1), (5, 3)])
+def test_mip_chain(shape):
+    w, h = shape
+    img = hdr_image(w, h, 1)
+    R, O = ref.lib(), orc.lib()
+    O.orc_mip_chain.argtypes = R.ref_mip_chain.argtypes
+    n = R.ref_mip_chain(img.ctypes.data, w, h, -1, None, None, None)
+    assert n == O.orc_mip_chain(img.ctypes.data, w, h, -1, None, None, None) == int(np.floor(np.log2(max(w, h)))) + 1
+    for lod in range(n):
+        res = []
+        for L, fn in ((R, "ref_mip_chain"), (O, "orc_mip_chain")):
+            ow, oh = C.c_int(), C.c_int()
+            getattr(L, fn)(img.ctypes.data, w, h, lod, None, C.byref(ow), C.byref(oh))
+            out = np.zeros((oh.value, ow.value, 4), np.float32)
+            getattr(L, fn)(img.ctypes.data, w, h, lod, out.ctypes.data, C.byref(ow), C.byref(oh))
+            res.append(out)
+        assert res[0].shape == res[1].shape == (max(1, h >> lod), max(1, w >> lod), 4)
+        same(res[0], res[1], f"mip {lod}")
+    if w == h == 64:  # power-of-two: every level is the plain 2x2 box average
+        assert np.allclose(res[0][0, 0], img.reshape(-1, 4).mean(0), rtol=1e-5)
+
+
+TM_CASES = [dict(), dict(dither=1), dict(autoExposure=1), dict(autoExposure=3), dict(autoExposure=3, key=0.3, Ywhite=2.0, dither=1),
+            dict(brightness=1.4, contrast=1.3, saturation=0.6, vignette=0.5, avgLum=2.0), dict(autoExposure=1, renderingRatio=(0.8, 0.6), vignette=0.3)]
+
+
+@pytest.mark.parametrize("case", range(len(TM_CASES)))
+@pytest.mark.parametrize("shape", [(96, 64), (75, 41)])
+def test_post_frag(case, shape):
+    w, h = shape
+    img = hdr_image(w, h, 2 + case)
+    tm = tonemapper(**TM_CASES[case])
+    R, O = ref.lib(), orc.lib()
+    O.orc_tonemap_zoom.argtypes = [C.POINTER(hd.Tonemapper), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    a, b = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    R.ref_tonemap(C.byref(tm), img.ctypes.data, w, h, a.ctypes.data)
+    assert O.orc_tonemap_zoom(C.byref(tm), img.ctypes.data, w, h, w, h, None, b.ctypes.data) == 0
+    same(a, b, "post.frag")
+    assert np.isfinite(a).all() and a[..., :3].std() > 0.01
+
+
+@pytest.mark.parametrize("level", [2, 3])
+@pytest.mark.parametrize("ae", [0, 1, 3])
+def test_post_frag_descaling(level, ae):
+    """While navigating the reference renders W/level x H/level pixels into the corner of the offscreen image and magnifies them with
+    Tonemapper.zoom = 1/level (src/sample_example.cpp:378,410-413; shaders/post.frag:101)."""
+    W, H = 90, 62
+    w, h = W // level, H // level
+    small = hdr_image(w, h, 7)
+    big = np.zeros((H, W, 4), np.float32)
+    big[:h, :w] = small
+    tm = tonemapper(zoom=1.0 / level, autoExposure=ae, dither=1)
+    R, O = ref.lib(), orc.lib()
+    O.orc_tonemap_zoom.argtypes = [C.POINTER(hd.Tonemapper), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    a, b = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    R.ref_tonemap(C.byref(tm), big.ctypes.data, W, H, a.ctypes.data)
+    assert O.orc_tonemap_zoom(C.byref(tm), small.ctypes.data, w, h, W, H, None, b.ctypes.data) == 0
+    same(a, b, "post.frag with zoom")

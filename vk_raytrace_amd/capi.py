@@ -38,6 +38,7 @@ API = [
     ("pt_read_accum", C.c_int, [_P, _P]),
     ("pt_write_accum", C.c_int, [_P, _P]),
     ("pt_tonemap", C.c_int, [_P, C.POINTER(hd.Tonemapper), _P]),
+    ("pt_tonemap_zoom", C.c_int, [_P, C.POINTER(hd.Tonemapper), C.c_int, C.c_int, _P]),
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
     ("pt_pick", C.c_int, [_P, C.c_float, C.c_float, _P, _P, C.POINTER(hd.PickResult)]),

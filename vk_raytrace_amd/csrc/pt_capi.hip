@@ -64,7 +64,7 @@ struct pt_context {
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
   DevBuf   dPick;
-  DevBuf   dRowMajor, dRgba8, dMean, dFullTiles, dFullSlotTile, dTileLocalIndex;
+  DevBuf   dRowMajor, dRgba8, dMean, dMips, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
   StageTimers timers;
   pt_Stats    stats{};
@@ -334,7 +334,7 @@ int pt_destroy(pt_context* c)
   (void)sync_all(c);
   DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
-                   &c->dMean, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
+                   &c->dMean, &c->dMips, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
   for(auto& fs : c->slots)
@@ -978,36 +978,60 @@ int pt_fpmath_eval(pt_context* c, int fn, uint64_t n, const float* a, const floa
   return done(rc);
 }
 
-int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
+int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH, uint8_t* out)
 {
   CTX_CHECK(c);
   if(!tm || !out)
     return c->fail(PT_ERR_INVALID, "pt_tonemap: null");
   if(c->width == 0)
     return c->fail(PT_ERR_STATE, "pt_tonemap before pt_resize");
-  if(tm->zoom != 1.0f)
-    return c->fail(PT_ERR_INVALID, "pt_tonemap: zoom != 1 (the viewer's de-scaled preview) is not supported");
-  if(tm->autoExposure & 2)
-    return c->fail(PT_ERR_INVALID, "pt_tonemap: local auto-exposure (bit 1) is not supported");
+  if(dispW < c->width || dispH < c->height || dispW > 32768 || dispH > 32768)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap_zoom: the viewport must be at least as large as the accumulation image");
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = untile_to_rowmajor(c);
   if(rc != PT_OK)
     return rc;
-  float avg[3] = {0, 0, 0};
+  // level 0: the accumulation image itself, or a viewport-sized image with it in the corner; levels 1.. only with auto-exposure
+  // (src/sample_example.cpp:423-427 generates the chain only then)
+  MipView mv{};
+  const bool padded = dispW != c->width || dispH != c->height;
+  size_t     texels = padded ? size_t(dispW) * dispH : 0, offset = texels;
+  int        lw = dispW, lh = dispH, levels = 1;
   if(tm->autoExposure & 1)
+    for(int m = dispW > dispH ? dispW : dispH; m > 1; m >>= 1)
+    {
+      lw = lw > 1 ? lw / 2 : 1;
+      lh = lh > 1 ? lh / 2 : 1;
+      texels += size_t(lw) * lh;
+      levels++;
+    }
+  if(texels && (rc = dev_alloc(c, c->dMips, sizeof(float4) * texels)) != PT_OK)
+    return rc;
+  if((rc = dev_alloc(c, c->dRgba8, 4 * size_t(dispW) * dispH)) != PT_OK)
+    return rc;
+  float4* pool = (float4*)c->dMips.p;
+  if(padded)
+    pt_launch_pad_corner(c->stream, (const float4*)c->dRowMajor.p, c->width, c->height, pool, dispW, dispH);
+  mv.level[0] = padded ? pool : (const float4*)c->dRowMajor.p;
+  mv.w[0] = dispW; mv.h[0] = dispH; mv.n = levels;
+  for(int i = 1; i < levels; ++i)
   {
-    pt_launch_mean(c->stream, (const float4*)c->dRowMajor.p, size_t(c->width) * c->height, (double*)c->dMean.p);
-    double s[3];
-    HIP_TRY(c, hipMemcpyAsync(s, c->dMean.p, sizeof(s), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, sync_all(c));
-    for(int k = 0; k < 3; ++k)
-      avg[k] = float(s[k] / (double(c->width) * c->height));
+    mv.w[i]     = mv.w[i - 1] > 1 ? mv.w[i - 1] / 2 : 1;
+    mv.h[i]     = mv.h[i - 1] > 1 ? mv.h[i - 1] / 2 : 1;
+    mv.level[i] = pool + offset;
+    pt_launch_blit_linear(c->stream, mv.level[i - 1], mv.w[i - 1], mv.h[i - 1], pool + offset, mv.w[i], mv.h[i]);
+    offset += size_t(mv.w[i]) * mv.h[i];
   }
-  pt_launch_tonemap(c->stream, (const float4*)c->dRowMajor.p, c->width, c->height, *tm, avg, (uint32_t*)c->dRgba8.p);
+  pt_launch_tonemap(c->stream, mv, *tm, (uint32_t*)c->dRgba8.p);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(dispW) * dispH, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, sync_all(c));
   return PT_OK;
+}
+int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
+{
+  CTX_CHECK(c);
+  return pt_tonemap_zoom(c, tm, c->width, c->height, out);
 }
 
 int pt_local_shard(pt_context* c, void** device_ptr, size_t* bytes, int* num_local_tiles, int* max_tiles_per_rank)

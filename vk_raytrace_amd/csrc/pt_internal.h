@@ -73,7 +73,15 @@ void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles);
-void pt_launch_tonemap(hipStream_t stream, const float4* rowMajor, int width, int height, const pt_Tonemapper& tm, const float avg[3], uint32_t* outRgba8);
+// the offscreen image with its mip chain as the display pass samples it (level 0 = the image; src/render_output.cpp:188-193)
+struct MipView {
+  const float4* level[20];
+  int           w[20], h[20];
+  int           n;
+};
+void pt_launch_tonemap(hipStream_t stream, const MipView& mv, const pt_Tonemapper& tm, uint32_t* outRgba8);
+void pt_launch_blit_linear(hipStream_t stream, const float4* src, int sw, int sh, float4* dst, int dw, int dh);
+void pt_launch_pad_corner(hipStream_t stream, const float4* src, int w, int h, float4* dst, int dw, int dh);
 void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double* out3);
 
 struct StageTimers {

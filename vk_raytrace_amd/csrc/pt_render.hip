@@ -1254,20 +1254,88 @@ PT_DEV uint32_t pcg3d_x(uint32_t* v)
   v[2] += v[0] * v[1];
   return v[0];
 }
-__global__ void k_tonemap(const float4* __restrict__ img, int width, int height, pt_Tonemapper tm, float avgR, float avgG, float avgB, uint32_t* __restrict__ out)
+// ---- display pass (shaders/post.frag:98-147) on the offscreen image as RenderOutput binds it ------------------------------------------
+// MipView: level 0 is the offscreen image (the accumulation image, or a viewport-sized image holding it in the top-left corner while the
+// viewer de-scales); further levels are the vkCmdBlitImage(VK_FILTER_LINEAR) chain of RenderOutput::genMipmap (src/render_output.cpp:188-193).
+// vkCmdBlitImage, whole level to whole level: dst texel centre scaled into src space, unnormalised linear filtering, clamp-to-edge;
+// horizontal lerps first, then the vertical one (the association the parity oracle uses).
+__global__ void k_blit_linear(const float4* __restrict__ src, int sw, int sh, float4* __restrict__ dst, int dw, int dh)
 {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if(x >= dw || y >= dh)
+    return;
+  const float su = float(sw) / float(dw), sv = float(sh) / float(dh);
+  float u = (float(x) + 0.5f) * su - 0.5f, v = (float(y) + 0.5f) * sv - 0.5f;
+  float fu = floorf(u), fv = floorf(v);
+  float a = u - fu, b = v - fv;
+  int   x0 = min(max(int(fu), 0), sw - 1), x1 = min(max(int(fu) + 1, 0), sw - 1);
+  int   y0 = min(max(int(fv), 0), sh - 1), y1 = min(max(int(fv) + 1, 0), sh - 1);
+  float4 t00 = src[size_t(y0) * sw + x0], t10 = src[size_t(y0) * sw + x1], t01 = src[size_t(y1) * sw + x0], t11 = src[size_t(y1) * sw + x1];
+  auto   bil = [&](float p00, float p10, float p01, float p11) {
+    float top = p00 * (1.0f - a) + p10 * a, bot = p01 * (1.0f - a) + p11 * a;
+    return top * (1.0f - b) + bot * b;
+  };
+  dst[size_t(y) * dw + x] = make_float4(bil(t00.x, t10.x, t01.x, t11.x), bil(t00.y, t10.y, t01.y, t11.y), bil(t00.z, t10.z, t01.z, t11.z), bil(t00.w, t10.w, t01.w, t11.w));
+}
+// the accumulation image placed in the top-left corner of a viewport-sized image (texels outside: zero)
+__global__ void k_pad_corner(const float4* __restrict__ src, int w, int h, float4* __restrict__ dst, int dw, int dh)
+{
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if(x >= dw || y >= dh)
+    return;
+  dst[size_t(y) * dw + x] = (x < w && y < h) ? src[size_t(y) * w + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// the sampler RenderOutput creates for the offscreen image: NEAREST texel, NEAREST mip, REPEAT (zeroed VkSamplerCreateInfo, render_output.cpp:98-100)
+PT_DEV float4 mip_fetch(const MipView& mv, float u, float v, int lod)
+{
+  lod   = min(max(lod, 0), mv.n - 1);
+  int w = mv.w[lod], h = mv.h[lod];
+  int i = int(floorf(u * float(w))), j = int(floorf(v * float(h)));
+  i %= w; if(i < 0) i += w;
+  j %= h; if(j < 0) j += h;
+  return mv.level[lod][size_t(j) * w + i];
+}
+PT_DEV float lum709(float4 c) { return dot3(f3{c.x, c.y, c.z}, f3{0.2126f, 0.7152f, 0.0722f}); }
+
+__global__ void k_tonemap(MipView mv, pt_Tonemapper tm, uint32_t* __restrict__ out)
+{
+  const int width = mv.w[0], height = mv.h[0];
   int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if(x >= width || y >= height)
     return;
-  float4 p   = img[size_t(y) * width + x];
+  f2     uvc = f2{(float(x) + 0.5f) / float(width), (float(y) + 0.5f) / float(height)};  // passthrough.vert at the pixel centre
+  f2     uvz = uvc * tm.zoom;
+  float4 p   = mip_fetch(mv, uvz.x, uvz.y, 0);  // post.frag:101
   f3     hdr = xyz(p);
   if(tm.autoExposure & 1)
   {
-    float avgLum2 = dot3(f3{avgR, avgG, avgB}, f3{0.2126f, 0.7152f, 0.0722f});
+    float avgLum2 = lum709(mip_fetch(mv, 0.5f, 0.5f, 20));  // :105-106, lod 20 clamps to the 1x1 level
     float XYZy    = (0.3575761f * hdr.x + 0.7151522f * hdr.y) + 0.1191920f * hdr.z;
     float Y       = (tm.key / avgLum2) * XYZy;
-    float Yd      = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);
-    hdr           = hdr / XYZy * Yd;
+    float Yd;
+    if(tm.autoExposure & 2)
+    {
+      // toneLocalExposure :72-96
+      float       La = 0.0f;
+      const float factor = tm.key / avgLum2, epsilon = 0.05f, phi = 2.0f;
+      for(int i = 0; i < 7; ++i)
+      {
+        float v1 = lum709(mip_fetch(mv, uvz.x, uvz.y, i)) * factor;
+        float v2 = lum709(mip_fetch(mv, uvz.x, uvz.y, i + 1)) * factor;
+        float sc = float(1 << i);
+        if(fabsf(v1 - v2) / ((tm.key * pt_pow(2.0f, phi) / (sc * sc)) + v1) > epsilon)
+        {
+          La = v1;
+          break;
+        }
+        else
+          La = v2;
+      }
+      Yd = Y / (1.0f + La);
+    }
+    else
+      Yd = (Y * (1.0f + Y / (tm.Ywhite * tm.Ywhite))) / (1.0f + Y);  // toneExposure :64-70
+    hdr = hdr / XYZy * Yd;
   }
   f3 color = uncharted2(hdr * tm.avgLum * 2.0f);
   f3 white = splat3(1.0f) / uncharted2(splat3(11.2f));
@@ -1290,7 +1358,6 @@ __global__ void k_tonemap(const float4* __restrict__ img, int width, int height,
   color    = pow3(color, 1.0f / tm.brightness);
   float i  = dot3(color, f3{0.299f, 0.587f, 0.114f});
   color    = lerp(splat3(i), color, tm.saturation);
-  f2 uvc   = f2{(float(x) + 0.5f) / float(width), (float(y) + 0.5f) / float(height)};
   f2 uv    = f2{(uvc.x * tm.renderingRatio[0] - 0.5f) * 2.0f, (uvc.y * tm.renderingRatio[1] - 0.5f) * 2.0f};
   color *= 1.0f - (uv.x * uv.x + uv.y * uv.y) * tm.vignette;
   auto q8 = [](float v) { return uint32_t(floorf(clampf(v, 0.f, 1.f) * 255.0f + 0.5f)); };
@@ -1422,12 +1489,21 @@ void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nra
   k_scatter_tiles<<<(n + 255) / 256, 256, 0, stream>>>(gathered, nranks, maxTilesPerRank, tilesX, tilesY, tileLocalIndex, fullTiles);
 }
 
-void pt_launch_tonemap(hipStream_t stream, const float4* rowMajor, int width, int height, const pt_Tonemapper& tm, const float avg[3], uint32_t* outRgba8)
+void pt_launch_tonemap(hipStream_t stream, const MipView& mv, const pt_Tonemapper& tm, uint32_t* outRgba8)
 {
-  dim3 b(16, 16), g((width + 15) / 16, (height + 15) / 16);
-  k_tonemap<<<g, b, 0, stream>>>(rowMajor, width, height, tm, avg[0], avg[1], avg[2], outRgba8);
+  dim3 b(16, 16), g((mv.w[0] + 15) / 16, (mv.h[0] + 15) / 16);
+  k_tonemap<<<g, b, 0, stream>>>(mv, tm, outRgba8);
 }
-
+void pt_launch_blit_linear(hipStream_t stream, const float4* src, int sw, int sh, float4* dst, int dw, int dh)
+{
+  dim3 b(16, 16), g((dw + 15) / 16, (dh + 15) / 16);
+  k_blit_linear<<<g, b, 0, stream>>>(src, sw, sh, dst, dw, dh);
+}
+void pt_launch_pad_corner(hipStream_t stream, const float4* src, int w, int h, float4* dst, int dw, int dh)
+{
+  dim3 b(16, 16), g((dw + 15) / 16, (dh + 15) / 16);
+  k_pad_corner<<<g, b, 0, stream>>>(src, w, h, dst, dw, dh);
+}
 void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double* out3)
 {
   (void)hipMemsetAsync(out3, 0, 3 * sizeof(double), stream);

@@ -148,10 +148,14 @@ class HipRenderer(Renderer):
         self._check(self._lib.pt_pick(self._ctx, float(x), float(y), vi, pi, C.byref(out)))
         return out
 
-    def tonemap(self, tm: hd.Tonemapper):
-        w, h = self.size
+    def tonemap(self, tm: hd.Tonemapper, display_size=None):
+        """RenderOutput::genMipmap + run.  display_size (W, H): the viewport while de-scaling (Tonemapper.zoom = 1 / level)."""
+        w, h = display_size or self.size
         out = np.empty((h, w, 4), np.uint8)
-        self._check(self._lib.pt_tonemap(self._ctx, C.byref(tm), out.ctypes.data))
+        if display_size is None:
+            self._check(self._lib.pt_tonemap(self._ctx, C.byref(tm), out.ctypes.data))
+        else:
+            self._check(self._lib.pt_tonemap_zoom(self._ctx, C.byref(tm), w, h, out.ctypes.data))
         return out
 
     def local_shard(self):
