@@ -25,7 +25,8 @@
 //     number is drawn; otherwise non-opaque candidates are HitTest-ed in key order until one passes
 //     (E7).  Vulkan leaves candidate order to the implementation; this is one legal order.
 //
-// "Parity unpinned": the reference holds no test vectors for any of this.
+// "Parity unpinned" for T1-T6 themselves: the reference holds no code or test vectors for traversal; everything the
+// reference DOES specify (the shader code driving these queries) is pinned through oracle/_ref.
 #pragma once
 #include <algorithm>
 #include <cfloat>

@@ -3,11 +3,10 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
 // only as the checker / the reported CPU baseline.  The product (libptmi.so) never links or calls it.
 //
-// PARITY UNPINNED: the reference ships no tests, golden images or known-answer vectors for this
-// path and cannot be built or run here (no Vulkan, no glslang, nvpro_core absent -- SURVEY.md 8(c)).
-// The oracle is a restatement of the reference's GLSL + host code, pinned only by (a) integer
-// known-answer vectors minted by an independent numpy implementation (tests/golden/) and (b)
-// analytic properties (furnace, alias-table sums, brute-force == BVH).
+// PARITY PINNED to the reference's own code: oracle/_ref/libref.so (the reference's shaders and host sources compiled where they
+// lie by the recipe oracle/ref_glue/) agrees with this restatement bit for bit -- tests/test_oracle_vs_ref.py, and through the
+// fixtures it mints, tests/test_golden.py.  Unpinned remains only what the reference has no code for (BVH build / traversal /
+// ray-triangle test: the Vulkan driver; fixed here as the trace contract T1-T6 of orc_scene.h).
 #include <omp.h>
 #include <atomic>
 #include <cstdio>

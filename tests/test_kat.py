@@ -1,5 +1,8 @@
-"""Integer / bit-level known answers (tests/golden/kat.npz, minted by tests/golden/gen_kat.py) checked
-against BOTH the CPU oracle and the product's host helpers.  Bar: bit-exact."""
+"""Integer / bit-level known answers checked against BOTH the CPU oracle and the product's host helpers.  Bar: bit-exact.
+
+Two independent sources: tests/golden/kat.npz, minted by an independent numpy implementation (tests/golden/gen_kat.py), used here; and
+tests/golden/ref_golden.npz, minted from the reference's own compiled code (tests/test_golden.py).  The numpy vectors additionally cover
+the handedness-bit packing of src/scene.cpp:232-239, which needs nvh::GltfScene and therefore has no compiled-reference counterpart."""
 import ctypes as C
 import os
 
