@@ -178,6 +178,11 @@ int pt_sampler_from_gltf(int has_sampler, int gltf_mag, int gltf_min, int gltf_w
  * face culling or alpha test, like the picker's flag-less traceRayEXT.  Synchronous. */
 int pt_pick(pt_context* ctx, float pick_x, float pick_y, const float view_inverse[16], const float proj_inverse[16], pt_PickResult* out);
 
+/* Measures, on this device, the two ceilings the measurement contract prices kernels against (no reference counterpart): VALU issue
+ * (independent wave64 v_fma_f32 at 8 waves per SIMD on every CU, wave-instructions per second) and HBM streaming (float4 copy and
+ * read-only over 1 GiB buffers, bytes per second).  Synchronous, a few tens of milliseconds. */
+int pt_measure_peaks(pt_context* ctx, pt_Peaks* out);
+
 /* Evaluates one function of the fp32 transcendental contract (include/pt_fpmath.h; enum PT_FN_* in pt_types.h) on the device for n
  * arguments (b is the second argument of atan2(a, b) / pow(a, b), otherwise ignored and may be NULL).  No reference counterpart: GLSL
  * leaves these functions' accuracy to the driver; the contract fixes one IEEE operation sequence and this entry point lets a test hold

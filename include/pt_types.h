@@ -253,6 +253,15 @@ typedef struct pt_Stats {
   uint64_t bytesScene;       /* resident HBM bytes of scene+BVH+textures+env */
 } pt_Stats;
 
+/* pt_measure_peaks: ceilings measured on the device */
+typedef struct pt_Peaks {
+  double  valuWaveInstrPerSec; /* wave64 VALU instructions issued per second, whole chip */
+  double  hbmCopyBytesPerSec;  /* read + written bytes per second of a streaming copy */
+  double  hbmReadBytesPerSec;  /* bytes per second of a streaming read */
+  int32_t computeUnits;
+  int32_t clockMHz;
+} pt_Peaks;
+
 #ifdef __cplusplus
 }
 static_assert(sizeof(pt_RtxState) == 48, "RtxState");

@@ -108,6 +108,67 @@ def test_cpp_importer_errors(tmp_path):
         CppScene(_write(tmp_path, doc))
 
 
+def test_cpp_importer_rejects_hostile_files(tmp_path):
+    """Untrusted input: every malformed offset / size / hierarchy must come back as PT_ERR_INVALID with a message, never as an
+    out-of-bounds read, a signal or unbounded recursion (ASan / UBSan build: tools/asan_gltf_main.cpp)."""
+    import struct
+    import zlib
+
+    def bad(mutate, match=None):
+        doc = _tri_doc()
+        mutate(doc)
+        with pytest.raises(ValueError, match=match):
+            CppScene(_write(tmp_path, doc))
+
+    # sizes that wrap size_t when added, are negative, fractional or not finite
+    bad(lambda d: d["bufferViews"][0].update(byteOffset=1e19, byteLength=48), "valid size|exceeds")
+    bad(lambda d: d["bufferViews"][0].update(byteOffset=2 ** 63, byteLength=2 ** 63), "valid size|exceeds")
+    bad(lambda d: d["bufferViews"][0].update(byteStride=2 ** 63), "valid size|byteStride")
+    bad(lambda d: d["bufferViews"][0].update(byteStride=8), "byteStride smaller")
+    bad(lambda d: d["bufferViews"][0].update(byteOffset=-4), "valid size")
+    bad(lambda d: d["bufferViews"][0].update(byteLength=47.5), "valid size")
+    bad(lambda d: d["accessors"][0].update(byteOffset=2 ** 62), "exceeds|valid size")
+    bad(lambda d: d["accessors"][0].update(byteOffset=2 ** 40), "exceeds")
+    bad(lambda d: d["accessors"][0].update(count=2 ** 40), "count too large|exceeds")
+    bad(lambda d: d["accessors"][0].update(count=5), "exceeds")
+    bad(lambda d: d["accessors"][0].update(sparse={"count": 2 ** 60, "indices": {"bufferView": 1, "componentType": 5123}, "values": {"bufferView": 0}}), "sparse|valid size")
+    # node hierarchy with a cycle, directly and through a chain
+    bad(lambda d: d.update(nodes=[{"children": [1]}, {"children": [0], "mesh": 0}]), "cycle")
+    bad(lambda d: d.update(nodes=[{"children": [0], "mesh": 0}]), "cycle")
+    # a diamond (one node under two parents) is legal glTF-wise for this importer: instanced twice, no error
+    doc = _tri_doc()
+    doc["nodes"] = [{"children": [1, 2]}, {"children": [3]}, {"children": [3]}, {"mesh": 0}]
+    assert len(CppScene(_write(tmp_path, doc)).nodes) == 2
+    # JSON nested beyond any sane depth
+    (tmp_path / "deep.gltf").write_text("[" * 100000 + "]" * 100000)
+    with pytest.raises(ValueError, match="nesting"):
+        CppScene(str(tmp_path / "deep.gltf"))
+
+    # PNG headers with bit depths outside the table of the PNG specification (0 used to divide by zero, 3/5/6/7 read past the row)
+    def png(depth, ctype, w=4, h=4):
+        def chunk(t, b):
+            return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+        raw = b"".join(b"\0" + bytes((w * max(depth, 1) * {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype] + 7) // 8) for _ in range(h))
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"PLTE", bytes(6)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    for depth, ctype in ((0, 0), (3, 0), (5, 3), (6, 0), (7, 3), (16, 3), (4, 2), (1, 6)):
+        with pytest.raises(ValueError, match="unsupported colour type"):
+            CppScene(_image_doc(tmp_path, png(depth, ctype), f"bad_{depth}_{ctype}.png"))
+    ok = CppScene(_image_doc(tmp_path, png(2, 0), "ok_2_0.png"))
+    assert ok.textures[0][0].shape == (4, 4, 4)
+
+
+def test_png_trns_for_low_and_high_bit_depths(tmp_path):
+    """tRNS of grey images below 8 bits and of 16-bit images (was honoured for 8 bits only)."""
+    from PIL import Image
+    g = Image.fromarray((np.arange(64, dtype=np.uint8).reshape(8, 8) % 4).astype(np.uint8), "L")
+    b = io.BytesIO()
+    g.point(lambda v: v * 85).convert("L").save(b, format="PNG", bits=2, transparency=85 * 2)
+    cpp = CppScene(_image_doc(tmp_path, b.getvalue(), "trns2.png"))
+    want = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGBA"))
+    assert np.array_equal(cpp.textures[0][0], want)
+    cpp.close()
+
+
 def test_cpp_importer_sparse_accessors(tmp_path):
     from tests.test_gltf import sparse_doc
     path = _write(tmp_path, sparse_doc())

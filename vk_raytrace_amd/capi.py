@@ -43,6 +43,7 @@ API = [
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
     ("pt_pick", C.c_int, [_P, C.c_float, C.c_float, _P, _P, C.POINTER(hd.PickResult)]),
     ("pt_fpmath_eval", C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
+    ("pt_measure_peaks", C.c_int, [_P, C.POINTER(hd.Peaks)]),
     ("pt_set_profiling", C.c_int, [_P, C.c_int]),
     ("pt_get_stats", C.c_int, [_P, C.POINTER(hd.Stats)]),
     ("pt_reset_stats", C.c_int, [_P]),

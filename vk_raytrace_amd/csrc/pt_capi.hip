@@ -33,7 +33,8 @@ struct pt_context {
 
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
-  uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0;
+  uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
+  bool     renderedSinceCheck = false;  // frames were launched since the traversal-stack overflow counter was last looked at
   bool     haveScene = false, haveAccel = false, haveEnv = false;
   DeviceScene scene{};
 
@@ -46,7 +47,7 @@ struct pt_context {
   // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
   // running-mean accumulate is ordered across frames (events).
   struct FrameSlot {
-    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dCounts;
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dQueueT, dSortKeys, dSortHist, dCounts;
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
@@ -166,6 +167,19 @@ hipError_t sync_all(pt_context* c)
   for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
     c->slots[i].launched = false;
   return hipStreamSynchronize(c->stream);
+}
+// After a synchronisation: a traversal that ran out of stack (STACK_LDS + STACK_SPILL entries) dropped a subtree, so the image is wrong --
+// every call that hands results to the caller reports it instead of returning PT_OK with missing geometry.
+int check_traversal(pt_context* c)
+{
+  if(!c->renderedSinceCheck)
+    return PT_OK;
+  unsigned int n = 0;
+  HIP_TRY(c, hipMemcpy(&n, (const char*)c->dCounters.p + offsetof(Counters, stackOverflow), sizeof(n), hipMemcpyDeviceToHost));
+  c->renderedSinceCheck = false;
+  if(n)
+    return c->fail(PT_ERR_STATE, "BVH traversal stack overflowed %u times (the image is invalid: the acceleration structure is deeper than the traversal stack)", n);
+  return PT_OK;
 }
 
 void refresh_scene_ptrs(pt_context* c)
@@ -297,6 +311,10 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
+    if(const char* p = strstr(tune, "shadeSpec=")) if(sscanf(p, "shadeSpec=%d", &v) == 1) g_tuning.shadeSpecialised = v;
+    if(const char* p = strstr(tune, "sortClosest=")) if(sscanf(p, "sortClosest=%d", &v) == 1) g_tuning.sortClosest = v;
+    if(const char* p = strstr(tune, "sortShadow=")) if(sscanf(p, "sortShadow=%d", &v) == 1) g_tuning.sortShadow = v;
+    if(const char* p = strstr(tune, "sortCells=")) if(sscanf(p, "sortCells=%d", &v) == 1) g_tuning.sortCellBits = v;
   }
   pt_context* c = new pt_context();
   c->device     = device_ordinal;
@@ -341,7 +359,7 @@ int pt_destroy(pt_context* c)
   {
     for(DevBuf& b : fs.dState)
       dev_free(b);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dCounts};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys, &fs.dSortHist, &fs.dCounts};
     for(DevBuf* b : q)
       dev_free(*b);
     if(fs.accumDone)
@@ -521,6 +539,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   {
     pt_Light dummy{};  // "cannot be null" (src/scene.cpp:329-330); never read because nbLights == 0 then
     if((rc = upload(c, c->dLights, d->numLights ? d->lights : &dummy, sizeof(pt_Light) * size_t(d->numLights ? d->numLights : 1))) != PT_OK) return rc;
+    c->numLights = d->numLights;
   }
   {
     std::vector<TexRec> recs(d->numTextures ? d->numTextures : 1);
@@ -609,6 +628,26 @@ int pt_build_accel(pt_context* c)
     return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
   HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // world bounds of the triangles = union of the root's two child boxes (origin cells of the ray-sort keys)
+  for(int k = 0; k < 3; ++k)
+  {
+    c->scene.boundsMin[k]    = 0.f;
+    c->scene.boundsInvExt[k] = 0.f;
+  }
+  if(c->numTris > 0)
+  {
+    BvhNode root;
+    HIP_TRY(c, hipMemcpy(&root, c->dBvh.p, sizeof(root), hipMemcpyDeviceToHost));
+    const float lmin[3] = {root.a.x, root.a.y, root.a.z}, lmax[3] = {root.a.w, root.b.x, root.b.y};
+    const float rmin[3] = {root.b.z, root.b.w, root.c.x}, rmax[3] = {root.c.y, root.c.z, root.c.w};
+    const bool  two = c->numTris > 1 && root.d.y != BVH_NONE;
+    for(int k = 0; k < 3; ++k)
+    {
+      const float mn = two ? std::min(lmin[k], rmin[k]) : lmin[k], mx = two ? std::max(lmax[k], rmax[k]) : lmax[k];
+      c->scene.boundsMin[k]    = std::isfinite(mn) ? mn : 0.f;
+      c->scene.boundsInvExt[k] = (std::isfinite(mx - mn) && mx > mn) ? 1.0f / (mx - mn) : 0.f;
+    }
+  }
   c->haveAccel = true;
   refresh_scene_ptrs(c);
   return PT_OK;
@@ -726,9 +765,10 @@ int pt_resize(pt_context* c, int width, int height)
     pt_context::FrameSlot& fs = c->slots[i];
     for(DevBuf& bf : fs.dState)
       if((rc = dev_alloc(c, bf, sizeof(float4) * n)) != PT_OK) return rc;
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
     for(DevBuf* bf : q)
       if((rc = dev_alloc(c, *bf, 4 * n)) != PT_OK) return rc;
+    if((rc = dev_alloc(c, fs.dSortHist, sizeof(uint32_t) * SORT_BINS)) != PT_OK) return rc;
     if((rc = dev_alloc(c, fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2))) != PT_OK) return rc;
     HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
   }
@@ -757,6 +797,9 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.queueX2  = (uint32_t*)fs.dQueueX2.p;
     fs.rb.queueR   = (uint32_t*)fs.dQueueR.p;
     fs.rb.queueR2  = (uint32_t*)fs.dQueueR2.p;
+    fs.rb.queueT   = (uint32_t*)fs.dQueueT.p;
+    fs.rb.sortKeys = (uint32_t*)fs.dSortKeys.p;
+    fs.rb.sortHist = (uint32_t*)fs.dSortHist.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
@@ -780,8 +823,10 @@ int pt_render_frame(pt_context* c, const pt_RtxState* st)
     return c->fail(PT_ERR_INVALID, "RtxState.size %dx%d != pt_resize %dx%d", st->size[0], st->size[1], c->width, c->height);
   if(st->maxSamples < 1 || st->maxDepth < 0 || st->maxDepth > PT_MAX_DEPTH || st->frame < 0)
     return c->fail(PT_ERR_INVALID, "RtxState: maxSamples %d maxDepth %d (limit %d) frame %d", st->maxSamples, st->maxDepth, PT_MAX_DEPTH, st->frame);
-  if(c->scene.camera.nbLights < 0)
-    return c->fail(PT_ERR_INVALID, "camera.nbLights < 0");
+  // the lights buffer holds numLights records (pt_set_scene); the shader indexes it with camera.nbLights (pathtrace.glsl:120-121), and the two
+  // arrive through independent calls
+  if(c->scene.camera.nbLights < 0 || uint32_t(c->scene.camera.nbLights) > c->numLights)
+    return c->fail(PT_ERR_INVALID, "camera.nbLights = %d but the scene holds %u lights", c->scene.camera.nbLights, c->numLights);
   HIP_TRY(c, hipSetDevice(c->device));
   if(c->numSlots == 0)
     return PT_OK;
@@ -839,8 +884,9 @@ int flush_pending(pt_context* c)
     const int minPart = total < c->batchMax ? 2 : ((g_tuning.splitFull > 0 && busy == 0) ? g_tuning.splitFull : total);
     parts = std::max(1, std::min(freeSlots, total / minPart));
   }
-  c->pendCount = 0;
-  int done     = 0;
+  c->pendCount          = 0;
+  c->renderedSinceCheck = true;
+  int done              = 0;
   for(int p = 0; p < parts; ++p)
   {
     const int n = (total - done) / (parts - p);
@@ -862,7 +908,7 @@ int pt_synchronize(pt_context* c)
   CTX_CHECK(c);
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, sync_all(c));
-  return PT_OK;
+  return check_traversal(c);
 }
 
 static int untile_to_rowmajor(pt_context* c)
@@ -895,7 +941,7 @@ int pt_read_accum(pt_context* c, float* out)
     return rc;
   HIP_TRY(c, hipMemcpyAsync(out, c->dRowMajor.p, sizeof(float4) * size_t(c->width) * c->height, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, sync_all(c));
-  return PT_OK;
+  return check_traversal(c);
 }
 
 int pt_write_accum(pt_context* c, const float* in)
@@ -931,6 +977,91 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
   HIP_TRY(c, hipMemcpyAsync(out, c->dPick.p, sizeof(pt_PickResult), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PT_OK;
+}
+
+// ---- on-box calibration of the two rooflines bench.py prices against (no reference counterpart) ------------------------------------------
+// VALU issue: every lane runs 8 independent v_fma_f32 chains (inline asm: the compiler can neither pack two of them into v_pk_fma_f32 nor
+// drop them), 8 waves per SIMD on every CU; the result is wave-instructions per second over the whole chip.
+__global__ void __launch_bounds__(256) k_calib_valu(int iters, float* out)
+{
+  float a0 = threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+  const float m = 0.999f, c = 0.001f;
+  for(int i = 0; i < iters; ++i)
+  {
+    asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                 "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                 : "v"(m), "v"(c));
+  }
+  float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  if(s == 12345.678f)
+    out[0] = s;
+}
+// HBM streaming: float4 copy (read + write) and float4 read-only reduction over buffers far larger than the 256 MB Infinity Cache
+__global__ void __launch_bounds__(256) k_calib_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+  for(size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+    dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) k_calib_read(const float4* __restrict__ src, size_t n, float* out)
+{
+  float acc = 0.f;
+  for(size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+  {
+    float4 v = src[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if(acc == 12345.678f)
+    out[0] = acc;
+}
+int pt_measure_peaks(pt_context* c, pt_Peaks* out)
+{
+  CTX_CHECK(c);
+  if(!out)
+    return c->fail(PT_ERR_INVALID, "pt_measure_peaks: null");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));
+  hipDeviceProp_t prop;
+  HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+  const int    cus = prop.multiProcessorCount;
+  const size_t n   = size_t(1) << 26;  // 2^26 float4 = 1 GiB per buffer
+  float4 *     a = nullptr, *b = nullptr;
+  float*       sink = nullptr;
+  hipEvent_t   e0 = nullptr, e1 = nullptr;
+  auto         done = [&](int rc) {
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+    if(e0) (void)hipEventDestroy(e0);
+    if(e1) (void)hipEventDestroy(e1);
+    return rc;
+  };
+  if(hipMalloc(&a, n * 16) != hipSuccess || hipMalloc(&b, n * 16) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess)
+    return done(c->fail(PT_ERR_OOM, "pt_measure_peaks: out of device memory"));
+  if(hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(a, 0, n * 16, c->stream) != hipSuccess)
+    return done(c->fail(PT_ERR_HIP, "pt_measure_peaks: setup failed"));
+  auto timed = [&](auto&& launch, int reps) -> double {
+    launch();  // warm-up
+    (void)hipEventRecord(e0, c->stream);
+    for(int i = 0; i < reps; ++i)
+      launch();
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return double(ms) * 1e-3 / reps;
+  };
+  const int      iters = 4096;
+  const unsigned blocks = unsigned(cus) * 8u;  // 8 blocks of 4 waves per CU = 8 waves per SIMD
+  double         t = timed([&] { k_calib_valu<<<blocks, 256, 0, c->stream>>>(iters, sink); }, 5);
+  out->valuWaveInstrPerSec = double(blocks) * 4.0 * double(iters) * 8.0 / t;
+  t = timed([&] { k_calib_copy<<<unsigned(cus) * 16u, 256, 0, c->stream>>>(a, b, n); }, 5);
+  out->hbmCopyBytesPerSec = 2.0 * double(n) * 16.0 / t;
+  t = timed([&] { k_calib_read<<<unsigned(cus) * 16u, 256, 0, c->stream>>>(a, n, sink); }, 5);
+  out->hbmReadBytesPerSec = double(n) * 16.0 / t;
+  out->computeUnits = cus;
+  out->clockMHz     = prop.clockRate / 1000;
+  if(hipGetLastError() != hipSuccess)
+    return done(c->fail(PT_ERR_HIP, "pt_measure_peaks: kernel failed"));
+  return done(PT_OK);
 }
 
 // The fp32 transcendental contract evaluated on the device (include/pt_fpmath.h); tests hold it bit for bit to the host evaluation.
@@ -1026,7 +1157,7 @@ int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(dispW) * dispH, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, sync_all(c));
-  return PT_OK;
+  return check_traversal(c);
 }
 int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
 {

@@ -119,6 +119,8 @@ struct DeviceScene {
   uint32_t                    numInstances;
   pt_SceneCamera              camera;
   pt_SunAndSky                sunsky;
+  float                       boundsMin[3];     // world bounds of the triangles (ray-sort keys: origin cell)
+  float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
 };
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------

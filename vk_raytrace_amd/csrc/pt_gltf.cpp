@@ -71,9 +71,20 @@ struct JVal {
 struct JParser {
   const char* p;
   const char* end;
+  int         nest = 0;  // current nesting depth: the parser recurses per container, an adversarial file must not exhaust the stack
   void        ws() { while(p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
-  JVal        parse()
+  struct Nest {
+    int& n;
+    explicit Nest(int& d) : n(d)
+    {
+      if(++n > 256)
+        fail("JSON: nesting deeper than 256 levels");
+    }
+    ~Nest() { --n; }
+  };
+  JVal parse()
   {
+    Nest guard(nest);
     ws();
     if(p >= end)
       fail("JSON: unexpected end");
@@ -276,8 +287,13 @@ Image decode_png(const Bytes& d)
   if(interlace > 1)
     fail("PNG: unknown interlace method %d", interlace);
   const int ch  = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-  if(!ch || (depth != 8 && depth != 16 && !(depth < 8 && (ctype == 0 || ctype == 3))))
+  // PNG 1.2 table 11.1: allowed bit depths per colour type
+  const bool depthOk = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8))
+                       || ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+  if(!ch || !depthOk)
     fail("PNG: unsupported colour type %d / depth %d", ctype, depth);
+  if(size_t(w) > 32768 || size_t(h) > 32768)
+    fail("PNG: %d x %d is larger than 32768 x 32768", w, h);
   const size_t bpp = std::max<size_t>(1, size_t(ch) * depth / 8);  // bytes per complete pixel for filtering
   // (x0, y0, dx, dy) of the passes: one for a plain image, Adam7's seven for an interlaced one
   static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
@@ -347,8 +363,16 @@ Image decode_png(const Bytes& d)
           return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
         };
         int r, g, b, a = 255;
-        if(ctype == 0) { r = g = b = sample(0); if(trns.size() >= 2 && depth == 8 && r == trns[1]) a = 0; }
-        else if(ctype == 2) { r = sample(0); g = sample(1); b = sample(2); if(trns.size() >= 6 && depth == 8 && r == trns[1] && g == trns[3] && b == trns[5]) a = 0; }
+        // tRNS of grey / RGB images: one 16-bit big-endian sample value per channel, compared with the RAW sample of the pixel
+        auto raw = [&](int q) -> int {
+          if(depth == 8) return cur[size_t(x) * ch + q];
+          if(depth == 16) return (cur[(size_t(x) * ch + q) * 2] << 8) | cur[(size_t(x) * ch + q) * 2 + 1];
+          const int per = 8 / depth, byte = x / per, sh = (per - 1 - x % per) * depth;
+          return (cur[byte] >> sh) & ((1 << depth) - 1);
+        };
+        auto key = [&](int q) -> int { return (trns[size_t(q) * 2] << 8) | trns[size_t(q) * 2 + 1]; };
+        if(ctype == 0) { r = g = b = sample(0); if(trns.size() >= 2 && raw(0) == key(0)) a = 0; }
+        else if(ctype == 2) { r = sample(0); g = sample(1); b = sample(2); if(trns.size() >= 6 && raw(0) == key(0) && raw(1) == key(1) && raw(2) == key(2)) a = 0; }
         else if(ctype == 3)
         {
           const int i = sample(0);
@@ -963,6 +987,15 @@ struct Importer {
     }
   }
 
+  // a JSON number that must be a byte offset / length / element count: finite, non-negative, integral, below 2^53
+  size_t size_field(const JVal& v, const char* key, const char* what)
+  {
+    const double d = v.number(key, 0);
+    if(!(d >= 0.0) || !(d <= 9007199254740992.0) || d != std::floor(d))
+      fail("%s: %s is not a valid size", what, key);
+    return size_t(d);
+  }
+
   // (pointer, length, stride) of a buffer view
   void view(int index, const uint8_t*& p, size_t& len, size_t& stride)
   {
@@ -973,12 +1006,15 @@ struct Importer {
     const int   b = v.integer("buffer", 0);
     if(b < 0 || size_t(b) >= buffers.size())
       fail("buffer %d out of range", b);
-    const size_t off = size_t(v.number("byteOffset", 0));
-    len              = size_t(v.number("byteLength", 0));
-    if(off + len > buffers[size_t(b)].size())
+    const size_t off  = size_field(v, "byteOffset", "bufferView");
+    const size_t size = buffers[size_t(b)].size();
+    len               = size_field(v, "byteLength", "bufferView");
+    if(off > size || len > size - off)  // written so that it cannot wrap
       fail("bufferView %d exceeds its buffer", index);
     p      = buffers[size_t(b)].data() + off;
-    stride = size_t(v.number("byteStride", 0));
+    stride = size_field(v, "byteStride", "bufferView");
+    if(stride > 252)  // glTF 2.0: byteStride in [4, 252]
+      fail("bufferView %d: byteStride %zu out of range", index, stride);
   }
 
   // accessor as floats (normalised integers converted per the specification) or as raw integers
@@ -991,7 +1027,9 @@ struct Importer {
     const int         ct = a.integer("componentType", 5126);
     const std::string ty = a.string("type", "SCALAR");
     ncomp                = ty == "SCALAR" ? 1 : ty == "VEC2" ? 2 : ty == "VEC3" ? 3 : ty == "VEC4" ? 4 : ty == "MAT2" ? 4 : ty == "MAT3" ? 9 : 16;
-    count                = size_t(a.number("count", 0));
+    count                = size_field(a, "count", "accessor");
+    if(count > (size_t(1) << 31))
+      fail("accessor %d: count too large", index);
     const size_t csize   = (ct == 5120 || ct == 5121) ? 1 : (ct == 5122 || ct == 5123) ? 2 : 4;
     const size_t elem    = csize * size_t(ncomp);
     const bool   norm    = a.boolean("normalized", false);
@@ -1002,10 +1040,13 @@ struct Importer {
     if(hasView)
     {
       view(a.integer("bufferView", -1), p, len, stride);
-      const size_t off = size_t(a.number("byteOffset", 0));
+      const size_t off = size_field(a, "byteOffset", "accessor");
       if(stride == 0)
         stride = elem;
-      if(count && off + stride * (count - 1) + elem > len)
+      if(stride < elem)
+        fail("accessor %d: byteStride smaller than an element", index);
+      // count elements of `elem` bytes, `stride` apart, starting at `off`, inside `len` bytes -- without overflow
+      if(count && (off > len || elem > len - off || (count - 1) > (len - off - elem) / stride))
         fail("accessor %d exceeds its bufferView", index);
       p += off;
     }
@@ -1034,7 +1075,7 @@ struct Importer {
     }
     if(const JVal* sp = a.get("sparse"))
     {  // substituted elements on top of the (possibly absent = zero) base data
-      const size_t n  = size_t(sp->number("count", 0));
+      const size_t n  = size_field(*sp, "count", "sparse accessor");
       const JVal*  si = sp->get("indices");
       const JVal*  sv = sp->get("values");
       if(!si || !sv)
@@ -1043,10 +1084,10 @@ struct Importer {
       size_t         il, vl, st;
       view(si->integer("bufferView", -1), ip, il, st);
       view(sv->integer("bufferView", -1), vp, vl, st);
-      const size_t ioff = size_t(si->number("byteOffset", 0)), voff = size_t(sv->number("byteOffset", 0));
+      const size_t ioff = size_field(*si, "byteOffset", "sparse indices"), voff = size_field(*sv, "byteOffset", "sparse values");
       const int    ict  = si->integer("componentType", 5125);
       const size_t isz  = ict == 5121 ? 1 : ict == 5123 ? 2 : 4;
-      if(ioff + isz * n > il || voff + elem * n > vl)
+      if(n > count || ioff > il || n > (il - ioff) / isz || voff > vl || n > (vl - voff) / elem)
         fail("accessor %d: sparse data exceeds its bufferView", index);
       long long prev = -1;
       for(size_t j = 0; j < n; ++j)
@@ -1354,11 +1395,21 @@ struct Importer {
     return id;
   }
 
+  std::vector<uint8_t> onPath;  // nodes on the current root-to-node path: a child that is already on it closes a cycle
   void visit(int ni, const M4& parent)
   {
     const auto& nodes = doc.array("nodes");
     if(ni < 0 || size_t(ni) >= nodes.size())
       fail("node %d out of range", ni);
+    if(onPath.size() != nodes.size())
+      onPath.assign(nodes.size(), 0);
+    if(onPath[size_t(ni)])
+      fail("node hierarchy has a cycle through node %d", ni);
+    struct Mark {
+      uint8_t& m;
+      explicit Mark(uint8_t& r) : m(r) { m = 1; }
+      ~Mark() { m = 0; }
+    } mark(onPath[size_t(ni)]);
     const JVal& n     = nodes[size_t(ni)];
     const M4    world = mul(parent, local_matrix(n));
     if(n.has("mesh"))

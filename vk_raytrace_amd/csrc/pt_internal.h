@@ -39,6 +39,9 @@ struct RenderBuffers {
   uint32_t* queueX2;
   uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
   uint32_t* queueR2;   // same for shadow rays
+  uint32_t* queueT;    // a queue re-ordered by the ray sort (closest-hit rays of bounce >= 1, shadow rays)
+  uint32_t* sortKeys;  // sort key of every entry of the queue being sorted
+  uint32_t* sortHist;  // SORT_BINS bin counters -> bin offsets
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
@@ -60,6 +63,11 @@ struct PtTuning {
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
   int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of
                                    // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
+  int shadeSpecialised     = 0;    // k_shade<0 / 1>: the common case (no debug output, no sun & sky, no punctual lights) compiled per BSDF
+  int sortClosest          = 0;    // bounce >= 1: the closest-hit queue is binned by (direction octant, origin cell) before it is traced, so that the 64 rays a
+                                   // wave of the trace machine pulls together (and refills with) start in the same region with the same direction signs
+  int sortShadow           = 0;    // same for the shadow-ray queue of every bounce
+  int sortCellBits         = 4;    // origin cells per axis = 2^sortCellBits (<= 5)
   int sahBuild             = 1;    // 1: host SAH topology (fast trace, the default), 0: device LBVH (fast build)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
@@ -69,6 +77,8 @@ struct StageTimers;  // pt_capi.hip
 // waitBeforeAccum (may be null): accumDone event of the previous frame; recordAfterAccum: this frame's
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
                      hipEvent_t recordAfterAccum);
+#define SORT_MAX_CELL_BITS 5
+#define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);

@@ -536,16 +536,23 @@ PT_DEV f3 bsdf_sample(int pbrMode, const Surface& s, f3 V, f3 N, f3& L, float& p
 // ---- k_shade ----------------------------------------------------------------------------------------------
 // One path: everything between the closest-hit trace and the shadow trace of a bounce.
 // Returns where the path goes next (SHADE_*) and ORs the events it counted into `events` (EV_*).
+// MODE: 0 / 1 = the common case compiled on its own -- Disney / glTF BSDF, no debug output, no sun & sky, no punctual lights (the host picks the
+// kernel from the frame's uniform state), so that neither the other BSDF nor sun_and_sky() nor the debug / light branches cost registers or
+// instruction-cache space; -1 = everything decided at run time.  Same arithmetic in every instantiation.
+template <int MODE>
 PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, int depth, uint32_t& events)
 {
   const pt_RtxState& st   = fp.st;
+  const int          pbrMode  = MODE >= 0 ? MODE : st.pbrMode;
+  const bool         useSky   = MODE >= 0 ? false : (S.sunsky.in_use == 1);
+  const int          nbLights = MODE >= 0 ? 0 : S.camera.nbLights;
   const float4       dw   = rb.ps.rayD[slot];
   const f3           rdir = xyz(dw);
   uint32_t           seed = __float_as_uint(dw.w);
   const float4       hit  = rb.ps.hit[slot];
   f3                 radiance   = xyz(rb.ps.rad[slot]);
   f3                 throughput = xyz(rb.ps.thr[slot]);
-  const int          dbg        = st.debugging_mode;
+  const int          dbg        = MODE >= 0 ? PT_DEBUG_NONE : st.debugging_mode;
 
   // ---- miss: environment (pathtrace.glsl:204-228) ----
   if(__float_as_uint(hit.y) == BVH_NONE)
@@ -569,7 +576,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
     if(!done)
     {
       events |= EV_MISS;
-      f3 env = (S.sunsky.in_use == 1) ? sun_and_sky(S.sunsky, rdir) : sample_env(S, spherical_uv(rdir));
+      f3 env = useSky ? sun_and_sky(S.sunsky, rdir) : sample_env(S, spherical_uv(rdir));
       result = radiance + (env * st.hdrMultiplier * throughput);
     }
     rb.ps.rad[slot] = make_float4(result.x, result.y, result.z, 0.f);
@@ -627,11 +634,11 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
     float lightPdf;
     bool  isLight = false;
     float pSelect = st.hdrMultiplier > 0.0f ? 0.5f : 1.0f;
-    if(S.camera.nbLights != 0 && rng_next(seed) <= pSelect)
+    if(nbLights != 0 && rng_next(seed) <= pSelect)
     {
       isLight            = true;
-      int            li  = int(fmin2(rng_next(seed) * float(S.camera.nbLights), float(S.camera.nbLights)));
-      li                 = li < S.camera.nbLights - 1 ? li : S.camera.nbLights - 1;
+      int            li  = int(fmin2(rng_next(seed) * float(nbLights), float(nbLights)));
+      li                 = li < nbLights - 1 ? li : nbLights - 1;
       const pt_Light lt  = S.lights[li];
       const f3       ldir = f3{lt.direction[0], lt.direction[1], lt.direction[2]};
       f3             pointToLight = -ldir;
@@ -647,7 +654,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
       lightDir     = unit(pointToLight);
       lightPdf     = 1.0f;
     }
-    else if(S.sunsky.in_use == 1)
+    else if(useSky)
     {
       float sunRadius = (0.00465f * 10.0f) * S.sunsky.sun_disk_scale;
       f3    sd        = f3{S.sunsky.sun_direction[0], S.sunsky.sun_direction[1], S.sunsky.sun_direction[2]};
@@ -672,7 +679,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
     if(dot3(lightDir, sf.ffnormal) > 0.0f)  // (state.isSubsurface is always false here: Sample() works on a copy)
     {
       float bsdfPdf = 0.0f;
-      f3    f       = bsdf_eval(st.pbrMode, sf, -rdir, sf.ffnormal, lightDir, bsdfPdf);
+      f3    f       = bsdf_eval(pbrMode, sf, -rdir, sf.ffnormal, lightDir, bsdfPdf);
       float mis     = isLight ? 1.0f : fmax2(0.0f, power_heuristic(lightPdf, bsdfPdf));
       neeRadiance   = f * mis * fabsf(dot3(lightDir, sf.ffnormal)) * lightContrib / lightPdf;
       visible       = true;
@@ -683,7 +690,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   // ---- BSDF sample ----
   f3    L;
   float pdf = 0.0f;
-  f3    f   = bsdf_sample(st.pbrMode, sf, -rdir, sf.ffnormal, L, pdf, seed);
+  f3    f   = bsdf_sample(pbrMode, sf, -rdir, sf.ffnormal, L, pdf, seed);
 
   if(dot3(sf.ffnormal, L) < 0.0f)
     absorption = -log3(sf.attenuationColor) / splat3(sf.attenuationDistance);
@@ -747,6 +754,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 #ifdef PT_SHADE_VGPRS
 __attribute__((amdgpu_num_vgpr(PT_SHADE_VGPRS)))
 #endif
+template <int MODE>
 __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
 {
   __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups
@@ -762,7 +770,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceSce
   if(i < count)
   {
     slot = queueIn[i];
-    to   = shade_path(S, rb, fp, slot, depth, events);
+    to   = shade_path<MODE>(S, rb, fp, slot, depth, events);
   }
   // queue appends and statistics: wave totals into LDS, one global atomic per workgroup and counter (a returning
   // atomic per wave on one address costs ~11 ns each, serialised: 2.9 ms for the 260 k waves of a bounce-0 batch)
@@ -1105,6 +1113,72 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(Device
 }
 
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
+// ---- ray sorting (north_star: "per-wavefront ray compaction / sorting"; no reference counterpart: the Vulkan driver schedules rays) ------
+// After bounce 0 the rays of a queue are incoherent: consecutive entries start anywhere and point anywhere, so the 64 rays a wave of the trace
+// machine works on share no BVH nodes and leave its two loop phases half empty.  A queue is therefore binned by the key
+//   (direction octant : 3 bits) | (Morton code of the origin's cell in the scene bounds : 3 * cellBits bits)
+// with a counting sort: histogram (fire-and-forget atomics), one-block scan, scatter (one returning atomic per ray; the order inside a bin is
+// whatever the hardware makes it -- results never depend on queue order, tests/test_gpu_parity.py::test_launch_policy_never_changes_results).
+PT_DEV uint32_t spread3(uint32_t v)  // 5 bits -> every third bit
+{
+  v = (v | (v << 8)) & 0x0000f00fu;
+  v = (v | (v << 4)) & 0x000c30c3u;
+  v = (v | (v << 2)) & 0x00249249u;
+  return v;
+}
+PT_DEV uint32_t ray_sort_key(const DeviceScene& S, float4 o, float4 d, int cellBits)
+{
+  const float    n  = float(1 << cellBits);
+  const int      hi = (1 << cellBits) - 1;
+  const int      cx = min(max(int((o.x - S.boundsMin[0]) * S.boundsInvExt[0] * n), 0), hi);
+  const int      cy = min(max(int((o.y - S.boundsMin[1]) * S.boundsInvExt[1] * n), 0), hi);
+  const int      cz = min(max(int((o.z - S.boundsMin[2]) * S.boundsInvExt[2] * n), 0), hi);
+  const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+  return (oct << (3 * cellBits)) | spread3(uint32_t(cx)) | (spread3(uint32_t(cy)) << 1) | (spread3(uint32_t(cz)) << 2);
+}
+__global__ void __launch_bounds__(256) k_raysort_hist(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countPtr, int useNee, int cellBits)
+{
+  const uint32_t count = *countPtr;
+  const float4*  dir   = useNee ? rb.ps.neeDir : rb.ps.rayD;
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+  {
+    const uint32_t slot = queueIn[i];
+    const uint32_t k    = ray_sort_key(S, rb.ps.rayO[slot], dir[slot], cellBits);
+    rb.sortKeys[i]      = k;
+    atomicAdd(&rb.sortHist[k], 1u);
+  }
+}
+__global__ void __launch_bounds__(1024) k_raysort_scan(uint32_t* __restrict__ hist, uint32_t bins)
+{
+  __shared__ uint32_t part[1024];
+  const uint32_t      per = (bins + 1023u) / 1024u, first = threadIdx.x * per;
+  uint32_t            sum = 0;
+  for(uint32_t i = 0; i < per && first + i < bins; ++i)
+    sum += hist[first + i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for(uint32_t off = 1; off < 1024u; off <<= 1)
+  {
+    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's span
+  for(uint32_t i = 0; i < per && first + i < bins; ++i)
+  {
+    const uint32_t h = hist[first + i];
+    hist[first + i]  = run;
+    run += h;
+  }
+}
+__global__ void __launch_bounds__(256) k_raysort_scatter(RenderBuffers rb, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countPtr)
+{
+  const uint32_t count = *countPtr;
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    rb.queueT[atomicAdd(&rb.sortHist[rb.sortKeys[i]], 1u)] = queueIn[i];
+}
+
 __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParams fp)
 {
   uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1395,6 +1469,18 @@ __global__ void k_mean(const float4* __restrict__ img, size_t n, double* out3)
 // ---- host-side launchers ----------------------------------------------------------------------------------------
 PtTuning g_tuning;
 
+// counting sort of queueIn[0 .. *countPtr) by ray_sort_key into rb.queueT (slots: the capacity of the queue, which sizes the grids)
+static void sort_queue(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const uint32_t* queueIn, const uint32_t* countPtr, int useNee, uint32_t slots)
+{
+  const int      cellBits = g_tuning.sortCellBits < 1 ? 1 : (g_tuning.sortCellBits > SORT_MAX_CELL_BITS ? SORT_MAX_CELL_BITS : g_tuning.sortCellBits);
+  const uint32_t bins     = 8u << (3 * cellBits);
+  const uint32_t grid     = std::min<uint32_t>((slots + 255u) / 256u, 2048u);
+  (void)hipMemsetAsync(rb.sortHist, 0, sizeof(uint32_t) * bins, stream);
+  k_raysort_hist<<<grid, 256, 0, stream>>>(scene, rb, queueIn, countPtr, useNee, cellBits);
+  k_raysort_scan<<<1, 1024, 0, stream>>>(rb.sortHist, bins);
+  k_raysort_scatter<<<grid, 256, 0, stream>>>(rb, queueIn, countPtr);
+}
+
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
                      hipEvent_t recordAfterAccum)
 {
@@ -1418,6 +1504,12 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     {
       const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
       pt_timers_begin(tm, stream, 1);
+      const uint32_t* traceIn = qIn;
+      if(depth >= 1 && g_tuning.sortClosest)
+      {
+        sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
+        traceIn = rb.queueT;
+      }
       if(depth < g_tuning.packetClosestBounces)
       {
         const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
@@ -1425,15 +1517,30 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
         k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
       }
       else if(depth < g_tuning.simpleClosestBounces)
-        k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
+        k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
       else
-        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
       k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
-      k_shade<<<(n + SHADE_BLOCK - 1) / SHADE_BLOCK, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth);
+      {
+        const dim3 sg((n + SHADE_BLOCK - 1) / SHADE_BLOCK), sb(SHADE_BLOCK);
+        const bool plain = g_tuning.shadeSpecialised && fp.st.debugging_mode == PT_DEBUG_NONE && scene.sunsky.in_use != 1 && scene.camera.nbLights == 0;
+        if(plain && fp.st.pbrMode == 0)
+          k_shade<0><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
+        else if(plain && fp.st.pbrMode == 1)
+          k_shade<1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
+        else
+          k_shade<-1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
+      }
       pt_timers_end(tm, stream, 2);
       pt_timers_begin(tm, stream, 3);
+      const uint32_t* shadowIn = rb.queueS;
+      if(g_tuning.sortShadow && depth >= g_tuning.simpleShadowBounces && depth >= g_tuning.packetShadowBounces)
+      {
+        sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
+        shadowIn = rb.queueT;
+      }
       if(depth < g_tuning.simpleShadowBounces)
         k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       else
@@ -1445,7 +1552,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
           k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
         }
         else
-          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
       }
       k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       pt_timers_end(tm, stream, 3);

@@ -104,6 +104,12 @@ class PickResult(C.Structure):
                 ("instanceID", C.c_uint32), ("instanceCustomIndex", C.c_int32), ("baryCoord", C.c_float * 3)]
 
 
+class Peaks(C.Structure):
+    """pt_Peaks (pt_measure_peaks): ceilings measured on the device"""
+    _fields_ = [("valuWaveInstrPerSec", C.c_double), ("hbmCopyBytesPerSec", C.c_double), ("hbmReadBytesPerSec", C.c_double), ("computeUnits", C.c_int32),
+                ("clockMHz", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closestRays", C.c_uint64), ("shadowRays", C.c_uint64),
                 ("shadedHits", C.c_uint64), ("misses", C.c_uint64), ("alphaTests", C.c_uint64),

@@ -158,6 +158,12 @@ class HipRenderer(Renderer):
             self._check(self._lib.pt_tonemap_zoom(self._ctx, C.byref(tm), w, h, out.ctypes.data))
         return out
 
+    def measure_peaks(self):
+        """pt_measure_peaks: VALU issue and HBM streaming ceilings measured on this device (dict)"""
+        p = hd.Peaks()
+        self._check(self._lib.pt_measure_peaks(self._ctx, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in hd.Peaks._fields_}
+
     def local_shard(self):
         ptr, nbytes, nloc, nmax = C.c_void_p(), C.c_size_t(), C.c_int(), C.c_int()
         self._check(self._lib.pt_local_shard(self._ctx, C.byref(ptr), C.byref(nbytes), C.byref(nloc), C.byref(nmax)))
