@@ -78,6 +78,13 @@ int pt_set_camera(pt_context* ctx, const pt_SceneCamera* cam);
  * fireflyClampThreshold = 4 * integral like src/sample_example.cpp:110. */
 int pt_set_env(pt_context* ctx, const float* rgba32f, int width, int height, float* out_integral, float* out_average);
 
+/* replaces stbi_loadf(file, &w, &h, &comp, STBI_rgb_alpha) in HdrSampling::loadEnvironment [src/hdr_sampling.cpp:56-66] for Radiance
+ * RGBE files (.hdr): row 0 first, RGBA32F with alpha 1, value = mantissa * 2^(exponent - 136) like stb_image; flat and run-length
+ * encoded scanlines.  Host only (no GPU).  The image is malloc'ed: free it with pt_hdr_free (the reference: stbi_image_free), then hand
+ * it to pt_set_env.  On failure returns PT_ERR_INVALID and writes a message to `err` (may be NULL). */
+int  pt_hdr_load(const char* path, float** out_rgba32f, int* out_width, int* out_height, char* err, size_t err_len);
+void pt_hdr_free(float* rgba32f);
+
 /* replaces the SunAndSky UBO update in SampleExample::updateUniformBuffer [src/sample_example.cpp:168-178] */
 int pt_set_sunsky(pt_context* ctx, const pt_SunAndSky* ss);
 
@@ -101,6 +108,11 @@ int pt_set_shard(pt_context* ctx, int rank, int nranks);
  * (samplePixel, PathTrace, the BSDFs) is the same pathtrace.glsl. */
 /* (enum PT_VARIANT_* lives in pt_types.h) */
 int pt_set_variant(pt_context* ctx, int variant);
+
+/* replaces RtxPipeline::useAnyHit(enable) [src/rtx_pipeline.cpp:269-276, GUI: src/sample_gui.cpp:140-148].  enable == 0 removes the
+ * any-hit stage: every triangle is treated as opaque (no stochastic alpha test, no random draw), which "can be faster, but the scene must
+ * be fully opaque".  Default 1.  Rebuilds the acceleration structure if one exists (the reference re-creates its pipeline). */
+int pt_use_any_hit(pt_context* ctx, int enable);
 
 /* replaces Renderer::setPushContants(state) + Renderer::run(cmdBuf, size, profiler, descSets)
  * [src/renderer.h:38-45; src/rayquery.cpp:97-109 -> shaders/pathtrace.comp:87-134]: renders

@@ -61,6 +61,21 @@ public:
   void setVariant(int variant) { check(pt_set_variant(m_ctx, variant)); }
   void setSunAndSky(const pt_SunAndSky& s) { check(pt_set_sunsky(m_ctx, &s)); }
   void setEnvironment(const float* rgba32f, int w, int h, float* integral, float* average) { check(pt_set_env(m_ctx, rgba32f, w, h, integral, average)); }
+  // HdrSampling::loadEnvironment (src/hdr_sampling.cpp:56-99) for a Radiance .hdr file: decode (the stbi_loadf of :64), upload, alias table
+  bool loadEnvironment(const char* hdrPath, float* integral, float* average)
+  {
+    float* px = nullptr;
+    int    w = 0, h = 0;
+    char   err[256] = {0};
+    if(pt_hdr_load(hdrPath, &px, &w, &h, err, sizeof(err)) != PT_OK)
+    {
+      m_error = err;
+      return false;
+    }
+    const bool ok = check(pt_set_env(m_ctx, px, w, h, integral, average));
+    pt_hdr_free(px);
+    return ok;
+  }
   // Scene::load for a .gltf / .glb file (src/scene.cpp:56-118): imports, uploads, builds the acceleration structure and sets the
   // file's first camera (or a fit to the bounding box) for the given aspect ratio.  Returns false and keeps lastError() on failure.
   bool loadGltf(const char* path, float aspect)
@@ -89,6 +104,7 @@ public:
   bool pick(float x, float y, const pt_SceneCamera& cam, pt_PickResult* out) { return check(pt_pick(m_ctx, x, y, cam.viewInverse, cam.projInverse, out)); }
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
   void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
+  void useAnyHit(bool enable) { check(pt_use_any_hit(m_ctx, enable ? 1 : 0)); }  // RtxPipeline::useAnyHit
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
   // while SampleExample de-scales (m_descaling, src/sample_example.cpp:410-413): viewport of dispW x dispH from the reduced-size render
   void tonemapZoom(const pt_Tonemapper& tm, int dispW, int dispH, uint8_t* rgba8) { check(pt_tonemap_zoom(m_ctx, &tm, dispW, dispH, rgba8)); }

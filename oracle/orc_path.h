@@ -39,6 +39,21 @@ inline vec2 GetSphericalUv(vec3 v)
   return vec2(theta * M_1_OVER_PI * 0.5f + 0.5f, gamma * M_1_OVER_PI + 0.5f);
 }
 // :80-92 (identical body: shade_state.glsl:34-39 CreateTangent)
+// ---- shaders/common.glsl:39-62 (heat-map palette) ------------------------------------------------
+inline float fade(float low, float high, float value)
+{
+  float mid   = (low + high) * 0.5f;
+  float range = (high - low) * 0.5f;
+  float x     = 1.0f - gclamp(std::fabs(mid - value) / range, 0.0f, 1.0f);
+  return gsmoothstep(0.0f, 1.0f, x);
+}
+inline vec3 temperature(float intensity)
+{
+  const vec3 blue(0.0f, 0.0f, 1.0f), cyan(0.0f, 1.0f, 1.0f), green(0.0f, 1.0f, 0.0f), yellow(1.0f, 1.0f, 0.0f), red(1.0f, 0.0f, 0.0f);
+  return (((fade(-0.25f, 0.25f, intensity) * blue + fade(0.0f, 0.5f, intensity) * cyan) + fade(0.25f, 0.75f, intensity) * green) + fade(0.5f, 1.0f, intensity) * yellow)
+         + gsmoothstep(0.75f, 1.0f, intensity) * red;
+}
+
 inline void CreateCoordinateSystem(vec3 N, vec3& Nt, vec3& Nb)
 {
   Nt = normalize((std::fabs(N.z) > 0.99999f) ? vec3(-N.x * N.y, 1.0f - N.y * N.y, -N.y * N.z) : vec3(-N.x * N.z, -N.y * N.z, 1.0f - N.z * N.z));
@@ -722,10 +737,20 @@ struct Tracer {
   {
     // pathtrace.comp:97 seeds with frame * maxSamples, pathtrace.rgen:72 (initRandom) with the frame alone
     prd.seed = tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(variant == 1 ? st.frame : st.frame * st.maxSamples));
+    // pathtrace.comp:89 `start = clockRealtimeEXT()`: real time has no CPU restatement; the oracle's clock ticks once per BVH node visited and
+    // once per triangle tested (deterministic, and proportional to where the time goes)
+    const uint64_t start = stats.nodesVisited + stats.trisTested;
     vec3 pixelColor(0);
     for(int smpl = 0; smpl < st.maxSamples; ++smpl)
       pixelColor += samplePixel(px, py, st.size[0], st.size[1]);
     pixelColor /= float(st.maxSamples);
+    if(st.debugging_mode == 12)  // eHeatmap, pathtrace.comp:108-119
+    {
+      const uint64_t end  = stats.nodesVisited + stats.trisTested;
+      const float    low  = float(st.minHeatmap), high = float(st.maxHeatmap);
+      const float    val  = gclamp((float(end - start) - low) / (high - low), 0.0f, 1.0f);
+      pixelColor          = temperature(val);
+    }
 
     if(st.frame > 0)
     {

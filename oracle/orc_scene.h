@@ -89,6 +89,7 @@ struct Scene {
   std::vector<uint32_t> triOrder;  // BVH leaf order -> world index
   std::vector<BvhNode>  bvh;
   bool                  useBvh = true;
+  bool                  anyHit = true;  // RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276): false = hit groups without an any-hit shader, every triangle opaque
   // environment
   std::vector<float>       env;  // RGBA32F
   int                      envW = 0, envH = 0;
@@ -154,7 +155,7 @@ struct Scene {
       double det3 = md[0] * (md[5] * md[10] - md[9] * md[6]) - md[4] * (md[1] * md[10] - md[9] * md[2]) + md[8] * (md[1] * md[6] - md[5] * md[2]);
 
       uint32_t flags = 0;
-      if(mat.alphaMode == 0 || (mat.pbrBaseColorFactor[3] == 1.0f && mat.pbrBaseColorTexture == -1))
+      if(!anyHit || mat.alphaMode == 0 || (mat.pbrBaseColorFactor[3] == 1.0f && mat.pbrBaseColorTexture == -1))
         flags |= TRI_OPAQUE;
       if(mat.doubleSided == 1)
         flags |= TRI_NOCULL;

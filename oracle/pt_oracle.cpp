@@ -90,6 +90,13 @@ int orc_set_variant(orc_ctx* c, int variant)
   c->variant = variant ? 1 : 0;
   return 0;
 }
+int orc_use_any_hit(orc_ctx* c, int enable)
+{
+  c->scene.anyHit = enable != 0;
+  if(!c->scene.nodes.empty())
+    c->scene.build_world();
+  return 0;
+}
 int orc_set_use_bvh(orc_ctx* c, int use)
 {
   c->scene.useBvh = use != 0;
@@ -444,6 +451,11 @@ void orc_hook_sample_env(void* user, float u, float v, float* out)
 const pt_EnvAccel* orc_env_accel(orc_ctx* c) { return c->scene.envAccel.data(); }
 
 // ---- function-level probes with the signatures of oracle/ref_glue/ref_comp.cpp (compared bit for bit in tests/test_oracle_vs_ref.py)
+void orc_temperature(float x, float* o)
+{
+  vec3 c = temperature(x);
+  o[0] = c.x; o[1] = c.y; o[2] = c.z;
+}
 void orc_spherical_uv(const float* d, float* o)
 {
   vec2 r = GetSphericalUv(vec3(d[0], d[1], d[2]));

@@ -9,7 +9,7 @@ from vk_raytrace_amd import capi, host_device as hd, synth
 
 
 class Config:
-    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0, firefly=None, variant=0):
+    def __init__(self, scene, env, width, height, depth=10, pbr=0, sunsky=None, debug=0, max_samples=1, hdr_multiplier=1.0, firefly=None, variant=0, any_hit=True):
         self.scene = scene
         if scene.vertices is None:
             scene.finalize(capi.pack_vertices)
@@ -20,6 +20,7 @@ class Config:
         self.hdr_multiplier = hdr_multiplier
         self.firefly = firefly
         self.variant = variant  # capi.PT_VARIANT_RAYQUERY / PT_VARIANT_RTX
+        self.any_hit = any_hit  # RtxPipeline::useAnyHit
         self.camera = capi.camera_lookat(scene.camera, width / height, nb_lights=len(scene.lights))
 
     def state(self, integral):
@@ -36,6 +37,7 @@ def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False, math_m
     o = orc.Oracle(threads)
     o.set_use_bvh(use_bvh)
     o.set_variant(cfg.variant)
+    o.use_any_hit(cfg.any_hit)
     o.set_scene(cfg.scene)
     integral, _ = o.set_env(cfg.env)
     o.set_camera(cfg.camera)
@@ -59,6 +61,7 @@ def render_hip(cfg, frames, device=0, shard=None, return_obj=False):
     r.set_camera(cfg.camera)
     r.set_sunsky(cfg.sunsky)
     r.set_variant(cfg.variant)
+    r.useAnyHit(cfg.any_hit)
     r.create((cfg.width, cfg.height))
     st = cfg.state(integral)
     for f in range(frames):

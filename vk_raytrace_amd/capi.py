@@ -29,10 +29,13 @@ API = [
     ("pt_build_accel", C.c_int, [_P]),
     ("pt_set_camera", C.c_int, [_P, C.POINTER(hd.SceneCamera)]),
     ("pt_set_env", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("pt_hdr_load", C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    ("pt_hdr_free", None, [C.POINTER(C.c_float)]),
     ("pt_set_sunsky", C.c_int, [_P, C.POINTER(hd.SunAndSky)]),
     ("pt_resize", C.c_int, [_P, C.c_int, C.c_int]),
     ("pt_set_shard", C.c_int, [_P, C.c_int, C.c_int]),
     ("pt_set_variant", C.c_int, [_P, C.c_int]),
+    ("pt_use_any_hit", C.c_int, [_P, C.c_int]),
     ("pt_render_frame", C.c_int, [_P, C.POINTER(hd.RtxState)]),
     ("pt_synchronize", C.c_int, [_P]),
     ("pt_read_accum", C.c_int, [_P, _P]),
@@ -121,3 +124,16 @@ def build_env_accel(env):
     if rc != PT_OK:
         raise PtError(rc, "pt_build_env_accel")
     return acc, i.value, a.value
+
+
+def load_hdr(path):
+    """pt_hdr_load: a Radiance .hdr file as an (h, w, 4) float32 array (reference: stbi_loadf in src/hdr_sampling.cpp:64)."""
+    p, w, h = C.POINTER(C.c_float)(), C.c_int(), C.c_int()
+    err = C.create_string_buffer(256)
+    rc = lib().pt_hdr_load(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h), err, 256)
+    if rc != PT_OK:
+        raise PtError(rc, err.value.decode())
+    try:
+        return np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+    finally:
+        lib().pt_hdr_free(p)

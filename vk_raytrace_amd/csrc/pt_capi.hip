@@ -34,7 +34,9 @@ struct pt_context {
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
-  bool     renderedSinceCheck = false;  // frames were launched since the traversal-stack overflow counter was last looked at
+  bool     renderedSinceCheck = false;
+  bool     anyHit = true;               // RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276); false: every triangle is opaque
+  std::vector<InstanceRec> hInstances;  // as built by pt_set_scene (flags without the useAnyHit override)  // frames were launched since the traversal-stack overflow counter was last looked at
   bool     haveScene = false, haveAccel = false, haveEnv = false;
   DeviceScene scene{};
 
@@ -180,6 +182,18 @@ int check_traversal(pt_context* c)
   if(n)
     return c->fail(PT_ERR_STATE, "BVH traversal stack overflowed %u times (the image is invalid: the acceleration structure is deeper than the traversal stack)", n);
   return PT_OK;
+}
+
+// the instance records as the kernels see them: with useAnyHit(false) every instance carries FORCE_OPAQUE, which is what a hit group
+// without an any-hit shader amounts to (src/rtx_pipeline.cpp:186-195)
+int upload_instances(pt_context* c)
+{
+  std::vector<InstanceRec> inst = c->hInstances;
+  if(!c->anyHit)
+    for(InstanceRec& I : inst)
+      I.flags |= TRI_OPAQUE;
+  InstanceRec dummy{};
+  return upload(c, c->dInstances, inst.empty() ? &dummy : inst.data(), sizeof(InstanceRec) * (inst.empty() ? 1 : inst.size()));
 }
 
 void refresh_scene_ptrs(pt_context* c)
@@ -534,7 +548,8 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   int rc;
   if((rc = upload(c, c->dVertices, d->vertices, sizeof(pt_VertexAttributes) * size_t(d->numVertices))) != PT_OK) return rc;
   if((rc = upload(c, c->dIndices, d->indices, 4 * size_t(d->numIndices))) != PT_OK) return rc;
-  if((rc = upload(c, c->dInstances, inst.data(), sizeof(InstanceRec) * inst.size())) != PT_OK) return rc;
+  c->hInstances = inst;
+  if((rc = upload_instances(c)) != PT_OK) return rc;
   if((rc = upload(c, c->dMaterials, d->materials, sizeof(pt_GltfShadeMaterial) * size_t(d->numMaterials))) != PT_OK) return rc;
   {
     pt_Light dummy{};  // "cannot be null" (src/scene.cpp:329-330); never read because nbLights == 0 then
@@ -709,6 +724,29 @@ int pt_set_variant(pt_context* c, int variant)
   if(rc != PT_OK)
     return rc;
   c->variant = variant;
+  return PT_OK;
+}
+
+int pt_use_any_hit(pt_context* c, int enable)
+{
+  CTX_CHECK(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));  // frames already handed over keep the mode they were given
+  const bool on = enable != 0;
+  if(on == c->anyHit)
+    return PT_OK;
+  c->anyHit = on;
+  if(!c->haveScene)
+    return PT_OK;
+  int rc = upload_instances(c);
+  if(rc != PT_OK)
+    return rc;
+  refresh_scene_ptrs(c);
+  if(c->haveAccel)
+  {  // the opaque / non-opaque classification is baked into the triangle records: rebuild, like useAnyHit re-creates the pipeline
+    c->haveAccel = false;
+    return pt_build_accel(c);
+  }
   return PT_OK;
 }
 

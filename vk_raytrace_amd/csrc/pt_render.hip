@@ -159,6 +159,22 @@ PT_DEV f3 offset_ray(f3 p, f3 n)
 }
 
 // ---- k_generate -----------------------------------------------------------------------------------------
+// heat-map support: nanoseconds since t0 (low 32 bits of the 100 MHz wall clock)
+PT_DEV float heat_ns(uint32_t t0) { return float(uint32_t(wall_clock64()) - t0) * 10.0f; }
+// shaders/common.glsl:39-62
+PT_DEV float heat_fade(float low, float high, float value)
+{
+  float mid = (low + high) * 0.5f, range = (high - low) * 0.5f;
+  float x   = 1.0f - clampf(fabsf(mid - value) / range, 0.0f, 1.0f);
+  return smooth(0.0f, 1.0f, x);
+}
+PT_DEV f3 heat_temperature(float intensity)
+{
+  const f3 blue = f3{0.f, 0.f, 1.f}, cyan = f3{0.f, 1.f, 1.f}, green = f3{0.f, 1.f, 0.f}, yellow = f3{1.f, 1.f, 0.f}, red = f3{1.f, 0.f, 0.f};
+  return (((blue * heat_fade(-0.25f, 0.25f, intensity) + cyan * heat_fade(0.0f, 0.5f, intensity)) + green * heat_fade(0.25f, 0.75f, intensity)) + yellow * heat_fade(0.5f, 1.0f, intensity))
+         + red * smooth(0.75f, 1.0f, intensity);
+}
+
 __global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
 {
   uint32_t       slot  = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,8 +249,12 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
 //            queue is empty, until all are done).
 // Settling rays outside the run loop keeps the hot loop to the node step and the triangle test; a finished lane
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
+// HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
+// instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
+template <bool HEAT>
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
+  uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -281,6 +301,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
         }
         if(fallback)
           enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
+        if(HEAT)
+          rb.ps.rayO[pslot].w += heat_ns(heatT0);
         alive = false;
       }
     }
@@ -293,6 +315,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
       alive = true;
       ++nRays;
+      if(HEAT)
+        heatT0 = uint32_t(wall_clock64());
     }
     if(!__ballot(alive))
       break;
@@ -770,7 +794,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceSce
   if(i < count)
   {
     slot = queueIn[i];
-    to   = shade_path<MODE>(S, rb, fp, slot, depth, events);
+    if(MODE < 0 && fp.st.debugging_mode == PT_DEBUG_HEATMAP)
+    {  // heat map: the path's cost travels in rayO.w (shade_path rewrites rayO for the next bounce: carry the old value over)
+      const uint32_t t0   = uint32_t(wall_clock64());
+      const float    cost = rb.ps.rayO[slot].w;
+      to                  = shade_path<MODE>(S, rb, fp, slot, depth, events);
+      rb.ps.rayO[slot].w  = cost + heat_ns(t0);
+    }
+    else
+      to = shade_path<MODE>(S, rb, fp, slot, depth, events);
   }
   // queue appends and statistics: wave totals into LDS, one global atomic per workgroup and counter (a returning
   // atomic per wave on one address costs ~11 ns each, serialised: 2.9 ms for the 260 k waves of a bounce-0 batch)
@@ -836,9 +868,11 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
+template <bool HEAT>
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
+  uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
@@ -890,6 +924,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
           enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
         else
           survivor = finish_bounce_core(rb, pslot, inShadow, seed) && !lastBounce;
+        if(HEAT)
+          rb.ps.rayO[pslot].w += heat_ns(heatT0);
         alive = false;
       }
     }
@@ -902,6 +938,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
       alive = true;
       ++nRays;
+      if(HEAT)
+        heatT0 = uint32_t(wall_clock64());
     }
     if(!__ballot(alive))
       break;
@@ -1198,14 +1236,22 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
     if(lum > st.fireflyClampThreshold)
       r *= st.fireflyClampThreshold / lum;
 
-    f3 sum = (fp.sample == 0) ? splat3(0.0f) : xyz(rb.ps.sum[slot]);
+    const bool heat = st.debugging_mode == PT_DEBUG_HEATMAP;
+    float4     prev = (fp.sample == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : rb.ps.sum[slot];
+    f3         sum  = xyz(prev);
     sum += r;
+    const float cost = prev.w + (heat ? rb.ps.rayO[slot].w : 0.0f);  // nanoseconds this pixel's samples spent in the trace and shade kernels
     if(fp.sample + 1 < st.maxSamples)
     {
-      rb.ps.sum[slot] = make_float4(sum.x, sum.y, sum.z, 0.f);
+      rb.ps.sum[slot] = make_float4(sum.x, sum.y, sum.z, cost);
       continue;
     }
-    const f3  pixel = sum / float(st.maxSamples);
+    f3 pixel = sum / float(st.maxSamples);
+    if(heat)
+    {  // pathtrace.comp:108-119
+      const float low = float(st.minHeatmap), high = float(st.maxHeatmap);
+      pixel           = heat_temperature(clampf((cost - low) / (high - low), 0.0f, 1.0f));
+    }
     const int frame = st.frame + int(fb);
     acc             = frame > 0 ? lerp(acc, pixel, 1.0f / float(frame + 1)) : pixel;
   }
@@ -1510,16 +1556,19 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
         sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
         traceIn = rb.queueT;
       }
-      if(depth < g_tuning.packetClosestBounces)
+      const bool heat = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage
+      if(heat)
+        k_closest_p<true><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+      else if(depth < g_tuning.packetClosestBounces)
       {
         const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
         k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
-        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+        k_closest_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
       }
       else if(depth < g_tuning.simpleClosestBounces)
         k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
       else
-        k_closest_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+        k_closest_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
       k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
@@ -1541,7 +1590,9 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
         sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
         shadowIn = rb.queueT;
       }
-      if(depth < g_tuning.simpleShadowBounces)
+      if(heat)
+        k_shadow_p<true><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+      else if(depth < g_tuning.simpleShadowBounces)
         k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       else
       {
@@ -1549,10 +1600,10 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
         {
           const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
           k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
-          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+          k_shadow_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
         }
         else
-          k_shadow_p<<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
       }
       k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       pt_timers_end(tm, stream, 3);

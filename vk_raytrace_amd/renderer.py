@@ -11,6 +11,7 @@ Vulkan handles do not exist on the target: what reached the shaders through desc
 the command buffer is the context's own HIP stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -116,6 +117,10 @@ class HipRenderer(Renderer):
     def set_sunsky(self, ss: hd.SunAndSky):
         self._check(self._lib.pt_set_sunsky(self._ctx, C.byref(ss)))
 
+    def useAnyHit(self, enable):
+        """RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276)"""
+        self._check(self._lib.pt_use_any_hit(self._ctx, int(bool(enable))))
+
     def set_variant(self, variant):
         """capi.PT_VARIANT_RAYQUERY (the reference's RayQuery renderer, default) or capi.PT_VARIANT_RTX (its RtxPipeline)."""
         self._check(self._lib.pt_set_variant(self._ctx, int(variant)))
@@ -212,7 +217,10 @@ class SampleExample:
         self.resetFrame()
 
     # sample_example.cpp:103-111 (the image arrives decoded: stbi_loadf has no counterpart here)
-    def loadEnvironmentHdr(self, env_rgba32f):
+    def loadEnvironmentHdr(self, env):
+        """SampleExample::loadEnvironmentHdr (sample_example.cpp:102-112): `env` is the path of a Radiance .hdr file (decoded by
+        pt_hdr_load, the stbi_loadf of hdr_sampling.cpp:64) or an (h, w, 4) float32 array."""
+        env_rgba32f = capi.load_hdr(env) if isinstance(env, (str, bytes, os.PathLike)) else env
         integral, _ = self.m_pRender.set_env(env_rgba32f)
         self.m_rtxState.fireflyClampThreshold = integral * 4.0  # "magic", sample_example.cpp:110
         self.resetFrame()
