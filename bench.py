@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"], help="BASELINE.json configuration (stand-in scene); c3 is the bench line, the others are for the results table")
     ap.add_argument("--emulate-shard", default="", help="R/N: render only rank R's tiles of an N-GPU run on this one GPU (scaling estimate; value = this shard's rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events (roofline fields become null)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the serialised profiling pass (roofline fields become null)")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the frame-by-frame (render + tonemap) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     return ap.parse_args()
 
@@ -119,7 +120,6 @@ def main():
         frame += 1
     sync()
     r.reset_stats()
-    r.set_profiling(not args.no_profile)
 
     sync()
     t0 = time.perf_counter()
@@ -138,22 +138,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = r.stats()
-    r.set_profiling(False)
 
-    # the one collective of the path (untimed, reported)
-    t0 = time.perf_counter()
-    img = shard.gather_framebuffer(r, rank, world, f"cuda:{local_rank}" if dist is not None else None, force=force_dist)
-    gather_ms = (time.perf_counter() - t0) * 1e3
+    # the one collective of the path (untimed, reported): libptmi's own RCCL gather behind the C ABI (pt_gather_shards / pt_gather_finish)
+    if world > 1 or force_dist:
+        gatherer = shard.NativeGather(rank, world, local_rank, dist)
+        r.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        img = gatherer.gather(r)
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        gatherer.close()
+    else:
+        t0 = time.perf_counter()
+        img = r.read_accum()
+        gather_ms = (time.perf_counter() - t0) * 1e3
 
     if dist is not None:
         # whole-job counters
         keys = ["closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups"]
-        v = torch.tensor([float(stats[k]) for k in keys] + [stats["msTraceClosest"], stats["msShade"], stats["msTraceShadow"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+        v = torch.tensor([float(stats[k]) for k in keys], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         for i, k in enumerate(keys):
             stats[k] = int(v[i].item())
-        # kernel time: mean over ranks (each rank runs its own launches)
-        stats["msTraceClosest"], stats["msShade"], stats["msTraceShadow"] = (float(v[len(keys) + i].item()) / world for i in range(3))
 
     if rank != 0:
         if dist is not None:
@@ -231,49 +238,114 @@ def main():
         }
     elif os.path.exists(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")):
         alg = json.load(open(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")))
-
-    # ---- roofline of the dominant kernel (k_closest: BVH traversal + ray/triangle tests) ----
     if alg is not None:
         rays = out["rays"]
-        bytes_closest = rays["closestRays"] * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36)
-        bytes_shadow = rays["shadowRays"] * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36)
-        b_total = (bytes_closest + bytes_shadow + rays["shadedHits"] * (348 + 16 * alg["tex_taps_per_hit"]) + rays["alphaTests"] * 340 + rays["neeLookups"] * 80
-                   + rays["misses"] * 64 + samples * 32)
+        b_total = (rays["closestRays"] * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + rays["shadowRays"] * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36)
+                   + rays["shadedHits"] * (348 + 16 * alg["tex_taps_per_hit"]) + rays["alphaTests"] * 340 + rays["neeLookups"] * 80 + rays["misses"] * 64 + samples * 32)
         out["alg_bytes_per_sample"] = b_total / samples
-        out["alg_GBps_whole_pipeline"] = b_total / elapsed / 1e9
         out["alg_model"] = alg
-        ms_c = stats["msTraceClosest"]
-        launches = max(1, stats["launchesTraceClosest"])
+
+    # ---- measurement passes after the timed region (never part of `value`) ---------------------------------------------------------
+    # (1) ceilings measured on this box: VALU issue (independent wave64 v_fmac_f32, 8 waves/SIMD on every CU) and HBM streaming
+    peaks = r.measure_peaks()
+    out["calibration"] = {"valu_G_wave_instr_per_s": peaks["valuWaveInstrPerSec"] / 1e9, "hbm_copy_GBps": peaks["hbmCopyBytesPerSec"] / 1e9,
+                          "hbm_read_GBps": peaks["hbmReadBytesPerSec"] / 1e9, "compute_units": peaks["computeUnits"], "clock_MHz": peaks["clockMHz"],
+                          "note": "pt_measure_peaks on this device; theoretical VALU issue = CUs x 4 SIMDs x clock / 2 cycles (MI355X_MICROARCH.md), tools/valu_peak.hip shows 0.45-0.8 of it depending on the instruction form"}
+    # (2) the interactive path: SampleExample's loop tonemaps after every frame, so every frame is its own batch of one
+    if not args.no_interactive and world == 1:
+        tm = hd.default_tonemapper()
+        n_i = 24
+        for _ in range(4):
+            st.frame = frame; r.setPushContants(st); r.run(); r.tonemap(tm); frame += 1
+        t0 = time.perf_counter()
+        for _ in range(n_i):
+            st.frame = frame; r.setPushContants(st); r.run(); r.tonemap(tm); frame += 1
+        ti = time.perf_counter() - t0
+        out["interactive"] = {"value": W * H * n_i / ti / 1e6, "unit": "Msamples/s", "ms_per_frame": ti / n_i * 1e3, "frames": n_i,
+                              "note": "render + pt_tonemap (RGBA8 read back to the host) per frame: batch = 1, like SampleExample's display loop"}
+    # (3) standalone kernel durations: the timed loop overlaps four launch sequences on separate streams, so a HIP-event bracket there is not a
+    # kernel's own duration.  One batch is rendered again on a second context with ONE frame slot (PT_TUNE inflight=1): nothing overlaps,
+    # HIP events on the launching stream bracket each stage.
+    serial = None
+    if not args.no_profile and not args.emulate_shard:
+        os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1").lstrip(",")
+        r2 = HipRenderer()
+        r2.setup(local_rank)
+        r2.set_shard(rank, world)
+        r2.set_scene(wl.scene)
+        r2.set_env(wl.env)
+        r2.set_camera(cam)
+        r2.set_sunsky(hd.default_sun_and_sky())
+        r2.create((W, H))
+        nser = min(args.steps, 32)
+        for phase in range(2):  # warm-up batch, then the measured one
+            r2.reset_stats()
+            r2.set_profiling(phase == 1)
+            t0 = time.perf_counter()
+            for f in range(nser):
+                st.frame = f; r2.setPushContants(st); r2.run()
+            r2.synchronize()
+            tser = time.perf_counter() - t0
+        s2 = r2.stats()
+        r2.set_profiling(False)
+        r2.destroy()
+        nsamp = (W * H * nser) / max(1, world)  # samples of the measured batch on this GPU (image tiles are split evenly)
+        serial = {"frames": nser, "wall_ms": tser * 1e3, "launches_per_stage": int(s2["launchesTraceClosest"]),
+                  "stage_ms": {"generate": s2["msGenerate"], "closest": s2["msTraceClosest"], "shade": s2["msShade"], "shadow": s2["msTraceShadow"], "accumulate": s2["msAccumulate"]},
+                  "rays": {k: s2[k] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")}, "samples": nsamp}
+        out["serialised"] = serial
+
+    # ---- roofline of the dominant kernel: chosen by its standalone time, priced on algorithmic bytes --------------------
+    if alg is not None and serial is not None:
+        sr = serial["rays"]
+        stage_bytes = {
+            "closest": sr["closestRays"] * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + sr["alphaTests"] * 340 * (sr["closestRays"] / max(1, sr["closestRays"] + sr["shadowRays"])),
+            "shadow": sr["shadowRays"] * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36) + sr["alphaTests"] * 340 * (sr["shadowRays"] / max(1, sr["closestRays"] + sr["shadowRays"])),
+            "shade": sr["shadedHits"] * (348 + 16 * alg["tex_taps_per_hit"]) + sr["neeLookups"] * 80 + sr["misses"] * 64,
+            "generate": 0.0,
+            "accumulate": serial["samples"] * 32.0,
+        }
+        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "generate": "k_generate", "accumulate": "k_accumulate"}
+        launches = max(1, serial["launches_per_stage"])
+        table = {}
+        for k, ms in serial["stage_ms"].items():
+            n_l = launches if k in ("closest", "shade", "shadow") else max(1, launches // max(1, wl.depth))
+            table[k] = {"kernel": kernels[k], "ms": ms, "launches": n_l, "avg_launch_ms": ms / n_l, "alg_bytes": stage_bytes[k],
+                        "alg_GBps": (stage_bytes[k] / (ms * 1e-3) / 1e9) if ms > 0 else None}
+        out["stages_serialised"] = table
+        dom = max(("closest", "shade", "shadow"), key=lambda k: serial["stage_ms"][k])
+        d = table[dom]
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r1.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_closest_bytes_per_launch")
+                tj = json.load(open(tpath))
+                per_sample = tj["hbm_bytes_per_sample"].get(dom)
+                traffic = per_sample * serial["samples"] / d["launches"] if per_sample else None
+                out["hbm_measured"] = {"bytes_per_sample": tj["hbm_bytes_per_sample"]["total"], "GBps": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9,
+                                       "frac": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
+                                       "source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, gfx950 corrections) x this run's rate",
+                                       "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
             except Exception:
                 traffic = None
-        if ms_c > 0:
-            achieved = bytes_closest / max(1, world) / (ms_c * 1e-3) / 1e9  # per GPU: whole-job bytes / ranks over the mean per-rank stage time
-            out["roofline"] = {"bound": "hbm", "kernel": "k_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": traffic, "alg_bytes_per_launch": bytes_closest / max(1, world) / launches, "avg_launch_ms": ms_c / launches, "launches": launches,
-                               "note": "algorithmic bytes (reference-layout BVH2 visits x 32 B + triangle tests x 36 B of this stage's rays) are served from L2 / Infinity Cache: "
-                                       "`traffic` is the measured HBM bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE passes), so `frac` can exceed 1; "
-                                       "the binding resource is VALU issue -- see issue_roofline"}
-        else:
-            out["roofline"] = None
-    # ---- what actually bounds the path: VALU issue.  Instruction counts per sample are a property of the code and the workload
-    # (rocprofv3 PMC pass, profiles/valu_r1.json); the rate is this run's.  Peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per
-    # 4 cycles and SIMD, 2.4 GHz (MI355X_MICROARCH.md).
-    vpath = os.path.join(ROOT, "profiles", "valu_r1.json")
+        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": (d["alg_GBps"] / HBM_PEAK_GBS) if d["alg_GBps"] else None, "traffic": traffic,
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                           "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
+                           "note": "dominant stage = largest STANDALONE time (serialised pass: one frame slot, nothing overlapped, HIP events on the launching stream); "
+                                   "achieved = algorithmic bytes of that stage per launch / its average launch duration; `traffic` = measured HBM bytes per launch (PMC)"}
+    # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round,
+    # profiles/r02_valu.json); the rate is this run's; the ceiling is the one measured above on this box.
+    vpath = os.path.join(ROOT, "profiles", "r02_valu.json")
     if args.workload == "c3" and os.path.exists(vpath):
         try:
             per_sample = json.load(open(vpath))["valu_wave_instr_per_sample"]
-            peak = 256 * 4 * 2.4e9 / 4
+            peak = out["calibration"]["valu_G_wave_instr_per_s"] * 1e9
             ach = per_sample * samples / elapsed / max(1, world)
             out["issue_roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU", "frac": ach / peak,
-                                     "valu_wave_instr_per_sample": per_sample, "source": "profiles/valu_r1.json"}
+                                     "valu_wave_instr_per_sample": per_sample, "source": "profiles/r02_valu.json x this run's rate / this run's calibration"}
         except Exception:
             pass
-    out["stage_ms"] = {k: stats[k] for k in ("msGenerate", "msTraceClosest", "msShade", "msTraceShadow", "msAccumulate")}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

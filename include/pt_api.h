@@ -153,6 +153,25 @@ int pt_local_shard(pt_context* ctx, void** device_ptr, size_t* bytes, int* num_l
  * pt_tonemap see the full image. */
 int pt_scatter_shards(pt_context* ctx, const void* gathered_dev, int nranks);
 
+/* The one collective of the path, natively over RCCL / xGMI (no reference counterpart): every rank's shard goes to `root`
+ * in one grouped operation (nranks-1 ncclRecv on the root, one ncclSend per peer: each shard on its own point-to-point link), then the root
+ * places the tiles.  librccl.so is opened on first use.
+ *   one process per GPU : rank 0 calls pt_comm_get_unique_id and distributes the 128 bytes; every rank pt_comm_init_rank; after rendering
+ *                         every rank pt_gather_shards(ctx, comm, 0); rank 0 pt_gather_finish(ctx), then pt_read_accum / pt_tonemap.
+ *   one process, N GPUs : pt_comm_init_all; pt_comm_group_begin(); pt_gather_shards(ctx[i], comm[i], 0) for every i; pt_comm_group_end();
+ *                         pt_gather_finish(ctx[0]).
+ * The communicator's rank / size must equal pt_set_shard's. */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+int pt_comm_get_unique_id(unsigned char id_out[PT_COMM_ID_BYTES]);
+int pt_comm_init_rank(int nranks, const unsigned char id[PT_COMM_ID_BYTES], int rank, int device_ordinal, pt_comm** out_comm);
+int pt_comm_init_all(int ndev, const int* device_ordinals, pt_comm** out_comms);
+int pt_comm_destroy(pt_comm* comm);
+int pt_comm_group_begin(void);
+int pt_comm_group_end(void);
+int pt_gather_shards(pt_context* ctx, pt_comm* comm, int root);
+int pt_gather_finish(pt_context* ctx);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 
 /* enable != 0: bracket every kernel with HIP events on the render stream and accumulate per-stage

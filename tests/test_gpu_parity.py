@@ -297,6 +297,37 @@ print("GATHER_OK")
     assert "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_native_rccl_gather_single_rank():
+    """The C-ABI gather (pt_comm_init_rank -> pt_gather_shards -> pt_gather_finish: RCCL opened by libptmi itself, no torch) on one rank must
+    reproduce pt_read_accum bit for bit; a communicator whose size disagrees with pt_set_shard is rejected.  Fresh process: RCCL start-up."""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np
+from tests.common import Config, render_hip
+from vk_raytrace_amd import synth, shard, capi
+cfg = Config(synth.feature_box(tex_size=32), synth.procedural_sky(128, 64), 100, 70)
+h, r = render_hip(cfg, 2, return_obj=True)
+g = shard.NativeGather(0, 1, 0)
+img = g.gather(r)
+assert np.array_equal(img, h)
+r.set_shard(0, 2)
+r.create((cfg.width, cfg.height))
+try:
+    r._check(capi.lib().pt_gather_shards(r._ctx, g.comm, 0))
+    raise SystemExit("a 1-rank communicator was accepted for a 2-rank shard")
+except capi.PtError as e:
+    assert e.code == capi.PT_ERR_INVALID
+g.close()
+print("NATIVE_GATHER_OK")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "NATIVE_GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def _render_in_subprocess(tune, frames=5, max_samples=1, scene="feature"):
     """Renders in a fresh process with PT_TUNE set (the launch-policy knobs are read once at pt_create) and returns
     the accumulation buffer."""

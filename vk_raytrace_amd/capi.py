@@ -44,6 +44,14 @@ API = [
     ("pt_tonemap_zoom", C.c_int, [_P, C.POINTER(hd.Tonemapper), C.c_int, C.c_int, _P]),
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
+    ("pt_comm_get_unique_id", C.c_int, [_P]),
+    ("pt_comm_init_rank", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("pt_comm_init_all", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    ("pt_comm_destroy", C.c_int, [_P]),
+    ("pt_comm_group_begin", C.c_int, []),
+    ("pt_comm_group_end", C.c_int, []),
+    ("pt_gather_shards", C.c_int, [_P, _P, C.c_int]),
+    ("pt_gather_finish", C.c_int, [_P]),
     ("pt_pick", C.c_int, [_P, C.c_float, C.c_float, _P, _P, C.POINTER(hd.PickResult)]),
     ("pt_fpmath_eval", C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
     ("pt_measure_peaks", C.c_int, [_P, C.POINTER(hd.Peaks)]),

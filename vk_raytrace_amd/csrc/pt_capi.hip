@@ -56,7 +56,8 @@ struct pt_context {
     bool          launched  = false;  // a launch sequence was enqueued on this slot since the last synchronisation
   };
   FrameSlot slots[PT_MAX_INFLIGHT];
-  int       inflight     = 1;
+  int       inflight     = 1;  // frame slots in use (<= inflightMax: pt_resize drops slots when the device memory is short)
+  int       inflightMax  = 1;  // frame slots created (streams / events exist for these)
   // frames handed to pt_render_frame but not launched yet: consecutive frames with identical state are traced as one
   // batch (flushed when full and by every call that reads results or changes inputs)
   pt_RtxState pendState{};
@@ -67,7 +68,7 @@ struct pt_context {
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
   DevBuf   dPick;
-  DevBuf   dRowMajor, dRgba8, dMean, dMips, dFullTiles, dFullSlotTile, dTileLocalIndex;
+  DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
   StageTimers timers;
   pt_Stats    stats{};
@@ -112,6 +113,23 @@ int dev_alloc(pt_context* c, DevBuf& b, size_t bytes)
   HIP_TRY(c, hipMalloc(&b.p, bytes));
   b.bytes = bytes;
   return PT_OK;
+}
+void dev_free(DevBuf& b);
+// like dev_alloc, but a failed allocation is an answer (false), not an error
+bool dev_alloc_quiet(DevBuf& b, size_t bytes)
+{
+  if(b.p && b.bytes >= bytes && b.bytes <= bytes * 2 + 4096)
+    return true;
+  dev_free(b);
+  if(bytes == 0)
+    bytes = 16;
+  if(hipMalloc(&b.p, bytes) != hipSuccess)
+  {
+    b.p = nullptr;
+    return false;
+  }
+  b.bytes = bytes;
+  return true;
 }
 void dev_free(DevBuf& b)
 {
@@ -325,6 +343,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
+    if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) g_tuning.stateGB = v;
     if(const char* p = strstr(tune, "shadeSpec=")) if(sscanf(p, "shadeSpec=%d", &v) == 1) g_tuning.shadeSpecialised = v;
     if(const char* p = strstr(tune, "sortClosest=")) if(sscanf(p, "sortClosest=%d", &v) == 1) g_tuning.sortClosest = v;
     if(const char* p = strstr(tune, "sortShadow=")) if(sscanf(p, "sortShadow=%d", &v) == 1) g_tuning.sortShadow = v;
@@ -340,6 +359,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   }
   c->timers.stream = c->stream;
   c->inflight      = g_tuning.framesInFlight < 1 ? 1 : (g_tuning.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : g_tuning.framesInFlight);
+  c->inflightMax = c->inflight;
   for(int i = 0; i < c->inflight; ++i)
     if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess)
     {
@@ -366,7 +386,7 @@ int pt_destroy(pt_context* c)
   (void)sync_all(c);
   DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
-                   &c->dMean, &c->dMips, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
+                   &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
   for(auto& fs : c->slots)
@@ -797,18 +817,51 @@ int pt_resize(pt_context* c, int width, int height)
   // frames per batch: the tuning value, bounded so that one frame slot's path state stays below 2^26 paths (~11 GB):
   // 32 frames of a full 1080p image, 64 of an 8-GPU shard (measured best for both, profiles/r01_scaling_estimate.txt)
   c->batchMax = std::max(1, std::min(g_tuning.batch, int((1u << 26) / (c->numSlots ? c->numSlots : 1u))));
-  const size_t n = size_t(c->numSlots ? c->numSlots : 1) * size_t(c->batchMax);
-  for(int i = 0; i < c->inflight; ++i)
+  // In-flight path state: 9 float4 arrays + 9 index queues per path slot, times the batch, times the frame slots -- 38 GB for a 1080p image at
+  // the defaults, sized for 288 GB of HBM.  It is a budget, not a requirement: PT_TUNE stateGB=<n> (or what hipMemGetInfo reports as free,
+  // minus a reserve) caps it, and an allocation that still fails halves the batch / drops frame slots and retries, down to one frame on
+  // one slot, before PT_ERR_OOM is reported.  Smaller batches only cost throughput, never results.
+  const size_t perPath = 9 * sizeof(float4) + 9 * sizeof(uint32_t);
+  c->inflight          = c->inflightMax;
   {
-    pt_context::FrameSlot& fs = c->slots[i];
-    for(DevBuf& bf : fs.dState)
-      if((rc = dev_alloc(c, bf, sizeof(float4) * n)) != PT_OK) return rc;
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
-    for(DevBuf* bf : q)
-      if((rc = dev_alloc(c, *bf, 4 * n)) != PT_OK) return rc;
-    if((rc = dev_alloc(c, fs.dSortHist, sizeof(uint32_t) * SORT_BINS)) != PT_OK) return rc;
-    if((rc = dev_alloc(c, fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2))) != PT_OK) return rc;
-    HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
+    size_t freeB = 0, totalB = 0;
+    (void)hipMemGetInfo(&freeB, &totalB);
+    double budget = g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : double(freeB) * 0.85;
+    while(c->batchMax > 1 && double(perPath) * double(c->numSlots ? c->numSlots : 1) * c->batchMax * c->inflight > budget)
+      c->batchMax = (c->batchMax + 1) / 2;
+  }
+  for(;;)
+  {
+    const size_t n  = size_t(c->numSlots ? c->numSlots : 1) * size_t(c->batchMax);
+    bool         ok = true;
+    for(int i = 0; i < c->inflight && ok; ++i)
+    {
+      pt_context::FrameSlot& fs = c->slots[i];
+      for(DevBuf& bf : fs.dState)
+        ok = ok && dev_alloc_quiet(bf, sizeof(float4) * n);
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      for(DevBuf* bf : q)
+        ok = ok && dev_alloc_quiet(*bf, 4 * n);
+      ok = ok && dev_alloc_quiet(fs.dSortHist, sizeof(uint32_t) * SORT_BINS) && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
+      if(ok)
+        HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
+    }
+    if(ok)
+      break;
+    (void)hipGetLastError();
+    for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+    {  // release everything before retrying smaller
+      pt_context::FrameSlot& fs = c->slots[i];
+      for(DevBuf& bf : fs.dState) dev_free(bf);
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      for(DevBuf* bf : q) dev_free(*bf);
+    }
+    if(c->batchMax > 1)
+      c->batchMax = (c->batchMax + 1) / 2;
+    else if(c->inflight > 1)
+      c->inflight = (c->inflight + 1) / 2;
+    else
+      return c->fail(PT_ERR_OOM, "pt_resize: not enough device memory for the path state of one %dx%d frame (%zu bytes per path)", width, height, perPath);
   }
   if((rc = dev_alloc(c, c->dFrame, sizeof(float4) * size_t(c->maxTilesPerRank ? c->maxTilesPerRank : 1) * 1024u)) != PT_OK) return rc;
   if((rc = upload(c, c->dSlotTile, local.data(), 4 * local.size())) != PT_OK) return rc;
@@ -1018,16 +1071,16 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
 }
 
 // ---- on-box calibration of the two rooflines bench.py prices against (no reference counterpart) ------------------------------------------
-// VALU issue: every lane runs 8 independent v_fma_f32 chains (inline asm: the compiler can neither pack two of them into v_pk_fma_f32 nor
-// drop them), 8 waves per SIMD on every CU; the result is wave-instructions per second over the whole chip.
+// VALU issue: every lane runs 8 independent v_fmac_f32 chains (the form with the highest measured issue rate, tools/valu_peak.hip; inline asm: the
+// compiler can neither pack two of them into v_pk_fma_f32 nor drop them), 8 waves per SIMD on every CU; the result is wave-instructions per second over the whole chip.
 __global__ void __launch_bounds__(256) k_calib_valu(int iters, float* out)
 {
   float a0 = threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
   const float m = 0.999f, c = 0.001f;
   for(int i = 0; i < iters; ++i)
   {
-    asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
-                 "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+    asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                 "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                  : "v"(m), "v"(c));
   }
@@ -1244,6 +1297,41 @@ int pt_scatter_shards(pt_context* c, const void* gathered_dev, int nranks)
   HIP_TRY(c, sync_all(c));
   c->haveFull = true;
   return PT_OK;
+}
+
+// internal hooks of pt_comm.cpp (hidden: not part of the ABI)
+__attribute__((visibility("hidden"))) int pt_comm_internal_shard(pt_context* c, void** shard, size_t* bytes, int* rank, int* nranks, void** gatherBuf, hipStream_t* stream, int* device)
+{
+  CTX_CHECK(c);
+  if(c->width == 0)
+    return c->fail(PT_ERR_STATE, "pt_gather_shards before pt_resize");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));  // the shard is complete; the gather is enqueued on the context's stream
+  *shard  = c->dFrame.p;
+  *bytes  = sizeof(float4) * size_t(c->maxTilesPerRank) * 1024u;
+  *rank   = c->rank;
+  *nranks = c->nranks;
+  *stream = c->stream;
+  *device = c->device;
+  if(gatherBuf)
+  {
+    int rc = dev_alloc(c, c->dGather, *bytes * size_t(c->nranks));
+    if(rc != PT_OK)
+      return rc;
+    *gatherBuf = c->dGather.p;
+  }
+  return PT_OK;
+}
+__attribute__((visibility("hidden"))) void pt_comm_internal_fail(pt_context* c, int code, const char* msg) { c->fail(code, "%s", msg); }
+
+int pt_gather_finish(pt_context* c)
+{
+  CTX_CHECK(c);
+  if(!c->dGather.p)
+    return c->fail(PT_ERR_STATE, "pt_gather_finish without pt_gather_shards on the root");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return pt_scatter_shards(c, c->dGather.p, c->nranks);
 }
 
 int pt_set_profiling(pt_context* c, int enable)

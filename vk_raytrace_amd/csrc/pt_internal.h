@@ -63,6 +63,7 @@ struct PtTuning {
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
   int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of
                                    // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
+  int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
   int shadeSpecialised     = 0;    // k_shade<0 / 1>: the common case (no debug output, no sun & sky, no punctual lights) compiled per BSDF
   int sortClosest          = 0;    // bounce >= 1: the closest-hit queue is binned by (direction octant, origin cell) before it is traced, so that the 64 rays a
                                    // wave of the trace machine pulls together (and refills with) start in the same region with the same direction signs

@@ -64,6 +64,45 @@ def gather_framebuffer(renderer, rank, nranks, device, force=False):
     return renderer.read_accum()
 
 
+class NativeGather:
+    """The gather through libptmi's own RCCL path (pt_comm_* / pt_gather_shards / pt_gather_finish, csrc/pt_comm.cpp) -- what a C++ host
+    calls; torch is used for nothing but handing rank 0's ncclUniqueId to the other processes.  `gather_framebuffer` above is the same
+    exchange through torch.distributed and serves as its cross-check."""
+
+    def __init__(self, rank, nranks, device_ordinal, dist=None):
+        import ctypes as C
+        from . import capi
+        self._C, self._capi, self._lib = C, capi, capi.lib()
+        self.rank, self.nranks = rank, nranks
+        ident = (C.c_ubyte * 128)()
+        if rank == 0 and self._lib.pt_comm_get_unique_id(ident) != capi.PT_OK:
+            raise capi.PtError(capi.PT_ERR_HIP, "pt_comm_get_unique_id (is librccl.so present?)")
+        if nranks > 1:
+            if dist is None:
+                raise ValueError("more than one rank needs a torch.distributed process group to distribute the ncclUniqueId")
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.comm = C.c_void_p()
+        rc = self._lib.pt_comm_init_rank(nranks, ident, rank, device_ordinal, C.byref(self.comm))
+        if rc != capi.PT_OK:
+            raise capi.PtError(rc, "pt_comm_init_rank")
+
+    def gather(self, renderer):
+        """Full RGBA32F image on rank 0, None elsewhere."""
+        renderer._check(self._lib.pt_gather_shards(renderer._ctx, self.comm, 0))
+        if self.rank != 0:
+            renderer.synchronize()
+            return None
+        renderer._check(self._lib.pt_gather_finish(renderer._ctx))
+        return renderer.read_accum()
+
+    def close(self):
+        if self.comm:
+            self._lib.pt_comm_destroy(self.comm)
+            self.comm = None
+
+
 def assemble_rowmajor(shards, width, height):
     """Host-side assembly used on the CPU (gloo) path: shards[r] is rank r's row-major image in which
     only its own pixels are valid."""
