@@ -215,27 +215,32 @@ struct Tracer {
   }
 
   // ---- shaders/traceray_rq.glsl:153-185 on trace contract T6
+  // shaders/traceray_rq.glsl:153-185 on trace contract T6: candidates strictly in key order inside (0, maxDist); an opaque candidate commits
+  // without a draw, a non-opaque one runs HitTest; the first commit ends the ray (gl_RayFlagsTerminateOnFirstHitEXT)
   bool AnyHitRq(const Ray& r, float maxDist)
   {
     stats.shadowRays++;
     const uint64_t n0 = stats.nodesVisited, t0 = stats.trisTested;
-    Candidate      o  = sc.query(r.origin, r.direction, maxDist, 0.0f, ~0u, 2, &stats);
-    stats.nodesShadow += stats.nodesVisited - n0;
-    stats.trisShadow += stats.trisTested - t0;
-    if(o.found)
-      return true;
-    float    tPrev = 0.0f;
-    uint32_t wPrev = ~0u;
+    float          tPrev = 0.0f;
+    uint32_t       wPrev = ~0u;
+    bool           first = true, found = false;
     for(;;)
     {
-      Candidate c = sc.query(r.origin, r.direction, maxDist, tPrev, wPrev, 1, nullptr);
+      Candidate c = sc.query(r.origin, r.direction, maxDist, tPrev, wPrev, 0, first ? &stats : nullptr);
+      first       = false;
       if(!c.found)
-        return false;
-      if(HitTest(c.w, c.u, c.v))
-        return true;
+        break;
+      if((sc.tris[c.w].flags & TRI_OPAQUE) || HitTest(c.w, c.u, c.v))
+      {
+        found = true;
+        break;
+      }
       tPrev = c.t;
       wPrev = c.w;
     }
+    stats.nodesShadow += stats.nodesVisited - n0;
+    stats.trisShadow += stats.trisTested - t0;
+    return found;
   }
 
   // ---- shaders/shade_state.glsl:63-145

@@ -127,7 +127,7 @@ struct rayQueryEXT {
   vec3     o, d;
   float    tmax = 0;
   uint     flags = 0;
-  bool     done = false, committed = false, opaqueChecked = false;
+  bool     done = false, committed = false;
   float    tPrev = 0;
   uint32_t wPrev = 0xffffffffu;
   RqHit    cand, hit;
@@ -145,30 +145,15 @@ inline bool rq_query(rayQueryEXT& q, float tmax, int want, RqHit& out)
   return g_hooks.query(g_hooks.user, q.o.d, q.d.d, tmax, q.tPrev, q.wPrev, want, &out.t, &out.u, &out.v, &out.w) != 0;
 }
 // Candidates are produced in the order of the trace contract (oracle/orc_scene.h T4-T6): by key (t, w); opaque candidates commit
-// without the shader; with gl_RayFlagsTerminateOnFirstHitEXT any opaque triangle inside the interval ends the query first.
+// without the shader; with gl_RayFlagsTerminateOnFirstHitEXT the first commit ends the query.
 inline bool rayQueryProceedEXT(rayQueryEXT& q)
 {
   if(q.done)
     return false;
-  if((q.flags & gl_RayFlagsTerminateOnFirstHitEXT) && !q.opaqueChecked)
-  {
-    q.opaqueChecked = true;
-    RqHit    h;
-    float    tp = q.tPrev;
-    uint32_t wp = q.wPrev;
-    if(rq_query(q, q.tmax, 2, h))
-    {
-      g_clock++;
-      q.hit = h; q.committed = true; q.done = true;
-      return false;
-    }
-    q.tPrev = tp; q.wPrev = wp;
-  }
   for(;;)
   {
     RqHit h;
-    int   want = (q.flags & gl_RayFlagsTerminateOnFirstHitEXT) ? 1 : 0;
-    if(!rq_query(q, q.committed ? q.hit.t : q.tmax, want, h))
+    if(!rq_query(q, q.committed ? q.hit.t : q.tmax, 0, h))
     {
       q.done = true;
       return false;

@@ -868,6 +868,8 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
     enqueue(queueOut, nextCount, slot);
 }
 
+// Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
+// zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
 template <bool HEAT>
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
@@ -899,17 +901,17 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
     bool survivor = false;
     if(alive && L.done)
     {
-      bool fallback = !L.opaqueHit && (L.flags & TF_SAW_FRAC) != 0;
-      if(!fallback && !L.opaqueHit && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
+      bool fallback = (L.flags & TF_SAW_FRAC) != 0;
+      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
         lane_begin_count(L);
       else
       {
-        bool inShadow = L.opaqueHit;  // an opaque occluder ends the ray without a draw (trace contract T6)
-        if(!fallback && !L.opaqueHit)
+        bool inShadow = false;
+        if(!fallback)
         {
-          uint32_t nDraw = L.cnt;
-          if(L.bslot != BVH_NONE)
-            ++nDraw;
+          uint32_t nDraw = L.cnt;  // zero-opacity candidates in front of the hit: one rejected draw each
+          if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
+            ++nDraw;               // a certain non-opaque hit consumes its own (always passing) draw; an opaque one commits without
           uint32_t s2 = seed;
           if(consume_rejected_draws(s2, nDraw))
           {
@@ -954,13 +956,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<true>(S, L, lds, spill, rb.counters);
+        lane_inner<false>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
-        lane_leaf<true>(S, L, lds, spill);
+        lane_leaf<false>(S, L, lds, spill);
     }
   }
 #ifdef PT_HIST
@@ -1015,18 +1017,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_shadow_k(Devic
     const bool inPacket = __popcll(bestMask) >= minPacket && ((bestMask >> (threadIdx.x & 63)) & 1ull);
     RayHit     h;
     bool       inShadow = false;
-    const bool packet   = traverse_packet<true>(S, inPacket, o, d, maxDist, wstack, h, inShadow, rb.counters);
+    bool       unusedOpaque;
+    const bool packet   = traverse_packet<false>(S, inPacket, o, d, maxDist, wstack, h, unusedOpaque, rb.counters);
     bool       redo     = valid && !(inPacket && packet);
     bool       survivor = false;
     if(valid && !redo)
     {
-      if(!inShadow)
       {
         redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
         if(!redo)
         {
           uint32_t nDraw = h.count;
-          if(h.slot != BVH_NONE)
+          if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
             ++nDraw;
           uint32_t s2 = seed;
           if(consume_rejected_draws(s2, nDraw))
@@ -1072,8 +1074,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
     const float    maxDist = rb.ps.absorb[slot].w;
     bool           dummy;
     RayHit         h;
-    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
-    if(!inShadow)
+    traverse<TM_CLOSEST>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
     {
       fallback       = (h.flags & TF_SAW_FRAC) != 0;
       const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
@@ -1088,7 +1089,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
       }
       if(!fallback)
       {
-        if(h.slot != BVH_NONE)
+        if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
           ++nDraw;
         uint32_t s2 = seed;
         if(consume_rejected_draws(s2, nDraw))
@@ -1124,27 +1125,28 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(Device
     const f3       o       = xyz(rb.ps.rayO[slot]);
     const f3       d       = xyz(rb.ps.neeDir[slot]);
     const float    maxDist = rb.ps.absorb[slot].w;
-    bool           inShadow, dummy;
+    bool           inShadow = false, dummy;
     RayHit         h;
-    traverse<TM_SHADOW>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, inShadow, rb.counters);
-    if(!inShadow)
+    float          tPrev = 0.0f;
+    uint32_t       wPrev = 0xffffffffu;
+    for(;;)
     {
-      float    tPrev = 0.0f;
-      uint32_t wPrev = 0xffffffffu;
-      for(;;)
+      traverse<TM_RAW_ALL>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+      if(h.slot == BVH_NONE)
+        break;
+      if((h.w >> 29) & TRI_OPAQUE)
       {
-        traverse<TM_RAW_NONOPAQUE>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-        if(h.slot == BVH_NONE)
-          break;
-        atomicAdd(&rb.counters->alphaTests, 1ull);
-        if(alpha_test(S, h.slot, h.u, h.v, seed))
-        {
-          inShadow = true;
-          break;
-        }
-        tPrev = h.t;
-        wPrev = h.w & TRI_INDEX_MASK;
+        inShadow = true;
+        break;
       }
+      atomicAdd(&rb.counters->alphaTests, 1ull);
+      if(alpha_test(S, h.slot, h.u, h.v, seed))
+      {
+        inShadow = true;
+        break;
+      }
+      tPrev = h.t;
+      wPrev = h.w & TRI_INDEX_MASK;
     }
     finish_bounce(rb, slot, inShadow, variant == PT_VARIANT_RTX ? seed0 : seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
   }
