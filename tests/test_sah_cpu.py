@@ -13,9 +13,9 @@ LEAF = 0x80000000
 NONE = 0xFFFFFFFF
 
 
-def build(tri9):
+def build(tri9, which="host"):
     L = capi.lib()
-    fn = L.pt_debug_sah_topology
+    fn = L.pt_debug_sah_topology if which == "host" else L.pt_debug_sahdev_topology   # "device": pt_sahdev.h's kernels' bodies emulated on the host
     fn.restype = C.c_int
     fn.argtypes = [C.c_uint32] + [C.c_void_p] * 6
     n = len(tri9)
@@ -75,31 +75,52 @@ def boxes_cost(tri9, vals, cl, cr):
     return float((d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]).sum())
 
 
-@pytest.mark.parametrize("n", [2, 3, 7, 64, 5000, 70000])
-def test_random_soup(n):
+@pytest.mark.parametrize("which", ["host", "device"])
+@pytest.mark.parametrize("n", [2, 3, 7, 12, 13, 14, 64, 5000, 70000])
+def test_random_soup(n, which):
     rng = np.random.default_rng(n)
     tri9 = np.concatenate([rng.uniform(-10, 10, (n, 3)), rng.normal(0, 0.3, (n, 6))], 1).astype(np.float32)
-    check_tree(n, *build(tri9))
+    check_tree(n, *build(tri9, which))
 
 
-def test_coincident_and_degenerate():
+@pytest.mark.parametrize("which", ["host", "device"])
+def test_coincident_and_degenerate(which):
     n = 300
     tri9 = np.zeros((n, 9), np.float32)                     # every triangle is the same point
-    check_tree(n, *build(tri9))
+    check_tree(n, *build(tri9, which))
     tri9[:, 3] = 1.0                                        # identical segments
-    check_tree(n, *build(tri9))
+    check_tree(n, *build(tri9, which))
     tri9[:150, 0] = np.linspace(0, 1, 150)                  # half distinct, half coincident
-    check_tree(n, *build(tri9))
+    check_tree(n, *build(tri9, which))
 
 
-def test_non_finite_vertices_do_not_break_the_builder():
+@pytest.mark.parametrize("which", ["host", "device"])
+def test_non_finite_vertices_do_not_break_the_builder(which):
     rng = np.random.default_rng(2)
     n = 500
     tri9 = np.concatenate([rng.uniform(-5, 5, (n, 3)), rng.normal(0, 0.3, (n, 6))], 1).astype(np.float32)
     tri9[::7, 0] = np.nan
     tri9[3::11, 4] = np.inf
     tri9[5::13, 8] = -np.inf
-    check_tree(n, *build(tri9))
+    check_tree(n, *build(tri9, which))
+
+
+def test_device_builder_reaches_the_host_builders_quality():
+    """Same algorithm (32 bins, exact sweeps <= 12, one triangle per leaf) as data-parallel passes: the SAH cost of the tree must equal the
+    host builder's up to what differs by design (degenerate ranges are halved by position instead of by nth_element)."""
+    rng = np.random.default_rng(5)
+    for n, spread in ((4096, 0.05), (30000, 0.3)):
+        tri9 = np.concatenate([rng.uniform(-10, 10, (n, 3)), rng.normal(0, spread, (n, 6))], 1).astype(np.float32)
+        h, d = build(tri9, "host"), build(tri9, "device")
+        ch, cd = boxes_cost(tri9, h[0], h[1], h[2]), boxes_cost(tri9, d[0], d[1], d[2])
+        assert abs(cd - ch) <= 1e-3 * ch, (n, ch, cd)
+    # a mesh-like input: a tessellated sheet plus clutter
+    u, v = np.meshgrid(np.linspace(0, 10, 80), np.linspace(0, 10, 80))
+    p0 = np.stack([u.ravel(), np.sin(u.ravel()) * 0.5, v.ravel()], 1)
+    tri9 = np.concatenate([p0, np.tile([0.13, 0, 0], (len(p0), 1)), np.tile([0, 0.02, 0.13], (len(p0), 1))], 1).astype(np.float32)
+    h, d = build(tri9, "host"), build(tri9, "device")
+    ch, cd = boxes_cost(tri9, h[0], h[1], h[2]), boxes_cost(tri9, d[0], d[1], d[2])
+    assert abs(cd - ch) <= 1e-3 * ch, (ch, cd)
 
 
 def test_surface_area_quality():

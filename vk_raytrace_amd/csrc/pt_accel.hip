@@ -17,6 +17,7 @@
 #include <cstdio>
 #include "pt_device.h"
 #include "pt_internal.h"
+#include "pt_sahdev.h"
 
 namespace {
 
@@ -353,6 +354,408 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ childL, const uint32
   }
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) -------------------------------------------------
+// Bottom-up agglomerative build over the Morton-sorted leaves, all on the device: every cluster looks at the `radius` clusters on either side
+// of it in the (Morton-ordered) cluster array and picks the one whose union with it has the smallest surface area; mutual choices merge
+// into a new inner node; the array is compacted; repeat until one cluster is left.  Unlike the radix tree of Karras 2012 (k_hierarchy) the
+// topology follows the surface-area heuristic locally, which is what makes the host SAH builder's trees fast to trace.
+// Ties in area are broken by (i xor j): a symmetric key, so runs of identical boxes still pair up as buddies instead of forming one merge per round.
+PT_DEV float half_area(float4 lo, float4 hi);
+PT_DEV float union_half_area(float4 alo, float4 ahi, float4 blo, float4 bhi)
+{
+  float dx = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), dy = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), dz = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_ploc_init(uint32_t n, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi, uint32_t* __restrict__ cid, float4* __restrict__ clo, float4* __restrict__ chi)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  cid[i] = i | BVH_LEAF;
+  clo[i] = leafLo[i];
+  chi[i] = leafHi[i];
+}
+__global__ void __launch_bounds__(256) k_ploc_nn(uint32_t m, int radius, const float4* __restrict__ clo, const float4* __restrict__ chi, uint32_t* __restrict__ nn)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= m)
+    return;
+  const float4 lo = clo[i], hi = chi[i];
+  const int    j0 = int(i) - radius < 0 ? 0 : int(i) - radius, j1 = int(i) + radius > int(m) - 1 ? int(m) - 1 : int(i) + radius;
+  float        bestA = FLT_MAX;
+  uint32_t     best = BVH_NONE, bestX = 0xffffffffu;
+  for(int j = j0; j <= j1; ++j)
+  {
+    if(j == int(i))
+      continue;
+    const float    a = union_half_area(lo, hi, clo[j], chi[j]);
+    const uint32_t x = i ^ uint32_t(j);
+    if(a < bestA || (a == bestA && x < bestX))
+    {
+      bestA = a;
+      best  = uint32_t(j);
+      bestX = x;
+    }
+  }
+  nn[i] = best;
+}
+// mutual nearest neighbours merge: the lower index keeps the merged cluster, the higher one is dropped.  Inner node ids are handed out
+// downwards from n-2, so that the last merge -- the root -- is node 0 like in the other builders.
+__global__ void __launch_bounds__(256) k_ploc_merge(uint32_t m, uint32_t numInner, const uint32_t* __restrict__ nn, uint32_t* __restrict__ cid, float4* __restrict__ clo, float4* __restrict__ chi,
+                                                    uint32_t* __restrict__ valid, uint32_t* __restrict__ mergeCounter, uint32_t* __restrict__ childL, uint32_t* __restrict__ childR,
+                                                    uint32_t* __restrict__ parentOfInner, uint32_t* __restrict__ parentOfLeaf, float4* __restrict__ nodeLo, float4* __restrict__ nodeHi)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= m)
+    return;
+  const uint32_t j = nn[i];
+  if(j == BVH_NONE || nn[j] != i)
+  {
+    valid[i] = 1u;
+    return;
+  }
+  if(i > j)
+  {
+    valid[i] = 0u;
+    return;
+  }
+  const uint32_t id = numInner - 1u - atomicAdd(mergeCounter, 1u);
+  const uint32_t a = cid[i], b = cid[j];
+  childL[id] = a;
+  childR[id] = b;
+  if(a & BVH_LEAF) parentOfLeaf[a & ~BVH_LEAF] = id; else parentOfInner[a] = id;
+  if(b & BVH_LEAF) parentOfLeaf[b & ~BVH_LEAF] = id; else parentOfInner[b] = id;
+  const float4 alo = clo[i], ahi = chi[i], blo = clo[j], bhi = chi[j];
+  const float4 lo  = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), fmaxf(alo.w, blo.w));  // .w: subtree holds non-opaque triangles
+  const float4 hi  = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+  nodeLo[id] = lo;
+  nodeHi[id] = hi;
+  cid[i]     = id;
+  clo[i]     = lo;
+  chi[i]     = hi;
+  valid[i]   = 1u;
+}
+// compaction of the surviving clusters: block-local exclusive scan + block totals, scan of the totals by one block, scatter
+__global__ void __launch_bounds__(1024) k_ploc_scan_blocks(uint32_t m, const uint32_t* __restrict__ valid, uint32_t* __restrict__ pos, uint32_t* __restrict__ blockSum)
+{
+  __shared__ uint32_t sh[1024];
+  const uint32_t      i = blockIdx.x * 1024u + threadIdx.x;
+  const uint32_t      v = i < m ? valid[i] : 0u;
+  sh[threadIdx.x]       = v;
+  __syncthreads();
+  for(uint32_t off = 1; off < 1024u; off <<= 1)
+  {
+    uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if(i < m)
+    pos[i] = sh[threadIdx.x] - v;
+  if(threadIdx.x == 1023u)
+    blockSum[blockIdx.x] = sh[1023];
+}
+__global__ void __launch_bounds__(1024) k_ploc_scan_sums(uint32_t numBlocks, uint32_t* __restrict__ blockSum, uint32_t* __restrict__ total)
+{
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if(threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  for(uint32_t base = 0; base < numBlocks; base += 1024u)
+  {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < numBlocks ? blockSum[i] : 0u;
+    sh[threadIdx.x]  = v;
+    __syncthreads();
+    for(uint32_t off = 1; off < 1024u; off <<= 1)
+    {
+      uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if(i < numBlocks)
+      blockSum[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if(threadIdx.x == 1023u)
+      carry += sh[1023];
+    __syncthreads();
+  }
+  if(threadIdx.x == 0)
+    *total = carry;
+}
+__global__ void __launch_bounds__(256) k_ploc_compact(uint32_t m, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blockSum,
+                                                      const uint32_t* __restrict__ cid, const float4* __restrict__ clo, const float4* __restrict__ chi, uint32_t* __restrict__ cid2,
+                                                      float4* __restrict__ clo2, float4* __restrict__ chi2)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= m || !valid[i])
+    return;
+  const uint32_t p = blockSum[i >> 10] + pos[i];
+  cid2[p] = cid[i];
+  clo2[p] = clo[i];
+  chi2[p] = chi[i];
+}
+
+// ---- binned SAH on the device: kernels around the per-thread bodies of pt_sahdev.h ----------------------------------------------------
+__global__ void k_sd_prims(uint32_t n, const TriRec* __restrict__ tris, float4* __restrict__ plo, float4* __restrict__ phi, uint32_t* __restrict__ idx, uint32_t* __restrict__ primWork,
+                           uint32_t rootWork)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  sd_prim(i, tris, plo, phi);
+  idx[i]      = i;
+  primWork[i] = rootWork;
+}
+__global__ void k_sd_init_bins(size_t nBins, uint32_t* __restrict__ binCnt, uint32_t* __restrict__ binBox)
+{
+  size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if(b >= nBins)
+    return;
+  binCnt[b] = 0u;
+  for(int q = 0; q < 6; ++q)
+    binBox[b * 6 + q] = q < 3 ? SD_ORD_PLUS_INF : SD_ORD_MINUS_INF;
+}
+// The three per-triangle passes below do what sd_cbounds / sd_bin / sd_partition (pt_sahdev.h, the plain bodies the host emulation runs)
+// specify, with the atomics aggregated: near the top of the tree every triangle of a level targets the same few addresses, and same-address
+// atomics serialise at ~11 ns each on this chip (269 k triangles x 6 min/max = 18 ms for level 0 alone when issued per lane).
+// Lanes of a wave are grouped by the node they belong to (positions are contiguous per node, so a wave holds one or a few groups).
+template <class F>
+PT_DEV void sd_wave_groups(uint32_t key, bool active, F f)
+{
+  unsigned long long rem = __ballot(active);
+  while(rem)
+  {
+    const int                leader = __ffsll((long long)rem) - 1;
+    const uint32_t           k0     = __shfl(key, leader);
+    const unsigned long long m      = __ballot(active && key == k0);
+    f(k0, m, leader);
+    rem &= ~m;
+  }
+}
+__global__ void __launch_bounds__(256) k_sd_cbounds(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ primWork, SdWork* work, const float4* __restrict__ plo,
+                                                    const float4* __restrict__ phi)
+{
+  const uint32_t pos    = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w      = pos < n ? primWork[pos] : SD_NONE;
+  const bool     active = w != SD_NONE;
+  float          c[3]   = {0.f, 0.f, 0.f};
+  if(active)
+  {
+    const uint32_t p  = idx[pos];
+    const float4   lo = plo[p], hi = phi[p];
+    c[0] = 0.5f * (lo.x + hi.x); c[1] = 0.5f * (lo.y + hi.y); c[2] = 0.5f * (lo.z + hi.z);
+  }
+  const int lane = threadIdx.x & 63;
+  sd_wave_groups(w, active, [&](uint32_t w0, unsigned long long m, int leader) {
+    const bool in = (m >> lane) & 1ull;
+    float      mn[3], mx[3];
+    for(int a = 0; a < 3; ++a)
+    {
+      mn[a] = in ? c[a] : FLT_MAX;
+      mx[a] = in ? c[a] : -FLT_MAX;
+      for(int off = 32; off > 0; off >>= 1)
+      {
+        mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+        mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+      }
+    }
+    if(lane == leader)
+      for(int a = 0; a < 3; ++a)
+      {
+        atomicMin(&work[w0].cbLo[a], sd_order(mn[a]));
+        atomicMax(&work[w0].cbHi[a], sd_order(mx[a]));
+      }
+  });
+}
+__global__ void __launch_bounds__(256) k_sd_bin(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ primWork, const SdWork* __restrict__ work,
+                                                const float4* __restrict__ plo, const float4* __restrict__ phi, uint32_t* binCnt, uint32_t* binBox)
+{
+  __shared__ uint32_t lCnt[3 * SD_BINS], lBox[3 * SD_BINS * 6];
+  __shared__ uint32_t sW;
+  const uint32_t      pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t      w   = pos < n ? primWork[pos] : SD_NONE;
+  if(threadIdx.x == 0)
+    sW = w;
+  for(int i = threadIdx.x; i < 3 * SD_BINS; i += blockDim.x)
+    lCnt[i] = 0u;
+  for(int i = threadIdx.x; i < 3 * SD_BINS * 6; i += blockDim.x)
+    lBox[i] = (i % 6) < 3 ? SD_ORD_PLUS_INF : SD_ORD_MINUS_INF;
+  __syncthreads();
+  const uint32_t w0 = sW;
+  // a block whose triangles all belong to one node (every block near the top of the tree) bins into LDS and flushes once
+  const bool uniform = __syncthreads_and((pos >= n || w == w0) ? 1 : 0) && w0 != SD_NONE;
+  if(!uniform)
+  {
+    if(pos < n)
+      sd_bin(pos, idx, primWork, work, plo, phi, binCnt, binBox);
+    return;
+  }
+  if(pos < n)
+  {
+    const uint32_t p  = idx[pos];
+    const float4   lo = plo[p], hi = phi[p];
+    const float    l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    for(int a = 0; a < 3; ++a)
+    {
+      const float cl = sd_unorder(work[w0].cbLo[a]), ch = sd_unorder(work[w0].cbHi[a]);
+      const float ext = ch - cl;
+      if(!(ext > 0.f))
+        continue;
+      const int b = a * SD_BINS + sd_bin_of(0.5f * (l[a] + h[a]), cl, float(SD_BINS) / ext);
+      atomicAdd(&lCnt[b], 1u);
+      for(int q = 0; q < 3; ++q)
+      {
+        atomicMin(&lBox[b * 6 + q], sd_order(l[q]));
+        atomicMax(&lBox[b * 6 + 3 + q], sd_order(h[q]));
+      }
+    }
+  }
+  __syncthreads();
+  for(int b = threadIdx.x; b < 3 * SD_BINS; b += blockDim.x)
+    if(lCnt[b])
+    {
+      const size_t g = size_t(w0) * 3 * SD_BINS + b;
+      atomicAdd(&binCnt[g], lCnt[b]);
+      for(int q = 0; q < 3; ++q)
+      {
+        atomicMin(&binBox[g * 6 + q], lBox[b * 6 + q]);
+        atomicMax(&binBox[g * 6 + 3 + q], lBox[b * 6 + 3 + q]);
+      }
+    }
+}
+__global__ void __launch_bounds__(256) k_sd_partition(uint32_t n, const uint32_t* __restrict__ idxIn, const uint32_t* __restrict__ primWorkIn, SdWork* work, const float4* __restrict__ plo,
+                                                      const float4* __restrict__ phi, uint32_t* __restrict__ idxOut, uint32_t* __restrict__ primWorkOut)
+{
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     inRange = pos < n;
+  const uint32_t w = inRange ? primWorkIn[pos] : SD_NONE;
+  const uint32_t p = inRange ? idxIn[pos] : 0u;
+  if(inRange && w == SD_NONE)
+  {  // finished ranges keep their place
+    idxOut[pos]      = p;
+    primWorkOut[pos] = SD_NONE;
+  }
+  const bool active = w != SD_NONE;
+  bool       left   = false;
+  if(active)
+  {
+    const SdWork& W = work[w];
+    if(W.axis < 0)
+      left = pos < W.first + W.nl;
+    else
+    {
+      const float4 lo = plo[p], hi = phi[p];
+      const float  c = W.axis == 0 ? 0.5f * (lo.x + hi.x) : (W.axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+      left           = sd_bin_of(c, W.lo, W.scale) < W.kSplit;
+    }
+  }
+  const int                lane = threadIdx.x & 63;
+  const unsigned long long lt   = (1ull << lane) - 1ull;
+  sd_wave_groups(w, active, [&](uint32_t w0, unsigned long long m, int leader) {
+    const bool               in = (m >> lane) & 1ull;
+    const unsigned long long mL = __ballot(in && left), mR = __ballot(in && !left);
+    uint32_t                 baseL = 0, baseR = 0;
+    if(lane == leader)
+    {
+      if(mL) baseL = atomicAdd(&work[w0].curL, (uint32_t)__popcll(mL));
+      if(mR) baseR = atomicAdd(&work[w0].curR, (uint32_t)__popcll(mR));
+    }
+    baseL = __shfl(baseL, leader);
+    baseR = __shfl(baseR, leader);
+    if(in)
+    {
+      const SdWork&  W   = work[w0];
+      const uint32_t dst = left ? W.first + baseL + (uint32_t)__popcll(mL & lt) : W.first + W.nl + baseR + (uint32_t)__popcll(mR & lt);
+      idxOut[dst]        = p;
+      primWorkOut[dst]   = left ? W.leftW : W.rightW;
+    }
+  });
+}
+__global__ void k_sd_split(uint32_t nActive, SdWork* work, const uint32_t* __restrict__ binCnt, const uint32_t* __restrict__ binBox, SdLists L, uint32_t* childL, uint32_t* childR,
+                           uint32_t* parI, uint32_t* parL)
+{
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if(w < nActive)
+    sd_split(w, work, binCnt, binBox, L, childL, childR, parI, parL);
+}
+__global__ void k_sd_small(uint32_t nSmall, const SdWork* __restrict__ small, uint32_t* idx, const float4* __restrict__ plo, const float4* __restrict__ phi, uint32_t* childL, uint32_t* childR,
+                           uint32_t* parI, uint32_t* parL)
+{
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s < nSmall)
+    sd_small(s, small, idx, plo, phi, childL, childR, parI, parL);
+}
+
+// ---- tree rotations (Kensler 2008), bottom-up like k_refit ---------------------------------------------------------------
+// At inner node X with children (L, R): if L is inner with children (La, Lb), exchanging R with La (or Lb) leaves X's box unchanged and
+// replaces L's box by union(R, Lb) (or union(R, La)); symmetric for R.  The exchange with the largest reduction of the child's surface area
+// is applied.  One thread owns X and its two children when it gets there (second arrival, subtrees below are finished, nothing above has
+// started), so the pointer updates need no further synchronisation than k_refit's hand-off.
+__global__ void k_rotate(int n, uint32_t* childL, uint32_t* childR, uint32_t* parentOfInner, uint32_t* parentOfLeaf, const float4* __restrict__ leafLo,
+                         const float4* __restrict__ leafHi, float4* nodeLo, float4* nodeHi, unsigned int* arrive)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  auto lo_of = [&](uint32_t c) { return (c & BVH_LEAF) ? leafLo[c & ~BVH_LEAF] : nodeLo[c]; };
+  auto hi_of = [&](uint32_t c) { return (c & BVH_LEAF) ? leafHi[c & ~BVH_LEAF] : nodeHi[c]; };
+  auto set_parent = [&](uint32_t c, uint32_t p) {
+    if(c & BVH_LEAF) parentOfLeaf[c & ~BVH_LEAF] = p; else parentOfInner[c] = p;
+  };
+  uint32_t cur = parentOfLeaf[i];
+  while(cur != BVH_NONE)
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int prev = __hip_atomic_fetch_add(&arrive[cur], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(prev == 0)
+      return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t L = childL[cur], R = childR[cur];
+    float          bestGain = 0.0f;
+    int            best     = -1;  // 0: R <-> La, 1: R <-> Lb, 2: L <-> Ra, 3: L <-> Rb
+    if(!(L & BVH_LEAF))
+    {
+      const uint32_t La = childL[L], Lb = childR[L];
+      const float    aL = half_area(nodeLo[L], nodeHi[L]);
+      const float    g0 = aL - union_half_area(lo_of(R), hi_of(R), lo_of(Lb), hi_of(Lb));
+      const float    g1 = aL - union_half_area(lo_of(R), hi_of(R), lo_of(La), hi_of(La));
+      if(g0 > bestGain) { bestGain = g0; best = 0; }
+      if(g1 > bestGain) { bestGain = g1; best = 1; }
+    }
+    if(!(R & BVH_LEAF))
+    {
+      const uint32_t Ra = childL[R], Rb = childR[R];
+      const float    aR = half_area(nodeLo[R], nodeHi[R]);
+      const float    g2 = aR - union_half_area(lo_of(L), hi_of(L), lo_of(Rb), hi_of(Rb));
+      const float    g3 = aR - union_half_area(lo_of(L), hi_of(L), lo_of(Ra), hi_of(Ra));
+      if(g2 > bestGain) { bestGain = g2; best = 2; }
+      if(g3 > bestGain) { bestGain = g3; best = 3; }
+    }
+    if(best >= 0)
+    {
+      const bool     left  = best < 2;           // the inner child that is rebuilt
+      const uint32_t C     = left ? L : R;       // ... it
+      const uint32_t S     = left ? R : L;       // the sibling that moves down
+      const bool     first = (best & 1) == 0;    // the grandchild that moves up: C's first (a) or second (b) child
+      const uint32_t up    = first ? childL[C] : childR[C];
+      const uint32_t stay  = first ? childR[C] : childL[C];
+      childL[C] = S;
+      childR[C] = stay;
+      const float4 slo = lo_of(S), shi = hi_of(S), tlo = lo_of(stay), thi = hi_of(stay);
+      nodeLo[C] = make_float4(fminf(slo.x, tlo.x), fminf(slo.y, tlo.y), fminf(slo.z, tlo.z), fmaxf(slo.w, tlo.w));
+      nodeHi[C] = make_float4(fmaxf(shi.x, thi.x), fmaxf(shi.y, thi.y), fmaxf(shi.z, thi.z), 0.f);
+      set_parent(S, C);
+      set_parent(up, uint32_t(cur));
+      if(left) { childL[cur] = C; childR[cur] = up; } else { childL[cur] = up; childR[cur] = C; }
+    }
+    cur = parentOfInner[cur];
+  }
+}
+
 // leaf reference of sorted slot `i`: non-opaque triangles are tagged so that traversal fetches their AlphaRec up front
 PT_DEV uint32_t leaf_ref(const TriRec* __restrict__ tris, uint32_t leaf)
 {
@@ -508,7 +911,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr, *dHist = nullptr, *dBounds = nullptr;
   uint32_t *dChildL = nullptr, *dChildR = nullptr, *dParI = nullptr, *dParL = nullptr;
   unsigned* dArrive = nullptr;
-  bool      sah     = false;
+  bool      sah     = false, ploc = false, sahDev = false;
   uint32_t  initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
 
   HIPCHK(hipMalloc(&dUnsorted, sizeof(TriRec) * size_t(n)));
@@ -533,10 +936,84 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   HIPCHK(hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream));
 
   k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
-  sah = g_tuning.sahBuild != 0 && n >= 2;
+  sah = g_tuning.sahBuild == 1 && n >= 2;  // sahBuild: 0 device LBVH (Karras), 1 host SAH topology, 2 device PLOC, 3 device binned SAH (default)
+  ploc = g_tuning.sahBuild == 2 && n >= 2;
+  sahDev = g_tuning.sahBuild == 3 && n >= 2;
+  if(sahDev)
+  {
+    // ---- device binned SAH (pt_sahdev.h): level-synchronous; the number of open nodes comes back to the host between levels
+    float4 *  plo = nullptr, *phi = nullptr;
+    uint32_t *idxA = nullptr, *idxB = nullptr, *pwA = nullptr, *pwB = nullptr, *binCnt = nullptr, *binBox = nullptr, *dCounts = nullptr;
+    SdWork *  workA = nullptr, *workB = nullptr, *small = nullptr;
+    const size_t maxWork = size_t(n) / (SD_SMALL + 1) + 2, maxSmall = size_t(n) / 2 + 2;
+    bool      okAlloc = true;
+    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && hipMalloc(p, bytes) == hipSuccess; };
+    grab((void**)&plo, 16 * size_t(n)); grab((void**)&phi, 16 * size_t(n)); grab((void**)&idxA, 4 * size_t(n)); grab((void**)&idxB, 4 * size_t(n)); grab((void**)&pwA, 4 * size_t(n));
+    grab((void**)&pwB, 4 * size_t(n)); grab((void**)&workA, sizeof(SdWork) * maxWork); grab((void**)&workB, sizeof(SdWork) * maxWork); grab((void**)&small, sizeof(SdWork) * maxSmall);
+    grab((void**)&binCnt, 4 * maxWork * 3 * SD_BINS); grab((void**)&binBox, 4 * maxWork * 3 * SD_BINS * 6); grab((void**)&dCounts, 8);
+    void* tmp[] = {plo, phi, idxA, idxB, pwA, pwB, workA, workB, small, binCnt, binBox, dCounts};
+    bool  done  = false;
+    if(okAlloc)
+    {
+      uint32_t nActive = 0, nSmall = 0;
+      SdWork   root;
+      sd_init_work(root, 0, n, 0);
+      uint32_t zero2[2] = {0u, 0u};
+      const uint32_t noneParent = BVH_NONE;
+      bool     ok = hipMemcpyAsync(dParI, &noneParent, 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+      if(n <= SD_SMALL)
+      {
+        nSmall   = 1;
+        zero2[1] = 1;
+        ok       = ok && hipMemcpyAsync(small, &root, sizeof(root), hipMemcpyHostToDevice, stream) == hipSuccess;
+      }
+      else
+      {
+        nActive = 1;
+        ok      = ok && hipMemcpyAsync(workA, &root, sizeof(root), hipMemcpyHostToDevice, stream) == hipSuccess;
+      }
+      ok = ok && hipMemcpyAsync(dCounts, zero2, 8, hipMemcpyHostToDevice, stream) == hipSuccess;
+      k_sd_prims<<<G, B, 0, stream>>>(n, dUnsorted, plo, phi, idxA, pwA, nActive ? 0u : SD_NONE);
+      int levels = 0;
+      while(nActive && ok && levels < 4096)
+      {
+        const size_t nBins = size_t(nActive) * 3 * SD_BINS;
+        k_sd_init_bins<<<unsigned((nBins + 255) / 256), 256, 0, stream>>>(nBins, binCnt, binBox);
+        k_sd_cbounds<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi);
+        k_sd_bin<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi, binCnt, binBox);
+        (void)hipMemsetAsync(dCounts, 0, 4, stream);  // next-level counter; the small-node counter keeps running
+        SdLists L{workB, dCounts, small, dCounts + 1};
+        k_sd_split<<<(nActive + 63) / 64, 64, 0, stream>>>(nActive, workA, binCnt, binBox, L, dChildL, dChildR, dParI, dParL);
+        k_sd_partition<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi, idxB, pwB);
+        uint32_t counts[2] = {0u, 0u};
+        ok = hipMemcpyAsync(counts, dCounts, 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && counts[0] <= maxWork && counts[1] <= maxSmall;
+        nActive = counts[0];
+        nSmall  = counts[1];
+        std::swap(idxA, idxB); std::swap(pwA, pwB); std::swap(workA, workB);
+        ++levels;
+      }
+      if(ok && nActive == 0)
+      {
+        if(nSmall)
+          k_sd_small<<<(nSmall + 63) / 64, 64, 0, stream>>>(nSmall, small, idxA, plo, phi, dChildL, dChildR, dParI, dParL);
+        ok   = hipMemcpyAsync(dValsA, idxA, 4 * size_t(n), hipMemcpyDeviceToDevice, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+        done = ok;
+      }
+    }
+    for(void* q : tmp)
+      (void)hipFree(q);
+    (void)hipGetLastError();
+    if(!done)
+    {
+      snprintf(err, errLen, "device SAH build failed (out of memory or a kernel error)");
+      goto fail;
+    }
+    sah = true;  // from here on like the host SAH builder: topology + leaf order are given
+  }
+  else
   if(sah)
   {
-    // fast-trace build: SAH topology on the host from the world-space triangles (pt_sah.hip); boxes stay on the device
+    // cross-check build: SAH topology on the host from the world-space triangles (pt_sah.hip); boxes stay on the device
     std::vector<TriRec>   hTris(n);
     std::vector<uint32_t> hVals(n), hL(n), hR(n), hPI(n), hPL(n);
     HIPCHK(hipMemcpyAsync(hTris.data(), dUnsorted, sizeof(TriRec) * size_t(n), hipMemcpyDeviceToHost, stream));
@@ -565,15 +1042,75 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     // after 4 passes the sorted data is back in A
   }
   k_gather<<<G, B, 0, stream>>>(n, dValsA, dUnsorted, dTrisOut, dAlphaUnsorted, dAlphaOut, dLeafLo, dLeafHi);
+  if(ploc)
+  {
+    // PLOC rounds; the cluster count comes back to the host between rounds (the build is not on the timed path).  A round merges at least the
+    // globally best pair; if an adversarial input makes the rounds crawl, the radix tree takes over.
+    uint32_t *cidA = nullptr, *cidB = nullptr, *dNn = nullptr, *dValid = nullptr, *dPos = nullptr, *dBlockSum = nullptr, *dCnt = nullptr;
+    float4 *  cloA = nullptr, *cloB = nullptr, *chiA = nullptr, *chiB = nullptr;
+    void*     tmp[11];
+    bool      okAlloc = true;
+    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && hipMalloc(p, bytes) == hipSuccess; };
+    grab((void**)&cidA, 4 * size_t(n)); grab((void**)&cidB, 4 * size_t(n)); grab((void**)&dNn, 4 * size_t(n)); grab((void**)&dValid, 4 * size_t(n)); grab((void**)&dPos, 4 * size_t(n));
+    grab((void**)&dBlockSum, 4 * size_t((n + 1023) / 1024 + 1)); grab((void**)&dCnt, 8);
+    grab((void**)&cloA, 16 * size_t(n)); grab((void**)&cloB, 16 * size_t(n)); grab((void**)&chiA, 16 * size_t(n)); grab((void**)&chiB, 16 * size_t(n));
+    tmp[0] = cidA; tmp[1] = cidB; tmp[2] = dNn; tmp[3] = dValid; tmp[4] = dPos; tmp[5] = dBlockSum; tmp[6] = dCnt; tmp[7] = cloA; tmp[8] = cloB; tmp[9] = chiA; tmp[10] = chiB;
+    bool done = false;
+    if(okAlloc)
+    {
+      const int radius = g_tuning.plocRadius < 1 ? 1 : (g_tuning.plocRadius > 64 ? 64 : g_tuning.plocRadius);
+      (void)hipMemsetAsync(dCnt, 0, 8, stream);
+      k_ploc_init<<<G, B, 0, stream>>>(n, dLeafLo, dLeafHi, cidA, cloA, chiA);
+      uint32_t m = n;
+      int      rounds = 0, maxRounds = 64;
+      for(uint32_t t = n; t > 1; t >>= 1)
+        maxRounds += 6;
+      bool ok = true;
+      while(m > 1 && rounds < maxRounds && ok)
+      {
+        const uint32_t g = (m + 255) / 256, nb = (m + 1023) / 1024;
+        // the top of the tree decides how many subtrees a ray enters: once few clusters are left every cluster considers ALL others
+        // (exact agglomerative clustering), not just its Morton neighbourhood
+        const int rad = m <= uint32_t(g_tuning.plocFull) ? int(m) : radius;
+        k_ploc_nn<<<g, 256, 0, stream>>>(m, rad, cloA, chiA, dNn);
+        k_ploc_merge<<<g, 256, 0, stream>>>(m, n - 1, dNn, cidA, cloA, chiA, dValid, dCnt, dChildL, dChildR, dParI, dParL, dNodeLo, dNodeHi);
+        k_ploc_scan_blocks<<<nb, 1024, 0, stream>>>(m, dValid, dPos, dBlockSum);
+        k_ploc_scan_sums<<<1, 1024, 0, stream>>>(nb, dBlockSum, dCnt + 1);
+        k_ploc_compact<<<g, 256, 0, stream>>>(m, dValid, dPos, dBlockSum, cidA, cloA, chiA, cidB, cloB, chiB);
+        uint32_t m2 = 0;
+        ok = hipMemcpyAsync(&m2, dCnt + 1, 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && m2 >= 1 && m2 < m;
+        m = m2;
+        std::swap(cidA, cidB); std::swap(cloA, cloB); std::swap(chiA, chiB);
+        ++rounds;
+      }
+      done = ok && m == 1;
+      if(done)
+      {
+        const uint32_t none = BVH_NONE;
+        (void)hipMemcpyAsync(dParI, &none, 4, hipMemcpyHostToDevice, stream);  // the root (node 0) has no parent
+      }
+    }
+    for(void* q : tmp)
+      (void)hipFree(q);
+    (void)hipGetLastError();
+    if(!done)
+      ploc = false;  // fall back to the radix tree below
+  }
   if(n == 1)
   {
     k_single_leaf<<<1, 1, 0, stream>>>(dLeafLo, dLeafHi, dTrisOut, dNodesOut);
   }
   else
   {
-    if(!sah)
+    if(!sah && !ploc)
       k_hierarchy<<<G, B, 0, stream>>>(int(n), dKeysA, dChildL, dChildR, dParI, dParL);
-    k_refit<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
+    if(!ploc)  // PLOC wrote the inner boxes while merging
+      k_refit<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
+    for(int pass = 0; pass < g_tuning.rotatePasses && !sah; ++pass)
+    {
+      (void)hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream);
+      k_rotate<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
+    }
     k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut);
   }
   HIPCHK(hipGetLastError());

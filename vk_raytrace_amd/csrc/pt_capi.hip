@@ -340,6 +340,11 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
     if(strstr(tune, "build=lbvh")) g_tuning.sahBuild = 0;
     if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
+    if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
+    if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
+    if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
+    if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) g_tuning.plocFull = v;
+    if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) g_tuning.plocRadius = v;
     if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;

@@ -69,7 +69,10 @@ struct PtTuning {
                                    // wave of the trace machine pulls together (and refills with) start in the same region with the same direction signs
   int sortShadow           = 0;    // same for the shadow-ray queue of every bounce
   int sortCellBits         = 4;    // origin cells per axis = 2^sortCellBits (<= 5)
-  int sahBuild             = 1;    // 1: host SAH topology (fast trace, the default), 0: device LBVH (fast build)
+  int rotatePasses         = 2;    // device builders: bottom-up tree-rotation passes after the topology is built
+  int plocFull             = 0;    // PLOC: below this many clusters the search covers all of them (exact agglomerative clustering of the top levels)
+  int plocRadius           = 16;   // PLOC: clusters examined on either side of a cluster per round
+  int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
 extern PtTuning g_tuning;

@@ -13,6 +13,7 @@
 #include <vector>
 #include "pt_device.h"
 #include "pt_internal.h"
+#include "pt_sahdev.h"
 
 namespace {
 
@@ -250,5 +251,67 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_sah_topology(uint
     t[i].e2p = make_float4(p[6], p[7], p[8], 0.f);
   }
   pt_sah_topology(n, t.data(), vals, childL, childR, parI, parL);
+  return 0;
+}
+
+// Test hook: the DEVICE builder (pt_sahdev.h) emulated on the host -- the same per-thread bodies the HIP kernels run, executed one "thread"
+// after the other, level by level.  tests/test_sah_cpu.py holds its output to the tree invariants and to the host builder's SAH cost.
+extern "C" __attribute__((visibility("default"))) int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL)
+{
+  if(n < 2 || !tri9)
+    return -1;
+  std::vector<TriRec> t(n);
+  for(uint32_t i = 0; i < n; ++i)
+  {
+    const float* p = tri9 + 9 * size_t(i);
+    t[i].p0w = make_float4(p[0], p[1], p[2], 0.f);
+    t[i].e1n = make_float4(p[3], p[4], p[5], 0.f);
+    t[i].e2p = make_float4(p[6], p[7], p[8], 0.f);
+  }
+  std::vector<float4>   plo(n), phi(n);
+  std::vector<uint32_t> idxA(n), idxB(n), pwA(n, 0u), pwB(n, SD_NONE);
+  for(uint32_t i = 0; i < n; ++i)
+  {
+    sd_prim(i, t.data(), plo.data(), phi.data());
+    idxA[i] = i;
+  }
+  const size_t        maxWork = size_t(n) / (SD_SMALL + 1) + 2;
+  std::vector<SdWork> workA(maxWork), workB(maxWork), small(size_t(n) / 2 + 2);
+  uint32_t            nActive = 0, nextCount = 0, smallCount = 0;
+  parI[0] = BVH_NONE;
+  if(n <= SD_SMALL)
+  {
+    sd_init_work(small[smallCount++], 0, n, 0);
+    std::fill(pwA.begin(), pwA.end(), SD_NONE);
+  }
+  else
+    sd_init_work(workA[nActive++], 0, n, 0);
+  std::vector<uint32_t> binCnt, binBox;
+  while(nActive)
+  {
+    binCnt.assign(size_t(nActive) * 3 * SD_BINS, 0u);
+    binBox.resize(size_t(nActive) * 3 * SD_BINS * 6);
+    for(size_t b = 0; b < size_t(nActive) * 3 * SD_BINS; ++b)
+      for(int q = 0; q < 6; ++q)
+        binBox[b * 6 + q] = q < 3 ? SD_ORD_PLUS_INF : SD_ORD_MINUS_INF;
+    for(uint32_t pos = 0; pos < n; ++pos)
+      sd_cbounds(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data());
+    for(uint32_t pos = 0; pos < n; ++pos)
+      sd_bin(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data(), binCnt.data(), binBox.data());
+    nextCount = 0;
+    SdLists L{workB.data(), &nextCount, small.data(), &smallCount};
+    for(uint32_t w = 0; w < nActive; ++w)
+      sd_split(w, workA.data(), binCnt.data(), binBox.data(), L, childL, childR, parI, parL);
+    for(uint32_t pos = 0; pos < n; ++pos)
+      sd_partition(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data(), idxB.data(), pwB.data());
+    idxA.swap(idxB);
+    pwA.swap(pwB);
+    workA.swap(workB);
+    nActive = nextCount;
+  }
+  for(uint32_t s = 0; s < smallCount; ++s)
+    sd_small(s, small.data(), idxA.data(), plo.data(), phi.data(), childL, childR, parI, parL);
+  for(uint32_t i = 0; i < n; ++i)
+    vals[i] = idxA[i];
   return 0;
 }
