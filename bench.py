@@ -9,9 +9,19 @@ and environment are resident in HBM before the timed region starts.
   python bench.py --gpus 1 --steps 256 --warmup 8
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-With N > 1 the image tiles are sharded over the ranks (vk_raytrace_amd/shard.py); the ranks do not
-communicate while rendering and the single RCCL framebuffer gather happens after the timed loop (its time is
-reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).
+With N > 1 the image tiles are sharded over the ranks (vk_raytrace_amd/shard.py); the ranks do not communicate while rendering and
+the single framebuffer gather -- libptmi's own RCCL path, pt_gather_shards / pt_gather_finish -- happens after the timed loop (its time
+is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).
+
+After the timed region (never part of `value`), rank 0 measures what the JSON line's evidence fields need, all in this run:
+  calibration        pt_measure_peaks: the VALU-issue and HBM-streaming ceilings of this box
+  interactive        render + tonemap per frame (batch = 1, SampleExample's display loop)
+  serialised         one batch on a second context with one frame slot: standalone stage durations (HIP events, nothing overlapped)
+  roofline           the stage with the largest standalone time, algorithmic bytes per launch / its average launch duration vs 8 TB/s;
+                     `traffic` = measured HBM bytes per launch from profiles/r02_traffic.json (this round's PMC passes, tools/pmc_r02.sh)
+  hbm_measured       measured HBM bytes per sample x this run's rate
+  issue_roofline     VALU wave-instructions per sample (profiles/r02_valu.json, same PMC run) x this run's rate / the calibrated ceiling
+  cpu_baseline       the CPU oracle (kind "port") on a bounded sample of the same workload, N = 1 only
 """
 import argparse
 import json

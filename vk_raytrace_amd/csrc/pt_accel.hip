@@ -626,8 +626,8 @@ __global__ void __launch_bounds__(256) k_sd_bin(uint32_t n, const uint32_t* __re
       }
     }
 }
-__global__ void __launch_bounds__(256) k_sd_partition(uint32_t n, const uint32_t* __restrict__ idxIn, const uint32_t* __restrict__ primWorkIn, SdWork* work, const float4* __restrict__ plo,
-                                                      const float4* __restrict__ phi, uint32_t* __restrict__ idxOut, uint32_t* __restrict__ primWorkOut)
+__global__ void __launch_bounds__(256) k_sd_partition(uint32_t n, const uint32_t* __restrict__ idxIn, const uint32_t* __restrict__ primWorkIn, SdWork* work, SdWork* next,
+                                                      const float4* __restrict__ plo, const float4* __restrict__ phi, uint32_t* __restrict__ idxOut, uint32_t* __restrict__ primWorkOut)
 {
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
   const bool     inRange = pos < n;
@@ -640,17 +640,13 @@ __global__ void __launch_bounds__(256) k_sd_partition(uint32_t n, const uint32_t
   }
   const bool active = w != SD_NONE;
   bool       left   = false;
+  float      c[3]   = {0.f, 0.f, 0.f};
   if(active)
   {
-    const SdWork& W = work[w];
-    if(W.axis < 0)
-      left = pos < W.first + W.nl;
-    else
-    {
-      const float4 lo = plo[p], hi = phi[p];
-      const float  c = W.axis == 0 ? 0.5f * (lo.x + hi.x) : (W.axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
-      left           = sd_bin_of(c, W.lo, W.scale) < W.kSplit;
-    }
+    const SdWork& W  = work[w];
+    const float4  lo = plo[p], hi = phi[p];
+    c[0] = 0.5f * (lo.x + hi.x); c[1] = 0.5f * (lo.y + hi.y); c[2] = 0.5f * (lo.z + hi.z);
+    left = W.axis < 0 ? pos < W.first + W.nl : sd_bin_of(c[W.axis], W.lo, W.scale) < W.kSplit;
   }
   const int                lane = threadIdx.x & 63;
   const unsigned long long lt   = (1ull << lane) - 1ull;
@@ -665,12 +661,38 @@ __global__ void __launch_bounds__(256) k_sd_partition(uint32_t n, const uint32_t
     }
     baseL = __shfl(baseL, leader);
     baseR = __shfl(baseR, leader);
+    const SdWork& W = work[w0];
     if(in)
     {
-      const SdWork&  W   = work[w0];
       const uint32_t dst = left ? W.first + baseL + (uint32_t)__popcll(mL & lt) : W.first + W.nl + baseR + (uint32_t)__popcll(mR & lt);
       idxOut[dst]        = p;
       primWorkOut[dst]   = left ? W.leftW : W.rightW;
+    }
+    // centroid bounds of the two children (what sd_cbounds would compute for them on the next level), reduced over the wave first
+    for(int side = 0; side < 2; ++side)
+    {
+      const uint32_t           cw = side == 0 ? W.leftW : W.rightW;
+      const unsigned long long ms = side == 0 ? mL : mR;
+      if(cw == SD_NONE || ms == 0ull)
+        continue;
+      const bool mine = (ms >> lane) & 1ull;
+      float      mn[3], mx[3];
+      for(int a = 0; a < 3; ++a)
+      {
+        mn[a] = mine ? c[a] : FLT_MAX;
+        mx[a] = mine ? c[a] : -FLT_MAX;
+        for(int off = 32; off > 0; off >>= 1)
+        {
+          mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+          mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+      }
+      if(lane == leader)
+        for(int a = 0; a < 3; ++a)
+        {
+          atomicMin(&next[cw].cbLo[a], sd_order(mn[a]));
+          atomicMax(&next[cw].cbHi[a], sd_order(mx[a]));
+        }
     }
   });
 }
@@ -979,12 +1001,13 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
       {
         const size_t nBins = size_t(nActive) * 3 * SD_BINS;
         k_sd_init_bins<<<unsigned((nBins + 255) / 256), 256, 0, stream>>>(nBins, binCnt, binBox);
-        k_sd_cbounds<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi);
+        if(levels == 0)  // deeper levels get their centroid bounds from their parents' partition pass
+          k_sd_cbounds<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi);
         k_sd_bin<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi, binCnt, binBox);
         (void)hipMemsetAsync(dCounts, 0, 4, stream);  // next-level counter; the small-node counter keeps running
         SdLists L{workB, dCounts, small, dCounts + 1};
         k_sd_split<<<(nActive + 63) / 64, 64, 0, stream>>>(nActive, workA, binCnt, binBox, L, dChildL, dChildR, dParI, dParL);
-        k_sd_partition<<<G, B, 0, stream>>>(n, idxA, pwA, workA, plo, phi, idxB, pwB);
+        k_sd_partition<<<G, B, 0, stream>>>(n, idxA, pwA, workA, workB, plo, phi, idxB, pwB);
         uint32_t counts[2] = {0u, 0u};
         ok = hipMemcpyAsync(counts, dCounts, 8, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && counts[0] <= maxWork && counts[1] <= maxSmall;
         nActive = counts[0];

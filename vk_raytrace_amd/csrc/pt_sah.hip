@@ -287,6 +287,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_sahdev_topology(u
   else
     sd_init_work(workA[nActive++], 0, n, 0);
   std::vector<uint32_t> binCnt, binBox;
+  int                   level = 0;
   while(nActive)
   {
     binCnt.assign(size_t(nActive) * 3 * SD_BINS, 0u);
@@ -294,8 +295,10 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_sahdev_topology(u
     for(size_t b = 0; b < size_t(nActive) * 3 * SD_BINS; ++b)
       for(int q = 0; q < 6; ++q)
         binBox[b * 6 + q] = q < 3 ? SD_ORD_PLUS_INF : SD_ORD_MINUS_INF;
-    for(uint32_t pos = 0; pos < n; ++pos)
-      sd_cbounds(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data());
+    if(level == 0)  // deeper levels get their centroid bounds from the partition pass of their parents
+      for(uint32_t pos = 0; pos < n; ++pos)
+        sd_cbounds(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data());
+    ++level;
     for(uint32_t pos = 0; pos < n; ++pos)
       sd_bin(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data(), binCnt.data(), binBox.data());
     nextCount = 0;
@@ -303,7 +306,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_sahdev_topology(u
     for(uint32_t w = 0; w < nActive; ++w)
       sd_split(w, workA.data(), binCnt.data(), binBox.data(), L, childL, childR, parI, parL);
     for(uint32_t pos = 0; pos < n; ++pos)
-      sd_partition(pos, idxA.data(), pwA.data(), workA.data(), plo.data(), phi.data(), idxB.data(), pwB.data());
+      sd_partition(pos, idxA.data(), pwA.data(), workA.data(), workB.data(), plo.data(), phi.data(), idxB.data(), pwB.data());
     idxA.swap(idxB);
     pwA.swap(pwB);
     workA.swap(workB);

@@ -267,7 +267,9 @@ SD_FN void sd_split(uint32_t w, SdWork* work, const uint32_t* binCnt, const uint
   child(first + nl, nr, rightId, childR, W.rightW);
 }
 
-SD_FN void sd_partition(uint32_t pos, const uint32_t* idxIn, const uint32_t* primWorkIn, SdWork* work, const float4* plo, const float4* phi, uint32_t* idxOut, uint32_t* primWorkOut)
+// (also accumulates the centroid bounds of the child the triangle goes to, so that only the root needs a sd_cbounds pass)
+SD_FN void sd_partition(uint32_t pos, const uint32_t* idxIn, const uint32_t* primWorkIn, SdWork* work, SdWork* next, const float4* plo, const float4* phi, uint32_t* idxOut,
+                        uint32_t* primWorkOut)
 {
   const uint32_t w = primWorkIn[pos];
   const uint32_t p = idxIn[pos];
@@ -288,8 +290,19 @@ SD_FN void sd_partition(uint32_t pos, const uint32_t* idxIn, const uint32_t* pri
     left           = sd_bin_of(c, W.lo, W.scale) < W.kSplit;
   }
   const uint32_t dst = left ? W.first + sd_add(&W.curL, 1u) : W.first + W.nl + sd_add(&W.curR, 1u);
+  const uint32_t cw  = left ? W.leftW : W.rightW;
   idxOut[dst]        = p;
-  primWorkOut[dst]   = left ? W.leftW : W.rightW;
+  primWorkOut[dst]   = cw;
+  if(cw != SD_NONE)
+  {
+    const float4 lo = plo[p], hi = phi[p];
+    const float  c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    for(int a = 0; a < 3; ++a)
+    {
+      sd_min(&next[cw].cbLo[a], sd_order(c[a]));
+      sd_max(&next[cw].cbHi[a], sd_order(c[a]));
+    }
+  }
 }
 
 // one thread per small node: the whole subtree over <= SD_SMALL triangles by exact sweeps (pt_sah.hip Builder::split, sweep branch)
