@@ -334,16 +334,22 @@ def main():
                 traffic = per_sample * serial["samples"] / d["launches"] if per_sample else None
                 out["hbm_measured"] = {"bytes_per_sample": tj["hbm_bytes_per_sample"]["total"], "GBps": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9,
                                        "frac": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
-                                       "source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, gfx950 corrections) x this run's rate",
+                                       "source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r02.sh, gfx950 corrections) x this run's rate",
                                        "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": (d["alg_GBps"] / HBM_PEAK_GBS) if d["alg_GBps"] else None, "traffic": traffic,
-                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
-                           "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
-                           "note": "dominant stage = largest STANDALONE time (serialised pass: one frame slot, nothing overlapped, HIP events on the launching stream); "
-                                   "achieved = algorithmic bytes of that stage per launch / its average launch duration; `traffic` = measured HBM bytes per launch (PMC)"}
+        # `achieved` is what the stage moves across the HBM interface (measured, PMC) per second of its own standalone run time; the
+        # algorithmic bytes (reference-layout BVH2 visits x 32 B, triangle tests x 36 B, material / texture / light records)
+        # are reported next to it -- most of them are served by L2 / Infinity Cache (the whole scene + BVH is ~115 MB), which is why the
+        # algorithmic rate can exceed the HBM peak while the interface is far from saturated.
+        ach = (traffic / (d["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None
+        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": ach if ach is not None else d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ((ach if ach is not None else d["alg_GBps"]) / HBM_PEAK_GBS), "traffic": traffic,
+                           "achieved_basis": "measured HBM bytes per launch (profiles/r02_traffic.json) / standalone launch duration" if ach is not None else "algorithmic bytes / standalone launch duration",
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "alg_GBps": d["alg_GBps"], "alg_frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
+                           "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
+                           "note": "dominant stage = largest STANDALONE time (serialised pass of this run: one frame slot, nothing overlapped, HIP events on the launching stream; "
+                                   "profiles/r02_trace_batch.txt holds the rocprofv3 per-dispatch durations of the same kind of batch)"}
     # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round,
     # profiles/r02_valu.json); the rate is this run's; the ceiling is the one measured above on this box.
     vpath = os.path.join(ROOT, "profiles", "r02_valu.json")
