@@ -559,3 +559,16 @@ def test_ray_picker(env_small):
         assert p.hitT == t[0] and p.baryCoord[1] == uv[0, 0] and p.baryCoord[2] == uv[0, 1]
     assert hits >= 3
     r.destroy(); o.close()
+    # the picker ignores face culling (flag-less traceRayEXT, src/sample_example.cpp:485-490): a single-sided triangle seen from behind is
+    # picked although the renderer does not see it
+    back = Scene("back")
+    m = back.add_material(pbrBaseColorFactor=(0.8, 0.8, 0.8, 1.0), doubleSided=0)
+    pm = back.add_prim_mesh([(-1, -1, 0), (0, 1, 0), (1, -1, 0)], [(0, 0, -1)] * 3, [(0, 0), (0.5, 1), (1, 0)], [0, 1, 2], m)   # winding faces -z
+    back.add_node(pm)
+    back.camera = Camera(eye=(0, 0, 3), center=(0, 0, 0), fov=45)
+    cfg = Config(back, env_small, 32, 32, debug=hd.eNormal)
+    img, r = render_hip(cfg, 1, return_obj=True)
+    assert np.array_equal(img, render_oracle(cfg, 1)) and not img[16, 16, :3].any()      # culled: the debug AOV of a miss is black
+    p = r.pick(0.5, 0.5, cfg.camera)
+    assert p.instanceID == 0 and p.primitiveID == 0 and abs(p.hitT - 3.0) < 1e-3
+    r.destroy()

@@ -1068,7 +1068,7 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
   int rc;
   if((rc = dev_alloc(c, c->dPick, sizeof(pt_PickResult))) != PT_OK)
     return rc;
-  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p);
+  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p, (Counters*)c->dCounters.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dPick.p, sizeof(pt_PickResult), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -84,7 +84,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
 #define SORT_MAX_CELL_BITS 5
 #define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut);
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles);
 // the offscreen image with its mip chain as the display pass samples it (level 0 = the image; src/render_output.cpp:188-193)

@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
 }
 
 // ---- ray picker (src/sample_example.cpp:468-511; nvvk::RayPickerKHR shoots a flag-less ray: no culling, no any-hit) ------------------
-__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out)
+__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters)
 {
   const f2 d         = f2{pickX * 2.0f - 1.0f, pickY * 2.0f - 1.0f};
   const f4 origin    = mat4_mul(cam.viewInverse, f4{0, 0, 0, 1});
@@ -1270,29 +1270,14 @@ __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float p
   const f3 tn        = unit(xyz(target));
   const f4 direction = mat4_mul(cam.viewInverse, f4{tn.x, tn.y, tn.z, 0});
   const f3 o = xyz(origin), dir = xyz(direction);
-  // nearest triangle in key order (t, world index), no culling: one ray against every triangle record, 64 lanes in parallel
-  // (a pick is a rare, latency-insensitive query; the BVH is not worth a second traversal flavour for it)
-  float    bt = PT_INFINITY, bu = 0.f, bv = 0.f;
-  uint32_t bw = 0xffffffffu, bs = BVH_NONE;
-  for(uint32_t i = threadIdx.x; i < S.numTris; i += 64u)
-  {
-    const TriRec   tr    = S.tris[i];
-    const uint32_t wbits = __float_as_uint(tr.p0w.w);
-    float          t, u, v;
-    if(tri_test(tr, (wbits >> 29) | TRI_NOCULL, o, dir, t, u, v) && t > 0.0f && (bs == BVH_NONE || key_less(t, wbits & TRI_INDEX_MASK, bt, bw)))
-    {
-      bt = t; bu = u; bv = v; bw = wbits & TRI_INDEX_MASK; bs = i;
-    }
-  }
-  for(int off = 32; off > 0; off >>= 1)
-  {
-    const float    ot = __shfl_xor(bt, off), ou = __shfl_xor(bu, off), ov = __shfl_xor(bv, off);
-    const uint32_t ow = __shfl_xor(bw, off), os = __shfl_xor(bs, off);
-    if(os != BVH_NONE && (bs == BVH_NONE || key_less(ot, ow, bt, bw)))
-    {
-      bt = ot; bu = ou; bv = ov; bw = ow; bs = os;
-    }
-  }
+  // nearest triangle in key order (t, world index), no culling: one BVH traversal (the 64 lanes of the wave walk the same ray; a pick is a
+  // rare query, what matters is that it does not scale with the triangle count: 3.8 M records per click on C5 with the old brute force)
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  RayHit              h;
+  bool                dummy;
+  traverse<TM_PICK>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, counters);
+  const float    bt = h.t, bu = h.u, bv = h.v;
+  const uint32_t bs = h.slot;
   if(threadIdx.x != 0)
     return;
   pt_PickResult r;
@@ -1622,12 +1607,12 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
   }
 }
 
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut)
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters)
 {
   pt_SceneCamera cam = scene.camera;
   std::memcpy(cam.viewInverse, viewInv, sizeof(cam.viewInverse));
   std::memcpy(cam.projInverse, projInv, sizeof(cam.projInverse));
-  k_pick<<<1, 64, 0, stream>>>(scene, px, py, cam, dOut);
+  k_pick<<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
 }
 
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor)

@@ -39,7 +39,8 @@ enum TraceMode {
   TM_RAW_NONOPAQUE = 1,  // exact: same, non-opaque triangles only
   TM_CLOSEST = 2,        // pass A of ClosestHit: nearest certain hit, flags for uncertain candidates in front of it
   TM_SHADOW = 3,         // pass A of AnyHit: any opaque hit ends the ray; else nearest certain non-opaque hit + flags
-  TM_COUNT = 4           // pass B: number of zero-opacity candidates with key < (tmax, wLimit)
+  TM_COUNT = 4,          // pass B: number of zero-opacity candidates with key < (tmax, wLimit)
+  TM_PICK = 5            // the ray picker's query: TM_RAW_ALL without face culling (every triangle counts)
 };
 #define TF_SAW_ZERO 1u  // a candidate with opacity <= 0 was seen in front of the (then) best hit
 #define TF_SAW_FRAC 2u  // a candidate with 0 < opacity < 1 was seen in front of the (then) best hit
@@ -325,10 +326,10 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
 #endif
         float t, u, v;
         // (TM_COUNT's upper key (tmax, wLimit) includes candidates that tie with the hit in t)
-        if(tri_test(tr, flags, o, d, t, u, v) && (MODE == TM_COUNT ? t <= tmax : t < tmax))
+        if(tri_test(tr, MODE == TM_PICK ? (flags | TRI_NOCULL) : flags, o, d, t, u, v) && (MODE == TM_COUNT ? t <= tmax : t < tmax))
         {
           const uint32_t w = wbits & TRI_INDEX_MASK;
-          if(MODE == TM_RAW_ALL || MODE == TM_RAW_NONOPAQUE)
+          if(MODE == TM_RAW_ALL || MODE == TM_RAW_NONOPAQUE || MODE == TM_PICK)
           {
             if(key_less(tPrev, wPrev, t, w) && (best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK)))
             {
