@@ -19,6 +19,9 @@ The rewrite is purely lexical -- the arithmetic, the control flow and the call o
         layout(..) uniform <opaque type> name;           -> <opaque type> name;
         layout(buffer_reference, ..) buffer B { T m[]; };-> struct B { const T* m; B(uint64_t a) : m((const T*)a) {} };
         layout(location = n) in|out T name;              -> thread_local T name;
+        layout(location = n) rayPayload[In]EXT T name;   -> thread_local T name;   (ref_rtx_*.cpp move the payload bytes between stages)
+        hitAttributeEXT T name;                          -> thread_local T name;
+        ignoreIntersectionEXT;                           -> { gl_IgnoreIntersection = true; return; }
         layout(local_size_x = ..) in;                    -> (blank)
   R6  `void main()` -> `void shader_main()`;  shader-global mutable variables (`PtPayload prd;` ...) become thread_local
   R7  array constructor `T[n](a, b, ..)` -> `{a, b, ..}`
@@ -103,6 +106,8 @@ def rewrite(name, src):
     s = re.sub(r"layout\s*\([^)]*\)\s*uniform\s+(\w+)\s+(\w+)\s*;", lambda m: keep_lines(m, f"{m.group(1)} {m.group(2)};"), s)
     s = re.sub(r"layout\s*\(\s*location[^)]*\)\s*(?:in|out)\s+(\w+)\s+(\w+)\s*;", lambda m: keep_lines(m, f"thread_local {m.group(1)} {m.group(2)};"), s)
     s = re.sub(r"layout\s*\(\s*location[^)]*\)\s*rayPayload(?:In)?EXT\s+(\w+)\s+(\w+)\s*;", lambda m: keep_lines(m, f"thread_local {m.group(1)} {m.group(2)};"), s)
+    s = re.sub(r"^[ \t]*hitAttributeEXT\s+(\w+)\s+(\w+)\s*;", r"thread_local \1 \2;", s, flags=re.M)
+    s = re.sub(r"\bignoreIntersectionEXT\s*;", "{ gl_IgnoreIntersection = true; return; }", s)
     left = re.search(r"\blayout\s*\(", s)
     assert not left, f"{name}: unhandled layout declaration: " + s[left.start():left.start() + 120]
     # R3

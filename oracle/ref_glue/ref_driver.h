@@ -211,4 +211,23 @@ inline mat4x3 rq_matrix(const rayQueryEXT& q, bool c, int which)
 inline mat4x3 rayQueryGetIntersectionObjectToWorldEXT(const rayQueryEXT& q, bool c) { return rq_matrix(q, c, 0); }
 inline mat4x3 rayQueryGetIntersectionWorldToObjectEXT(const rayQueryEXT& q, bool c) { return rq_matrix(q, c, 1); }
 
+
+// ---- GL_EXT_ray_tracing (the RtxPipeline flavour: pathtrace.rgen / .rchit / .rahit / .rmiss / pathtraceShadow.rmiss) ---------------
+// Built-in variables of the stages, and traceRayEXT as a call into the pipeline emulation of ref_rtx_rgen.cpp: candidates in the order of the
+// trace contract; an instance with FORCE_OPAQUE commits without the any-hit stage, any other candidate runs pathtrace.rahit on the payload
+// the trace call named (that is what makes the shadow ray's alpha tests draw from a COPY of the path's seed: pathtrace.rahit declares the
+// payload of location 0 and is handed the one of location 1, traceray_rtx.glsl:54-55); the closest-hit stage unless
+// gl_RayFlagsSkipClosestHitShaderEXT; the miss stage `missIndex` when nothing was committed.
+extern thread_local GlobalInvocationID gl_LaunchIDEXT, gl_LaunchSizeEXT;  // uvec3 with its .xy swizzle
+extern thread_local float  gl_HitTEXT;
+extern thread_local int    gl_PrimitiveID, gl_InstanceID, gl_InstanceCustomIndexEXT;
+extern thread_local mat4x3 gl_ObjectToWorldEXT, gl_WorldToObjectEXT;
+extern thread_local bool   gl_IgnoreIntersection;
+typedef void (*RtxTraceFn)(uint flags, uint missIndex, vec3 origin, vec3 dir, float tmax, int payload);
+extern RtxTraceFn g_rtxTrace;
+inline void traceRayEXT(const accelerationStructureEXT&, uint flags, uint /*cullMask*/, uint, uint, uint missIndex, vec3 origin, float /*tmin = 0*/, vec3 dir, float tmax, int payload)
+{
+  g_rtxTrace(flags, missIndex, origin, dir, tmax, payload);
+}
+
 }  // namespace glslc

@@ -43,6 +43,9 @@ def frame_configs():
     out["fbox_dof_clamp"] = (Config(sc, env, 48, 36, firefly=0.5), 2)
     out["fuzz1"] = (Config(synth.fuzz_scene(1), env, 64, 48, depth=6, pbr=1), 2)
     out["fuzz2"] = (Config(synth.fuzz_scene(2), env, 64, 48, depth=6, pbr=0), 2)
+    out["fbox_rtx"] = (Config(synth.feature_box(tex_size=32), env, 64, 48, depth=6, max_samples=2, variant=1), 2)       # pathtrace.rgen + hit / miss stages
+    out["fbox_rtx_no_anyhit"] = (Config(synth.feature_box(tex_size=32), env, 64, 48, depth=6, variant=1, any_hit=False), 2)  # RtxPipeline::useAnyHit(false)
+    out["fbox_rq_no_anyhit"] = (Config(synth.feature_box(tex_size=32), env, 64, 48, depth=6, any_hit=False), 2)
     sp = synth.sponza_like(target_tris=20000, tex_size=64)
     out["sponza_small"] = (Config(sp, env, 64, 36, depth=8), 2)
     return out

@@ -63,6 +63,11 @@ def lib():
         L.ref_spot_attenuation.restype = C.c_float
         L.ref_bsdf_eval.argtypes = [C.c_int, P, P, P, P, C.c_float, C.c_int, P, P, P, P]
         L.ref_bsdf_sample.argtypes = [C.c_int, P, P, P, P, C.c_float, C.c_int, P, P, P, P, P]
+        L.ref_rtx_bind.argtypes = [C.POINTER(hd.SceneDesc), P, C.c_int, C.c_int, C.POINTER(Hooks)]
+        L.ref_rtx_set_camera.argtypes = [C.POINTER(hd.SceneCamera)]
+        L.ref_rtx_set_sunsky.argtypes = [C.POINTER(hd.SunAndSky)]
+        L.ref_rtx_use_any_hit.argtypes = [C.c_int]
+        L.ref_rtx_render_frame.argtypes = [C.POINTER(hd.RtxState), P, P, C.c_uint64, C.c_int]
         L.ref_host_compress_unit_vec.argtypes = [P]
         L.ref_host_compress_unit_vec.restype = C.c_uint32
         L.ref_host_pack_unorm4x8.argtypes = [P]
@@ -84,11 +89,15 @@ class Reference:
     """pathtrace.comp dispatched on the CPU.  What the Vulkan driver would supply (triangle candidates in the order of the trace contract,
     instance matrices, bilinear sampling) is bound to an Oracle instance holding the same scene; everything else is the reference's code."""
 
-    def __init__(self, scene, env, oracle=None):
+    def __init__(self, scene, env, oracle=None, rtx=False, any_hit=True):
+        """rtx: the RtxPipeline flavour (pathtrace.rgen + .rchit / .rahit / .rmiss through an emulated vkCmdTraceRaysKHR) instead of the
+        ray-query compute shader; any_hit: RtxPipeline::useAnyHit (the hooks' oracle must be in the same mode: opaque flags come from it)"""
         self.L = lib()
+        self.rtx = rtx
         self.o = oracle or orc.Oracle()
         self.own = oracle is None
         if self.own:
+            self.o.use_any_hit(any_hit)
             self.o.set_scene(scene)
             self.o.set_env(env)
         OL = self.o.L
@@ -98,13 +107,15 @@ class Reference:
         env = np.ascontiguousarray(env, np.float32)
         self.hooks = Hooks(self.o.ctx, _fn_addr(OL, "orc_hook_query"), _fn_addr(OL, "orc_hook_tri_info"), _fn_addr(OL, "orc_hook_instance"),
                            _fn_addr(OL, "orc_hook_sample_texture"), _fn_addr(OL, "orc_hook_sample_env"))
-        self.L.ref_bind(C.byref(self.desc), OL.orc_env_accel(self.o.ctx), env.shape[1], env.shape[0], C.byref(self.hooks))
+        (self.L.ref_rtx_bind if rtx else self.L.ref_bind)(C.byref(self.desc), OL.orc_env_accel(self.o.ctx), env.shape[1], env.shape[0], C.byref(self.hooks))
+        if rtx:
+            self.L.ref_rtx_use_any_hit(int(bool(any_hit)))
 
     def set_camera(self, cam):
-        self.L.ref_set_camera(C.byref(cam))
+        (self.L.ref_rtx_set_camera if self.rtx else self.L.ref_set_camera)(C.byref(cam))
 
     def set_sunsky(self, ss):
-        self.L.ref_set_sunsky(C.byref(ss))
+        (self.L.ref_rtx_set_sunsky if self.rtx else self.L.ref_set_sunsky)(C.byref(ss))
 
     def render(self, state, frames, accum=None, first_frame=0, pixel_ids=None, threads=0):
         W, H = state.size[0], state.size[1]
@@ -113,13 +124,14 @@ class Reference:
         ids = None if pixel_ids is None else np.ascontiguousarray(pixel_ids, np.uint32)
         for f in range(first_frame, first_frame + frames):
             state.frame = f
-            self.L.ref_render_frame(C.byref(state), accum.ctypes.data, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids), threads)
+            (self.L.ref_rtx_render_frame if self.rtx else self.L.ref_render_frame)(C.byref(state), accum.ctypes.data, None if ids is None else ids.ctypes.data,
+                                                                                    0 if ids is None else len(ids), threads)
         return accum
 
 
 def render_reference(cfg, frames, pixel_ids=None):
     """Same call shape as tests.common.render_oracle."""
-    r = Reference(cfg.scene, cfg.env)
+    r = Reference(cfg.scene, cfg.env, rtx=cfg.variant == 1, any_hit=cfg.any_hit)
     r.set_camera(cfg.camera)
     r.set_sunsky(cfg.sunsky)
     return r.render(cfg.state(r.o.integral), frames, pixel_ids=pixel_ids)

@@ -280,6 +280,23 @@ def test_frame_lights_sunsky_samples_dof(env_small):
     frames_equal(Config(sc, env_small, 64, 48, firefly=0.5), 2)
 
 
+def test_frame_rtx_pipeline_flavour(env_small):
+    """The reference's second renderer (src/rtx_pipeline.cpp): pathtrace.rgen + pathtrace.rchit / .rahit / .rmiss / pathtraceShadow.rmiss
+    compiled from their own sources and driven through an emulated vkCmdTraceRaysKHR -- against the oracle's restatement of its two
+    observable differences (seed without the maxSamples factor, pathtrace.rgen:72; shadow-ray any-hit draws on a copy of the seed because
+    pathtrace.rahit is handed the payload of location 1, traceray_rtx.glsl:54-55).  And RtxPipeline::useAnyHit(false)."""
+    sc = synth.feature_box(tex_size=32)
+    rtx = Config(sc, env_small, 80, 60, depth=6, max_samples=2, variant=1)
+    a = frames_equal(rtx, 3)
+    rq = Config(sc, env_small, 80, 60, depth=6, max_samples=2)
+    assert not np.array_equal(a, render_oracle(rq, 3))          # the flavours do differ
+    frames_equal(Config(synth.fuzz_scene(1), env_small, 64, 48, depth=6, variant=1), 2)
+    off = frames_equal(Config(sc, env_small, 80, 60, depth=6, variant=1, any_hit=False), 2)
+    assert not np.array_equal(off, render_oracle(Config(sc, env_small, 80, 60, depth=6, variant=1), 2))
+    # the ray-query flavour with every instance forced opaque (what pt_use_any_hit(0) means there) against the compute shader on the same hooks
+    frames_equal(Config(sc, env_small, 64, 48, depth=6, any_hit=False), 2)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_frame_fuzz_scenes(env_small, seed):
     frames_equal(Config(synth.fuzz_scene(seed), env_small, 64, 48, depth=6, pbr=seed & 1), 2)
