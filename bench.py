@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--tris", type=int, default=262_267)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"], help="BASELINE.json configuration (stand-in scene); c3 is the bench line, the others are for the results table")
     ap.add_argument("--emulate-shard", default="", help="R/N: render only rank R's tiles of an N-GPU run on this one GPU (scaling estimate; value = this shard's rate)")
+    ap.add_argument("--accel", default="flat", choices=["flat", "two"], help="acceleration structure: flat world-space hierarchy (default) or the reference's BLAS per prim-mesh + TLAS (pt_set_accel_mode)")
+    ap.add_argument("--refit", type=int, default=0, help="with --accel two: time this many pt_update_instances calls (TLAS refit) after the run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the serialised profiling pass (roofline fields become null)")
     ap.add_argument("--no-interactive", action="store_true", help="skip the frame-by-frame (render + tonemap) measurement")
@@ -97,6 +99,8 @@ def main():
 
     r = HipRenderer()
     r.setup(local_rank)
+    if args.accel == "two":
+        r.set_accel_mode(capi.PT_ACCEL_TWO_LEVEL)
     if args.emulate_shard:
         er, en = (int(x) for x in args.emulate_shard.split("/"))
         r.set_shard(er, en)
@@ -198,9 +202,19 @@ def main():
         "setup_s": t_setup,
         "gather_ms": gather_ms,
         "bvh_build_ms": stats["msBuildAccel"],
+        "accel": {"mode": args.accel, "bytes": stats["bytesAccel"], "blas": stats["numBlas"], "tlas_nodes": stats["numTlasNodes"], "nodes": stats["numBvhNodes"]},
         "rays": {k: stats[k] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")},
         "image_mean": float(np.mean(img[..., :3])) if img is not None else None,
     }
+
+    if args.refit > 0:
+        # instance update (pt_update_instances): every node's world matrix is re-sent; two-level mode redoes only the instance boxes + TLAS
+        nodes = wl.scene.node_array()
+        r.update_instances(nodes)
+        t0 = time.perf_counter()
+        for _ in range(args.refit):
+            r.update_instances(nodes)
+        out["accel"]["update_instances_ms"] = (time.perf_counter() - t0) * 1e3 / args.refit
 
     # ---- CPU baseline (oracle == literal restatement of pathtrace.comp, kind "port") + algorithmic bytes ----
     alg = None

@@ -67,6 +67,19 @@ int pt_set_scene(pt_context* ctx, const pt_SceneDesc* scene);
  * world-space triangles of every node. */
 int pt_build_accel(pt_context* ctx);
 
+/* Layout of the acceleration structure pt_build_accel creates.  PT_ACCEL_FLAT (default): one hierarchy over the world-space triangles of
+ * every node (an instanced mesh is stored once per instance).  PT_ACCEL_TWO_LEVEL: the reference's own shape [src/accelstruct.cpp:110-127
+ * createBottomLevelAS: one BLAS per prim-mesh; :132-162 createTopLevelAS: one TLAS instance per node carrying node.worldMatrix] -- every
+ * prim-mesh is built once in object space and shared by its instances, the top level holds the instances' world boxes.  Rendered pixels are
+ * bit-identical in both modes (the triangle test runs on the same world-space vertices).  Rebuilds if a structure exists. */
+int pt_set_accel_mode(pt_context* ctx, int mode);
+
+/* New world matrices for the nodes of the current scene (same count, same primMesh per node), e.g. an animated or edited scene: the
+ * counterpart of rebuilding the reference's TLAS from node.worldMatrix [src/accelstruct.cpp:137-161] without touching the BLASes
+ * (nvvk::RaytracingBuilderKHR::buildTlas with update = true).  PT_ACCEL_TWO_LEVEL refits: instance boxes + instance hierarchy only.
+ * PT_ACCEL_FLAT rebuilds the whole structure.  Frames already handed to pt_render_frame keep the old transforms. */
+int pt_update_instances(pt_context* ctx, const pt_Node* nodes, uint32_t num_nodes);
+
 /* replaces Scene::updateCamera's UBO upload [src/scene.cpp:629-668] */
 int pt_set_camera(pt_context* ctx, const pt_SceneCamera* cam);
 

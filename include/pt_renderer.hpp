@@ -105,6 +105,8 @@ public:
   void readAccum(float* rgba32f) { check(pt_read_accum(m_ctx, rgba32f)); }
   void writeAccum(const float* rgba32f) { check(pt_write_accum(m_ctx, rgba32f)); }  // checkpoint restore
   void useAnyHit(bool enable) { check(pt_use_any_hit(m_ctx, enable ? 1 : 0)); }  // RtxPipeline::useAnyHit
+  void setAccelMode(int mode) { check(pt_set_accel_mode(m_ctx, mode)); }  // PT_ACCEL_TWO_LEVEL: AccelStructure's BLAS per prim-mesh + TLAS (src/accelstruct.cpp:110-162)
+  void updateInstances(const pt_Node* nodes, uint32_t n) { check(pt_update_instances(m_ctx, nodes, n)); }  // new node.worldMatrix values: TLAS refit
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
   // while SampleExample de-scales (m_descaling, src/sample_example.cpp:410-413): viewport of dispW x dispH from the reduced-size render
   void tonemapZoom(const pt_Tonemapper& tm, int dispW, int dispH, uint8_t* rgba8) { check(pt_tonemap_zoom(m_ctx, &tm, dispW, dispH, rgba8)); }

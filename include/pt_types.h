@@ -187,6 +187,8 @@ typedef struct pt_Node {
  * reference: src/scene.cpp:447-482,561-571). Only the mag filter matters: every tap is LOD 0. */
 /* the reference's two Renderer implementations (src/sample_example.hpp:136-137), see pt_set_variant */
 enum { PT_VARIANT_RAYQUERY = 0, PT_VARIANT_RTX = 1 };
+/* layout of the acceleration structure, see pt_set_accel_mode */
+enum { PT_ACCEL_FLAT = 0, PT_ACCEL_TWO_LEVEL = 1 };
 /* functions of the fp32 transcendental contract (pt_fpmath.h), for pt_fpmath_eval */
 enum { PT_FN_SIN = 0, PT_FN_COS, PT_FN_TAN, PT_FN_ASIN, PT_FN_ACOS, PT_FN_ATAN2, PT_FN_EXP, PT_FN_LOG, PT_FN_POW };
 enum { PT_FILTER_NEAREST = 0, PT_FILTER_LINEAR = 1 };
@@ -251,6 +253,9 @@ typedef struct pt_Stats {
   uint32_t numBvhNodes;
   double   msBuildAccel;     /* last pt_build_accel */
   uint64_t bytesScene;       /* resident HBM bytes of scene+BVH+textures+env */
+  uint64_t bytesAccel;       /* of which the acceleration structure (nodes + leaf records + any-hit records) */
+  uint32_t numBlas;          /* PT_ACCEL_TWO_LEVEL: bottom-level structures (prim-meshes instantiated), else 0 */
+  uint32_t numTlasNodes;     /* PT_ACCEL_TWO_LEVEL: nodes of the instance hierarchy, else 0 */
 } pt_Stats;
 
 /* pt_measure_peaks: ceilings measured on the device */

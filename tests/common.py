@@ -50,10 +50,13 @@ def render_oracle(cfg, frames, use_bvh=True, threads=0, return_obj=False, math_m
     return acc
 
 
-def render_hip(cfg, frames, device=0, shard=None, return_obj=False):
+def render_hip(cfg, frames, device=0, shard=None, return_obj=False, accel=None):
+    """accel: capi.PT_ACCEL_FLAT / PT_ACCEL_TWO_LEVEL (None: the context's default, i.e. flat unless PT_TUNE says accel=two)"""
     from vk_raytrace_amd.renderer import HipRenderer
     r = HipRenderer()
     r.setup(device)
+    if accel is not None:
+        r.set_accel_mode(accel)
     if shard is not None:
         r.set_shard(*shard)
     r.set_scene(cfg.scene)

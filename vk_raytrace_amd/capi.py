@@ -12,6 +12,7 @@ import numpy as np
 from . import host_device as hd
 
 PT_VARIANT_RAYQUERY, PT_VARIANT_RTX = 0, 1
+PT_ACCEL_FLAT, PT_ACCEL_TWO_LEVEL = 0, 1
 PT_FN = {"sin": 0, "cos": 1, "tan": 2, "asin": 3, "acos": 4, "atan2": 5, "exp": 6, "log": 7, "pow": 8}
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
 
@@ -27,6 +28,8 @@ API = [
     ("pt_last_error", C.c_char_p, [_P]),
     ("pt_set_scene", C.c_int, [_P, C.POINTER(hd.SceneDesc)]),
     ("pt_build_accel", C.c_int, [_P]),
+    ("pt_set_accel_mode", C.c_int, [_P, C.c_int]),
+    ("pt_update_instances", C.c_int, [_P, _P, C.c_uint32]),
     ("pt_set_camera", C.c_int, [_P, C.POINTER(hd.SceneCamera)]),
     ("pt_set_env", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("pt_hdr_load", C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),

@@ -15,6 +15,8 @@
 #include <vector>
 #include <cfloat>
 #include <cstdio>
+#include <cstring>
+#include <algorithm>
 #include "pt_device.h"
 #include "pt_internal.h"
 #include "pt_sahdev.h"
@@ -817,6 +819,130 @@ __global__ void k_single_leaf(const float4* leafLo, const float4* leafHi, const 
 }
 
 
+// ---- two-level structure: kernels around pt_accel_build (reference: src/accelstruct.cpp:110-162) ---------------------------------------
+// centroids + their bounds of ready-made primitive records (the TLAS's instance boxes)
+__global__ void k_proxy_centroids(uint32_t n, const TriRec* __restrict__ prox, float4* __restrict__ cen, uint32_t* __restrict__ bounds)
+{
+  const uint32_t i     = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     valid = i < n;
+  f3             c     = f3{0, 0, 0};
+  if(valid)
+  {
+    const TriRec r = prox[i];
+    c      = xyz(r.p0w) + xyz(r.e1n) * 0.5f;
+    cen[i] = make_float4(c.x, c.y, c.z, 0.f);
+  }
+  float mn[3] = {valid ? c.x : FLT_MAX, valid ? c.y : FLT_MAX, valid ? c.z : FLT_MAX};
+  float mx[3] = {valid ? c.x : -FLT_MAX, valid ? c.y : -FLT_MAX, valid ? c.z : -FLT_MAX};
+  for(int off = 32; off > 0; off >>= 1)
+    for(int a = 0; a < 3; ++a)
+    {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+    }
+  if((threadIdx.x & 63) == 0)
+    for(int a = 0; a < 3; ++a)
+    {
+      atomicMin(&bounds[a], order_bits(mn[a]));
+      atomicMax(&bounds[3 + a], order_bits(mx[a]));
+    }
+}
+
+// BLAS leaf records from the builder's edge form (p0, e1, e2 under the identity transform) to the vertex form the two-level walk transforms
+// per instance: the three OBJECT-space positions exactly as the vertex buffer holds them, p0w.w = primitive index
+__global__ void k_blas_vertex_form(uint32_t n, TriRec* __restrict__ tris, const float4* __restrict__ vertices, const uint32_t* __restrict__ indices, uint32_t vertexOffset,
+                                   uint32_t firstIndex)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const uint32_t  k = __float_as_uint(tris[i].e2p.w);
+  const uint32_t* t = indices + firstIndex + 3 * size_t(k);
+  const f3        v0 = load_pos(vertices, vertexOffset + t[0]), v1 = load_pos(vertices, vertexOffset + t[1]), v2 = load_pos(vertices, vertexOffset + t[2]);
+  TriRec          r;
+  r.p0w   = make_float4(v0.x, v0.y, v0.z, __uint_as_float(k));
+  r.e1n   = make_float4(v1.x, v1.y, v1.z, 0.f);
+  r.e2p   = make_float4(v2.x, v2.y, v2.z, 0.f);
+  tris[i] = r;
+}
+// child references of a BLAS from local to global indices (nodes: + nodeBase, leaf slots: + slotBase), tags kept
+__global__ void k_blas_rebase(uint32_t numWide, WideNode* __restrict__ wide, uint32_t nodeBase, uint32_t slotBase)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= numWide)
+    return;
+  for(int q = 0; q < PT_WIDE_Q; ++q)
+  {
+    uint32_t* ch = &wide[i].child[q].x;
+    for(int k = 0; k < 4; ++k)
+      if(ch[k] != BVH_NONE)
+        ch[k] = (ch[k] & ~BVH_SLOT_MASK) | ((ch[k] & BVH_SLOT_MASK) + ((ch[k] & BVH_LEAF) ? slotBase : nodeBase));
+  }
+}
+
+// World box of an instance = exact bounds of its T1 world triangles (the same xform_point the leaf test applies, so the box encloses every
+// triangle the walk can test inside it), written as the "diagonal" primitive record the builder takes.  One block per active instance.
+__global__ void __launch_bounds__(256) k_instance_proxies(const uint32_t* __restrict__ active, const InstanceRec* __restrict__ inst, const float4* __restrict__ vertices,
+                                                          const uint32_t* __restrict__ indices, TriRec* __restrict__ out)
+{
+  __shared__ float red[6][4];
+  const uint32_t     id = active[blockIdx.x];
+  const InstanceRec& I  = inst[id];
+  const Affine       M  = I.objectToWorld;
+  float              mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for(uint32_t j = threadIdx.x; j < 3u * I.triCount; j += blockDim.x)
+  {
+    const f3 p = xform_point(M, load_pos(vertices, I.vertexOffset + indices[I.firstIndex + j]));
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  for(int off = 32; off > 0; off >>= 1)
+    for(int a = 0; a < 3; ++a)
+    {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+    }
+  const int wave = threadIdx.x >> 6;
+  if((threadIdx.x & 63) == 0)
+    for(int a = 0; a < 3; ++a)
+    {
+      red[a][wave]     = mn[a];
+      red[3 + a][wave] = mx[a];
+    }
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    for(int a = 0; a < 3; ++a)
+      for(int w = 1; w < 4; ++w)
+      {
+        red[a][0]     = fminf(red[a][0], red[a][w]);
+        red[3 + a][0] = fmaxf(red[3 + a][0], red[3 + a][w]);
+      }
+    TriRec r;  // box = bounds of {p0, p0 + e1, p0 + e2}; p0 + e1 may miss the upper corner by an ulp, which the leaf padding of tri_box covers
+    r.p0w = make_float4(red[0][0], red[1][0], red[2][0], __uint_as_float(id | (I.flags << 29)));
+    r.e1n = make_float4(red[3][0] - red[0][0], red[4][0] - red[1][0], red[5][0] - red[2][0], 0.f);
+    r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
+    out[blockIdx.x] = r;
+  }
+}
+__global__ void k_tlas_leaves(uint32_t n, const TriRec* __restrict__ leafOrder, const InstanceRec* __restrict__ inst, const uint32_t* __restrict__ instNodeBase,
+                              const float* __restrict__ instPad, TlasLeaf* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const uint32_t id = __float_as_uint(leafOrder[i].p0w.w) & TRI_INDEX_MASK;
+  TlasLeaf       l;
+  l.inst     = id;
+  l.nodeBase = instNodeBase[id];
+  l.wflags   = inst[id].triBase | (inst[id].flags << 29);
+  l._pad0    = 0;
+  l.padC0    = instPad[2 * size_t(id)];
+  l.padC1    = instPad[2 * size_t(id) + 1];
+  l._pad1[0] = l._pad1[1] = 0;
+  out[i]     = l;
+}
+
 // ---- collapse BVH2 -> wide BVH (level-synchronous; one thread per wide node) -------------------------------------
 struct CollapseItem {
   uint32_t b2;    // binary node to expand
@@ -916,12 +1042,18 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
   } while(0)
 
 // Builds TriRec[numTris] (leaf order) and BvhNode[max(1,numTris-1)] into caller-allocated device memory.
+// dProxies (may be null): the primitives are given as ready-made records instead of (instance, triangle) pairs -- the TLAS of the two-level
+// structure is built over one "diagonal" record per instance (p0 = box min, e1 = box extent, e2 = 0: its bounding box is the instance's box).
+// scratch (may be null): temporaries come out of the caller's arena instead of one device allocation each (a scene of hundreds of BLASes).
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen)
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen, const TriRec* dProxies,
+                   PtScratch* scratch)
 {
   *numWideOut = 0;
   if(numTris == 0)
     return 0;
+  PtScratch  localScratch;
+  PtScratch& sc = scratch ? *scratch : localScratch;
   const uint32_t n          = numTris;
   const uint32_t sortBlocks = (n + SORT_ITEMS - 1) / SORT_ITEMS;
   const int      B          = 256;
@@ -936,28 +1068,35 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   bool      sah     = false, ploc = false, sahDev = false;
   uint32_t  initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
 
-  HIPCHK(hipMalloc(&dUnsorted, sizeof(TriRec) * size_t(n)));
-  HIPCHK(hipMalloc(&dAlphaUnsorted, sizeof(AlphaRec) * size_t(n)));
-  HIPCHK(hipMalloc(&dCen, sizeof(float4) * size_t(n)));
-  HIPCHK(hipMalloc(&dLeafLo, sizeof(float4) * size_t(n)));
-  HIPCHK(hipMalloc(&dLeafHi, sizeof(float4) * size_t(n)));
-  HIPCHK(hipMalloc(&dNodeLo, sizeof(float4) * size_t(n)));
-  HIPCHK(hipMalloc(&dNodeHi, sizeof(float4) * size_t(n)));
-  HIPCHK(hipMalloc(&dKeysA, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dKeysB, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dValsA, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dValsB, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dHist, 4 * size_t(256) * sortBlocks));
-  HIPCHK(hipMalloc(&dBounds, 4 * 6));
-  HIPCHK(hipMalloc(&dChildL, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dChildR, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dParI, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dParL, 4 * size_t(n)));
-  HIPCHK(hipMalloc(&dArrive, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dUnsorted, sizeof(TriRec) * size_t(n)));
+  HIPCHK(sc.get((void**)&dAlphaUnsorted, sizeof(AlphaRec) * size_t(n)));
+  HIPCHK(sc.get((void**)&dCen, sizeof(float4) * size_t(n)));
+  HIPCHK(sc.get((void**)&dLeafLo, sizeof(float4) * size_t(n)));
+  HIPCHK(sc.get((void**)&dLeafHi, sizeof(float4) * size_t(n)));
+  HIPCHK(sc.get((void**)&dNodeLo, sizeof(float4) * size_t(n)));
+  HIPCHK(sc.get((void**)&dNodeHi, sizeof(float4) * size_t(n)));
+  HIPCHK(sc.get((void**)&dKeysA, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dKeysB, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dValsA, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dValsB, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dHist, 4 * size_t(256) * sortBlocks));
+  HIPCHK(sc.get((void**)&dBounds, 4 * 6));
+  HIPCHK(sc.get((void**)&dChildL, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dChildR, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dParI, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dParL, 4 * size_t(n)));
+  HIPCHK(sc.get((void**)&dArrive, 4 * size_t(n)));
   HIPCHK(hipMemcpyAsync(dBounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream));
 
-  k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
+  if(dProxies)
+  {
+    HIPCHK(hipMemcpyAsync(dUnsorted, dProxies, sizeof(TriRec) * size_t(n), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemsetAsync(dAlphaUnsorted, 0, sizeof(AlphaRec) * size_t(n), stream));
+    k_proxy_centroids<<<G, B, 0, stream>>>(n, dProxies, dCen, dBounds);
+  }
+  else
+    k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
   sah = g_tuning.sahBuild == 1 && n >= 2;  // sahBuild: 0 device LBVH (Karras), 1 host SAH topology, 2 device PLOC, 3 device binned SAH (default)
   ploc = g_tuning.sahBuild == 2 && n >= 2;
   sahDev = g_tuning.sahBuild == 3 && n >= 2;
@@ -969,7 +1108,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     SdWork *  workA = nullptr, *workB = nullptr, *small = nullptr;
     const size_t maxWork = size_t(n) / (SD_SMALL + 1) + 2, maxSmall = size_t(n) / 2 + 2;
     bool      okAlloc = true;
-    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && hipMalloc(p, bytes) == hipSuccess; };
+    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && sc.get(p, bytes) == hipSuccess; };
     grab((void**)&plo, 16 * size_t(n)); grab((void**)&phi, 16 * size_t(n)); grab((void**)&idxA, 4 * size_t(n)); grab((void**)&idxB, 4 * size_t(n)); grab((void**)&pwA, 4 * size_t(n));
     grab((void**)&pwB, 4 * size_t(n)); grab((void**)&workA, sizeof(SdWork) * maxWork); grab((void**)&workB, sizeof(SdWork) * maxWork); grab((void**)&small, sizeof(SdWork) * maxSmall);
     grab((void**)&binCnt, 4 * maxWork * 3 * SD_BINS); grab((void**)&binBox, 4 * maxWork * 3 * SD_BINS * 6); grab((void**)&dCounts, 8);
@@ -1023,8 +1162,6 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
         done = ok;
       }
     }
-    for(void* q : tmp)
-      (void)hipFree(q);
     (void)hipGetLastError();
     if(!done)
     {
@@ -1073,7 +1210,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     float4 *  cloA = nullptr, *cloB = nullptr, *chiA = nullptr, *chiB = nullptr;
     void*     tmp[11];
     bool      okAlloc = true;
-    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && hipMalloc(p, bytes) == hipSuccess; };
+    auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && sc.get(p, bytes) == hipSuccess; };
     grab((void**)&cidA, 4 * size_t(n)); grab((void**)&cidB, 4 * size_t(n)); grab((void**)&dNn, 4 * size_t(n)); grab((void**)&dValid, 4 * size_t(n)); grab((void**)&dPos, 4 * size_t(n));
     grab((void**)&dBlockSum, 4 * size_t((n + 1023) / 1024 + 1)); grab((void**)&dCnt, 8);
     grab((void**)&cloA, 16 * size_t(n)); grab((void**)&cloB, 16 * size_t(n)); grab((void**)&chiA, 16 * size_t(n)); grab((void**)&chiB, 16 * size_t(n));
@@ -1113,8 +1250,6 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
         (void)hipMemcpyAsync(dParI, &none, 4, hipMemcpyHostToDevice, stream);  // the root (node 0) has no parent
       }
     }
-    for(void* q : tmp)
-      (void)hipFree(q);
     (void)hipGetLastError();
     if(!done)
       ploc = false;  // fall back to the radix tree below
@@ -1144,9 +1279,9 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   {
     CollapseItem* dQ[2] = {nullptr, nullptr};
     uint32_t*     dCnt  = nullptr;
-    HIPCHK(hipMalloc(&dQ[0], sizeof(CollapseItem) * size_t(n)));
-    HIPCHK(hipMalloc(&dQ[1], sizeof(CollapseItem) * size_t(n)));
-    HIPCHK(hipMalloc(&dCnt, 8));
+    HIPCHK(sc.get((void**)&dQ[0], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(sc.get((void**)&dQ[1], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(sc.get((void**)&dCnt, 8));
     CollapseItem first{0u, 0u};
     uint32_t     cnt[2] = {0u, 1u};  // next-queue size, wide nodes allocated (root = 0)
     HIPCHK(hipMemcpyAsync(dQ[0], &first, sizeof(first), hipMemcpyHostToDevice, stream));
@@ -1164,23 +1299,130 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
       cur ^= 1;
     }
     *numWideOut = cnt[1];
-    (void)hipFree(dQ[0]);
-    (void)hipFree(dQ[1]);
-    (void)hipFree(dCnt);
   }
 
-  {
-    void* all[] = {dUnsorted, dAlphaUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
-    for(void* p : all)
-      (void)hipFree(p);
-  }
+  sc.release();
   return 0;
 fail:
-{
-  void* all[] = {dUnsorted, dAlphaUnsorted, dCen, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dKeysA, dKeysB, dValsA, dValsB, dHist, dBounds, dChildL, dChildR, dParI, dParL, dArrive};
-  for(void* p : all)
-    if(p)
-      (void)hipFree(p);
-}
+  (void)hipStreamSynchronize(stream);  // nothing of this build may still be running when the arena is reused
+  sc.release();
   return -1;
+}
+
+// ---- two-level structure: the builds -------------------------------------------------------------------------------------------------
+// Every BLAS is an ordinary pt_accel_build over ONE pseudo-instance with the identity transform (object space), written at its bases in the
+// shared arrays; then its leaf records are turned into vertex form and its references made global.
+int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
+                  char* err, size_t errLen)
+{
+  if(numBlas == 0)
+    return 0;
+  uint32_t maxTris = 1;
+  for(uint32_t b = 0; b < numBlas; ++b)
+    maxTris = std::max(maxTris, blas[b].triCount);
+  std::vector<InstanceRec> pseudo(numBlas);
+  for(uint32_t b = 0; b < numBlas; ++b)
+  {
+    InstanceRec& I = pseudo[b];
+    std::memset(&I, 0, sizeof(I));
+    I.objectToWorld.r0 = I.worldToObject.r0 = make_float4(1.f, 0.f, 0.f, 0.f);
+    I.objectToWorld.r1 = I.worldToObject.r1 = make_float4(0.f, 1.f, 0.f, 0.f);
+    I.objectToWorld.r2 = I.worldToObject.r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+    I.vertexOffset  = blas[b].vertexOffset;
+    I.firstIndex    = blas[b].firstIndex;
+    I.materialIndex = blas[b].materialIndex;
+    I.primMesh      = int32_t(blas[b].primMesh);
+    I.triBase       = 0;
+    I.triCount      = blas[b].triCount;
+    I.flags         = blas[b].flags & ~TRI_FLIP;
+  }
+  InstanceRec* dPseudo = nullptr;
+  BvhNode*     dNodes  = nullptr;
+  PtScratch    arena;
+  int          rc = -1;
+  // temporaries of one build: < 640 B per triangle (pt_accel_build's lists + the SAH builder's bins); whatever does not fit is allocated singly
+  const size_t arenaBytes = size_t(maxTris) * 640 + (size_t(1) << 20);
+  if(hipMalloc(&dPseudo, sizeof(InstanceRec) * size_t(numBlas)) != hipSuccess || hipMalloc(&dNodes, sizeof(BvhNode) * size_t(maxTris)) != hipSuccess)
+  {
+    snprintf(err, errLen, "BLAS build: out of device memory");
+    goto done;
+  }
+  if(hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
+    arena.cap = arenaBytes;
+  else
+  {
+    arena.base = nullptr;  // no arena: every temporary is its own allocation
+    (void)hipGetLastError();
+  }
+  if(hipMemcpyAsync(dPseudo, pseudo.data(), sizeof(InstanceRec) * size_t(numBlas), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+  {
+    snprintf(err, errLen, "BLAS build: upload failed");
+    goto done;
+  }
+  for(uint32_t b = 0; b < numBlas; ++b)
+  {
+    PtBlasDesc&    d = blas[b];
+    const uint32_t n = d.triCount;
+    if(pt_accel_build(stream, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, err, errLen, nullptr, &arena) != 0)
+      goto done;
+    if(d.numWide == 0 || d.numWide > std::max(1u, n - 1))
+    {
+      snprintf(err, errLen, "BLAS %u: %u wide nodes for %u triangles", b, d.numWide, n);
+      goto done;
+    }
+    k_blas_vertex_form<<<(n + 255) / 256, 256, 0, stream>>>(n, dTris + d.slotBase, dVertices, dIndices, d.vertexOffset, d.firstIndex);
+    k_blas_rebase<<<(d.numWide + 255) / 256, 256, 0, stream>>>(d.numWide, dWide + d.nodeBase, d.nodeBase, d.slotBase);
+  }
+  if(hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+  {
+    snprintf(err, errLen, "BLAS build: a kernel failed");
+    goto done;
+  }
+  rc = 0;
+done:
+  (void)hipStreamSynchronize(stream);
+  arena.release();
+  if(arena.base)
+    (void)hipFree(arena.base);
+  if(dPseudo)
+    (void)hipFree(dPseudo);
+  if(dNodes)
+    (void)hipFree(dNodes);
+  return rc;
+}
+
+int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
+                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen)
+{
+  *numWideOut = 0;
+  if(numActive == 0)
+    return 0;
+  const uint32_t n = numActive;
+  TriRec *       dProx = nullptr, *dLeafOrder = nullptr;
+  AlphaRec*      dAlpha = nullptr;
+  BvhNode*       dNodes = nullptr;
+  int            rc = -1;
+  if(hipMalloc(&dProx, sizeof(TriRec) * size_t(n)) != hipSuccess || hipMalloc(&dLeafOrder, sizeof(TriRec) * size_t(n)) != hipSuccess ||
+     hipMalloc(&dAlpha, sizeof(AlphaRec) * size_t(n)) != hipSuccess || hipMalloc(&dNodes, sizeof(BvhNode) * size_t(n)) != hipSuccess)
+  {
+    snprintf(err, errLen, "TLAS build: out of device memory");
+    goto done;
+  }
+  k_instance_proxies<<<n, 256, 0, stream>>>(dActive, dInst, dVertices, dIndices, dProx);
+  if(pt_accel_build(stream, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, numWideOut, err, errLen, dProx, nullptr) != 0)
+    goto done;
+  k_tlas_leaves<<<(n + 255) / 256, 256, 0, stream>>>(n, dLeafOrder, dInst, dInstNodeBase, dInstPad, dLeavesOut);
+  if(hipMemcpyAsync(rootOut, dNodes, sizeof(BvhNode), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+  {
+    snprintf(err, errLen, "TLAS build: a kernel failed");
+    goto done;
+  }
+  rc = 0;
+done:
+  (void)hipStreamSynchronize(stream);
+  void* all[] = {dProx, dLeafOrder, dAlpha, dNodes};
+  for(void* q : all)
+    if(q)
+      (void)hipFree(q);
+  return rc;
 }

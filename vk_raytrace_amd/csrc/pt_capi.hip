@@ -34,6 +34,13 @@ struct pt_context {
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
+  // two-level acceleration structure (pt_set_accel_mode): dWide / dTris / dAlphaRecs hold the concatenated BLASes, dTlas the instance hierarchy
+  int      accelMode = PT_ACCEL_FLAT;
+  DevBuf   dTlas, dTlasLeaves, dInstTriBase, dActive, dInstNodeBase, dInstPad;
+  uint32_t numBlas = 0, numTlasNodes = 0, numActive = 0;
+  std::vector<uint32_t> hInstNodeBase;  // per instance: root node of its BLAS (two-level mode, after the BLAS build)
+  std::vector<float>    hPrimBound;     // per prim-mesh: max |coordinate| of its vertices (object space); bounds the rounding of the ray transform
+  double   msBuildTlas = 0;
   bool     renderedSinceCheck = false;
   bool     anyHit = true;               // RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276); false: every triangle is opaque
   std::vector<InstanceRec> hInstances;  // as built by pt_set_scene (flags without the useAnyHit override)  // frames were launched since the traversal-stack overflow counter was last looked at
@@ -234,8 +241,165 @@ void refresh_scene_ptrs(pt_context* c)
   s.envAccel     = (const pt_EnvAccel*)c->dEnvAccel.p;
   s.numTris      = c->numTris;
   s.numInstances = c->numInstances;
+  const bool two = c->accelMode == PT_ACCEL_TWO_LEVEL && c->haveAccel;
+  s.tlas         = two ? (const WideNode*)c->dTlas.p : nullptr;
+  s.tlasLeaves   = two ? (const TlasLeaf*)c->dTlasLeaves.p : nullptr;
+  s.instTriBase  = two ? (const uint32_t*)c->dInstTriBase.p : nullptr;
+  s.twoLevel     = two ? 1u : 0u;
 }
 
+
+// fills the per-instance part of an InstanceRec that depends on the node's world matrix (pt_set_scene, pt_update_instances)
+bool set_instance_transform(InstanceRec& I, const float* m, uint32_t materialFlags)
+{
+  I.objectToWorld.r0 = make_float4(m[0], m[4], m[8], m[12]);
+  I.objectToWorld.r1 = make_float4(m[1], m[5], m[9], m[13]);
+  I.objectToWorld.r2 = make_float4(m[2], m[6], m[10], m[14]);
+  double inv[12], det3;
+  if(!affine_inverse(m, inv, det3))
+    return false;
+  I.worldToObject.r0 = make_float4(float(inv[0]), float(inv[3]), float(inv[6]), float(inv[9]));
+  I.worldToObject.r1 = make_float4(float(inv[1]), float(inv[4]), float(inv[7]), float(inv[10]));
+  I.worldToObject.r2 = make_float4(float(inv[2]), float(inv[5]), float(inv[8]), float(inv[11]));
+  I.flags = (materialFlags & ~TRI_FLIP) | (det3 < 0.0 ? TRI_FLIP : 0u);
+  return true;
+}
+
+// Two-level walk: how far the object-space image of a world-space hit point can lie from the transformed ray (TlasLeaf::padC0 / padC1,
+// pt_trace.h enter_instance).  With u = 2^-24, A = max abs row sum of the 3x3 parts, T = max |translation|, Bo = max |object coordinate|
+// of the mesh, |p| <= Am Bo + Tm for every world point of the instance:
+//   ray transform          <= u (7 Ainv |o| + 3 Ainv |p| + 4 Tinv)          (4-term dot products for o', 3-term for d', scaled by t |d| <= |p| + |o|)
+//   inverse rounded to f32 <= u (Ainv |p| + Tinv)
+//   T1 rounding of the world triangle, seen from object space <= 4 u Ainv (Am Bo + Tm)
+//   the triangle test accepts points a few ulps of |p| off the triangle (the flat structure pads its leaf boxes by 67 u |p| for that)
+// eps = 2^-17 (Ainv |o|  +  Ainv (Am Bo + 2 Tm) + Tinv + Bo) = 128 u (...) covers their sum with room to spare and is still ~1e-3 of a
+// world unit for a scene 50 units across.
+void two_level_pad(const InstanceRec& I, float Bo, float& c0, float& c1)
+{
+  auto rs = [](const float4& r) { return double(std::fabs(r.x)) + std::fabs(r.y) + std::fabs(r.z); };
+  const double Am   = std::max(rs(I.objectToWorld.r0), std::max(rs(I.objectToWorld.r1), rs(I.objectToWorld.r2)));
+  const double Tm   = std::max(std::fabs(double(I.objectToWorld.r0.w)), std::max(std::fabs(double(I.objectToWorld.r1.w)), std::fabs(double(I.objectToWorld.r2.w))));
+  const double Ainv = std::max(rs(I.worldToObject.r0), std::max(rs(I.worldToObject.r1), rs(I.worldToObject.r2)));
+  const double Tinv = std::max(std::fabs(double(I.worldToObject.r0.w)), std::max(std::fabs(double(I.worldToObject.r1.w)), std::fabs(double(I.worldToObject.r2.w))));
+  const double k    = 1.0 / 131072.0;  // 2^-17
+  const double v1 = k * Ainv, v0 = k * (Ainv * (Am * double(Bo) + 2.0 * Tm) + Tinv + double(Bo));
+  c1 = std::nextafter(float(std::min(v1, 1e30)), INFINITY);
+  c0 = std::nextafter(float(std::min(v0, 1e30)), INFINITY);
+}
+
+// world bounds (origin cells of the ray-sort keys) from the binary root of a hierarchy
+void bounds_from_root(pt_context* c, const BvhNode& root, bool two)
+{
+  const float lmin[3] = {root.a.x, root.a.y, root.a.z}, lmax[3] = {root.a.w, root.b.x, root.b.y};
+  const float rmin[3] = {root.b.z, root.b.w, root.c.x}, rmax[3] = {root.c.y, root.c.z, root.c.w};
+  for(int k = 0; k < 3; ++k)
+  {
+    const float mn = two ? std::min(lmin[k], rmin[k]) : lmin[k], mx = two ? std::max(lmax[k], rmax[k]) : lmax[k];
+    c->scene.boundsMin[k]    = std::isfinite(mn) ? mn : 0.f;
+    c->scene.boundsInvExt[k] = (std::isfinite(mx - mn) && mx > mn) ? 1.0f / (mx - mn) : 0.f;
+  }
+}
+
+// the instance records as the kernels see them (see upload_instances)
+std::vector<InstanceRec> effective_instances(const pt_context* c)
+{
+  std::vector<InstanceRec> inst = c->hInstances;
+  if(!c->anyHit)
+    for(InstanceRec& I : inst)
+      I.flags |= TRI_OPAQUE;
+  return inst;
+}
+
+// TLAS of the two-level structure over the current instance transforms (also the refit after pt_update_instances: the BLASes stay)
+int build_tlas(pt_context* c)
+{
+  const std::vector<InstanceRec> inst = effective_instances(c);
+  std::vector<uint32_t>          active, triBase(inst.empty() ? 1 : inst.size(), 0u);
+  std::vector<float>             pad(inst.empty() ? 2 : 2 * inst.size(), 0.f);
+  for(uint32_t i = 0; i < inst.size(); ++i)
+  {
+    triBase[i] = inst[i].triBase;
+    if(inst[i].triCount == 0)
+      continue;
+    active.push_back(i);
+    two_level_pad(inst[i], c->hPrimBound[inst[i].primMesh], pad[2 * i], pad[2 * i + 1]);
+  }
+  c->numActive = uint32_t(active.size());
+  int rc;
+  const uint32_t none = 0;
+  if((rc = upload(c, c->dActive, active.empty() ? &none : active.data(), 4 * std::max<size_t>(1, active.size()))) != PT_OK) return rc;
+  if((rc = upload(c, c->dInstTriBase, triBase.data(), 4 * triBase.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dInstPad, pad.data(), 4 * pad.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dInstNodeBase, c->hInstNodeBase.empty() ? &none : c->hInstNodeBase.data(), 4 * std::max<size_t>(1, c->hInstNodeBase.size()))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dTlas, sizeof(WideNode) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dTlasLeaves, sizeof(TlasLeaf) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
+  auto    t0 = std::chrono::steady_clock::now();
+  char    msg[256];
+  BvhNode root{};
+  if(pt_tlas_build(c->stream, (const InstanceRec*)c->dInstances.p, (const uint32_t*)c->dActive.p, c->numActive, (const uint32_t*)c->dInstNodeBase.p, (const float*)c->dInstPad.p,
+                   (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (WideNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, msg, sizeof(msg)) != 0)
+    return c->fail(PT_ERR_HIP, "TLAS build: %s", msg);
+  c->msBuildTlas = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for(int k = 0; k < 3; ++k)
+    c->scene.boundsMin[k] = c->scene.boundsInvExt[k] = 0.f;
+  if(c->numActive > 0)
+    bounds_from_root(c, root, c->numActive > 1 && root.d.y != BVH_NONE);
+  return PT_OK;
+}
+
+// AccelStructure::create as the reference does it [src/accelstruct.cpp:110-162]: one BLAS per prim-mesh that some node instantiates, one TLAS
+// instance per node
+int build_two_level(pt_context* c)
+{
+  const std::vector<InstanceRec> inst = effective_instances(c);
+  std::map<int32_t, uint32_t>    blasOf;
+  std::vector<PtBlasDesc>        blas;
+  uint64_t                       slots = 0, nodes = 0;
+  c->hInstNodeBase.assign(inst.size(), 0u);
+  for(uint32_t i = 0; i < inst.size(); ++i)
+  {
+    const InstanceRec& I = inst[i];
+    if(I.triCount == 0)
+      continue;
+    auto it = blasOf.find(I.primMesh);
+    if(it == blasOf.end())
+    {
+      PtBlasDesc d{};
+      d.primMesh = uint32_t(I.primMesh); d.vertexOffset = I.vertexOffset; d.firstIndex = I.firstIndex; d.triCount = I.triCount;
+      d.flags = I.flags & ~TRI_FLIP; d.materialIndex = I.materialIndex;
+      d.slotBase = uint32_t(slots); d.nodeBase = uint32_t(nodes);
+      slots += I.triCount;
+      nodes += std::max(1u, I.triCount - 1);
+      it = blasOf.emplace(I.primMesh, uint32_t(blas.size())).first;
+      blas.push_back(d);
+    }
+    c->hInstNodeBase[i] = blas[it->second].nodeBase;
+  }
+  if(slots > BVH_SLOT_MASK || nodes > BVH_SLOT_MASK)
+    return c->fail(PT_ERR_INVALID, "two-level structure: %llu distinct triangles exceed the reference range", (unsigned long long)slots);
+  int rc;
+  if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(std::max<uint64_t>(1, slots)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(std::max<uint64_t>(1, slots)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dWide, sizeof(WideNode) * size_t(std::max<uint64_t>(1, nodes)))) != PT_OK) return rc;
+  dev_free(c->dBvh);  // the binary nodes are a build temporary here
+  auto t0 = std::chrono::steady_clock::now();
+  char msg[256];
+  if(pt_blas_build(c->stream, blas.data(), uint32_t(blas.size()), (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p,
+                   (WideNode*)c->dWide.p, msg, sizeof(msg)) != 0)
+    return c->fail(PT_ERR_HIP, "pt_build_accel (two-level): %s", msg);
+  c->numBlas      = uint32_t(blas.size());
+  c->numBvhNodes  = uint32_t(nodes);
+  c->numWideNodes = 0;
+  for(const PtBlasDesc& d : blas)
+    c->numWideNodes += d.numWide;
+  if((rc = build_tlas(c)) != PT_OK)
+    return rc;
+  HIP_TRY(c, sync_all(c));
+  c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  c->haveAccel = true;
+  refresh_scene_ptrs(c);
+  return PT_OK;
+}
 }  // namespace
 
 // ---- stage timers ------------------------------------------------------------------------------------------
@@ -342,6 +506,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
     if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
     if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
+    if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
     if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) g_tuning.plocFull = v;
     if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) g_tuning.plocRadius = v;
@@ -356,6 +521,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   }
   pt_context* c = new pt_context();
   c->device     = device_ordinal;
+  c->accelMode  = g_tuning.accelTwoLevel ? PT_ACCEL_TWO_LEVEL : PT_ACCEL_FLAT;
   if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
   {
     g_createError = "hipStreamCreate failed";
@@ -390,7 +556,7 @@ int pt_destroy(pt_context* c)
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
-                   &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
+                   &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
@@ -523,42 +689,41 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
       return c->fail(PT_ERR_INVALID, "primMesh %d: vertex/index range out of bounds", nd.primMesh);
     const pt_GltfShadeMaterial& mat = d->materials[pm.materialIndex < 0 ? 0 : pm.materialIndex];
     InstanceRec&                I   = inst[n];
-    const float*                m   = nd.worldMatrix;
-    I.objectToWorld.r0 = make_float4(m[0], m[4], m[8], m[12]);
-    I.objectToWorld.r1 = make_float4(m[1], m[5], m[9], m[13]);
-    I.objectToWorld.r2 = make_float4(m[2], m[6], m[10], m[14]);
-    double inv[12], det3;
-    if(!affine_inverse(m, inv, det3))
-      return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
-    I.worldToObject.r0 = make_float4(float(inv[0]), float(inv[3]), float(inv[6]), float(inv[9]));
-    I.worldToObject.r1 = make_float4(float(inv[1]), float(inv[4]), float(inv[7]), float(inv[10]));
-    I.worldToObject.r2 = make_float4(float(inv[2]), float(inv[5]), float(inv[8]), float(inv[11]));
-    I.vertexOffset  = pm.vertexOffset;
-    I.firstIndex    = pm.firstIndex;
-    I.materialIndex = pm.materialIndex;
-    I.primMesh      = nd.primMesh;
-    I.triBase       = uint32_t(triTotal);
-    I.triCount      = pm.indexCount / 3;
     // instance flags of the reference's TLAS (src/accelstruct.cpp:144-149)
     uint32_t flags = 0;
     if(mat.alphaMode == 0 || (mat.pbrBaseColorFactor[3] == 1.0f && mat.pbrBaseColorTexture == -1))
       flags |= TRI_OPAQUE;
     if(mat.doubleSided == 1)
       flags |= TRI_NOCULL;
-    if(det3 < 0.0)
-      flags |= TRI_FLIP;
-    I.flags = flags;
+    if(!set_instance_transform(I, nd.worldMatrix, flags))  // + TRI_FLIP for a mirroring matrix
+      return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
+    I.vertexOffset  = pm.vertexOffset;
+    I.firstIndex    = pm.firstIndex;
+    I.materialIndex = pm.materialIndex;
+    I.primMesh      = nd.primMesh;
+    I.triBase       = uint32_t(triTotal);
+    I.triCount      = pm.indexCount / 3;
     I._pad  = 0;
     triTotal += I.triCount;
   }
   if(triTotal > TRI_INDEX_MASK)
     return c->fail(PT_ERR_INVALID, "scene has %llu triangles; the limit is %u", (unsigned long long)triTotal, TRI_INDEX_MASK);
+  c->hPrimBound.assign(d->numPrimMeshes, 0.f);
   for(uint32_t p = 0; p < d->numPrimMeshes; ++p)
   {
     const pt_PrimMesh& pm = d->primMeshes[p];
     for(uint32_t k = 0; k < pm.indexCount; ++k)
       if(d->indices[pm.firstIndex + k] >= pm.vertexCount)
         return c->fail(PT_ERR_INVALID, "primMesh %u: index %u >= vertexCount", p, d->indices[pm.firstIndex + k]);
+    float b = 0.f;
+    for(uint32_t v = 0; v < pm.vertexCount; ++v)
+    {
+      const float* q = d->vertices[pm.vertexOffset + v].position;
+      for(int a = 0; a < 3; ++a)
+        if(std::isfinite(q[a]))
+          b = std::max(b, std::fabs(q[a]));
+    }
+    c->hPrimBound[p] = b;
   }
   for(uint32_t m = 0; m < d->numMaterials; ++m)
   {
@@ -655,7 +820,12 @@ int pt_build_accel(pt_context* c)
   if(!c->haveScene)
     return c->fail(PT_ERR_STATE, "pt_build_accel before pt_set_scene");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));
+  c->haveAccel = false;
+  if(c->accelMode == PT_ACCEL_TWO_LEVEL)
+    return build_two_level(c);
   int rc;
+  c->numBlas = c->numTlasNodes = c->numActive = 0;
   c->numBvhNodes = c->numTris > 1 ? c->numTris - 1 : 1;
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
@@ -678,15 +848,7 @@ int pt_build_accel(pt_context* c)
   {
     BvhNode root;
     HIP_TRY(c, hipMemcpy(&root, c->dBvh.p, sizeof(root), hipMemcpyDeviceToHost));
-    const float lmin[3] = {root.a.x, root.a.y, root.a.z}, lmax[3] = {root.a.w, root.b.x, root.b.y};
-    const float rmin[3] = {root.b.z, root.b.w, root.c.x}, rmax[3] = {root.c.y, root.c.z, root.c.w};
-    const bool  two = c->numTris > 1 && root.d.y != BVH_NONE;
-    for(int k = 0; k < 3; ++k)
-    {
-      const float mn = two ? std::min(lmin[k], rmin[k]) : lmin[k], mx = two ? std::max(lmax[k], rmax[k]) : lmax[k];
-      c->scene.boundsMin[k]    = std::isfinite(mn) ? mn : 0.f;
-      c->scene.boundsInvExt[k] = (std::isfinite(mx - mn) && mx > mn) ? 1.0f / (mx - mn) : 0.f;
-    }
+    bounds_from_root(c, root, c->numTris > 1 && root.d.y != BVH_NONE);
   }
   c->haveAccel = true;
   refresh_scene_ptrs(c);
@@ -773,6 +935,66 @@ int pt_use_any_hit(pt_context* c, int enable)
     return pt_build_accel(c);
   }
   return PT_OK;
+}
+
+
+int pt_set_accel_mode(pt_context* c, int mode)
+{
+  CTX_CHECK(c);
+  if(mode != PT_ACCEL_FLAT && mode != PT_ACCEL_TWO_LEVEL)
+    return c->fail(PT_ERR_INVALID, "pt_set_accel_mode: %d", mode);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));  // frames already handed over keep the structure they were given
+  if(mode == c->accelMode)
+    return PT_OK;
+  c->accelMode = mode;
+  if(c->haveAccel)
+  {
+    c->haveAccel = false;
+    return pt_build_accel(c);
+  }
+  refresh_scene_ptrs(c);
+  return PT_OK;
+}
+
+int pt_update_instances(pt_context* c, const pt_Node* nodes, uint32_t numNodes)
+{
+  CTX_CHECK(c);
+  if(!c->haveScene)
+    return c->fail(PT_ERR_STATE, "pt_update_instances before pt_set_scene");
+  if(!nodes || numNodes != c->hInstances.size())
+    return c->fail(PT_ERR_INVALID, "pt_update_instances: %u nodes, the scene has %zu", numNodes, c->hInstances.size());
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));  // frames already handed over keep the transforms they were given
+  std::vector<InstanceRec> inst = c->hInstances;
+  for(uint32_t n = 0; n < numNodes; ++n)
+  {
+    if(nodes[n].primMesh != inst[n].primMesh)
+      return c->fail(PT_ERR_INVALID, "pt_update_instances: node %u changes its primMesh (%d -> %d); only the world matrices may change", n, inst[n].primMesh, nodes[n].primMesh);
+    if(!set_instance_transform(inst[n], nodes[n].worldMatrix, inst[n].flags))
+      return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
+  }
+  c->hInstances = inst;
+  int rc = upload_instances(c);
+  if(rc != PT_OK)
+    return rc;
+  refresh_scene_ptrs(c);
+  if(!c->haveAccel)
+    return PT_OK;
+  if(c->accelMode == PT_ACCEL_TWO_LEVEL)
+  {  // refit: the object-space BLASes are untouched, only the instance boxes and the hierarchy over them are redone
+    auto t0 = std::chrono::steady_clock::now();
+    if((rc = build_tlas(c)) != PT_OK)
+    {
+      c->haveAccel = false;
+      return rc;
+    }
+    c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    refresh_scene_ptrs(c);
+    return PT_OK;
+  }
+  c->haveAccel = false;  // flat structure: the world-space triangles are baked in
+  return pt_build_accel(c);
 }
 
 int pt_set_shard(pt_context* c, int rank, int nranks)
@@ -1370,8 +1592,12 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.numTriangles = c->numTris;
   s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;
   s.msBuildAccel = c->msBuild;
+  s.numBlas      = c->numBlas;
+  s.numTlasNodes = c->numTlasNodes;
+  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes;
   uint64_t bytes = 0;
-  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel};
+  const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel,
+                        &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase};
   for(const DevBuf* b : sb)
     bytes += b->bytes;
   s.bytesScene = bytes;
@@ -1394,3 +1620,22 @@ int pt_reset_stats(pt_context* c)
 }
 
 }  // extern "C"
+
+// Test hook (not part of the ABI; CPU tests hold the bound to a float32 emulation of the ray transform): the instance record pt_set_scene
+// derives from a node's world matrix and the object-space padding of the two-level walk for a mesh whose |coordinates| are <= Bo.
+// out: objectToWorld rows (12), worldToObject rows (12), padC0, padC1, flags
+extern "C" __attribute__((visibility("default"))) int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27)
+{
+  InstanceRec I{};
+  if(!worldMatrix16 || !out27 || !set_instance_transform(I, worldMatrix16, 0u))
+    return PT_ERR_INVALID;
+  const float4 rows[6] = {I.objectToWorld.r0, I.objectToWorld.r1, I.objectToWorld.r2, I.worldToObject.r0, I.worldToObject.r1, I.worldToObject.r2};
+  for(int r = 0; r < 6; ++r)
+  {
+    out27[4 * r] = rows[r].x; out27[4 * r + 1] = rows[r].y; out27[4 * r + 2] = rows[r].z; out27[4 * r + 3] = rows[r].w;
+  }
+  two_level_pad(I, Bo, out27[24], out27[25]);
+  out27[26] = float(I.flags);
+  return PT_OK;
+}
+

@@ -73,6 +73,21 @@ struct WideNode {
   uint4  pad[PT_WIDE_Q];     // pads the node to 128 B (W=4) / 256 B (W=8)
 };
 
+// ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
+// One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
+// the instances' world boxes.  DeviceScene::wide / tris / alphaRecs then hold the concatenated BLASes (child references and leaf slots
+// are global indices into them), DeviceScene::tlas the instance hierarchy.  A BLAS leaf record keeps the three OBJECT-space vertex
+// positions (p0w.xyz, e1n.xyz, e2p.xyz; p0w.w = primitive index): the triangle test transforms them with the instance matrix exactly as
+// trace contract T1 does and runs in world space, so hits are bit-identical to the flat structure; only the box tests happen in object space.
+struct TlasLeaf {  // 32 B, one per TLAS leaf (= non-empty instance), TLAS leaf order
+  uint32_t inst;      // instance (glTF node) index
+  uint32_t nodeBase;  // root WideNode of the instance's BLAS
+  uint32_t wflags;    // world index of the instance's first triangle | TRI_* flags << 29
+  uint32_t _pad0;
+  float    padC0, padC1;  // object-space box padding for a ray with origin o: padC1 * max|o| + padC0 (covers the rounding of the ray transform)
+  uint32_t _pad1[2];
+};
+
 // ---- scene records -------------------------------------------------------------------------------
 // One per TLAS instance (glTF node): what the reference reads through gl_InstanceCustomIndex ->
 // InstanceData -> buffer_reference (shaders/host_device.h:200-205) plus the two 4x3 matrices of the
@@ -121,6 +136,11 @@ struct DeviceScene {
   pt_SunAndSky                sunsky;
   float                       boundsMin[3];     // world bounds of the triangles (ray-sort keys: origin cell)
   float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
+  // two-level mode (null / 0 otherwise)
+  const WideNode*             tlas;         // instance hierarchy; its leaf references index tlasLeaves
+  const TlasLeaf*             tlasLeaves;
+  const uint32_t*             instTriBase;  // InstanceRec::triBase of every instance, compact (world triangle index -> instance)
+  uint32_t                    twoLevel;
 };
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------

@@ -10,8 +10,52 @@
 #endif
 
 // pt_accel.hip
+// Bump arena for a build's temporaries (one device allocation for many builds); what does not fit is allocated individually and freed by release().
+struct PtScratch {
+  char*  base = nullptr;
+  size_t cap = 0, off = 0;
+  void*  owned[96];
+  int    numOwned = 0;
+  hipError_t get(void** p, size_t bytes)
+  {
+    bytes = bytes ? ((bytes + 255) & ~size_t(255)) : 256;
+    if(base && off + bytes <= cap)
+    {
+      *p = base + off;
+      off += bytes;
+      return hipSuccess;
+    }
+    if(numOwned >= 96)
+      return hipErrorOutOfMemory;
+    hipError_t e = hipMalloc(p, bytes);
+    if(e == hipSuccess)
+      owned[numOwned++] = *p;
+    return e;
+  }
+  void release()
+  {
+    for(int i = 0; i < numOwned; ++i)
+      (void)hipFree(owned[i]);
+    numOwned = 0;
+    off      = 0;
+  }
+};
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen);
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen,
+                   const TriRec* dProxies = nullptr, PtScratch* scratch = nullptr);
+// Two-level structure (reference: src/accelstruct.cpp:110-162).  One BLAS per prim-mesh in object space ...
+struct PtBlasDesc {
+  uint32_t primMesh, vertexOffset, firstIndex, triCount, flags;  // flags: TRI_OPAQUE / TRI_NOCULL of the mesh's material (no TRI_FLIP: that is per instance)
+  int32_t  materialIndex;
+  uint32_t slotBase, nodeBase;  // where its leaf records / wide nodes start in the shared arrays (nodeBase + max(1, triCount - 1) nodes reserved)
+  uint32_t numWide;             // out: wide nodes used
+};
+int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
+                  char* err, size_t errLen);
+// ... and one TLAS over the world boxes of the `numActive` non-empty instances listed in dActive (exact bounds of the T1 world triangles).
+// dInstNodeBase[inst]: root node of the instance's BLAS; dInstPad[2 * inst + {0,1}]: TlasLeaf::padC0 / padC1.  rootOut: the binary root (world bounds).
+int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
+                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen);
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
 // Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):
@@ -73,6 +117,7 @@ struct PtTuning {
   int plocFull             = 0;    // PLOC: below this many clusters the search covers all of them (exact agglomerative clustering of the top levels)
   int plocRadius           = 16;   // PLOC: clusters examined on either side of a cluster per round
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
+  int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
 extern PtTuning g_tuning;

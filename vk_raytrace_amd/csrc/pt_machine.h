@@ -32,6 +32,10 @@ struct TraceLane {
   int      pass;           // 0: pass A (nearest certain hit), 1: pass B (count zero-opacity candidates in front of it)
   bool     opaqueHit;      // shadow rays: an opaque occluder was found
   bool     done;
+#if PT_BVH_WIDTH != 2
+  InstCtx  ic;             // two-level instantiations only (the flat ones never touch it): the instance the lane is inside of
+  uint32_t steps;          //   and the loop-iteration guard
+#endif
 };
 
 PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
@@ -44,18 +48,38 @@ PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
 #endif
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
   L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f; L.zeroMaxT2 = -1.0f; L.zeroMaxT3 = -1.0f;
+#if PT_BVH_WIDTH != 2
+  L.ic = InstCtx{BVH_NONE, 0, 0u}; L.steps = 0;
+#endif
 }
 // pass B over the candidates with key < (best hit | ray end)
+template <bool TWO = false>
 PT_DEV void lane_begin_count(TraceLane& L)
 {
   const bool found = L.bslot != BVH_NONE;
   L.wLimit = found ? (L.bw & TRI_INDEX_MASK) : 0u;
   L.tmax   = found ? L.bt : L.tmax;
   L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.pass = 1; L.done = false;
+#if PT_BVH_WIDTH != 2
+  if(TWO)
+  {  // pass A may have ended inside an instance
+    L.ic.inst = BVH_NONE;
+    L.rbox    = make_raybox(L.o, L.d);
+  }
+#endif
 }
 
+template <bool TWO = false>
 PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
 {
+#if PT_BVH_WIDTH != 2
+  if(TWO && L.ic.inst != BVH_NONE && L.sp == L.ic.spBase)
+  {  // the instance's subtree is exhausted: back to TLAS level.  The world-space ray constants are recomputed rather than kept
+     // (12 VGPRs for the lifetime of the lane against ~40 instructions per instance visit)
+    L.ic.inst = BVH_NONE;
+    L.rbox    = make_raybox(L.o, L.d);
+  }
+#endif
   if(L.sp == 0)
   {
     L.done = true;
@@ -67,12 +91,18 @@ PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
 
 // One inner-node visit.  SHADOW: true for shadow rays (they must keep looking for opaque triangles behind the best
 // alpha candidate, so only tmax prunes).
-template <bool SHADOW>
+template <bool SHADOW, bool TWO = false>
 PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters)
 {
 #if PT_BVH_WIDTH != 2
+  if(TWO && ++L.steps > PT_TWO_GUARD)
+  {
+    atomicAdd(&counters->stackOverflow, 1u);
+    L.done = true;
+    return;
+  }
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
-  const uint32_t nxt = wide_node_step(S.wide, L.cur, L.rbox, lim, L.pass == 1, [&](uint32_t c) {
+  const uint32_t nxt = wide_node_step((TWO && L.ic.inst == BVH_NONE) ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, [&](uint32_t c) {
     if(L.sp < STACK_LDS)
       lds[L.sp++ * TRACE_BLOCK] = c;
     else if(L.sp < STACK_LDS + STACK_SPILL)
@@ -83,7 +113,7 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else
-    lane_pop(L, lds, spill);
+    lane_pop<TWO>(L, lds, spill);
 }
 #else
   const BvhNode* np = S.bvh + (L.cur & BVH_SLOT_MASK);
@@ -126,14 +156,28 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 #endif
 
 // One leaf (triangle) visit; same candidate rules as traverse<TM_CLOSEST / TM_SHADOW / TM_COUNT>.
-template <bool SHADOW>
+template <bool SHADOW, bool TWO = false>
 PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill)
 {
   const uint32_t slot  = L.cur & BVH_SLOT_MASK;
-  const TriRec   tr    = S.tris[slot];
+#if PT_BVH_WIDTH != 2
+  if(TWO && L.ic.inst == BVH_NONE)
+  {  // TLAS leaf: enter the instance (pt_trace.h: enter_instance)
+    const TlasLeaf tl = S.tlasLeaves[slot];
+    L.ic   = InstCtx{tl.inst, L.sp, tl.wflags};
+    L.rbox = enter_instance(S, tl, L.o, L.d);
+    L.cur  = tl.nodeBase;
+    return;
+  }
+#endif
+  TriRec         tr    = S.tris[slot];
   AlphaRec       ar;
   if(L.cur & BVH_ALPHA)
     ar = S.alphaRecs[slot];
+#if PT_BVH_WIDTH != 2
+  if(TWO)
+    tr = world_tri(S, L.ic, tr);
+#endif
   const uint32_t wbits = __float_as_uint(tr.p0w.w);
   const uint32_t flags = wbits >> 29;
   const bool     opq   = (flags & TRI_OPAQUE) != 0;
@@ -184,7 +228,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
       }
     }
   }
-  lane_pop(L, lds, spill);
+  lane_pop<TWO>(L, lds, spill);
 }
 
 // Wave-uniform ray supply: a wave reserves PT_CHUNK consecutive queue entries with one atomic and hands them to

@@ -44,6 +44,9 @@ namespace {
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 5  // 96 VGPRs; 6 (80 VGPRs) spills once the fused slab test's per-ray constants are live: 996 vs 1070 Msamples/s (r01)
 #endif
+#ifndef PT_TRACE_WAVES_TWO
+#define PT_TRACE_WAVES_TWO 4  // two-level instantiations: object-space ray constants + instance context are live on top of the flat state (128 VGPRs)
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 3
 #endif
@@ -234,12 +237,14 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
     atomicAdd(ctr, (unsigned long long)v);
 }
 
-PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, float t, float u, float v)
+// The hit record names the triangle by its leaf slot (flat structure: S.tris[slot] carries instance and primitive) or, with the two-level
+// structure (`two`: a BLAS leaf is shared by all instances of its mesh), by its world triangle index (k_shade: instance_of_world_tri).
+PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, uint32_t bw, bool two, float t, float u, float v)
 {
   if(bslot == BVH_NONE)
     rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
   else
-    rb.ps.hit[slot] = make_float4(t, __uint_as_float(bslot), u, v);
+    rb.ps.hit[slot] = make_float4(t, __uint_as_float(two ? (bw & TRI_INDEX_MASK) : bslot), u, v);
 }
 
 // Persistent wavefronts on the trace machine (pt_machine.h).  The loop alternates between
@@ -251,8 +256,8 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, fl
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
 // HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
 // instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
-template <bool HEAT>
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
+template <bool HEAT, bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
     {
       bool fallback = (L.flags & TF_SAW_FRAC) != 0;
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
-        lane_begin_count(L);  // stay alive: pass B runs in the same loop
+        lane_begin_count<TWO>(L);  // stay alive: pass B runs in the same loop
       else
       {
         if(!fallback)
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
           uint32_t s2 = seed;
           if(consume_rejected_draws(s2, nDraw))
           {
-            store_hit(rb, pslot, L.bslot, L.bt, L.bu, L.bv);
+            store_hit(rb, pslot, L.bslot, L.bw, TWO, L.bt, L.bu, L.bv);
             if(nDraw)
               rb.ps.rayD[pslot].w = __uint_as_float(s2);
             nAlpha += nDraw;
@@ -331,13 +336,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false>(S, L, lds, spill, rb.counters);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
-        lane_leaf<false>(S, L, lds, spill);
+        lane_leaf<false, TWO>(S, L, lds, spill);
     }
   }
 #ifdef PT_HIST
@@ -353,7 +358,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_p(Devic
 
 // Simple variant: one ray per lane for the lifetime of the wave (lock-step traversal: for coherent rays every
 // node fetch is a broadcast), pass A + pass B inline, exact fallback through queueX.
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
@@ -370,14 +376,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(Devic
     const uint32_t seed = __float_as_uint(dw.w);
     RayHit         h;
     bool           dummy;
-    traverse<TM_CLOSEST>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+    traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
     fallback       = (h.flags & TF_SAW_FRAC) != 0;
     const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
     uint32_t   nDraw = h.count;
     if(passB)
     {
       RayHit c;
-      traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+      traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
                          rb.counters);
       fallback = (c.flags & TF_SAW_FRAC) != 0;
       nDraw    = c.count;
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_s(Devic
       uint32_t s2 = seed;
       if(consume_rejected_draws(s2, nDraw))
       {
-        store_hit(rb, slot, h.slot, h.t, h.u, h.v);
+        store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
         if(nDraw)
           rb.ps.rayD[slot].w = __uint_as_float(s2);
         nAlpha = nDraw;
@@ -448,7 +454,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
         uint32_t s2 = seed;
         if(consume_rejected_draws(s2, nDraw))
         {
-          store_hit(rb, slot, h.slot, h.t, h.u, h.v);
+          store_hit(rb, slot, h.slot, h.w, false, h.t, h.u, h.v);
           if(nDraw)
             rb.ps.rayD[slot].w = __uint_as_float(s2);
           nAlpha += nDraw;
@@ -467,7 +473,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
 
 // Exact fallback: one ray per lane, key-ordered stochastic alpha (trace contract T5).  Runs on the rays the
 // machine could not settle (fractional opacity in front of the hit, or a rejected-candidate draw of exactly 0.0).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   const uint32_t      count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_x(Devic
     bool           dummy;
     for(;;)
     {
-      traverse<TM_RAW_ALL>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
       if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
         break;
       atomicAdd(&rb.counters->alphaTests, 1ull);
@@ -493,7 +500,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_closest_x(Devic
       tPrev = h.t;
       wPrev = h.w & TRI_INDEX_MASK;
     }
-    store_hit(rb, slot, h.slot, h.t, h.u, h.v);
+    store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
     rb.ps.rayD[slot].w = __uint_as_float(seed);
   }
 }
@@ -609,11 +616,23 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
   // ---- hit ----
   events |= EV_HIT;
-  const TriRec       tr = S.tris[__float_as_uint(hit.y)];
-  const InstanceRec& I  = S.instances[__float_as_uint(tr.e1n.w)];
+  uint32_t hitInst, hitPrim;
+  if(S.twoLevel)
+  {  // the hit names the world triangle (store_hit): a BLAS leaf is shared by every instance of its mesh
+    const uint32_t w = __float_as_uint(hit.y);
+    hitInst          = instance_of_world_tri(S, w);
+    hitPrim          = w - S.instTriBase[hitInst];
+  }
+  else
+  {
+    const TriRec tr = S.tris[__float_as_uint(hit.y)];
+    hitInst         = __float_as_uint(tr.e1n.w);
+    hitPrim         = __float_as_uint(tr.e2p.w);
+  }
+  const InstanceRec& I = S.instances[hitInst];
   Surface            sf;
   f3                 vcolor;
-  surface_at_hit(S, I, __float_as_uint(tr.e2p.w), hit.z, hit.w, sf, vcolor);
+  surface_at_hit(S, I, hitPrim, hit.z, hit.w, sf, vcolor);
   const f3 hitPos = sf.position;
   sf.ffnormal     = dot3(sf.normal, rdir) <= 0.0f ? sf.normal : -sf.normal;
   resolve_material(S, S.materials[I.materialIndex < 0 ? 0 : I.materialIndex], rdir, sf);
@@ -870,8 +889,8 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
 
 // Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
 // zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
-template <bool HEAT>
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
+template <bool HEAT, bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
@@ -903,7 +922,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
     {
       bool fallback = (L.flags & TF_SAW_FRAC) != 0;
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
-        lane_begin_count(L);
+        lane_begin_count<TWO>(L);
       else
       {
         bool inShadow = false;
@@ -956,13 +975,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_p(Device
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false>(S, L, lds, spill, rb.counters);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
-        lane_leaf<false>(S, L, lds, spill);
+        lane_leaf<false, TWO>(S, L, lds, spill);
     }
   }
 #ifdef PT_HIST
@@ -1057,7 +1076,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_shadow_k(Devic
 }
 
 // Simple variant of the shadow stage (one ray per lane).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
@@ -1074,7 +1094,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
     const float    maxDist = rb.ps.absorb[slot].w;
     bool           dummy;
     RayHit         h;
-    traverse<TM_CLOSEST>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+    traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
     {
       fallback       = (h.flags & TF_SAW_FRAC) != 0;
       const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
@@ -1082,7 +1102,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
       if(passB)
       {
         RayHit c;
-        traverse<TM_COUNT>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+        traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
                            rb.counters);
         fallback = (c.flags & TF_SAW_FRAC) != 0;
         nDraw    = c.count;
@@ -1112,7 +1132,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_s(Device
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -1131,7 +1152,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_TRACE_WAVES) k_shadow_x(Device
     uint32_t       wPrev = 0xffffffffu;
     for(;;)
     {
-      traverse<TM_RAW_ALL>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+      traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
       if(h.slot == BVH_NONE)
         break;
       if((h.w >> 29) & TRI_OPAQUE)
@@ -1262,6 +1283,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
 }
 
 // ---- ray picker (src/sample_example.cpp:468-511; nvvk::RayPickerKHR shoots a flag-less ray: no culling, no any-hit) ------------------
+template <bool TWO>
 __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters)
 {
   const f2 d         = f2{pickX * 2.0f - 1.0f, pickY * 2.0f - 1.0f};
@@ -1275,7 +1297,7 @@ __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float p
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   RayHit              h;
   bool                dummy;
-  traverse<TM_PICK>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, counters);
+  traverse<TM_PICK, TWO>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, counters);
   const float    bt = h.t, bu = h.u, bv = h.v;
   const uint32_t bs = h.slot;
   if(threadIdx.x != 0)
@@ -1287,10 +1309,19 @@ __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float p
   r.baryCoord[0] = r.baryCoord[1] = r.baryCoord[2] = 0.f;
   if(bs != BVH_NONE)
   {
-    const TriRec tr = S.tris[bs];
-    r.hitT                = bt;
-    r.instanceID          = __float_as_uint(tr.e1n.w);
-    r.primitiveID         = int(__float_as_uint(tr.e2p.w));
+    r.hitT = bt;
+    if(TWO)
+    {
+      const uint32_t w = h.w & TRI_INDEX_MASK;
+      r.instanceID     = instance_of_world_tri(S, w);
+      r.primitiveID    = int(w - S.instTriBase[r.instanceID]);
+    }
+    else
+    {
+      const TriRec tr = S.tris[bs];
+      r.instanceID    = __float_as_uint(tr.e1n.w);
+      r.primitiveID   = int(__float_as_uint(tr.e2p.w));
+    }
     r.instanceCustomIndex = S.instances[r.instanceID].primMesh;
     r.baryCoord[0] = 1.0f - bu - bv; r.baryCoord[1] = bu; r.baryCoord[2] = bv;
   }
@@ -1514,8 +1545,10 @@ static void sort_queue(hipStream_t stream, const DeviceScene& scene, const Rende
   k_raysort_scatter<<<grid, 256, 0, stream>>>(rb, queueIn, countPtr);
 }
 
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
-                     hipEvent_t recordAfterAccum)
+// TWO: the kernels instantiated for the two-level acceleration structure (no packet stage: a packet would have to agree on the instance too)
+template <bool TWO>
+static void launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
+                         hipEvent_t recordAfterAccum)
 {
   FrameParams    fp        = fpIn;
   const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
@@ -1545,18 +1578,18 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
       }
       const bool heat = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage
       if(heat)
-        k_closest_p<true><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-      else if(depth < g_tuning.packetClosestBounces)
+        k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+      else if(!TWO && depth < g_tuning.packetClosestBounces)
       {
         const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
         k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
-        k_closest_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+        k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
       }
       else if(depth < g_tuning.simpleClosestBounces)
-        k_closest_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
+        k_closest_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
       else
-        k_closest_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-      k_closest_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
+        k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+      k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
       pt_timers_end(tm, stream, 1);
       pt_timers_begin(tm, stream, 2);
       {
@@ -1578,21 +1611,21 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
         shadowIn = rb.queueT;
       }
       if(heat)
-        k_shadow_p<true><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
       else if(depth < g_tuning.simpleShadowBounces)
-        k_shadow_s<<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
+        k_shadow_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       else
       {
-        if(depth < g_tuning.packetShadowBounces)
+        if(!TWO && depth < g_tuning.packetShadowBounces)
         {
           const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
           k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
-          k_shadow_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+          k_shadow_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
         }
         else
-          k_shadow_p<false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
       }
-      k_shadow_x<<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
+      k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
       pt_timers_end(tm, stream, 3);
       std::swap(qIn, qOut);
     }
@@ -1607,12 +1640,23 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
   }
 }
 
+void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum)
+{
+  if(scene.twoLevel)
+    launch_frame<true>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum);
+  else
+    launch_frame<false>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum);
+}
+
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters)
 {
   pt_SceneCamera cam = scene.camera;
   std::memcpy(cam.viewInverse, viewInv, sizeof(cam.viewInverse));
   std::memcpy(cam.projInverse, projInv, sizeof(cam.projInverse));
-  k_pick<<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
+  if(scene.twoLevel)
+    k_pick<true><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
+  else
+    k_pick<false><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
 }
 
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor)

@@ -201,6 +201,63 @@ PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node
 }
 #endif
 
+#if PT_BVH_WIDTH != 2
+// ---- two-level walk (TLAS over instances, one object-space BLAS per prim-mesh; reference: src/accelstruct.cpp:110-162) -----------
+// A lane is either at TLAS level (InstCtx::inst == BVH_NONE: world-space ray constants, node references index DeviceScene::tlas) or inside
+// one instance (object-space ray constants, references index DeviceScene::wide / tris).  The ray parameter t is the same in both spaces
+// (the direction is transformed, not renormalised), so the current bound prunes in either.  An instance is left when the traversal stack
+// has shrunk back to the depth it had when the instance was entered.
+struct InstCtx {
+  uint32_t inst;    // BVH_NONE: at TLAS level
+  int      spBase;  // stack depth at entry
+  uint32_t wflags;  // world index of the instance's first triangle | TRI_* flags << 29
+};
+#define PT_TWO_GUARD (1u << 24)  // loop-iteration bound of the two-level walks (a corrupt structure must not hang the GPU; reported as a stack overflow)
+
+// Object-space ray constants of a ray entering the instance of TLAS leaf `tl`.  Transforming the ray rounds (o' and d' carry an absolute
+// error of a few 2^-24 x |worldToObject| x (|o| + |hit point|)); instead of tracking it per plane the BLAS boxes are grown by
+// eps = padC1 * max|o| + padC0 (host-computed bound with a 16x margin, pt_capi.hip: two_level_pad), folded into the per-ray constants:
+// (plane -+ eps) * idir + n  =  plane * idir + (n -+ eps * |idir|).
+PT_DEV RayBox enter_instance(const DeviceScene& S, const TlasLeaf& tl, f3 o, f3 d)
+{
+  const Affine W  = S.instances[tl.inst].worldToObject;
+  RayBox       rb = make_raybox(xform_point(W, o), xform_dir(W, d));
+  const float  eps = tl.padC1 * fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) + tl.padC0;
+  const f3     g   = f3{eps * fabsf(rb.idir.x), eps * fabsf(rb.idir.y), eps * fabsf(rb.idir.z)};
+  rb.nlo = rb.nlo - g;
+  rb.nhi = rb.nhi + g;
+  return rb;
+}
+// Trace contract T1 at the leaf: the instance matrix applied to the three object-space vertices in the operation order of k_world_tris
+// (pt_accel.hip), edges taken in world space -- the record the flat structure stores, rebuilt on the fly.
+PT_DEV TriRec world_tri(const DeviceScene& S, const InstCtx& ic, const TriRec& obj)
+{
+  const Affine   M  = S.instances[ic.inst].objectToWorld;
+  const f3       p0 = xform_point(M, xyz(obj.p0w)), p1 = xform_point(M, xyz(obj.e1n)), p2 = xform_point(M, xyz(obj.e2p));
+  const f3       e1 = p1 - p0, e2 = p2 - p0;
+  const uint32_t prim = __float_as_uint(obj.p0w.w);
+  TriRec         r;
+  r.p0w = make_float4(p0.x, p0.y, p0.z, __uint_as_float(((ic.wflags & TRI_INDEX_MASK) + prim) | (ic.wflags & ~TRI_INDEX_MASK)));
+  r.e1n = make_float4(e1.x, e1.y, e1.z, __uint_as_float(ic.inst));
+  r.e2p = make_float4(e2.x, e2.y, e2.z, __uint_as_float(prim));
+  return r;
+}
+// world triangle index -> instance: the LAST instance whose triBase is <= w (empty instances share a base and sort before the owner)
+PT_DEV uint32_t instance_of_world_tri(const DeviceScene& S, uint32_t w)
+{
+  uint32_t lo = 0, hi = S.numInstances - 1;
+  while(lo < hi)
+  {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if(S.instTriBase[mid] <= w)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+#endif
+
 #ifdef PT_HIST
 // measurement build only (tools/gpu_hist.py): per traversal mode, the distribution of per-ray loop iterations
 // ([0..31]: floor(log2)+1 buckets) and the wave-level lane utilisation ([32] sum of iterations, [33] sum over waves
@@ -210,7 +267,8 @@ __device__ unsigned long long g_hist[8][40];  // rows 5 / 6: persistent closest 
 
 // tPrev/wPrev: exclusive lower key (TM_RAW_*); wLimit: with tmax the exclusive upper key (TM_COUNT).
 // `opaqueHit` is only meaningful for TM_SHADOW.
-template <int MODE>
+// TWO: the two-level structure (see above); RayHit::slot is then the global BLAS leaf slot, RayHit::w the world index | flags as always.
+template <int MODE, bool TWO = false>
 PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, uint32_t wPrev, uint32_t wLimit, uint32_t* ldsStack, RayHit& best, bool& opaqueHit,
                      Counters* counters)
 {
@@ -227,8 +285,13 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
     return;
 
 #if PT_BVH_WIDTH != 2
-  const RayBox rbox = make_raybox(o, d);
+  RayBox          rbox = make_raybox(o, d);
+  const RayBox    rboxW = rbox;                      // (TWO) the world-space constants, restored when an instance is left
+  const WideNode* nodes = TWO ? S.tlas : S.wide;
+  InstCtx         ic{BVH_NONE, 0, 0u};
+  uint32_t        guard = 0;
 #else
+  static_assert(!TWO, "the two-level walk is written for the 4-wide layout");
   const f3 idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 #endif
   // TM_SHADOW must keep looking for opaque triangles behind the best alpha candidate; TM_COUNT has a fixed range
@@ -254,7 +317,12 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       ++nNodes;
 #endif
 #if PT_BVH_WIDTH != 2
-      const uint32_t nxt = wide_node_step(S.wide, cur, rbox, PT_TLIMIT, MODE == TM_COUNT || MODE == TM_RAW_NONOPAQUE, [&](uint32_t c) {
+      if(TWO && ++guard > PT_TWO_GUARD)
+      {
+        atomicAdd(&counters->stackOverflow, 1u);
+        break;
+      }
+      const uint32_t nxt = wide_node_step(nodes, cur, rbox, PT_TLIMIT, MODE == TM_COUNT || MODE == TM_RAW_NONOPAQUE, [&](uint32_t c) {
         if(sp < STACK_LDS)
           ldsStack[sp++ * TRACE_BLOCK] = c;
         else if(sp < STACK_LDS + STACK_SPILL)
@@ -308,13 +376,28 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       }
 #endif
     }
+#if PT_BVH_WIDTH != 2
+    else if(TWO && ic.inst == BVH_NONE)
+    {  // TLAS leaf: enter the instance (its BLAS root is an inner node)
+      const TlasLeaf tl = S.tlasLeaves[cur & BVH_SLOT_MASK];
+      ic    = InstCtx{tl.inst, sp, tl.wflags};
+      rbox  = enter_instance(S, tl, o, d);
+      nodes = S.wide;
+      cur   = tl.nodeBase;
+      continue;
+    }
+#endif
     else
     {
       const uint32_t slot  = cur & BVH_SLOT_MASK;
-      const TriRec   tr    = S.tris[slot];
+      TriRec         tr    = S.tris[slot];
       AlphaRec       ar;
       if(cur & BVH_ALPHA)  // non-opaque triangle: its any-hit inputs travel with the triangle (one round trip)
         ar = S.alphaRecs[slot];
+#if PT_BVH_WIDTH != 2
+      if(TWO)
+        tr = world_tri(S, ic, tr);
+#endif
       const uint32_t wbits = __float_as_uint(tr.p0w.w);
       const uint32_t flags = wbits >> 29;
       const bool     opq   = (flags & TRI_OPAQUE) != 0;
@@ -385,6 +468,14 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       }
     }
     // pop
+#if PT_BVH_WIDTH != 2
+    if(TWO && ic.inst != BVH_NONE && sp == ic.spBase)
+    {  // the instance's subtree is exhausted: back to TLAS level
+      ic.inst = BVH_NONE;
+      rbox    = rboxW;
+      nodes   = S.tlas;
+    }
+#endif
     if(sp == 0)
       break;
     --sp;

@@ -121,6 +121,16 @@ class HipRenderer(Renderer):
         """RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276)"""
         self._check(self._lib.pt_use_any_hit(self._ctx, int(bool(enable))))
 
+    def set_accel_mode(self, mode):
+        """capi.PT_ACCEL_FLAT (default: one hierarchy over all world-space triangles) or capi.PT_ACCEL_TWO_LEVEL (the reference's
+        BLAS per prim-mesh + TLAS instance per node, src/accelstruct.cpp:110-162)."""
+        self._check(self._lib.pt_set_accel_mode(self._ctx, int(mode)))
+
+    def update_instances(self, nodes):
+        """New world matrices for the scene's nodes (hd.node_dtype array or scene.Scene): TLAS refit in two-level mode, rebuild otherwise."""
+        arr = np.ascontiguousarray(nodes.node_array() if hasattr(nodes, "node_array") else nodes, hd.node_dtype)
+        self._check(self._lib.pt_update_instances(self._ctx, arr.ctypes.data, len(arr)))
+
     def set_variant(self, variant):
         """capi.PT_VARIANT_RAYQUERY (the reference's RayQuery renderer, default) or capi.PT_VARIANT_RTX (its RtxPipeline)."""
         self._check(self._lib.pt_set_variant(self._ctx, int(variant)))

@@ -124,16 +124,21 @@ class Scene:
     def num_triangles(self):
         return sum(self.prim_meshes[pm][3] // 3 for _, pm in self.nodes)
 
+    def node_array(self):
+        """pt_Node[]: one TLAS instance per node (pt_set_scene, pt_update_instances)"""
+        nd = np.zeros(len(self.nodes), hd.node_dtype)
+        for i, (m, p) in enumerate(self.nodes):
+            nd[i]["worldMatrix"] = m.T.reshape(16)  # row-major numpy -> column-major
+            nd[i]["primMesh"] = p
+        return nd
+
     def desc(self):
         """Builds the pt_SceneDesc; returns (desc, keepalive)."""
         assert self.vertices is not None, "call finalize() first"
         pm = np.zeros(len(self.prim_meshes), hd.primmesh_dtype)
         for i, t in enumerate(self.prim_meshes):
             pm[i] = t
-        nd = np.zeros(len(self.nodes), hd.node_dtype)
-        for i, (m, p) in enumerate(self.nodes):
-            nd[i]["worldMatrix"] = m.T.reshape(16)  # row-major numpy -> column-major
-            nd[i]["primMesh"] = p
+        nd = self.node_array()
         mats = np.array(self.materials, dtype=hd.material_dtype) if self.materials else np.zeros(0, hd.material_dtype)
         lights = np.array(self.lights, dtype=hd.light_dtype) if self.lights else np.zeros(0, hd.light_dtype)
         tex = (hd.TextureDesc * max(1, len(self.textures)))()
