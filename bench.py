@@ -292,7 +292,9 @@ def main():
     # HIP events on the launching stream bracket each stage.
     serial = None
     if not args.no_profile and not args.emulate_shard:
-        os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1").lstrip(",")
+        # tail=0: every bounce goes through the staged kernels, so that a stage's time and its rays belong together (the timed run hands the
+        # late, small bounces to the fused k_tail: stats["msTail"])
+        os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1,tail=0").lstrip(",")
         r2 = HipRenderer()
         r2.setup(local_rank)
         r2.set_shard(rank, world)

@@ -256,6 +256,7 @@ typedef struct pt_Stats {
   uint64_t bytesAccel;       /* of which the acceleration structure (nodes + leaf records + any-hit records) */
   uint32_t numBlas;          /* PT_ACCEL_TWO_LEVEL: bottom-level structures (prim-meshes instantiated), else 0 */
   uint32_t numTlasNodes;     /* PT_ACCEL_TWO_LEVEL: nodes of the instance hierarchy, else 0 */
+  double   msTail;           /* kernel time of the fused late bounces (closest + shade + shadow of small queues in one launch) */
 } pt_Stats;
 
 /* pt_measure_peaks: ceilings measured on the device */

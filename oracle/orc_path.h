@@ -11,6 +11,8 @@
 //   shaders/env_sampling.glsl       Environment_sample / EnvSample
 //   shaders/common.glsl             GetSphericalUv / CreateCoordinateSystem / OffsetRay
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "orc_bsdf.h"
 #include "orc_scene.h"
 #include "orc_sky.h"
@@ -600,9 +602,14 @@ struct Tracer {
   {
     vec3 radiance(0.0f), throughput(1.0f), absorption(0.0f);
 
+    static const bool traceOn = std::getenv("ORC_TRACE") != nullptr;  // diagnostics: the rays and hits of every path rendered (use with a pixel list)
     for(int depth = 0; depth < st.maxDepth; depth++)
     {
       ClosestHit(r);
+      if(traceOn)
+        std::fprintf(stderr, "ORC_TRACE frame %d depth %d o %.9g %.9g %.9g d %.9g %.9g %.9g t %.9g inst %d prim %d uv %.9g %.9g\n", st.frame, depth, r.origin.x, r.origin.y, r.origin.z,
+                     r.direction.x, r.direction.y, r.direction.z, prd.hitT, prd.hitT == INFINITY_RT ? -1 : prd.instanceID, prd.hitT == INFINITY_RT ? -1 : prd.primitiveID, prd.baryCoord.x,
+                     prd.baryCoord.y);
 
       if(prd.hitT == INFINITY_RT)
       {
@@ -686,6 +693,9 @@ struct Tracer {
       {
         Ray  shadowRay{r.origin, vcontrib.lightDir};
         bool inShadow = AnyHit(shadowRay, vcontrib.lightDist);
+        if(traceOn)
+          std::fprintf(stderr, "ORC_TRACE   shadow o %.9g %.9g %.9g d %.9g %.9g %.9g dist %.9g inShadow %d contrib %.9g %.9g %.9g\n", shadowRay.origin.x, shadowRay.origin.y, shadowRay.origin.z,
+                       shadowRay.direction.x, shadowRay.direction.y, shadowRay.direction.z, vcontrib.lightDist, int(inShadow), vcontrib.radiance.x, vcontrib.radiance.y, vcontrib.radiance.z);
         if(!inShadow)
           radiance += vcontrib.radiance;
       }

@@ -27,6 +27,16 @@ def env_small():
     return synth.procedural_sky(256, 128)
 
 
+@pytest.fixture(params=["tail=0", "tail=131072"])
+def tail_policy(request):
+    """Small images fit k_tail's threshold as a whole, so by default every bounce of these tests runs in the fused tail kernel; "tail=0"
+    sends the same test through the staged kernels (packet / lock-step / trace machine / exact fallback).  PT_TUNE is read by pt_create."""
+    old = os.environ.get("PT_TUNE")
+    os.environ["PT_TUNE"] = request.param
+    yield request.param
+    os.environ["PT_TUNE"] = "tail=131072" if old is None else old
+
+
 def assert_identical(h, o, what=""):
     """bit-for-bit, NaN-aware (the reference's thin-walled refraction produces a NaN about once per 1e6 hits; both sides must do so in the
     same pixels -- DESIGN.md section 2)"""
@@ -75,7 +85,7 @@ EXACT_AOVS = [hd.eNormal, hd.eMetallic, hd.eAlpha, hd.eRoughness, hd.eTexcoord, 
 
 
 @pytest.mark.parametrize("mode", EXACT_AOVS)
-def test_first_hit_aov_bit_exact(env_small, mode):
+def test_first_hit_aov_bit_exact(env_small, mode, tail_policy):
     cfg = Config(synth.feature_box(tex_size=64), env_small, 320, 240, debug=mode)
     assert np.array_equal(render_hip(cfg, 1), render_oracle(cfg, 1))
 
@@ -94,15 +104,15 @@ def test_c1_quad():
 
 
 @pytest.mark.parametrize("pbr", [0, 1])
-def test_path_traced_frames(env_small, pbr):
+def test_path_traced_frames(env_small, pbr, tail_policy):
     check_frames(Config(synth.feature_box(tex_size=64), env_small, 320, 240, pbr=pbr), 8)
 
 
-def test_punctual_lights(env_small):
+def test_punctual_lights(env_small, tail_policy):
     check_frames(Config(synth.feature_box(tex_size=64, lights=True), env_small, 256, 192), 4)
 
 
-def test_sun_and_sky(env_small):
+def test_sun_and_sky(env_small, tail_policy):
     ss = hd.default_sun_and_sky()
     ss.in_use = 1
     check_frames(Config(synth.feature_box(tex_size=64), env_small, 256, 192, sunsky=ss), 4)
@@ -110,7 +120,7 @@ def test_sun_and_sky(env_small):
     check_frames(Config(synth.feature_box(tex_size=64), env_small, 128, 96, sunsky=ss), 2)
 
 
-def test_multiple_samples_per_frame(env_small):
+def test_multiple_samples_per_frame(env_small, tail_policy):
     """maxSamples > 1: the RNG stream continues across the samples of a frame (pathtrace.comp:97-105)."""
     check_frames(Config(synth.feature_box(tex_size=64), env_small, 200, 150, max_samples=3), 2)
 
@@ -133,7 +143,7 @@ def test_odd_sizes_and_edge_tiles(env_small):
         assert np.array_equal(render_hip(cfg, 1), render_oracle(cfg, 1))
 
 
-def test_tiny_scenes(env_small):
+def test_tiny_scenes(env_small, tail_policy):
     """One triangle (single-leaf BVH) and an empty scene (every ray misses)."""
     from vk_raytrace_amd.scene import Scene, Camera
     sc = Scene("tri")
@@ -153,7 +163,7 @@ def test_tiny_scenes(env_small):
     assert_identical(render_hip(cfg, 2), render_oracle(cfg, 2))
 
 
-def test_sponza_like_reduced(env_small):
+def test_sponza_like_reduced(env_small, tail_policy):
     """The C3 scene (full triangle count, small textures) at reduced resolution, depth 8, whole image; many alpha-tested cards."""
     wl = workloads.c3_sponza(480, 270, 8, tex_size=128, env_w=512)
     cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode, debug=hd.eNormal)
@@ -377,9 +387,10 @@ def test_launch_policy_never_changes_results():
     """Frame batches, frames in flight, the persistent / lock-step kernels and the BVH builder are performance policy:
     every combination must produce bit-identical accumulation buffers (5 frames: a full batch, a partial one and the
     single-frame path all occur)."""
-    ref = _render_in_subprocess("batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh")
+    ref = _render_in_subprocess("tail=0,batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh")
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
-    for tune in ["batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7,packetShadow=2,minPacket=4", "packetClosest=0,simpleClosest=1", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=4,inflight=4,splitFull=2", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64", "build=ploc", "batch=2,build=ploc,plocRadius=3", "build=sahdev", "build=sah", "sortClosest=1,sortShadow=1,sortCells=3", "shadeSpec=1,stateGB=1",
+    for tune in ["tail=0", "tail=1000000000", "tail=3000,batch=2,inflight=2", "tail=700,batch=5", "tail=0,batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "accel=two,tail=2000", "accel=two,tail=0,batch=2",
+                 "batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7,packetShadow=2,minPacket=4", "packetClosest=0,simpleClosest=1", "batch=4,inflight=3,simpleClosest=0,simpleShadow=0", "batch=32,inflight=3,build=sah", "batch=4,inflight=4,splitFull=2", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64", "build=ploc", "batch=2,build=ploc,plocRadius=3", "build=sahdev", "build=sah", "sortClosest=1,sortShadow=1,sortCells=3", "shadeSpec=1,stateGB=1",
                  "accel=two", "accel=two,batch=4,inflight=2,simpleClosest=0,simpleShadow=9999", "accel=two,build=lbvh,batch=3,refill=8,waves=16", "accel=two,build=sah,simpleClosest=9999"]:
         got = _render_in_subprocess(tune)
         assert np.array_equal(got, ref), tune
@@ -387,8 +398,8 @@ def test_launch_policy_never_changes_results():
 
 def test_launch_policy_sponza_like_and_samples_per_frame():
     """Same on the alpha-heavy scene, with maxSamples > 1 (the per-frame sample loop inside a batch)."""
-    ref = _render_in_subprocess("batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh", frames=3, max_samples=2, scene="sponza")
-    for tune in ("batch=2,inflight=2,build=sah", "batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2"):
+    ref = _render_in_subprocess("tail=0,batch=1,inflight=1,packetClosest=0,simpleClosest=9999,simpleShadow=9999,build=lbvh", frames=3, max_samples=2, scene="sponza")
+    for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0"):
         got = _render_in_subprocess(tune, frames=3, max_samples=2, scene="sponza")
         assert np.array_equal(got, ref), tune
 
@@ -415,7 +426,7 @@ def test_gltf_round_trip_renders_identically(env_small, tmp_path):
     assert np.array_equal(a, b)
 
 
-def test_rtx_pipeline_variant(env_small):
+def test_rtx_pipeline_variant(env_small, tail_policy):
     """The reference's RtxPipeline flavour (pt_set_variant): seed without the maxSamples factor, shadow-ray alpha tests on a
     copy of the seed.  Parity against the oracle's restatement, and the two flavours must actually differ where they should."""
     sc = synth.feature_box(tex_size=64)
@@ -428,7 +439,7 @@ def test_rtx_pipeline_variant(env_small):
     assert np.array_equal(render_hip(a, 1), render_oracle(a, 1))
 
 
-def test_use_any_hit_false(env_small):
+def test_use_any_hit_false(env_small, tail_policy):
     """RtxPipeline::useAnyHit(false) (src/rtx_pipeline.cpp:269-276): hit groups without an any-hit stage -- every triangle opaque, no stochastic
     alpha test, no draw.  Parity with the oracle's restatement in both renderer flavours; toggling back restores the default image."""
     from vk_raytrace_amd.renderer import HipRenderer
@@ -520,7 +531,7 @@ _fuzz_scene = synth.fuzz_scene
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_fuzz_scenes(env_small, seed):
+def test_fuzz_scenes(env_small, seed, tail_policy):
     """Hit records (first-hit AOVs) bit-exact and path-traced frames in agreement on adversarial random scenes, with both
     closest-hit kernels for bounce 0 exercised by the default policy (packet + redo on the trace machine)."""
     sc = _fuzz_scene(seed)

@@ -61,6 +61,12 @@ struct pt_context {
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
     bool          launched  = false;  // a launch sequence was enqueued on this slot since the last synchronisation
+    // queue-size feedback: the per-bounce counters of the slot's latest launch sequence come back asynchronously (pinned memory)
+    uint32_t*     hCounts     = nullptr;
+    hipEvent_t    countsDone  = nullptr;
+    uint64_t      countsSeq   = 0;   // sequence number of the launch the copy belongs to (0: none)
+    uint32_t      countsPaths = 0;   // paths of that launch (frames of the batch x local pixels)
+    int           countsDepths = 0;  // bounces it ran staged (the counters of later bounces are not produced: k_tail took over)
   };
   FrameSlot slots[PT_MAX_INFLIGHT];
   int       inflight     = 1;  // frame slots in use (<= inflightMax: pt_resize drops slots when the device memory is short)
@@ -72,6 +78,12 @@ struct pt_context {
   int         batchMax  = 1;
   int         variant   = PT_VARIANT_RAYQUERY;
   uint64_t  frameCounter = 0;
+  // fraction of a launch's paths still alive at the start of bounce d, from the most recent finished launch (queue-size feedback; decides
+  // where k_tail takes over -- performance only)
+  double    qRatio[PT_MAX_DEPTH + 1];
+  int       qRatioDepths = 0;   // entries of qRatio that were observed (0: nothing observed yet)
+  uint64_t  qRatioSeq    = 0;   // launch they come from
+  uint64_t  launchSeq    = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
   DevBuf   dPick;
@@ -506,7 +518,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
     if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
     if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
-    if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
+    if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
+    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
     if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) g_tuning.plocFull = v;
     if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) g_tuning.plocRadius = v;
@@ -532,7 +545,9 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   c->inflight      = g_tuning.framesInFlight < 1 ? 1 : (g_tuning.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : g_tuning.framesInFlight);
   c->inflightMax = c->inflight;
   for(int i = 0; i < c->inflight; ++i)
-    if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess)
+    if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&c->slots[i].countsDone, hipEventDisableTiming) != hipSuccess ||
+       hipHostMalloc((void**)&c->slots[i].hCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2)) != hipSuccess)
     {
       g_createError = "hipStreamCreate / hipEventCreate failed";
       delete c;
@@ -569,6 +584,10 @@ int pt_destroy(pt_context* c)
       dev_free(*b);
     if(fs.accumDone)
       (void)hipEventDestroy(fs.accumDone);
+    if(fs.countsDone)
+      (void)hipEventDestroy(fs.countsDone);
+    if(fs.hCounts)
+      (void)hipHostFree(fs.hCounts);
     if(fs.stream)
       (void)hipStreamDestroy(fs.stream);
   }
@@ -808,6 +827,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   }
   c->numInstances = d->numNodes;
   c->numTris      = uint32_t(triTotal);
+  c->qRatioDepths = 0;  // queue-size feedback of the previous scene
   c->haveScene    = true;
   c->haveAccel    = false;
   refresh_scene_ptrs(c);
@@ -1204,6 +1224,20 @@ int flush_pending(pt_context* c)
   }
   c->pendCount          = 0;
   c->renderedSinceCheck = true;
+  // queue-size feedback: take the counters of the newest launch sequence that has finished
+  for(int i = 0; i < c->inflightMax; ++i)
+  {
+    pt_context::FrameSlot& fs = c->slots[i];
+    if(fs.countsSeq > c->qRatioSeq && fs.countsPaths > 0 && hipEventQuery(fs.countsDone) == hipSuccess)
+    {
+      const int nd = std::min(fs.countsDepths, PT_MAX_DEPTH);
+      for(int d = 0; d < nd; ++d)
+        c->qRatio[d] = double(fs.hCounts[size_t(d) * CNT_STRIDE + CNT_IN]) / double(fs.countsPaths);
+      c->qRatioDepths = nd;
+      c->qRatioSeq    = fs.countsSeq;
+    }
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is not an error
   int done              = 0;
   for(int p = 0; p < parts; ++p)
   {
@@ -1211,10 +1245,45 @@ int flush_pending(pt_context* c)
     fp.st.frame = c->pendState.frame + done;
     fp.batch    = uint32_t(n);
     done += n;
+    // where k_tail takes over: the first bounce whose queue is expected to hold <= tailBelow paths.  Expectation = this launch's paths x the
+    // alive fraction observed at that bounce; bounces beyond the observed ones continue the last observed shrink factor; before anything was
+    // observed a shrink of 0.3 per bounce is assumed.  A wrong guess costs time, never results.
+    int tailFrom = fp.st.maxDepth;
+    if(g_tuning.tailBelow > 0)
+    {
+      const double paths = double(n) * double(c->numSlots);
+      double       r = 1.0, step = 0.3;
+      for(int d = 0; d < fp.st.maxDepth; ++d)
+      {
+        if(d < c->qRatioDepths)
+        {
+          if(d > 0 && c->qRatio[d - 1] > 0.0)
+            step = std::min(1.0, c->qRatio[d] / c->qRatio[d - 1]);
+          r = c->qRatio[d];
+        }
+        else if(d > 0)
+          r *= step;
+        if(paths * r <= double(g_tuning.tailBelow))
+        {
+          tailFrom = d;
+          break;
+        }
+      }
+    }
     pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
-    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone);
+    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
     c->lastAccum = fs.accumDone;
     fs.launched  = true;
+    if(fs.hCounts && fp.st.debugging_mode != PT_DEBUG_HEATMAP)
+    {
+      fs.countsDepths = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);  // the bounce k_tail starts at still has its input count
+      fs.countsPaths  = uint32_t(n) * c->numSlots;
+      if(hipMemcpyAsync(fs.hCounts, fs.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(fs.countsDepths), hipMemcpyDeviceToHost, fs.stream) == hipSuccess &&
+         hipEventRecord(fs.countsDone, fs.stream) == hipSuccess)
+        fs.countsSeq = ++c->launchSeq;
+      else
+        fs.countsSeq = 0;
+    }
   }
   HIP_TRY(c, hipGetLastError());
   return PT_OK;
@@ -1588,6 +1657,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.neeLookups = k.neeLookups; s.nodesVisited = k.nodesVisited; s.trisTested = k.trisTested;
   s.msGenerate = c->timers.ms[0]; s.msTraceClosest = c->timers.ms[1]; s.msShade = c->timers.ms[2]; s.msTraceShadow = c->timers.ms[3];
   s.msAccumulate = c->timers.ms[4];
+  s.msTail       = c->timers.ms[5];
   s.launchesTraceClosest = c->timers.launchesClosest;
   s.numTriangles = c->numTris;
   s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;

@@ -70,6 +70,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 #define CNT_CHUNK_REDO 7     // ray-supply chunk counter of k_closest_p on queueR
 #define CNT_REDO_SHADOW 8         // size of queueR2 (shadow rays the packet kernel could not settle)
 #define CNT_CHUNK_REDO_SHADOW 9   // ray-supply chunk counter of k_shadow_p on queueR2
+#define CNT_CHUNK_TAIL 10         // path-supply chunk counter of k_tail (the bounce it starts at)
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
 #define PT_PERSISTENT_WAVES (256u * 20u)
@@ -117,6 +118,8 @@ struct PtTuning {
   int plocFull             = 0;    // PLOC: below this many clusters the search covers all of them (exact agglomerative clustering of the top levels)
   int plocRadius           = 16;   // PLOC: clusters examined on either side of a cluster per round
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
+  int tailBelow            = 131072; // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
+                                   // queue is expected to hold at most this many paths (0: never)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
@@ -124,8 +127,9 @@ extern PtTuning g_tuning;
 void pt_sah_topology(uint32_t n, const struct TriRec* tris, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);  // pt_sah.hip
 struct StageTimers;  // pt_capi.hip
 // waitBeforeAccum (may be null): accumDone event of the previous frame; recordAfterAccum: this frame's
+// tailFrom: first bounce handed to k_tail (>= maxDepth: none)
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
-                     hipEvent_t recordAfterAccum);
+                     hipEvent_t recordAfterAccum, int tailFrom);
 #define SORT_MAX_CELL_BITS 5
 #define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
@@ -146,7 +150,7 @@ void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double
 struct StageTimers {
   bool       enabled = false;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  double     ms[5] = {0, 0, 0, 0, 0};  // generate, closest, shade, shadow, accumulate
+  double     ms[6] = {0, 0, 0, 0, 0, 0};  // generate, closest, shade, shadow, accumulate, tail (k_tail: the late bounces of a launch sequence)
   uint64_t   launchesClosest = 0;
   hipStream_t stream = nullptr;
   // pending (start,stop) pairs are resolved lazily to keep the stream asynchronous

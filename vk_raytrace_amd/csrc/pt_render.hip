@@ -1173,6 +1173,187 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   }
 }
 
+// ---- tail of a batch: the late bounces in ONE launch ------------------------------------------------------------------------------------
+// Russian roulette from depth 0 shrinks the queues ~4x per bounce, so after two or three bounces a stage no longer fills the chip and its
+// duration is that of its slowest ray (200-300 us for the trace stages, measured: profiles/r02_trace_batch.txt) -- three such floors per
+// bounce, five or six bounces in a row, on every launch sequence.  Once a bounce's queue is small (host decision, pt_capi.hip: queue sizes
+// of earlier batches come back asynchronously) the rest of the path runs here: persistent wavefronts, one path per lane carried through
+// closest hit -> shade -> shadow ray -> Russian roulette -> next bounce, a lane whose path ended pulls the next one from the queue.  Nothing
+// waits for the slowest ray of a stage any more, only for the longest remaining PATH.  Every step is the function the staged kernels call
+// (traverse<>, shade_path, finish_bounce_core) on the same per-path state in the same order: results are bit-identical by construction
+// (paths never interact), which the launch-policy tests assert.
+template <bool TWO>
+PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, uint32_t* stack, uint32_t& nAlpha)
+{
+  const f3       o    = xyz(rb.ps.rayO[slot]);
+  const float4   dw   = rb.ps.rayD[slot];
+  const f3       d    = xyz(dw);
+  uint32_t       seed = __float_as_uint(dw.w);
+  RayHit         h;
+  bool           dummy;
+  traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack, h, dummy, rb.counters);
+  bool       fallback = (h.flags & TF_SAW_FRAC) != 0;
+  const bool passB    = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+  uint32_t   nDraw    = h.count;
+  if(passB)
+  {
+    RayHit c;
+    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, dummy, rb.counters);
+    fallback = (c.flags & TF_SAW_FRAC) != 0;
+    nDraw    = c.count;
+  }
+  if(!fallback)
+  {
+    if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+      ++nDraw;
+    uint32_t s2 = seed;
+    if(consume_rejected_draws(s2, nDraw))
+    {
+      store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
+      if(nDraw)
+        rb.ps.rayD[slot].w = __uint_as_float(s2);
+      nAlpha += nDraw;
+      return;
+    }
+  }
+  // exact key-ordered loop (k_closest_x)
+  float    tPrev = 0.0f;
+  uint32_t wPrev = 0xffffffffu;
+  for(;;)
+  {
+    traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
+    if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
+      break;
+    ++nAlpha;
+    if(alpha_test(S, h.slot, h.u, h.v, seed))
+      break;
+    tPrev = h.t;
+    wPrev = h.w & TRI_INDEX_MASK;
+  }
+  store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
+  rb.ps.rayD[slot].w = __uint_as_float(seed);
+}
+
+// the shadow ray of a path (k_shadow_s / k_shadow_x): returns inShadow, `seed` = the path's seed afterwards
+template <bool TWO>
+PT_DEV bool tail_shadow(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, uint32_t* stack, int variant, uint32_t& seed, uint32_t& nAlpha)
+{
+  seed                   = __float_as_uint(rb.ps.rayD[slot].w);
+  const uint32_t seed0   = seed;
+  const f3       o       = xyz(rb.ps.rayO[slot]);
+  const f3       d       = xyz(rb.ps.neeDir[slot]);
+  const float    maxDist = rb.ps.absorb[slot].w;
+  bool           dummy;
+  RayHit         h;
+  traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack, h, dummy, rb.counters);
+  bool       fallback = (h.flags & TF_SAW_FRAC) != 0;
+  const bool passB    = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+  uint32_t   nDraw    = h.count;
+  if(passB)
+  {
+    RayHit c;
+    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, dummy, rb.counters);
+    fallback = (c.flags & TF_SAW_FRAC) != 0;
+    nDraw    = c.count;
+  }
+  if(!fallback)
+  {
+    if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+      ++nDraw;
+    uint32_t s2 = seed;
+    if(consume_rejected_draws(s2, nDraw))
+    {
+      seed = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
+      nAlpha += nDraw;
+      return h.slot != BVH_NONE;
+    }
+  }
+  // exact key-ordered loop (k_shadow_x)
+  bool     inShadow = false;
+  float    tPrev    = 0.0f;
+  uint32_t wPrev    = 0xffffffffu;
+  for(;;)
+  {
+    traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
+    if(h.slot == BVH_NONE)
+      break;
+    if((h.w >> 29) & TRI_OPAQUE)
+    {
+      inShadow = true;
+      break;
+    }
+    ++nAlpha;
+    if(alpha_test(S, h.slot, h.u, h.v, seed))
+    {
+      inShadow = true;
+      break;
+    }
+    tPrev = h.t;
+    wPrev = h.w & TRI_INDEX_MASK;
+  }
+  if(variant == PT_VARIANT_RTX)
+    seed = seed0;
+  return inShadow;
+}
+
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int depth0)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C     = rb.counts + depth0 * CNT_STRIDE;
+  const uint32_t      count = C[CNT_IN];
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * TRACE_BLOCK >= count)
+    return;
+  uint32_t* lds = stack + threadIdx.x;
+  RaySupply rs;
+  rs.chunk       = 64;
+  uint32_t slot  = 0, nClosest = 0, nShadow = 0, nAlpha = 0, nMiss = 0, nHit = 0, nNee = 0;
+  int      depth = depth0;
+  bool     alive = false;
+  const int lastDepth = fp.st.maxDepth - 1;
+#pragma unroll 1
+  for(;;)
+  {
+    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_TAIL], count, !alive);
+    if(qi != 0xffffffffu)
+    {
+      slot  = queueIn[qi];
+      depth = depth0;
+      alive = true;
+    }
+    if(!__ballot(alive))
+      break;
+    if(alive)
+    {
+      tail_closest<TWO>(S, rb, slot, lds, nAlpha);
+      ++nClosest;
+    }
+    int      to     = SHADE_DONE;
+    uint32_t events = 0;
+    if(alive)
+      to = shade_path<-1>(S, rb, fp, slot, depth, events);
+    nMiss += (events & EV_MISS) ? 1u : 0u;
+    nHit += (events & EV_HIT) ? 1u : 0u;
+    nNee += (events & EV_NEE) ? 1u : 0u;
+    bool survive = to == SHADE_TO_NEXT;
+    if(to == SHADE_TO_SHADOW)
+    {
+      uint32_t   seed;
+      const bool inShadow = tail_shadow<TWO>(S, rb, slot, lds, fp.variant, seed, nAlpha);
+      ++nShadow;
+      survive = finish_bounce_core(rb, slot, inShadow, seed) && depth != lastDepth;
+    }
+    alive = survive;
+    ++depth;
+  }
+  wave_add(&rb.counters->closestRays, nClosest);
+  wave_add(&rb.counters->shadowRays, nShadow);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+  wave_add(&rb.counters->misses, nMiss);
+  wave_add(&rb.counters->shadedHits, nHit);
+  wave_add(&rb.counters->neeLookups, nNee);
+}
+
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
 // ---- ray sorting (north_star: "per-wavefront ray compaction / sorting"; no reference counterpart: the Vulkan driver schedules rays) ------
 // After bounce 0 the rays of a queue are incoherent: consecutive entries start anywhere and point anywhere, so the 64 rays a wave of the trace
@@ -1548,7 +1729,7 @@ static void sort_queue(hipStream_t stream, const DeviceScene& scene, const Rende
 // TWO: the kernels instantiated for the two-level acceleration structure (no packet stage: a packet would have to agree on the instance too)
 template <bool TWO>
 static void launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
-                         hipEvent_t recordAfterAccum)
+                         hipEvent_t recordAfterAccum, int tailFrom)
 {
   FrameParams    fp        = fpIn;
   const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
@@ -1569,6 +1750,13 @@ static void launch_frame(hipStream_t stream, const DeviceScene& scene, const Ren
     for(int depth = 0; depth < fp.st.maxDepth; ++depth)
     {
       const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
+      if(depth >= tailFrom && fp.st.debugging_mode != PT_DEBUG_HEATMAP)
+      {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost three latency floors
+        pt_timers_begin(tm, stream, 5);
+        k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
+        pt_timers_end(tm, stream, 5);
+        break;
+      }
       pt_timers_begin(tm, stream, 1);
       const uint32_t* traceIn = qIn;
       if(depth >= 1 && g_tuning.sortClosest)
@@ -1640,12 +1828,13 @@ static void launch_frame(hipStream_t stream, const DeviceScene& scene, const Ren
   }
 }
 
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum)
+void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum,
+                     int tailFrom)
 {
   if(scene.twoLevel)
-    launch_frame<true>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum);
+    launch_frame<true>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
   else
-    launch_frame<false>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum);
+    launch_frame<false>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
 }
 
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters)

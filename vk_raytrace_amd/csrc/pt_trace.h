@@ -212,7 +212,7 @@ struct InstCtx {
   int      spBase;  // stack depth at entry
   uint32_t wflags;  // world index of the instance's first triangle | TRI_* flags << 29
 };
-#define PT_TWO_GUARD (1u << 24)  // loop-iteration bound of the two-level walks (a corrupt structure must not hang the GPU; reported as a stack overflow)
+#define PT_TWO_GUARD (1u << 20)  // loop-iteration bound of the two-level walks (a corrupt structure must not hang the GPU; reported as a stack overflow)
 
 // Object-space ray constants of a ray entering the instance of TLAS leaf `tl`.  Transforming the ray rounds (o' and d' carry an absolute
 // error of a few 2^-24 x |worldToObject| x (|o| + |hit point|)); instead of tracking it per plane the BLAS boxes are grown by

@@ -117,7 +117,8 @@ class Stats(C.Structure):
                 ("msGenerate", C.c_double), ("msTraceClosest", C.c_double), ("msShade", C.c_double),
                 ("msTraceShadow", C.c_double), ("msAccumulate", C.c_double), ("launchesTraceClosest", C.c_uint64),
                 ("numTriangles", C.c_uint32), ("numBvhNodes", C.c_uint32), ("msBuildAccel", C.c_double),
-                ("bytesScene", C.c_uint64), ("bytesAccel", C.c_uint64), ("numBlas", C.c_uint32), ("numTlasNodes", C.c_uint32)]
+                ("bytesScene", C.c_uint64), ("bytesAccel", C.c_uint64), ("numBlas", C.c_uint32), ("numTlasNodes", C.c_uint32),
+                ("msTail", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
