@@ -27,14 +27,14 @@ def env_small():
     return synth.procedural_sky(256, 128)
 
 
-@pytest.fixture(params=["tail=0", "tail=131072"])
+@pytest.fixture(params=["tail=0", "tail=65536"])
 def tail_policy(request):
     """Small images fit k_tail's threshold as a whole, so by default every bounce of these tests runs in the fused tail kernel; "tail=0"
     sends the same test through the staged kernels (packet / lock-step / trace machine / exact fallback).  PT_TUNE is read by pt_create."""
     old = os.environ.get("PT_TUNE")
     os.environ["PT_TUNE"] = request.param
     yield request.param
-    os.environ["PT_TUNE"] = "tail=131072" if old is None else old
+    os.environ["PT_TUNE"] = "tail=65536" if old is None else old
 
 
 def assert_identical(h, o, what=""):

@@ -102,13 +102,13 @@ def env_small():
     return synth.procedural_sky(256, 128)
 
 
-@pytest.fixture(params=["tail=0", "tail=131072"])
+@pytest.fixture(params=["tail=0", "tail=65536"])
 def tail_policy(request):
     """staged kernels vs the fused tail kernel (see tests/test_gpu_parity.py)"""
     old = os.environ.get("PT_TUNE")
     os.environ["PT_TUNE"] = request.param
     yield request.param
-    os.environ["PT_TUNE"] = "tail=131072" if old is None else old
+    os.environ["PT_TUNE"] = "tail=65536" if old is None else old
 
 
 def _assert_identical(h, o, what=""):
