@@ -519,7 +519,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
     if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
     if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
-    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
+    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
+    if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
     if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) g_tuning.plocFull = v;
     if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) g_tuning.plocRadius = v;
@@ -1239,6 +1240,13 @@ int flush_pending(pt_context* c)
   }
   (void)hipGetLastError();  // hipErrorNotReady is not an error
   int done              = 0;
+  // interleaved submission needs every piece to have exactly one accumulate step, and the stage timers record their events in launch order
+  const bool                       interleave = g_tuning.interleave && parts > 1 && fp.st.maxSamples == 1 && !c->timers.enabled;
+  std::vector<std::vector<PtStep>> plans;
+  std::vector<pt_context::FrameSlot*> planSlot;
+  std::vector<int>                 planTail;
+  std::vector<uint32_t>            planPaths;
+  plans.reserve(size_t(parts));
   for(int p = 0; p < parts; ++p)
   {
     const int n = (total - done) / (parts - p);
@@ -1271,13 +1279,55 @@ int flush_pending(pt_context* c)
       }
     }
     pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
-    pt_launch_frame(fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
+    plans.emplace_back();
+    planSlot.push_back(&fs);
+    pt_plan_frame(plans.back(), fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
     c->lastAccum = fs.accumDone;
     fs.launched  = true;
+    if(!interleave)
+    {  // one sequence after the other
+      for(PtStep& st : plans.back())
+        st.fn();
+      plans.back().clear();
+    }
+    planTail.push_back(tailFrom);
+    planPaths.push_back(uint32_t(n) * c->numSlots);
+  }
+  if(interleave)
+  {  // stage by stage in turn over the pieces: every stream gets its first kernels at once, the host stays ahead of all of them; a piece's
+     // accumulate step (it waits on the previous piece's event) is never issued before the previous piece's
+    std::vector<size_t> at(plans.size(), 0);
+    std::vector<char>   accumIssued(plans.size(), 0);
+    for(bool more = true; more;)
+    {
+      more = false;
+      for(size_t q = 0; q < plans.size(); ++q)
+      {
+        if(at[q] >= plans[q].size())
+          continue;
+        PtStep& st = plans[q][at[q]];
+        if(st.accum && q > 0 && !accumIssued[q - 1])
+        {
+          more = true;
+          continue;
+        }
+        st.fn();
+        if(st.accum)
+          accumIssued[q] = 1;
+        ++at[q];
+        more = more || at[q] < plans[q].size();
+      }
+    }
+  }
+  for(size_t q = 0; q < planSlot.size(); ++q)
+  {
+    pt_context::FrameSlot& fs       = *planSlot[q];
+    const int              tailFrom = planTail[q];
+    const uint32_t         n        = planPaths[q];
     if(fs.hCounts && fp.st.debugging_mode != PT_DEBUG_HEATMAP)
     {
       fs.countsDepths = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);  // the bounce k_tail starts at still has its input count
-      fs.countsPaths  = uint32_t(n) * c->numSlots;
+      fs.countsPaths  = n;
       if(hipMemcpyAsync(fs.hCounts, fs.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(fs.countsDepths), hipMemcpyDeviceToHost, fs.stream) == hipSuccess &&
          hipEventRecord(fs.countsDone, fs.stream) == hipSuccess)
         fs.countsSeq = ++c->launchSeq;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <functional>
+#include <vector>
 #include "pt_device.h"
 #define PT_REFILL_BELOW_DEFAULT 48
 #ifndef PT_MIN_GENERATIONS
@@ -120,6 +122,7 @@ struct PtTuning {
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
   int tailBelow            = 65536;  // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
                                    // queue is expected to hold at most this many paths (0: never)
+  int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
 };
@@ -127,6 +130,14 @@ extern PtTuning g_tuning;
 void pt_sah_topology(uint32_t n, const struct TriRec* tris, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);  // pt_sah.hip
 struct StageTimers;  // pt_capi.hip
 // waitBeforeAccum (may be null): accumDone event of the previous frame; recordAfterAccum: this frame's
+// A launch sequence as steps that each enqueue one stage on the sequence's stream (pt_render.hip plan_frame).  `accum`: the step that folds the
+// batch into the running mean -- it waits on the previous sequence's event, so sequences must issue their accum steps in order.
+struct PtStep {
+  std::function<void()> fn;
+  bool                  accum;
+};
+void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
+                   hipEvent_t recordAfterAccum, int tailFrom);
 // tailFrom: first bounce handed to k_tail (>= maxDepth: none)
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
                      hipEvent_t recordAfterAccum, int tailFrom);

@@ -31,6 +31,8 @@
 // Random numbers are drawn in the reference's order from one PCG state per
 // path that travels with the path state.  Queue order never influences a pixel's value.
 #include <hip/hip_runtime.h>
+#include <functional>
+#include <vector>
 #include <cstring>
 #include "pt_bsdf.h"
 #include "pt_internal.h"
@@ -1726,61 +1728,69 @@ static void sort_queue(hipStream_t stream, const DeviceScene& scene, const Rende
   k_raysort_scatter<<<grid, 256, 0, stream>>>(rb, queueIn, countPtr);
 }
 
+// One launch sequence (a batch of frames, all bounces) as a list of STEPS -- generate, then per bounce the closest-hit stage, the shade stage
+// and the shadow stage (or k_tail for all remaining bounces), then accumulate.  A step only enqueues work on `stream`.  The caller either runs
+// the steps back to back (pt_launch_frame) or interleaves the steps of several sequences that go to different streams (pt_capi.hip
+// flush_pending): enqueueing ~55 launches costs the host ~1 ms, so with one sequence submitted after the other the fourth stream would start
+// 2-3 ms late -- a third of the whole run when a short run is cut into four pieces (profiles/r02b_shard_timeline_0of8.txt).
 // TWO: the kernels instantiated for the two-level acceleration structure (no packet stage: a packet would have to agree on the instance too)
 template <bool TWO>
-static void launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
-                         hipEvent_t recordAfterAccum, int tailFrom)
+static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
+                       hipEvent_t recordAfterAccum, int tailFrom)
 {
   FrameParams    fp        = fpIn;
   const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
-  const uint32_t gridAll   = (n + 255) / 256;
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
   const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
+  const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage, no k_tail
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
-    (void)hipMemsetAsync(rb.counts, 0, sizeof(uint32_t) * CNT_STRIDE * size_t(fp.st.maxDepth + 2), stream);
-    pt_timers_begin(tm, stream, 0);
-    k_generate<<<(n + 1023) / 1024, 1024, 0, stream>>>(scene, rb, fp);
-    pt_timers_end(tm, stream, 0);
+    steps.push_back(PtStep{[=]() {
+      (void)hipMemsetAsync(rb.counts, 0, sizeof(uint32_t) * CNT_STRIDE * size_t(fp.st.maxDepth + 2), stream);
+      pt_timers_begin(tm, stream, 0);
+      k_generate<<<(n + 1023) / 1024, 1024, 0, stream>>>(scene, rb, fp);
+      pt_timers_end(tm, stream, 0);
+    }, false});
     uint32_t* qIn  = rb.queueA;
     uint32_t* qOut = rb.queueB;
     for(int depth = 0; depth < fp.st.maxDepth; ++depth)
     {
       const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
-      if(depth >= tailFrom && fp.st.debugging_mode != PT_DEBUG_HEATMAP)
+      if(depth >= tailFrom && !heat)
       {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost three latency floors
-        pt_timers_begin(tm, stream, 5);
-        k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
-        pt_timers_end(tm, stream, 5);
+        steps.push_back(PtStep{[=]() {
+          pt_timers_begin(tm, stream, 5);
+          k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
+          pt_timers_end(tm, stream, 5);
+        }, false});
         break;
       }
-      pt_timers_begin(tm, stream, 1);
-      const uint32_t* traceIn = qIn;
-      if(depth >= 1 && g_tuning.sortClosest)
-      {
-        sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
-        traceIn = rb.queueT;
-      }
-      const bool heat = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage
-      if(heat)
-        k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-      else if(!TWO && depth < g_tuning.packetClosestBounces)
-      {
-        const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-        k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
-        k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
-      }
-      else if(depth < g_tuning.simpleClosestBounces)
-        k_closest_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
-      else
-        k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-      k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
-      pt_timers_end(tm, stream, 1);
-      pt_timers_begin(tm, stream, 2);
-      {
+      const bool      sortC   = depth >= 1 && g_tuning.sortClosest;
+      const uint32_t* traceIn = sortC ? rb.queueT : qIn;
+      steps.push_back(PtStep{[=]() {
+        pt_timers_begin(tm, stream, 1);
+        if(sortC)
+          sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
+        if(heat)
+          k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+        else if(!TWO && depth < g_tuning.packetClosestBounces)
+        {
+          const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+          k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
+          k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+        }
+        else if(depth < g_tuning.simpleClosestBounces)
+          k_closest_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
+        else
+          k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+        k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
+        pt_timers_end(tm, stream, 1);
+      }, false});
+      steps.push_back(PtStep{[=]() {
+        pt_timers_begin(tm, stream, 2);
         const dim3 sg((n + SHADE_BLOCK - 1) / SHADE_BLOCK), sb(SHADE_BLOCK);
         const bool plain = g_tuning.shadeSpecialised && fp.st.debugging_mode == PT_DEBUG_NONE && scene.sunsky.in_use != 1 && scene.camera.nbLights == 0;
         if(plain && fp.st.pbrMode == 0)
@@ -1789,52 +1799,66 @@ static void launch_frame(hipStream_t stream, const DeviceScene& scene, const Ren
           k_shade<1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
         else
           k_shade<-1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
-      }
-      pt_timers_end(tm, stream, 2);
-      pt_timers_begin(tm, stream, 3);
-      const uint32_t* shadowIn = rb.queueS;
-      if(g_tuning.sortShadow && depth >= g_tuning.simpleShadowBounces && depth >= g_tuning.packetShadowBounces)
-      {
-        sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
-        shadowIn = rb.queueT;
-      }
-      if(heat)
-        k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-      else if(depth < g_tuning.simpleShadowBounces)
-        k_shadow_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
-      else
-      {
-        if(!TWO && depth < g_tuning.packetShadowBounces)
+        pt_timers_end(tm, stream, 2);
+      }, false});
+      steps.push_back(PtStep{[=]() {
+        pt_timers_begin(tm, stream, 3);
+        const uint32_t* shadowIn = rb.queueS;
+        if(g_tuning.sortShadow && depth >= g_tuning.simpleShadowBounces && depth >= g_tuning.packetShadowBounces)
         {
-          const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-          k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
-          k_shadow_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+          sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
+          shadowIn = rb.queueT;
         }
+        if(heat)
+          k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        else if(depth < g_tuning.simpleShadowBounces)
+          k_shadow_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         else
-          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-      }
-      k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
-      pt_timers_end(tm, stream, 3);
+        {
+          if(!TWO && depth < g_tuning.packetShadowBounces)
+          {
+            const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+            k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
+            k_shadow_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+          }
+          else
+            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        }
+        k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
+        pt_timers_end(tm, stream, 3);
+      }, false});
       std::swap(qIn, qOut);
     }
-    // the running mean folds frames in order: wait for the previous frame's accumulate (another stream)
-    if(waitBeforeAccum && s == 0)
-      (void)hipStreamWaitEvent(stream, waitBeforeAccum, 0);
-    pt_timers_begin(tm, stream, 4);
-    k_accumulate<<<(fp.numSlots + 255) / 256, 256, 0, stream>>>(rb, fp);
-    pt_timers_end(tm, stream, 4);
-    if(recordAfterAccum && s == fp.st.maxSamples - 1)
-      (void)hipEventRecord(recordAfterAccum, stream);
+    const bool waitHere = waitBeforeAccum && s == 0, recordHere = recordAfterAccum && s == fp.st.maxSamples - 1;
+    steps.push_back(PtStep{[=]() {
+      // the running mean folds frames in order: wait for the previous frame's accumulate (another stream)
+      if(waitHere)
+        (void)hipStreamWaitEvent(stream, waitBeforeAccum, 0);
+      pt_timers_begin(tm, stream, 4);
+      k_accumulate<<<(fp.numSlots + 255) / 256, 256, 0, stream>>>(rb, fp);
+      pt_timers_end(tm, stream, 4);
+      if(recordHere)
+        (void)hipEventRecord(recordAfterAccum, stream);
+    }, true});
   }
+}
+
+void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum,
+                   hipEvent_t recordAfterAccum, int tailFrom)
+{
+  if(scene.twoLevel)
+    plan_frame<true>(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+  else
+    plan_frame<false>(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
 }
 
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum,
                      int tailFrom)
 {
-  if(scene.twoLevel)
-    launch_frame<true>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
-  else
-    launch_frame<false>(stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+  std::vector<PtStep> steps;
+  pt_plan_frame(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+  for(PtStep& st : steps)
+    st.fn();
 }
 
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters)
