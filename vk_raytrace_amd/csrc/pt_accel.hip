@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "pt_device.h"
 #include "pt_internal.h"
 #include "pt_sahdev.h"
@@ -1337,58 +1340,92 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
     I.flags         = blas[b].flags & ~TRI_FLIP;
   }
   InstanceRec* dPseudo = nullptr;
-  BvhNode*     dNodes  = nullptr;
-  PtScratch    arena;
-  int          rc = -1;
-  // temporaries of one build: < 640 B per triangle (pt_accel_build's lists + the SAH builder's bins); whatever does not fit is allocated singly
-  const size_t arenaBytes = size_t(maxTris) * 640 + (size_t(1) << 20);
-  if(hipMalloc(&dPseudo, sizeof(InstanceRec) * size_t(numBlas)) != hipSuccess || hipMalloc(&dNodes, sizeof(BvhNode) * size_t(maxTris)) != hipSuccess)
+  int          device  = 0;
+  (void)hipGetDevice(&device);
+  if(hipMalloc(&dPseudo, sizeof(InstanceRec) * size_t(numBlas)) != hipSuccess)
   {
     snprintf(err, errLen, "BLAS build: out of device memory");
-    goto done;
-  }
-  if(hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
-    arena.cap = arenaBytes;
-  else
-  {
-    arena.base = nullptr;  // no arena: every temporary is its own allocation
-    (void)hipGetLastError();
+    return -1;
   }
   if(hipMemcpyAsync(dPseudo, pseudo.data(), sizeof(InstanceRec) * size_t(numBlas), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
   {
-    snprintf(err, errLen, "BLAS build: upload failed");
-    goto done;
-  }
-  for(uint32_t b = 0; b < numBlas; ++b)
-  {
-    PtBlasDesc&    d = blas[b];
-    const uint32_t n = d.triCount;
-    if(pt_accel_build(stream, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, err, errLen, nullptr, &arena) != 0)
-      goto done;
-    if(d.numWide == 0 || d.numWide > std::max(1u, n - 1))
-    {
-      snprintf(err, errLen, "BLAS %u: %u wide nodes for %u triangles", b, d.numWide, n);
-      goto done;
-    }
-    k_blas_vertex_form<<<(n + 255) / 256, 256, 0, stream>>>(n, dTris + d.slotBase, dVertices, dIndices, d.vertexOffset, d.firstIndex);
-    k_blas_rebase<<<(d.numWide + 255) / 256, 256, 0, stream>>>(d.numWide, dWide + d.nodeBase, d.nodeBase, d.slotBase);
-  }
-  if(hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
-  {
-    snprintf(err, errLen, "BLAS build: a kernel failed");
-    goto done;
-  }
-  rc = 0;
-done:
-  (void)hipStreamSynchronize(stream);
-  arena.release();
-  if(arena.base)
-    (void)hipFree(arena.base);
-  if(dPseudo)
     (void)hipFree(dPseudo);
-  if(dNodes)
-    (void)hipFree(dNodes);
-  return rc;
+    snprintf(err, errLen, "BLAS build: upload failed");
+    return -1;
+  }
+  // A build is a chain of small level-synchronous launches with a host round trip per level: one mesh alone leaves the GPU and the host idle
+  // most of the time.  A few host threads, each with its own stream, arena and binary-node scratch, take the meshes from a shared counter
+  // (largest first would balance better; the meshes of a scene are usually of similar size).
+  const unsigned       numWorkers = std::max(1u, std::min(std::min(numBlas, 4u), uint32_t(g_tuning.blasWorkers > 0 ? g_tuning.blasWorkers : 1)));
+  std::atomic<uint32_t> next{0};
+  std::atomic<int>      failed{0};
+  std::mutex            errLock;
+  auto                  worker = [&](unsigned w) {
+    (void)hipSetDevice(device);
+    hipStream_t ws = nullptr;
+    BvhNode*    dNodes = nullptr;
+    PtScratch   arena;
+    char        msg[256] = "";
+    bool        ok = hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess && hipMalloc(&dNodes, sizeof(BvhNode) * size_t(maxTris)) == hipSuccess;
+    if(!ok)
+      snprintf(msg, sizeof(msg), "BLAS build: out of device memory");
+    // temporaries of one build: < 640 B per triangle (pt_accel_build's lists + the SAH builder's bins); whatever does not fit is allocated singly
+    const size_t arenaBytes = size_t(maxTris) * 640 + (size_t(1) << 20);
+    if(ok && hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
+      arena.cap = arenaBytes;
+    else
+    {
+      arena.base = nullptr;  // no arena: every temporary is its own allocation
+      (void)hipGetLastError();
+    }
+    while(ok && !failed.load())
+    {
+      const uint32_t b = next.fetch_add(1);
+      if(b >= numBlas)
+        break;
+      PtBlasDesc&    d = blas[b];
+      const uint32_t n = d.triCount;
+      if(pt_accel_build(ws, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, msg, sizeof(msg), nullptr, &arena) != 0)
+      {
+        ok = false;
+        break;
+      }
+      if(d.numWide == 0 || d.numWide > std::max(1u, n - 1))
+      {
+        snprintf(msg, sizeof(msg), "BLAS %u: %u wide nodes for %u triangles", b, d.numWide, n);
+        ok = false;
+        break;
+      }
+      k_blas_vertex_form<<<(n + 255) / 256, 256, 0, ws>>>(n, dTris + d.slotBase, dVertices, dIndices, d.vertexOffset, d.firstIndex);
+      k_blas_rebase<<<(d.numWide + 255) / 256, 256, 0, ws>>>(d.numWide, dWide + d.nodeBase, d.nodeBase, d.slotBase);
+    }
+    if(ws && (hipStreamSynchronize(ws) != hipSuccess || hipGetLastError() != hipSuccess) && ok)
+    {
+      snprintf(msg, sizeof(msg), "BLAS build: a kernel failed");
+      ok = false;
+    }
+    if(!ok)
+    {
+      std::lock_guard<std::mutex> g(errLock);
+      if(!failed.exchange(1))
+        snprintf(err, errLen, "%s", msg);
+    }
+    arena.release();
+    if(arena.base)
+      (void)hipFree(arena.base);
+    if(dNodes)
+      (void)hipFree(dNodes);
+    if(ws)
+      (void)hipStreamDestroy(ws);
+  };
+  std::vector<std::thread> threads;
+  for(unsigned w = 1; w < numWorkers; ++w)
+    threads.emplace_back(worker, w);
+  worker(0);
+  for(std::thread& t : threads)
+    t.join();
+  (void)hipFree(dPseudo);
+  return failed.load() ? -1 : 0;
 }
 
 int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
