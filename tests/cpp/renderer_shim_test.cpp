@@ -54,6 +54,39 @@ int main(int argc, char** argv)
     return 4;
   }
   const bool first = std::fabs(img[0] - 1.f) < 1e-5f && img[(32 * 64 + 32) * 4] > 0.1f;
+  {  // AccelStructure's own shape (BLAS per prim-mesh + TLAS): same pixels; then the node moves out of view and back (TLAS refit)
+    const std::vector<float> flat = img;
+    r.setAccelMode(PT_ACCEL_TWO_LEVEL);
+    r.setPushContants(st);
+    r.run({64, 64});
+    r.readAccum(img.data());
+    if(!r.ok() || std::memcmp(flat.data(), img.data(), flat.size() * sizeof(float)) != 0)
+    {
+      std::printf("ERROR two-level image differs (%s)\n", r.lastError().c_str());
+      return 8;
+    }
+    pt_Node moved = nd;
+    moved.worldMatrix[12] = 50.f;
+    r.updateInstances(&moved, 1);
+    r.setPushContants(st);
+    r.run({64, 64});
+    r.readAccum(img.data());
+    if(!r.ok() || std::fabs(img[(32 * 64 + 32) * 4] - 1.f) > 1e-5f)  // the constant environment where the quad was
+    {
+      std::printf("ERROR updateInstances: centre=%.3f (%s)\n", img[(32 * 64 + 32) * 4], r.lastError().c_str());
+      return 9;
+    }
+    r.updateInstances(&nd, 1);
+    r.setPushContants(st);
+    r.run({64, 64});
+    r.readAccum(img.data());
+    if(!r.ok() || std::memcmp(flat.data(), img.data(), flat.size() * sizeof(float)) != 0)
+    {
+      std::printf("ERROR image after moving back differs (%s)\n", r.lastError().c_str());
+      return 10;
+    }
+    r.setAccelMode(PT_ACCEL_FLAT);
+  }
   if(argc > 1)
   {  // Scene::load path: the same quad as a .glb written by vk_raytrace_amd.gltf.save_gltf must render the same image
     std::vector<float> ref = img;

@@ -261,6 +261,44 @@ def test_two_level_mode_switch_any_hit_and_variants(env_small):
 
 
 @gpu
+def test_two_level_tiny_and_ragged_scenes(env_small, tail_policy):
+    """edge cases of the two-level build: one triangle in one instance (single-leaf BLAS and TLAS), a scene whose only node has no
+    triangles, a node without triangles between nodes with, two meshes of one triangle each, instances of the same mesh stacked exactly on
+    top of each other (ties in t between instances: the world index decides)"""
+    from tests.common import Config, render_hip, render_oracle
+    two = capi.PT_ACCEL_TWO_LEVEL
+    tri = ([(-1, -1, 0), (1, -1, 0), (0, 1, 0)], [(0, 0, 1)] * 3, [(0, 0), (1, 0), (0.5, 1)], [0, 1, 2])
+    sc = Scene("tri")
+    m = sc.add_material(pbrBaseColorFactor=(0.9, 0.2, 0.1, 1), doubleSided=1, pbrMetallicFactor=0.0)
+    sc.add_node(sc.add_prim_mesh(*tri, m))
+    sc.camera = Camera(eye=(0, 0, 3), center=(0, 0, 0), fov=45)
+    cfg = Config(sc, env_small, 64, 64, debug=hd.eNormal)
+    assert np.array_equal(render_hip(cfg, 1, accel=two), render_oracle(cfg, 1))
+    cfg = Config(sc, env_small, 64, 64)
+    _assert_identical(render_hip(cfg, 2, accel=two), render_oracle(cfg, 2), "one triangle")
+    empty = Scene("empty")
+    m = empty.add_material()
+    empty.add_node(empty.add_prim_mesh(np.zeros((3, 3)), [(0, 0, 1)] * 3, np.zeros((3, 2)), np.zeros(0, np.uint32), m))
+    empty.camera = Camera(eye=(0, 0, 3), center=(0, 0, 0), fov=45)
+    cfg = Config(empty, env_small, 48, 32)
+    _assert_identical(render_hip(cfg, 2, accel=two), render_oracle(cfg, 2), "empty scene")
+    rag = Scene("ragged")
+    m = rag.add_material(pbrBaseColorFactor=(0.2, 0.7, 0.9, 1), doubleSided=1)
+    a = rag.add_prim_mesh(*tri, m)
+    hole = rag.add_prim_mesh(np.zeros((3, 3)), [(0, 0, 1)] * 3, np.zeros((3, 2)), np.zeros(0, np.uint32), m)
+    b = rag.add_prim_mesh([(-1, 1, -0.5), (1, 1, -0.5), (0, -1, -0.5)], [(0, 0, 1)] * 3, [(0, 0), (1, 0), (0.5, 1)], [0, 1, 2], m)
+    rag.add_node(a, translate(-0.6, 0, 0)); rag.add_node(hole); rag.add_node(b); rag.add_node(hole, translate(1, 1, 1)); rag.add_node(a, translate(0.6, 0, 0.2))
+    rag.add_node(a, translate(0.6, 0, 0.2))   # coincident with the previous instance
+    rag.add_node(a, translate(0.6, 0, 0.2) @ scale(1.0, 1.0, -1.0))   # and once more, mirrored
+    rag.camera = Camera(eye=(0, 0, 4), center=(0, 0, 0), fov=45)
+    for mode in (hd.eNormal, hd.eTexcoord):
+        cfg = Config(rag, env_small, 64, 48, debug=mode)
+        assert np.array_equal(render_hip(cfg, 1, accel=two), render_oracle(cfg, 1)), mode
+    cfg = Config(rag, env_small, 64, 48, depth=4)
+    _assert_identical(render_hip(cfg, 3, accel=two), render_oracle(cfg, 3), "ragged scene")
+
+
+@gpu
 def test_two_level_ray_picker(env_small):
     """pt_pick walks the two-level structure: same instance / primitive / t / barycentrics as the oracle's probe"""
     from tests import orc
