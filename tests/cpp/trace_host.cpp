@@ -1,0 +1,469 @@
+// CPU harness around the PRODUCT's traversal source (test infrastructure; built and used by tests/test_trace_host.py only).
+//
+// vk_raytrace_amd/csrc/pt_trace.h -- traverse<MODE, TWO>, wide_node_step, make_raybox, enter_instance, world_tri, tri_test -- is plain
+// inline C++ apart from a handful of intrinsics, so it is compiled here for the host (g++, -ffp-contract=off like the device build) and run
+// against a brute-force loop over every world triangle with the same tri_test.  What the GPU parity tests can only show through images is
+// checked ray by ray without a GPU: the flat walk and the two-level walk (TLAS + object-space BLASes, per-instance box padding from
+// pt_capi.hip's two_level_pad) must report exactly the candidates brute force reports -- every candidate along the ray, in key order.
+//
+// The acceleration structures are assembled on the host in the product's formats (TriRec, WideNode, TlasLeaf).  Topology comes from the
+// product's device builder run through its host emulation (pt_debug_sahdev_topology in libptmi.so); boxes, the 4-wide collapse, the vertex
+// form of BLAS leaves and the TLAS proxies restate pt_accel.hip (k_gather's tri_box, k_collapse, k_blas_vertex_form, k_instance_proxies)
+// -- they only have to be valid structures of that format, the code under test is the walk.
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime.h>  // vector types; nothing is launched
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+// the device intrinsics pt_trace.h and the headers it includes use
+static inline unsigned int __float_as_uint(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }
+static inline float        __uint_as_float(unsigned int u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline int          __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float        __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+template <class T>
+static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
+
+#include "pt_trace.h"
+
+extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
+extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
+
+namespace {
+
+struct Bvh {
+  std::vector<TriRec>   tris;   // leaf order
+  std::vector<WideNode> wide;   // node 0 = root
+  float                 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+};
+
+// pt_accel.hip tri_box: padded box of a record (p0, p0 + e1, p0 + e2)
+void tri_box_h(const TriRec& r, float lo[3], float hi[3])
+{
+  const float p0[3] = {r.p0w.x, r.p0w.y, r.p0w.z};
+  const float p1[3] = {r.p0w.x + r.e1n.x, r.p0w.y + r.e1n.y, r.p0w.z + r.e1n.z};
+  const float p2[3] = {r.p0w.x + r.e2p.x, r.p0w.y + r.e2p.y, r.p0w.z + r.e2p.z};
+  for(int a = 0; a < 3; ++a)
+  {
+    lo[a] = std::fmin(p0[a], std::fmin(p1[a], p2[a]));
+    hi[a] = std::fmax(p0[a], std::fmax(p1[a], p2[a]));
+    const float m = std::fmax(std::fabs(lo[a]), std::fabs(hi[a])), pad = m * 4e-6f + 1e-30f;
+    lo[a] -= pad;
+    hi[a] += pad;
+  }
+}
+
+struct Box {
+  float lo[3], hi[3];
+  bool  alpha;
+};
+float half_area_h(const Box& b)
+{
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// records (edge form, flags in p0w.w >> 29) -> leaf order + 4-wide nodes (k_gather, k_refit, k_emit, k_collapse)
+Bvh build_bvh(const std::vector<TriRec>& in)
+{
+  Bvh            out;
+  const uint32_t n = uint32_t(in.size());
+  if(n == 0)
+    return out;
+  std::vector<uint32_t> vals(n), cl(n), cr(n), pi(n), pl(n);
+  if(n >= 2)
+  {
+    std::vector<float> tri9(size_t(n) * 9);
+    for(uint32_t i = 0; i < n; ++i)
+    {
+      const float v[9] = {in[i].p0w.x, in[i].p0w.y, in[i].p0w.z, in[i].e1n.x, in[i].e1n.y, in[i].e1n.z, in[i].e2p.x, in[i].e2p.y, in[i].e2p.z};
+      std::memcpy(&tri9[size_t(i) * 9], v, sizeof(v));
+    }
+    if(pt_debug_sahdev_topology(n, tri9.data(), vals.data(), cl.data(), cr.data(), pi.data(), pl.data()) != 0)
+      return out;
+  }
+  else
+    vals[0] = 0;
+  out.tris.resize(n);
+  std::vector<Box> leaf(n), inner(n > 1 ? n - 1 : 1);
+  for(uint32_t i = 0; i < n; ++i)
+  {
+    out.tris[i] = in[vals[i]];
+    tri_box_h(out.tris[i], leaf[i].lo, leaf[i].hi);
+    leaf[i].alpha = !((__float_as_uint(out.tris[i].p0w.w) >> 29) & TRI_OPAQUE);
+  }
+  auto ref_box = [&](uint32_t r) -> const Box& { return (r & BVH_LEAF) ? leaf[r & ~BVH_LEAF] : inner[r]; };
+  if(n >= 2)
+  {  // boxes bottom-up: a subtree over k leaves owns k-1 consecutive ids starting at its root, so children have larger ids than parents
+    for(uint32_t k = n - 1; k-- > 0;)
+    {
+      const Box &a = ref_box(cl[k]), &b = ref_box(cr[k]);
+      for(int x = 0; x < 3; ++x)
+      {
+        inner[k].lo[x] = std::fmin(a.lo[x], b.lo[x]);
+        inner[k].hi[x] = std::fmax(a.hi[x], b.hi[x]);
+      }
+      inner[k].alpha = a.alpha || b.alpha;
+    }
+  }
+  auto child_ref = [&](uint32_t r) -> uint32_t {
+    if(r & BVH_LEAF)
+      return BVH_LEAF | (r & ~BVH_LEAF) | (leaf[r & ~BVH_LEAF].alpha ? BVH_ALPHA : 0u);
+    return r;
+  };
+  // collapse (k_collapse): per wide node, open the inner child of largest area until 4 children
+  struct Item { uint32_t b2, wide; };
+  std::vector<Item> queue{{0u, 0u}};
+  out.wide.resize(1);
+  for(size_t qi = 0; qi < queue.size(); ++qi)
+  {
+    const Item it = queue[qi];
+    uint32_t   id[4];
+    int        cnt = 0;
+    if(n == 1)
+      id[cnt++] = BVH_LEAF | 0u;
+    else
+    {
+      id[cnt++] = cl[it.b2];
+      id[cnt++] = cr[it.b2];
+      while(cnt < 4)
+      {
+        int   best = -1;
+        float bestA = -1.f;
+        for(int k = 0; k < cnt; ++k)
+          if(!(id[k] & BVH_LEAF))
+          {
+            const float a = half_area_h(inner[id[k]]);
+            if(a > bestA)
+            {
+              bestA = a;
+              best  = k;
+            }
+          }
+        if(best < 0)
+          break;
+        const uint32_t node = id[best];
+        id[best]            = id[cnt - 1];
+        --cnt;
+        id[cnt++] = cl[node];
+        id[cnt++] = cr[node];
+      }
+    }
+    WideNode w;
+    std::memset(&w, 0, sizeof(w));
+    float*    mnx = &w.minx[0].x; float* mny = &w.miny[0].x; float* mnz = &w.minz[0].x;
+    float*    mxx = &w.maxx[0].x; float* mxy = &w.maxy[0].x; float* mxz = &w.maxz[0].x;
+    uint32_t* ch  = &w.child[0].x;
+    for(int k = 0; k < 4; ++k)
+    {
+      if(k < cnt)
+      {
+        const Box& b = ref_box(id[k]);
+        mnx[k] = b.lo[0]; mny[k] = b.lo[1]; mnz[k] = b.lo[2]; mxx[k] = b.hi[0]; mxy[k] = b.hi[1]; mxz[k] = b.hi[2];
+        if(id[k] & BVH_LEAF)
+          ch[k] = child_ref(id[k]);
+        else
+        {
+          const uint32_t wid = uint32_t(out.wide.size());
+          out.wide.emplace_back();
+          queue.push_back({id[k], wid});
+          ch[k] = wid | (inner[id[k]].alpha ? BVH_ALPHA : 0u);
+        }
+      }
+      else
+      {
+        mnx[k] = mny[k] = mnz[k] = FLT_MAX;
+        mxx[k] = mxy[k] = mxz[k] = -FLT_MAX;
+        ch[k]                    = BVH_NONE;
+      }
+    }
+    out.wide[it.wide] = w;
+  }
+  const Box& root = n >= 2 ? inner[0] : leaf[0];
+  for(int a = 0; a < 3; ++a)
+  {
+    out.lo[a] = root.lo[a];
+    out.hi[a] = root.hi[a];
+  }
+  return out;
+}
+
+struct InstIn {
+  uint32_t vertexOffset, firstIndex, triCount, flags;  // flags: TRI_OPAQUE / TRI_NOCULL (TRI_FLIP is derived from the matrix)
+  int32_t  primMesh;
+  float    worldMatrix[16];  // column-major
+};
+
+struct Scene {
+  std::vector<float4>      vertices;  // 2 x float4 per vertex
+  std::vector<uint32_t>    indices;
+  std::vector<InstanceRec> inst;
+  std::vector<uint32_t>    instTriBase;
+  std::vector<TriRec>      world;     // world index order (brute force)
+  Bvh                      flat;
+  // two-level
+  std::vector<TriRec>      blasTris;
+  std::vector<AlphaRec>    blasAlpha;
+  std::vector<WideNode>    blasWide;
+  Bvh                      tlas;
+  std::vector<TlasLeaf>    tlasLeaves;
+  std::vector<AlphaRec>    flatAlpha;
+  AlphaMat                 alphaMat;
+  DeviceScene              dsFlat, dsTwo;
+  double                   maxPadRatio = 0;
+};
+
+f3 vpos(const Scene& s, uint32_t v) { const float4 a = s.vertices[size_t(v) * 2]; return f3{a.x, a.y, a.z}; }
+
+// k_world_tris (trace contract T1)
+TriRec world_record(const Scene& s, const InstanceRec& I, uint32_t inst, uint32_t k, uint32_t w)
+{
+  const uint32_t* t  = &s.indices[I.firstIndex + 3 * size_t(k)];
+  const f3        p0 = xform_point(I.objectToWorld, vpos(s, I.vertexOffset + t[0])), p1 = xform_point(I.objectToWorld, vpos(s, I.vertexOffset + t[1])),
+           p2 = xform_point(I.objectToWorld, vpos(s, I.vertexOffset + t[2]));
+  const f3 e1 = p1 - p0, e2 = p2 - p0;
+  TriRec   r;
+  r.p0w = make_float4(p0.x, p0.y, p0.z, __uint_as_float(w | (I.flags << 29)));
+  r.e1n = make_float4(e1.x, e1.y, e1.z, __uint_as_float(inst));
+  r.e2p = make_float4(e2.x, e2.y, e2.z, __uint_as_float(k));
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indices, uint32_t numIdx, const InstIn* in, uint32_t numInst, const float* primBound, uint32_t numPrimMeshes)
+{
+  Scene* s = new Scene();
+  s->vertices.resize(size_t(numVerts) * 2);
+  std::memcpy(s->vertices.data(), vertices8, sizeof(float) * 8 * size_t(numVerts));
+  s->indices.assign(indices, indices + numIdx);
+  s->inst.resize(numInst);
+  s->instTriBase.resize(numInst ? numInst : 1);
+  std::vector<float> padC0(numInst), padC1(numInst);
+  uint32_t           triTotal = 0;
+  for(uint32_t i = 0; i < numInst; ++i)
+  {
+    InstanceRec& I = s->inst[i];
+    std::memset(&I, 0, sizeof(I));
+    float rec[27];
+    if(in[i].primMesh < 0 || uint32_t(in[i].primMesh) >= numPrimMeshes || pt_debug_two_level_pad(in[i].worldMatrix, primBound[in[i].primMesh], rec) != 0)
+    {
+      delete s;
+      return nullptr;
+    }
+    I.objectToWorld.r0 = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    I.objectToWorld.r1 = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    I.objectToWorld.r2 = make_float4(rec[8], rec[9], rec[10], rec[11]);
+    I.worldToObject.r0 = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    I.worldToObject.r1 = make_float4(rec[16], rec[17], rec[18], rec[19]);
+    I.worldToObject.r2 = make_float4(rec[20], rec[21], rec[22], rec[23]);
+    padC0[i]           = rec[24];
+    padC1[i]           = rec[25];
+    I.vertexOffset = in[i].vertexOffset; I.firstIndex = in[i].firstIndex; I.materialIndex = 0; I.primMesh = in[i].primMesh;
+    I.triBase = triTotal; I.triCount = in[i].triCount;
+    I.flags   = (in[i].flags & (TRI_OPAQUE | TRI_NOCULL)) | (uint32_t(rec[26]) & TRI_FLIP);
+    s->instTriBase[i] = triTotal;
+    triTotal += I.triCount;
+  }
+  // ---- flat: world records of every instance, one hierarchy
+  s->world.reserve(triTotal);
+  for(uint32_t i = 0; i < numInst; ++i)
+    for(uint32_t k = 0; k < s->inst[i].triCount; ++k)
+      s->world.push_back(world_record(*s, s->inst[i], i, k, s->inst[i].triBase + k));
+  s->flat = build_bvh(s->world);
+  s->flatAlpha.assign(std::max<size_t>(1, s->flat.tris.size()), AlphaRec{});
+  // ---- two-level: one object-space BLAS per prim-mesh that is instantiated (pt_capi.hip build_two_level / pt_accel.hip pt_blas_build)
+  std::vector<int64_t> nodeBaseOf(numPrimMeshes, -1);
+  for(uint32_t i = 0; i < numInst; ++i)
+  {
+    const InstanceRec& I = s->inst[i];
+    if(I.triCount == 0 || nodeBaseOf[I.primMesh] >= 0)
+      continue;
+    InstanceRec P = I;  // the pseudo-instance: identity transform, no TRI_FLIP
+    P.objectToWorld.r0 = make_float4(1, 0, 0, 0); P.objectToWorld.r1 = make_float4(0, 1, 0, 0); P.objectToWorld.r2 = make_float4(0, 0, 1, 0);
+    P.flags &= ~TRI_FLIP;
+    std::vector<TriRec> obj(I.triCount);
+    for(uint32_t k = 0; k < I.triCount; ++k)
+      obj[k] = world_record(*s, P, 0, k, k);
+    Bvh            b        = build_bvh(obj);
+    const uint32_t nodeBase = uint32_t(s->blasWide.size()), slotBase = uint32_t(s->blasTris.size());
+    for(TriRec r : b.tris)
+    {  // vertex form (k_blas_vertex_form)
+      const uint32_t  k = __float_as_uint(r.e2p.w);
+      const uint32_t* t = &s->indices[I.firstIndex + 3 * size_t(k)];
+      const f3        v0 = vpos(*s, I.vertexOffset + t[0]), v1 = vpos(*s, I.vertexOffset + t[1]), v2 = vpos(*s, I.vertexOffset + t[2]);
+      r.p0w = make_float4(v0.x, v0.y, v0.z, __uint_as_float(k));
+      r.e1n = make_float4(v1.x, v1.y, v1.z, 0.f);
+      r.e2p = make_float4(v2.x, v2.y, v2.z, 0.f);
+      s->blasTris.push_back(r);
+    }
+    for(WideNode w : b.wide)
+    {  // global references (k_blas_rebase)
+      uint32_t* ch = &w.child[0].x;
+      for(int k = 0; k < 4; ++k)
+        if(ch[k] != BVH_NONE)
+          ch[k] = (ch[k] & ~BVH_SLOT_MASK) | ((ch[k] & BVH_SLOT_MASK) + ((ch[k] & BVH_LEAF) ? slotBase : nodeBase));
+      s->blasWide.push_back(w);
+    }
+    nodeBaseOf[I.primMesh] = nodeBase;
+  }
+  s->blasAlpha.assign(std::max<size_t>(1, s->blasTris.size()), AlphaRec{});
+  // TLAS over the exact world boxes of the instances (k_instance_proxies), as "diagonal" records
+  std::vector<TriRec>   prox;
+  std::vector<uint32_t> proxInst;
+  for(uint32_t i = 0; i < numInst; ++i)
+  {
+    const InstanceRec& I = s->inst[i];
+    if(I.triCount == 0)
+      continue;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for(uint32_t j = 0; j < 3 * I.triCount; ++j)
+    {
+      const f3    p    = xform_point(I.objectToWorld, vpos(*s, I.vertexOffset + s->indices[I.firstIndex + j]));
+      const float q[3] = {p.x, p.y, p.z};
+      for(int a = 0; a < 3; ++a)
+      {
+        lo[a] = std::fmin(lo[a], q[a]);
+        hi[a] = std::fmax(hi[a], q[a]);
+      }
+    }
+    TriRec r;
+    r.p0w = make_float4(lo[0], lo[1], lo[2], __uint_as_float(i | (I.flags << 29)));
+    r.e1n = make_float4(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 0.f);
+    r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
+    prox.push_back(r);
+  }
+  s->tlas = build_bvh(prox);
+  for(const TriRec& r : s->tlas.tris)
+  {
+    const uint32_t id = __float_as_uint(r.p0w.w) & TRI_INDEX_MASK;
+    TlasLeaf       l;
+    std::memset(&l, 0, sizeof(l));
+    l.inst     = id;
+    l.nodeBase = uint32_t(nodeBaseOf[s->inst[id].primMesh]);
+    l.wflags   = s->inst[id].triBase | (s->inst[id].flags << 29);
+    l.padC0    = padC0[id];
+    l.padC1    = padC1[id];
+    s->tlasLeaves.push_back(l);
+  }
+  if(s->tlasLeaves.empty())
+    s->tlasLeaves.emplace_back();
+  // ---- the scene records the walk reads
+  std::memset(&s->alphaMat, 0, sizeof(s->alphaMat));
+  s->alphaMat.factorA = 1.0f; s->alphaMat.tex = -1; s->alphaMat.mapOffset = ALPHA_NO_MAP;
+  DeviceScene d;
+  std::memset(&d, 0, sizeof(d));
+  d.vertices = s->vertices.data(); d.indices = s->indices.data(); d.instances = s->inst.data(); d.alphaMats = &s->alphaMat;
+  d.numTris = triTotal; d.numInstances = numInst;
+  s->dsFlat           = d;
+  s->dsFlat.wide      = s->flat.wide.data();
+  s->dsFlat.tris      = s->flat.tris.data();
+  s->dsFlat.alphaRecs = s->flatAlpha.data();
+  s->dsTwo            = d;
+  s->dsTwo.wide        = s->blasWide.data();
+  s->dsTwo.tris        = s->blasTris.data();
+  s->dsTwo.alphaRecs   = s->blasAlpha.data();
+  s->dsTwo.tlas        = s->tlas.wide.data();
+  s->dsTwo.tlasLeaves  = s->tlasLeaves.data();
+  s->dsTwo.instTriBase = s->instTriBase.data();
+  s->dsTwo.twoLevel    = 1;
+  return s;
+}
+
+void th_destroy(void* p) { delete static_cast<Scene*>(p); }
+
+uint32_t th_num_tris(void* p) { return uint32_t(static_cast<Scene*>(p)->world.size()); }
+void     th_sizes(void* p, uint32_t* out4)
+{
+  Scene* s = static_cast<Scene*>(p);
+  out4[0] = uint32_t(s->flat.wide.size()); out4[1] = uint32_t(s->blasWide.size()); out4[2] = uint32_t(s->tlas.wide.size()); out4[3] = uint32_t(s->blasTris.size());
+}
+// world record of triangle w (p0, e1, e2: 9 floats) and its flags -- for the test's double-precision re-evaluation of a disputed candidate
+void th_world_tri(void* p, uint32_t w, float* out9, uint32_t* flags)
+{
+  const TriRec& r = static_cast<Scene*>(p)->world[w];
+  const float   v[9] = {r.p0w.x, r.p0w.y, r.p0w.z, r.e1n.x, r.e1n.y, r.e1n.z, r.e2p.x, r.e2p.y, r.e2p.z};
+  std::memcpy(out9, v, sizeof(v));
+  *flags = __float_as_uint(r.p0w.w) >> 29;
+}
+
+// Every candidate of every ray in key order (t, world index), at most maxCand per ray: mode 0 brute force over all world triangles with the
+// product's tri_test, 1 the flat walk, 2 the two-level walk -- traverse<TM_RAW_ALL> restarted behind the previous candidate, exactly what the
+// exact fallback kernels (k_closest_x / k_shadow_x) do.  outW / outT: nrays x maxCand (0xffffffff: no further candidate).  Returns the
+// number of traversal-stack overflows (must be 0).
+uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, const float* dir, float tmax, uint32_t maxCand, uint32_t* outW, float* outT)
+{
+  Scene*   s = static_cast<Scene*>(p);
+  Counters total;
+  std::memset(&total, 0, sizeof(total));
+#pragma omp parallel
+  {
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+    Counters              cnt;
+    std::memset(&cnt, 0, sizeof(cnt));
+#pragma omp for schedule(dynamic, 64)
+    for(long long r = 0; r < (long long)nrays; ++r)
+    {
+      const f3 o = f3{org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d = f3{dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
+      float    tPrev = 0.0f;
+      uint32_t wPrev = 0xffffffffu;
+      for(uint32_t c = 0; c < maxCand; ++c)
+      {
+        uint32_t bw = 0xffffffffu;
+        float    bt = 0.f;
+        if(mode == 0)
+        {
+          bool found = false;
+          for(const TriRec& tr : s->world)
+          {
+            const uint32_t wbits = __float_as_uint(tr.p0w.w), w = wbits & TRI_INDEX_MASK;
+            float          t, u, v;
+            if(tri_test(tr, wbits >> 29, o, d, t, u, v) && t < tmax && key_less(tPrev, wPrev, t, w) && (!found || key_less(t, w, bt, bw)))
+            {
+              found = true;
+              bt    = t;
+              bw    = w;
+            }
+          }
+        }
+        else
+        {
+          RayHit h;
+          bool   dummy;
+          if(mode == 1)
+            traverse<TM_RAW_ALL, false>(s->dsFlat, o, d, tmax, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
+          else
+            traverse<TM_RAW_ALL, true>(s->dsTwo, o, d, tmax, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
+          if(h.slot != BVH_NONE)
+          {
+            bt = h.t;
+            bw = h.w & TRI_INDEX_MASK;
+          }
+        }
+        outW[size_t(r) * maxCand + c] = bw;
+        outT[size_t(r) * maxCand + c] = bt;
+        if(bw == 0xffffffffu)
+        {
+          for(uint32_t k = c + 1; k < maxCand; ++k)
+          {
+            outW[size_t(r) * maxCand + k] = 0xffffffffu;
+            outT[size_t(r) * maxCand + k] = 0.f;
+          }
+          break;
+        }
+        tPrev = bt;
+        wPrev = bw;
+      }
+    }
+#pragma omp critical
+    total.stackOverflow += cnt.stackOverflow;
+  }
+  return total.stackOverflow;
+}
+
+}  // extern "C"
