@@ -1,16 +1,17 @@
-// Device LBVH build for gfx950.  Replaces AccelStructure::create of the reference
-// (src/accelstruct.cpp:55-162: one BLAS per prim-mesh + one TLAS instance per node, built by the
-// Vulkan driver) with a single flattened world-space BVH2:
+// Device acceleration-structure build for gfx950.  Replaces AccelStructure::create of the reference
+// (src/accelstruct.cpp:55-162: one BLAS per prim-mesh + one TLAS instance per node, built by the Vulkan driver).
 //
-//   k_world_tris   instance transforms applied in fp32 (trace contract T1) -> TriRec + centroid
-//   k_bounds       wave-reduced atomic min/max of the centroids
-//   k_morton       30-bit Morton code of the centroid, value = world triangle index
-//   radix sort     4 passes x 8 bits, stable, one wave per 2048-key block (histogram / scan / scatter)
-//   k_hierarchy    Karras 2012 binary radix tree over the sorted codes (ties broken by position)
+// pt_accel_build: ONE hierarchy over a set of primitives, as 4-wide nodes (WideNode) over leaf-ordered records (TriRec):
+//   k_world_tris   instance transforms applied in fp32 (trace contract T1) -> TriRec + centroid   (or ready-made records: dProxies)
+//   topology       device binned SAH (default, pt_sahdev.h) | host SAH (cross-check) | PLOC | Karras radix tree (k_morton, radix sort, k_hierarchy)
+//   k_gather       records in leaf order + padded leaf boxes
 //   k_refit        bottom-up AABB merge with per-node arrival counters (agent-scope fence per hand-off)
-//   k_emit         64-byte traversal nodes holding both child boxes
-//
-// Everything runs on the caller's stream; temporaries are freed before returning.
+//   k_emit         64-byte binary nodes holding both child boxes
+//   k_collapse     4-wide nodes, greedy by surface area, one level per launch
+// It is used three ways: over the world-space triangles of every node (the flat structure, default), over the object-space triangles of
+// one prim-mesh (a BLAS of the two-level structure: pt_blas_build), and over the world boxes of the instances given as "diagonal" records
+// (the TLAS: pt_tlas_build).  Temporaries come out of the caller's arena (PtScratch) or are allocated singly; everything runs on the
+// caller's stream.
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <cfloat>
@@ -1115,7 +1116,6 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     grab((void**)&plo, 16 * size_t(n)); grab((void**)&phi, 16 * size_t(n)); grab((void**)&idxA, 4 * size_t(n)); grab((void**)&idxB, 4 * size_t(n)); grab((void**)&pwA, 4 * size_t(n));
     grab((void**)&pwB, 4 * size_t(n)); grab((void**)&workA, sizeof(SdWork) * maxWork); grab((void**)&workB, sizeof(SdWork) * maxWork); grab((void**)&small, sizeof(SdWork) * maxSmall);
     grab((void**)&binCnt, 4 * maxWork * 3 * SD_BINS); grab((void**)&binBox, 4 * maxWork * 3 * SD_BINS * 6); grab((void**)&dCounts, 8);
-    void* tmp[] = {plo, phi, idxA, idxB, pwA, pwB, workA, workB, small, binCnt, binBox, dCounts};
     bool  done  = false;
     if(okAlloc)
     {
@@ -1211,13 +1211,11 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     // globally best pair; if an adversarial input makes the rounds crawl, the radix tree takes over.
     uint32_t *cidA = nullptr, *cidB = nullptr, *dNn = nullptr, *dValid = nullptr, *dPos = nullptr, *dBlockSum = nullptr, *dCnt = nullptr;
     float4 *  cloA = nullptr, *cloB = nullptr, *chiA = nullptr, *chiB = nullptr;
-    void*     tmp[11];
     bool      okAlloc = true;
     auto      grab = [&](void** p, size_t bytes) { okAlloc = okAlloc && sc.get(p, bytes) == hipSuccess; };
     grab((void**)&cidA, 4 * size_t(n)); grab((void**)&cidB, 4 * size_t(n)); grab((void**)&dNn, 4 * size_t(n)); grab((void**)&dValid, 4 * size_t(n)); grab((void**)&dPos, 4 * size_t(n));
     grab((void**)&dBlockSum, 4 * size_t((n + 1023) / 1024 + 1)); grab((void**)&dCnt, 8);
     grab((void**)&cloA, 16 * size_t(n)); grab((void**)&cloB, 16 * size_t(n)); grab((void**)&chiA, 16 * size_t(n)); grab((void**)&chiB, 16 * size_t(n));
-    tmp[0] = cidA; tmp[1] = cidB; tmp[2] = dNn; tmp[3] = dValid; tmp[4] = dPos; tmp[5] = dBlockSum; tmp[6] = dCnt; tmp[7] = cloA; tmp[8] = cloB; tmp[9] = chiA; tmp[10] = chiB;
     bool done = false;
     if(okAlloc)
     {
