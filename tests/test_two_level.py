@@ -330,3 +330,28 @@ def test_two_level_ray_picker(env_small):
         assert p.hitT == t[0] and p.baryCoord[1] == uv[0, 0] and p.baryCoord[2] == uv[0, 1]
     assert hits >= 6, hits
     r.destroy(); o.close()
+
+
+# ---- launch policy (host logic) -------------------------------------------------------------------------------------------------------------
+def test_tail_depth_follows_the_observed_queue_sizes():
+    """flush_pending's decision where the fused tail kernel takes over (pt_capi.hip tail_from_depth), on plain numbers: the first bounce
+    whose expected queue is <= the threshold; observed alive fractions first, the last observed shrink factor beyond them, 0.3 per bounce
+    before any feedback; never when the threshold is 0.  (Performance policy only: tests/test_gpu_parity.py holds every threshold to
+    bit-identical images.)"""
+    L = capi.lib()
+    L.pt_debug_tail_from.restype = C.c_int
+    L.pt_debug_tail_from.argtypes = [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int]
+
+    def tail(paths, depth, below, ratios=()):
+        r = np.asarray(ratios, np.float64)
+        return L.pt_debug_tail_from(float(paths), depth, below, r.ctypes.data if len(r) else None, len(r))
+
+    assert tail(66e6, 8, 0) == 8                                   # off
+    assert tail(1000, 8, 65536) == 0                               # a tiny launch runs in the tail kernel as a whole
+    assert tail(66e6, 8, 65536) == 6                               # no feedback: 0.3^6 * 66e6 = 48 k
+    assert tail(66e6, 8, 65536, [1, 0.25, 0.0625, 0.0156]) == 5    # observed 4x shrink, continued: 66e6 / 4^5 = 64.5 k
+    assert tail(1.3e6, 8, 65536, [1, 0.25, 0.0625]) == 3           # an 8-GPU shard's 5-frame piece: 81 k at bounce 2, 20 k at bounce 3
+    assert tail(1.0e6, 8, 65536, [1, 0.25, 0.0625]) == 2
+    assert tail(66e6, 8, 65536, [1, 0.9, 0.81]) == 8               # an enclosed scene that barely shrinks: staged kernels all the way
+    assert tail(66e6, 3, 65536, [1, 0.25]) == 3                    # maxDepth reached first
+    assert tail(2e6, 8, 65536, [1, 0.0]) == 1                      # everything missed at bounce 0

@@ -261,6 +261,31 @@ void refresh_scene_ptrs(pt_context* c)
 }
 
 
+// Where k_tail takes over (flush_pending): the first bounce whose queue is expected to hold <= tailBelow paths (maxDepth: never).
+// Expectation = this launch's paths x the alive fraction observed at that bounce (ratio[0 .. numObserved), from the newest finished launch
+// sequence); bounces beyond the observed ones continue the last observed shrink factor; before anything was observed a shrink of 0.3 per bounce
+// is assumed (Russian roulette from depth 0 gives ~0.25 on the stand-in scenes).  A wrong guess costs time, never results.
+int tail_from_depth(double paths, int maxDepth, int tailBelow, const double* ratio, int numObserved)
+{
+  if(tailBelow <= 0)
+    return maxDepth;
+  double r = 1.0, step = 0.3;
+  for(int d = 0; d < maxDepth; ++d)
+  {
+    if(d < numObserved)
+    {
+      if(d > 0 && ratio[d - 1] > 0.0)
+        step = std::min(1.0, ratio[d] / ratio[d - 1]);
+      r = ratio[d];
+    }
+    else if(d > 0)
+      r *= step;
+    if(paths * r <= double(tailBelow))
+      return d;
+  }
+  return maxDepth;
+}
+
 // fills the per-instance part of an InstanceRec that depends on the node's world matrix (pt_set_scene, pt_update_instances)
 bool set_instance_transform(InstanceRec& I, const float* m, uint32_t materialFlags)
 {
@@ -1274,28 +1299,7 @@ int flush_pending(pt_context* c)
     // where k_tail takes over: the first bounce whose queue is expected to hold <= tailBelow paths.  Expectation = this launch's paths x the
     // alive fraction observed at that bounce; bounces beyond the observed ones continue the last observed shrink factor; before anything was
     // observed a shrink of 0.3 per bounce is assumed.  A wrong guess costs time, never results.
-    int tailFrom = fp.st.maxDepth;
-    if(g_tuning.tailBelow > 0)
-    {
-      const double paths = double(n) * double(c->numSlots);
-      double       r = 1.0, step = 0.3;
-      for(int d = 0; d < fp.st.maxDepth; ++d)
-      {
-        if(d < c->qRatioDepths)
-        {
-          if(d > 0 && c->qRatio[d - 1] > 0.0)
-            step = std::min(1.0, c->qRatio[d] / c->qRatio[d - 1]);
-          r = c->qRatio[d];
-        }
-        else if(d > 0)
-          r *= step;
-        if(paths * r <= double(g_tuning.tailBelow))
-        {
-          tailFrom = d;
-          break;
-        }
-      }
-    }
+    const int tailFrom = tail_from_depth(double(n) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, c->qRatioDepths);
     pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
     plans.emplace_back();
     planSlot.push_back(&fs);
@@ -1758,6 +1762,12 @@ int pt_reset_stats(pt_context* c)
 }
 
 }  // extern "C"
+
+// Test hook (not part of the ABI): the launch-policy decision of flush_pending on plain numbers
+extern "C" __attribute__((visibility("default"))) int pt_debug_tail_from(double paths, int maxDepth, int tailBelow, const double* ratio, int numObserved)
+{
+  return tail_from_depth(paths, maxDepth, tailBelow, ratio, numObserved);
+}
 
 // Test hook (not part of the ABI; CPU tests hold the bound to a float32 emulation of the ray transform): the instance record pt_set_scene
 // derives from a node's world matrix and the object-space padding of the two-level walk for a mesh whose |coordinates| are <= Bo.
