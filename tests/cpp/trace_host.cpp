@@ -27,6 +27,87 @@ static inline float        __int_as_float(int i) { float f; std::memcpy(&f, &i, 
 template <class T>
 static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
 
+#ifdef TH_ROBUST_T2
+// EXPERIMENT (tools/t2_robust_experiment.py; not the contract): T2 with a forward error bound.  The fp32 evaluation is kept whenever its verdict
+// cannot be an artefact of rounding: |det|, u, v, 1 - u - v and t are further from their decision boundaries than the rounding error of their
+// numerators allows.  Otherwise the same formulas are evaluated in double precision (IEEE, so identical on every side) and rounded once.
+#include <atomic>
+#include "pt_device.h"
+static std::atomic<unsigned long long> g_t2Calls{0}, g_t2Double{0};  // per mode of th_candidates: [brute force + walks], filled from thread-local counts
+static thread_local unsigned long long tl_t2Calls = 0, tl_t2Double = 0;
+extern "C" void th_t2_stats(unsigned long long* out2) { out2[0] = g_t2Calls.exchange(0); out2[1] = g_t2Double.exchange(0); }
+static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
+{
+  const f3    e1 = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
+  const f3    pv = cross3(d, e2);
+  const float det = dot3(e1, pv);
+  const f3    tv = o - p0;
+  const f3    qv = cross3(tv, e1);
+  const float nu = dot3(tv, pv), nv = dot3(d, qv), nt = dot3(e2, qv);
+  // magnitudes that bound the rounding of the three numerators and of det (gamma_k 2^-24 with a generous k = 16: cross products feed the dots)
+  const float an = fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z), ap = fabsf(pv.x) + fabsf(pv.y) + fabsf(pv.z), aq = fabsf(qv.x) + fabsf(qv.y) + fabsf(qv.z);
+  const float ae1 = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z), ae2 = fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z), ad = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+  const float k   = 16.0f * 5.9604645e-8f;
+  const float edet = k * ae1 * (ad * ae2), eu = k * an * (ad * ae2), ev = k * ad * (an * ae1), et = k * ae2 * (an * ae1);
+  const float adet = fabsf(det);
+  ++tl_t2Calls;
+  bool        sure = adet > 4.0f * edet;
+  if(sure)
+  {
+    const float s  = det < 0.0f ? -1.0f : 1.0f;
+    const float su = nu * s, sv = nv * s;  // compare numerators against 0 and |det| (no division needed for the verdict)
+    const bool  inside  = su > eu && sv > ev && (adet - su - sv) > (eu + ev + edet);
+    const bool  outside = su < -eu || sv < -ev || (su + sv - adet) > (eu + ev + edet);
+    const bool  tOk     = et <= 4.0e-6f * fabsf(nt);  // relative error of t below the slack of the box tests (leaf padding 4e-6 |coordinate|)
+    sure = outside || (inside && tOk);
+  }
+  if(sure)
+  {
+    if(det == 0.0f)
+      return false;
+    if(!(flags & TRI_NOCULL))
+    {
+      const bool front = (flags & TRI_FLIP) ? (det < 0.0f) : (det > 0.0f);
+      if(!front)
+        return false;
+    }
+    const float inv = 1.0f / det;
+    u = nu * inv;
+    if(u < 0.0f || u > 1.0f)
+      return false;
+    v = nv * inv;
+    if(v < 0.0f || u + v > 1.0f)
+      return false;
+    t = nt * inv;
+    return true;
+  }
+  // ambiguous in fp32: the same test in double
+  ++tl_t2Double;
+  const double E1[3] = {e1.x, e1.y, e1.z}, E2[3] = {e2.x, e2.y, e2.z}, D[3] = {d.x, d.y, d.z}, TV[3] = {double(o.x) - p0.x, double(o.y) - p0.y, double(o.z) - p0.z};
+  const double PV[3] = {D[1] * E2[2] - D[2] * E2[1], D[2] * E2[0] - D[0] * E2[2], D[0] * E2[1] - D[1] * E2[0]};
+  const double DET   = E1[0] * PV[0] + E1[1] * PV[1] + E1[2] * PV[2];
+  if(DET == 0.0)
+    return false;
+  if(!(flags & TRI_NOCULL))
+  {
+    const bool front = (flags & TRI_FLIP) ? (DET < 0.0) : (DET > 0.0);
+    if(!front)
+      return false;
+  }
+  const double U = (TV[0] * PV[0] + TV[1] * PV[1] + TV[2] * PV[2]) / DET;
+  if(U < 0.0 || U > 1.0)
+    return false;
+  const double QV[3] = {TV[1] * E1[2] - TV[2] * E1[1], TV[2] * E1[0] - TV[0] * E1[2], TV[0] * E1[1] - TV[1] * E1[0]};
+  const double V     = (D[0] * QV[0] + D[1] * QV[1] + D[2] * QV[2]) / DET;
+  if(V < 0.0 || U + V > 1.0)
+    return false;
+  u = float(U);
+  v = float(V);
+  t = float((E2[0] * QV[0] + E2[1] * QV[1] + E2[2] * QV[2]) / DET);
+  return true;
+}
+#define PT_TRI_TEST_OVERRIDE th_tri_test_robust
+#endif
 #include "pt_trace.h"
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
@@ -460,6 +541,10 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
         wPrev = bw;
       }
     }
+#ifdef TH_ROBUST_T2
+    g_t2Calls += tl_t2Calls; g_t2Double += tl_t2Double;
+    tl_t2Calls = tl_t2Double = 0;
+#endif
 #pragma omp critical
     total.stackOverflow += cnt.stackOverflow;
   }

@@ -85,6 +85,10 @@ PT_DEV void note_zero_candidate(float t, float& z1, float& z2, float& z3)
 PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta < tb || (ta == tb && wa < wb); }
 
 // Moeller-Trumbore on (p0, e1, e2) in the exact operation order of the trace contract (T2, T3).
+#ifdef PT_TRI_TEST_OVERRIDE
+// host experiments only (tests/cpp/trace_host.cpp -DTH_ROBUST_T2): a candidate replacement of T2 under evaluation takes the place of the contract's
+PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v) { return PT_TRI_TEST_OVERRIDE(tr, flags, o, d, t, u, v); }
+#else
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
 {
   f3    e1  = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
@@ -110,6 +114,7 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
   t = dot3(e2, qv) * inv;
   return true;
 }
+#endif
 
 #if PT_BVH_WIDTH != 2
 // Per-ray constants of the slab test.  The test runs in the fused form t = plane * idir + n with n = -(o * idir):
