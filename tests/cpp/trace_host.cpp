@@ -44,11 +44,16 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
   const f3    tv = o - p0;
   const f3    qv = cross3(tv, e1);
   const float nu = dot3(tv, pv), nv = dot3(d, qv), nt = dot3(e2, qv);
-  // magnitudes that bound the rounding of the three numerators and of det (gamma_k 2^-24 with a generous k = 16: cross products feed the dots)
-  const float an = fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z), ap = fabsf(pv.x) + fabsf(pv.y) + fabsf(pv.z), aq = fabsf(qv.x) + fabsf(qv.y) + fabsf(qv.z);
-  const float ae1 = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z), ae2 = fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z), ad = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
-  const float k   = 16.0f * 5.9604645e-8f;
-  const float edet = k * ae1 * (ad * ae2), eu = k * an * (ad * ae2), ev = k * ad * (an * ae1), et = k * ae2 * (an * ae1);
+  // forward error bounds of det and of the three numerators, componentwise: a cross product's component a_i b_j - a_j b_i is off by at most
+  // 2 ulp of |a_i b_j| + |a_j b_i|, a 3-term dot by 3 ulp of sum |x_i y_i| plus |x| . (error of y); 8 ulp covers every chain below
+  const f3    apv = f3{fabsf(d.y) * fabsf(e2.z) + fabsf(d.z) * fabsf(e2.y), fabsf(d.z) * fabsf(e2.x) + fabsf(d.x) * fabsf(e2.z), fabsf(d.x) * fabsf(e2.y) + fabsf(d.y) * fabsf(e2.x)};
+  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
+  const f3    aqv = f3{atv.y * fabsf(e1.z) + atv.z * fabsf(e1.y), atv.z * fabsf(e1.x) + atv.x * fabsf(e1.z), atv.x * fabsf(e1.y) + atv.y * fabsf(e1.x)};
+  const float k   = 8.0f * 5.9604645e-8f;
+  const float edet = k * (fabsf(e1.x) * apv.x + fabsf(e1.y) * apv.y + fabsf(e1.z) * apv.z);
+  const float eu   = k * (atv.x * apv.x + atv.y * apv.y + atv.z * apv.z);
+  const float ev   = k * (fabsf(d.x) * aqv.x + fabsf(d.y) * aqv.y + fabsf(d.z) * aqv.z);
+  const float et   = k * (fabsf(e2.x) * aqv.x + fabsf(e2.y) * aqv.y + fabsf(e2.z) * aqv.z);
   const float adet = fabsf(det);
   ++tl_t2Calls;
   bool        sure = adet > 4.0f * edet;
