@@ -710,31 +710,49 @@ static void build_opacity_maps(const pt_SceneDesc* d, std::vector<AlphaMat>& am,
   }
 }
 
-int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
-{
-  CTX_CHECK(c);
-  if(!d || !d->vertices || !d->indices || !d->primMeshes || !d->nodes || !d->materials || d->numMaterials == 0)
-    return c->fail(PT_ERR_INVALID, "pt_set_scene: null array or no material");
-  if((d->numLights && !d->lights) || (d->numTextures && !d->textures))
-    return c->fail(PT_ERR_INVALID, "pt_set_scene: count without array");
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, sync_all(c));
-
-  // ---- validate + build the per-instance records
-  std::vector<InstanceRec> inst(d->numNodes);
+// Everything pt_set_scene derives from a pt_SceneDesc on the HOST, before anything is uploaded: validation, the per-instance records
+// (transforms, inverse, TLAS flags of src/accelstruct.cpp:144-149), the texture records and the compact alpha view of the materials with their
+// opacity maps.  Shared with the test hook pt_debug_scene_records (CPU tests run the product's traversal on exactly these records).
+struct SceneRecords {
+  std::vector<InstanceRec> inst;
   uint64_t                 triTotal = 0;
+  std::vector<float>       primBound;  // per prim-mesh: max |coordinate| of its vertices
+  std::vector<TexRec>      texRecs;    // >= 1 (a 1x1 white default when the scene has no texture, src/scene.cpp:513-519)
+  size_t                   texels = 0; // texels of the RGBA8 pool
+  std::vector<AlphaMat>    alphaMats;
+  std::vector<uint32_t>    alphaMaps;
+};
+__attribute__((format(printf, 2, 3))) static int records_fail(std::string& err, const char* fmt, ...)
+{
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  err = buf;
+  return PT_ERR_INVALID;
+}
+static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::string& err)
+{
+  if(!d || !d->vertices || !d->indices || !d->primMeshes || !d->nodes || !d->materials || d->numMaterials == 0)
+    return records_fail(err, "pt_set_scene: null array or no material");
+  if((d->numLights && !d->lights) || (d->numTextures && !d->textures))
+    return records_fail(err, "pt_set_scene: count without array");
+  // ---- validate + build the per-instance records
+  R.inst.assign(d->numNodes, InstanceRec{});
+  R.triTotal = 0;
   for(uint32_t n = 0; n < d->numNodes; ++n)
   {
     const pt_Node& nd = d->nodes[n];
     if(nd.primMesh < 0 || uint32_t(nd.primMesh) >= d->numPrimMeshes)
-      return c->fail(PT_ERR_INVALID, "node %u: primMesh %d out of range", n, nd.primMesh);
+      return records_fail(err, "node %u: primMesh %d out of range", n, nd.primMesh);
     const pt_PrimMesh& pm = d->primMeshes[nd.primMesh];
     if(pm.materialIndex >= int(d->numMaterials))
-      return c->fail(PT_ERR_INVALID, "primMesh %d: materialIndex %d out of range", nd.primMesh, pm.materialIndex);
+      return records_fail(err, "primMesh %d: materialIndex %d out of range", nd.primMesh, pm.materialIndex);
     if(uint64_t(pm.vertexOffset) + pm.vertexCount > d->numVertices || uint64_t(pm.firstIndex) + pm.indexCount > d->numIndices || pm.indexCount % 3)
-      return c->fail(PT_ERR_INVALID, "primMesh %d: vertex/index range out of bounds", nd.primMesh);
+      return records_fail(err, "primMesh %d: vertex/index range out of bounds", nd.primMesh);
     const pt_GltfShadeMaterial& mat = d->materials[pm.materialIndex < 0 ? 0 : pm.materialIndex];
-    InstanceRec&                I   = inst[n];
+    InstanceRec&                I   = R.inst[n];
     // instance flags of the reference's TLAS (src/accelstruct.cpp:144-149)
     uint32_t flags = 0;
     if(mat.alphaMode == 0 || (mat.pbrBaseColorFactor[3] == 1.0f && mat.pbrBaseColorTexture == -1))
@@ -742,25 +760,25 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     if(mat.doubleSided == 1)
       flags |= TRI_NOCULL;
     if(!set_instance_transform(I, nd.worldMatrix, flags))  // + TRI_FLIP for a mirroring matrix
-      return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
+      return records_fail(err, "node %u: singular world matrix", n);
     I.vertexOffset  = pm.vertexOffset;
     I.firstIndex    = pm.firstIndex;
     I.materialIndex = pm.materialIndex;
     I.primMesh      = nd.primMesh;
-    I.triBase       = uint32_t(triTotal);
+    I.triBase       = uint32_t(R.triTotal);
     I.triCount      = pm.indexCount / 3;
     I._pad  = 0;
-    triTotal += I.triCount;
+    R.triTotal += I.triCount;
   }
-  if(triTotal > TRI_INDEX_MASK)
-    return c->fail(PT_ERR_INVALID, "scene has %llu triangles; the limit is %u", (unsigned long long)triTotal, TRI_INDEX_MASK);
-  c->hPrimBound.assign(d->numPrimMeshes, 0.f);
+  if(R.triTotal > TRI_INDEX_MASK)
+    return records_fail(err, "scene has %llu triangles; the limit is %u", (unsigned long long)R.triTotal, TRI_INDEX_MASK);
+  R.primBound.assign(d->numPrimMeshes, 0.f);
   for(uint32_t p = 0; p < d->numPrimMeshes; ++p)
   {
     const pt_PrimMesh& pm = d->primMeshes[p];
     for(uint32_t k = 0; k < pm.indexCount; ++k)
       if(d->indices[pm.firstIndex + k] >= pm.vertexCount)
-        return c->fail(PT_ERR_INVALID, "primMesh %u: index %u >= vertexCount", p, d->indices[pm.firstIndex + k]);
+        return records_fail(err, "primMesh %u: index %u >= vertexCount", p, d->indices[pm.firstIndex + k]);
     float b = 0.f;
     for(uint32_t v = 0; v < pm.vertexCount; ++v)
     {
@@ -769,7 +787,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
         if(std::isfinite(q[a]))
           b = std::max(b, std::fabs(q[a]));
     }
-    c->hPrimBound[p] = b;
+    R.primBound[p] = b;
   }
   for(uint32_t m = 0; m < d->numMaterials; ++m)
   {
@@ -777,14 +795,77 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     const int ids[] = {mt.pbrBaseColorTexture, mt.pbrMetallicRoughnessTexture, mt.emissiveTexture, mt.normalTexture, mt.transmissionTexture, mt.clearcoatTexture, mt.clearcoatRoughnessTexture};
     for(int id : ids)
       if(id >= int(d->numTextures))
-        return c->fail(PT_ERR_INVALID, "material %u references texture %d of %u", m, id, d->numTextures);
+        return records_fail(err, "material %u references texture %d of %u", m, id, d->numTextures);
   }
+  // ---- texture records (one RGBA8 pool)
+  R.texRecs.assign(d->numTextures ? d->numTextures : 1, TexRec{});
+  R.texels = 0;
+  for(uint32_t t = 0; t < d->numTextures; ++t)
+  {
+    const pt_TextureDesc& td = d->textures[t];
+    if(!td.rgba8 || td.width <= 0 || td.height <= 0)
+      return records_fail(err, "texture %u: empty image", t);
+    R.texRecs[t].offset = uint32_t(R.texels);
+    R.texRecs[t].w      = td.width;
+    R.texRecs[t].h      = td.height;
+    R.texRecs[t].mag    = td.magFilter;
+    R.texRecs[t].wrapS  = td.wrapS;
+    R.texRecs[t].wrapT  = td.wrapT;
+    R.texRecs[t].pot    = ((td.width & (td.width - 1)) == 0 ? 1 : 0) | ((td.height & (td.height - 1)) == 0 ? 2 : 0);
+    R.texels += size_t(td.width) * td.height;
+    if(R.texels > 0xffffffffull)
+      return records_fail(err, "texture pool exceeds 2^32 texels");
+  }
+  if(d->numTextures == 0)
+  {  // a 1x1 white default like src/scene.cpp:513-519
+    R.texRecs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, 3, 0};
+    R.texels     = 1;
+  }
+  // ---- compact alpha view of every material (what the any-hit evaluation reads)
+  R.alphaMats.assign(d->numMaterials, AlphaMat{});
+  for(uint32_t m = 0; m < d->numMaterials; ++m)
+  {
+    const pt_GltfShadeMaterial& mt = d->materials[m];
+    AlphaMat&                   a  = R.alphaMats[m];
+    std::memset(&a, 0, sizeof(a));
+    a.factorA = mt.pbrBaseColorFactor[3];
+    a.cutoff  = mt.alphaCutoff;
+    a.mode    = mt.alphaMode;
+    a.tex     = mt.pbrBaseColorTexture;
+    for(int k = 0; k < 8; ++k)
+      a.m[k] = mt.uvTransform[k];
+    a.mapOffset = ALPHA_NO_MAP;
+    if(mt.pbrBaseColorTexture > -1)
+    {
+      const TexRec& tr = R.texRecs[mt.pbrBaseColorTexture];
+      a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8) | (tr.pot << 16);
+      if(tr.wrapS == PT_WRAP_REPEAT && tr.wrapT == PT_WRAP_REPEAT && tr.pot == 3)
+        a.texWrap |= ALPHA_FAST_TAP;
+    }
+  }
+  build_opacity_maps(d, R.alphaMats, R.alphaMaps);
+  return PT_OK;
+}
+
+int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
+{
+  CTX_CHECK(c);
+  SceneRecords R;
+  {
+    std::string msg;
+    const int   vrc = build_scene_records(d, R, msg);
+    if(vrc != PT_OK)
+      return c->fail(vrc, "%s", msg.c_str());
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_all(c));
+  c->hPrimBound = R.primBound;
 
   // ---- uploads
   int rc;
   if((rc = upload(c, c->dVertices, d->vertices, sizeof(pt_VertexAttributes) * size_t(d->numVertices))) != PT_OK) return rc;
   if((rc = upload(c, c->dIndices, d->indices, 4 * size_t(d->numIndices))) != PT_OK) return rc;
-  c->hInstances = inst;
+  c->hInstances = R.inst;
   if((rc = upload_instances(c)) != PT_OK) return rc;
   if((rc = upload(c, c->dMaterials, d->materials, sizeof(pt_GltfShadeMaterial) * size_t(d->numMaterials))) != PT_OK) return rc;
   {
@@ -792,68 +873,19 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     if((rc = upload(c, c->dLights, d->numLights ? d->lights : &dummy, sizeof(pt_Light) * size_t(d->numLights ? d->numLights : 1))) != PT_OK) return rc;
     c->numLights = d->numLights;
   }
+  if((rc = dev_alloc(c, c->dTexels, R.texels * 4)) != PT_OK) return rc;
+  if(d->numTextures == 0)
   {
-    std::vector<TexRec> recs(d->numTextures ? d->numTextures : 1);
-    size_t              texels = 0;
-    for(uint32_t t = 0; t < d->numTextures; ++t)
-    {
-      const pt_TextureDesc& td = d->textures[t];
-      if(!td.rgba8 || td.width <= 0 || td.height <= 0)
-        return c->fail(PT_ERR_INVALID, "texture %u: empty image", t);
-      recs[t].offset = uint32_t(texels);
-      recs[t].w      = td.width;
-      recs[t].h      = td.height;
-      recs[t].mag    = td.magFilter;
-      recs[t].wrapS  = td.wrapS;
-      recs[t].wrapT  = td.wrapT;
-      recs[t].pot    = ((td.width & (td.width - 1)) == 0 ? 1 : 0) | ((td.height & (td.height - 1)) == 0 ? 2 : 0);
-      texels += size_t(td.width) * td.height;
-      if(texels > 0xffffffffull)
-        return c->fail(PT_ERR_INVALID, "texture pool exceeds 2^32 texels");
-    }
-    if(d->numTextures == 0)
-    {  // a 1x1 white default like src/scene.cpp:513-519
-      recs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, 3, 0};
-      texels  = 1;
-    }
-    if((rc = dev_alloc(c, c->dTexels, texels * 4)) != PT_OK) return rc;
-    if(d->numTextures == 0)
-    {
-      uint32_t white = 0xffffffffu;
-      HIP_TRY(c, hipMemcpy(c->dTexels.p, &white, 4, hipMemcpyHostToDevice));
-    }
-    for(uint32_t t = 0; t < d->numTextures; ++t)
-      HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + recs[t].offset, d->textures[t].rgba8, size_t(recs[t].w) * recs[t].h * 4, hipMemcpyHostToDevice));
-    if((rc = upload(c, c->dTexRecs, recs.data(), sizeof(TexRec) * recs.size())) != PT_OK) return rc;
-    // compact alpha view of every material (what the any-hit evaluation reads)
-    std::vector<AlphaMat> am(d->numMaterials);
-    for(uint32_t m = 0; m < d->numMaterials; ++m)
-    {
-      const pt_GltfShadeMaterial& mt = d->materials[m];
-      AlphaMat&                   a  = am[m];
-      std::memset(&a, 0, sizeof(a));
-      a.factorA = mt.pbrBaseColorFactor[3];
-      a.cutoff  = mt.alphaCutoff;
-      a.mode    = mt.alphaMode;
-      a.tex     = mt.pbrBaseColorTexture;
-      for(int k = 0; k < 8; ++k)
-        a.m[k] = mt.uvTransform[k];
-      a.mapOffset = ALPHA_NO_MAP;
-      if(mt.pbrBaseColorTexture > -1)
-      {
-        const TexRec& tr = recs[mt.pbrBaseColorTexture];
-        a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8) | (tr.pot << 16);
-        if(tr.wrapS == PT_WRAP_REPEAT && tr.wrapT == PT_WRAP_REPEAT && tr.pot == 3)
-          a.texWrap |= ALPHA_FAST_TAP;
-      }
-    }
-    std::vector<uint32_t> maps;
-    build_opacity_maps(d, am, maps);
-    if((rc = upload(c, c->dAlphaMaps, maps.data(), 4 * maps.size())) != PT_OK) return rc;
-    if((rc = upload(c, c->dAlphaMats, am.data(), sizeof(AlphaMat) * am.size())) != PT_OK) return rc;
+    uint32_t white = 0xffffffffu;
+    HIP_TRY(c, hipMemcpy(c->dTexels.p, &white, 4, hipMemcpyHostToDevice));
   }
+  for(uint32_t t = 0; t < d->numTextures; ++t)
+    HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + R.texRecs[t].offset, d->textures[t].rgba8, size_t(R.texRecs[t].w) * R.texRecs[t].h * 4, hipMemcpyHostToDevice));
+  if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;
   c->numInstances = d->numNodes;
-  c->numTris      = uint32_t(triTotal);
+  c->numTris      = uint32_t(R.triTotal);
   c->qRatioDepths = 0;  // queue-size feedback of the previous scene
   c->haveScene    = true;
   c->haveAccel    = false;
@@ -1762,6 +1794,45 @@ int pt_reset_stats(pt_context* c)
 }
 
 }  // extern "C"
+
+// Test hook (not part of the ABI; tests/cpp/trace_host.cpp): the host-side records pt_set_scene derives from a scene description, copied into
+// caller arrays (no GPU involved).  Call with null outputs to get the counts: counts[0] instances, [1] materials, [2] opacity-map words,
+// [3] texels of the RGBA8 pool, [4] world triangles.  instOut: InstanceRec[counts[0]] (128 B each); padOut: 2 floats per instance
+// (TlasLeaf::padC0 / padC1 of the two-level walk); alphaMatsOut: AlphaMat[counts[1]] (64 B each); texelsOut: the pool in upload order.
+extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut,
+                                                                            uint32_t* alphaMapsOut, uint32_t* texelsOut, char* err, size_t errLen)
+{
+  SceneRecords R;
+  std::string  msg;
+  const int    rc = build_scene_records(d, R, msg);
+  if(rc != PT_OK)
+  {
+    if(err && errLen)
+      snprintf(err, errLen, "%s", msg.c_str());
+    return rc;
+  }
+  if(counts5)
+  {
+    counts5[0] = R.inst.size(); counts5[1] = R.alphaMats.size(); counts5[2] = R.alphaMaps.size(); counts5[3] = R.texels; counts5[4] = R.triTotal;
+  }
+  if(instOut)
+    std::memcpy(instOut, R.inst.data(), sizeof(InstanceRec) * R.inst.size());
+  if(padOut)
+    for(size_t i = 0; i < R.inst.size(); ++i)
+      two_level_pad(R.inst[i], R.primBound[R.inst[i].primMesh], padOut[2 * i], padOut[2 * i + 1]);
+  if(alphaMatsOut)
+    std::memcpy(alphaMatsOut, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size());
+  if(alphaMapsOut)
+    std::memcpy(alphaMapsOut, R.alphaMaps.data(), 4 * R.alphaMaps.size());
+  if(texelsOut)
+  {
+    if(d->numTextures == 0)
+      texelsOut[0] = 0xffffffffu;
+    for(uint32_t t = 0; t < d->numTextures; ++t)
+      std::memcpy(texelsOut + R.texRecs[t].offset, d->textures[t].rgba8, size_t(R.texRecs[t].w) * R.texRecs[t].h * 4);
+  }
+  return PT_OK;
+}
 
 // Test hook (not part of the ABI): the launch-policy decision of flush_pending on plain numbers
 extern "C" __attribute__((visibility("default"))) int pt_debug_tail_from(double paths, int maxDepth, int tailBelow, const double* ratio, int numObserved)
