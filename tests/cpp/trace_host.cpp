@@ -113,10 +113,13 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 }
 #define PT_TRI_TEST_OVERRIDE th_tri_test_robust
 #endif
-#include "pt_trace.h"
+#include "pt_settle.h"  // pt_trace.h + the per-ray settle functions k_tail runs (tail_closest, tail_shadow)
+#include "../../include/pt_types.h"
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
 extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
+extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut, uint32_t* alphaMapsOut, uint32_t* texelsOut,
+                                      char* err, size_t errLen);
 
 namespace {
 
@@ -298,6 +301,8 @@ struct Scene {
   std::vector<TlasLeaf>    tlasLeaves;
   std::vector<AlphaRec>    flatAlpha;
   AlphaMat                 alphaMat;
+  std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
+  std::vector<uint32_t>    alphaMaps, texels;
   DeviceScene              dsFlat, dsTwo;
   double                   maxPadRatio = 0;
 };
@@ -322,39 +327,28 @@ TriRec world_record(const Scene& s, const InstanceRec& I, uint32_t inst, uint32_
 
 extern "C" {
 
-void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indices, uint32_t numIdx, const InstIn* in, uint32_t numInst, const float* primBound, uint32_t numPrimMeshes)
+// any-hit inputs of triangle k of instance I (k_world_tris): raw texcoords of the three vertices + material
+static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
 {
-  Scene* s = new Scene();
-  s->vertices.resize(size_t(numVerts) * 2);
-  std::memcpy(s->vertices.data(), vertices8, sizeof(float) * 8 * size_t(numVerts));
-  s->indices.assign(indices, indices + numIdx);
-  s->inst.resize(numInst);
-  s->instTriBase.resize(numInst ? numInst : 1);
-  std::vector<float> padC0(numInst), padC1(numInst);
-  uint32_t           triTotal = 0;
+  const uint32_t* t = &s.indices[I.firstIndex + 3 * size_t(k)];
+  const float4    b0 = s.vertices[size_t(I.vertexOffset + t[0]) * 2 + 1], b1 = s.vertices[size_t(I.vertexOffset + t[1]) * 2 + 1], b2 = s.vertices[size_t(I.vertexOffset + t[2]) * 2 + 1];
+  AlphaRec        ar;
+  ar.uv0[0] = b0.x; ar.uv0[1] = b0.y; ar.uv1[0] = b1.x; ar.uv1[1] = b1.y; ar.uv2[0] = b2.x; ar.uv2[1] = b2.y;
+  ar.material = uint32_t(I.materialIndex < 0 ? 0 : I.materialIndex);
+  ar._pad     = 0;
+  return ar;
+}
+
+// flat + two-level structures over s->inst (already filled), pads per instance
+static void build_structures(Scene* s, const std::vector<float>& padC0, const std::vector<float>& padC1, uint32_t numPrimMeshes)
+{
+  const uint32_t numInst  = uint32_t(s->inst.size());
+  uint32_t       triTotal = 0;
+  s->instTriBase.assign(numInst ? numInst : 1, 0u);
   for(uint32_t i = 0; i < numInst; ++i)
   {
-    InstanceRec& I = s->inst[i];
-    std::memset(&I, 0, sizeof(I));
-    float rec[27];
-    if(in[i].primMesh < 0 || uint32_t(in[i].primMesh) >= numPrimMeshes || pt_debug_two_level_pad(in[i].worldMatrix, primBound[in[i].primMesh], rec) != 0)
-    {
-      delete s;
-      return nullptr;
-    }
-    I.objectToWorld.r0 = make_float4(rec[0], rec[1], rec[2], rec[3]);
-    I.objectToWorld.r1 = make_float4(rec[4], rec[5], rec[6], rec[7]);
-    I.objectToWorld.r2 = make_float4(rec[8], rec[9], rec[10], rec[11]);
-    I.worldToObject.r0 = make_float4(rec[12], rec[13], rec[14], rec[15]);
-    I.worldToObject.r1 = make_float4(rec[16], rec[17], rec[18], rec[19]);
-    I.worldToObject.r2 = make_float4(rec[20], rec[21], rec[22], rec[23]);
-    padC0[i]           = rec[24];
-    padC1[i]           = rec[25];
-    I.vertexOffset = in[i].vertexOffset; I.firstIndex = in[i].firstIndex; I.materialIndex = 0; I.primMesh = in[i].primMesh;
-    I.triBase = triTotal; I.triCount = in[i].triCount;
-    I.flags   = (in[i].flags & (TRI_OPAQUE | TRI_NOCULL)) | (uint32_t(rec[26]) & TRI_FLIP);
-    s->instTriBase[i] = triTotal;
-    triTotal += I.triCount;
+    s->instTriBase[i] = s->inst[i].triBase;
+    triTotal += s->inst[i].triCount;
   }
   // ---- flat: world records of every instance, one hierarchy
   s->world.reserve(triTotal);
@@ -363,6 +357,8 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
       s->world.push_back(world_record(*s, s->inst[i], i, k, s->inst[i].triBase + k));
   s->flat = build_bvh(s->world);
   s->flatAlpha.assign(std::max<size_t>(1, s->flat.tris.size()), AlphaRec{});
+  for(size_t i = 0; i < s->flat.tris.size(); ++i)
+    s->flatAlpha[i] = alpha_record(*s, s->inst[__float_as_uint(s->flat.tris[i].e1n.w)], __float_as_uint(s->flat.tris[i].e2p.w));
   // ---- two-level: one object-space BLAS per prim-mesh that is instantiated (pt_capi.hip build_two_level / pt_accel.hip pt_blas_build)
   std::vector<int64_t> nodeBaseOf(numPrimMeshes, -1);
   for(uint32_t i = 0; i < numInst; ++i)
@@ -387,6 +383,7 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
       r.e1n = make_float4(v1.x, v1.y, v1.z, 0.f);
       r.e2p = make_float4(v2.x, v2.y, v2.z, 0.f);
       s->blasTris.push_back(r);
+      s->blasAlpha.push_back(alpha_record(*s, I, k));
     }
     for(WideNode w : b.wide)
     {  // global references (k_blas_rebase)
@@ -398,10 +395,10 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
     }
     nodeBaseOf[I.primMesh] = nodeBase;
   }
-  s->blasAlpha.assign(std::max<size_t>(1, s->blasTris.size()), AlphaRec{});
+  if(s->blasAlpha.empty())
+    s->blasAlpha.emplace_back();
   // TLAS over the exact world boxes of the instances (k_instance_proxies), as "diagonal" records
-  std::vector<TriRec>   prox;
-  std::vector<uint32_t> proxInst;
+  std::vector<TriRec> prox;
   for(uint32_t i = 0; i < numInst; ++i)
   {
     const InstanceRec& I = s->inst[i];
@@ -440,11 +437,20 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
   if(s->tlasLeaves.empty())
     s->tlasLeaves.emplace_back();
   // ---- the scene records the walk reads
-  std::memset(&s->alphaMat, 0, sizeof(s->alphaMat));
-  s->alphaMat.factorA = 1.0f; s->alphaMat.tex = -1; s->alphaMat.mapOffset = ALPHA_NO_MAP;
+  if(s->alphaMats.empty())
+  {
+    std::memset(&s->alphaMat, 0, sizeof(s->alphaMat));
+    s->alphaMat.factorA = 1.0f; s->alphaMat.tex = -1; s->alphaMat.mapOffset = ALPHA_NO_MAP;
+    s->alphaMats.push_back(s->alphaMat);
+  }
+  if(s->alphaMaps.empty())
+    s->alphaMaps.push_back(0u);
+  if(s->texels.empty())
+    s->texels.push_back(0xffffffffu);
   DeviceScene d;
   std::memset(&d, 0, sizeof(d));
-  d.vertices = s->vertices.data(); d.indices = s->indices.data(); d.instances = s->inst.data(); d.alphaMats = &s->alphaMat;
+  d.vertices = s->vertices.data(); d.indices = s->indices.data(); d.instances = s->inst.data();
+  d.alphaMats = s->alphaMats.data(); d.alphaMaps = s->alphaMaps.data(); d.texels = s->texels.data();
   d.numTris = triTotal; d.numInstances = numInst;
   s->dsFlat           = d;
   s->dsFlat.wide      = s->flat.wide.data();
@@ -458,6 +464,73 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
   s->dsTwo.tlasLeaves  = s->tlasLeaves.data();
   s->dsTwo.instTriBase = s->instTriBase.data();
   s->dsTwo.twoLevel    = 1;
+}
+
+// plain geometry + per-instance flags (every instance's material is the default: no any-hit evaluation is reachable with TRI_OPAQUE)
+void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indices, uint32_t numIdx, const InstIn* in, uint32_t numInst, const float* primBound, uint32_t numPrimMeshes)
+{
+  Scene* s = new Scene();
+  s->vertices.resize(size_t(numVerts) * 2);
+  std::memcpy(s->vertices.data(), vertices8, sizeof(float) * 8 * size_t(numVerts));
+  s->indices.assign(indices, indices + numIdx);
+  s->inst.resize(numInst);
+  std::vector<float> padC0(numInst), padC1(numInst);
+  uint32_t           triTotal = 0;
+  for(uint32_t i = 0; i < numInst; ++i)
+  {
+    InstanceRec& I = s->inst[i];
+    std::memset(&I, 0, sizeof(I));
+    float rec[27];
+    if(in[i].primMesh < 0 || uint32_t(in[i].primMesh) >= numPrimMeshes || pt_debug_two_level_pad(in[i].worldMatrix, primBound[in[i].primMesh], rec) != 0)
+    {
+      delete s;
+      return nullptr;
+    }
+    I.objectToWorld.r0 = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    I.objectToWorld.r1 = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    I.objectToWorld.r2 = make_float4(rec[8], rec[9], rec[10], rec[11]);
+    I.worldToObject.r0 = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    I.worldToObject.r1 = make_float4(rec[16], rec[17], rec[18], rec[19]);
+    I.worldToObject.r2 = make_float4(rec[20], rec[21], rec[22], rec[23]);
+    padC0[i]           = rec[24];
+    padC1[i]           = rec[25];
+    I.vertexOffset = in[i].vertexOffset; I.firstIndex = in[i].firstIndex; I.materialIndex = 0; I.primMesh = in[i].primMesh;
+    I.triBase = triTotal; I.triCount = in[i].triCount;
+    I.flags   = (in[i].flags & (TRI_OPAQUE | TRI_NOCULL)) | (uint32_t(rec[26]) & TRI_FLIP);
+    triTotal += I.triCount;
+  }
+  build_structures(s, padC0, padC1, numPrimMeshes);
+  return s;
+}
+
+// a full scene description (materials, textures): instance records, flags, alpha view, opacity maps and texel pool are the PRODUCT's
+// (pt_capi.hip build_scene_records through pt_debug_scene_records), so the any-hit evaluation reads exactly what the GPU reads
+void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
+{
+  unsigned long long counts[5] = {0, 0, 0, 0, 0};
+  if(pt_debug_scene_records(d, counts, nullptr, nullptr, nullptr, nullptr, nullptr, err, errLen) != 0)
+    return nullptr;
+  Scene* s = new Scene();
+  s->vertices.resize(size_t(d->numVertices) * 2);
+  std::memcpy(s->vertices.data(), d->vertices, sizeof(float) * 8 * size_t(d->numVertices));
+  s->indices.assign(d->indices, d->indices + d->numIndices);
+  s->inst.resize(counts[0]);
+  s->alphaMats.resize(counts[1]);
+  s->alphaMaps.resize(counts[2]);
+  s->texels.resize(counts[3]);
+  std::vector<float> pad(2 * counts[0] + 2);
+  if(pt_debug_scene_records(d, counts, s->inst.data(), pad.data(), s->alphaMats.data(), s->alphaMaps.data(), s->texels.data(), err, errLen) != 0)
+  {
+    delete s;
+    return nullptr;
+  }
+  std::vector<float> padC0(counts[0]), padC1(counts[0]);
+  for(size_t i = 0; i < counts[0]; ++i)
+  {
+    padC0[i] = pad[2 * i];
+    padC1[i] = pad[2 * i + 1];
+  }
+  build_structures(s, padC0, padC1, d->numPrimMeshes);
   return s;
 }
 
@@ -550,6 +623,109 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
     g_t2Calls += tl_t2Calls; g_t2Double += tl_t2Double;
     tl_t2Calls = tl_t2Double = 0;
 #endif
+#pragma omp critical
+    total.stackOverflow += cnt.stackOverflow;
+  }
+  return total.stackOverflow;
+}
+
+// The product's per-ray settle functions (pt_settle.h: what k_tail runs per lane) against the contract's exact loop, ray by ray.
+//   kind 0: closest-hit ray (T5), kind 1: shadow ray (T6, bounded by tmax[r]);  two: 0 flat structure, 1 two-level structure;
+//   exact 0: tail_closest / tail_shadow (pass A, pass B, consume_rejected_draws, fallback), exact 1: the key-ordered loop with one
+//   alpha_test per non-opaque candidate (k_closest_x / k_shadow_x = the definition).
+// out per ray: w (world triangle index of the hit, 0xffffffff none; for shadow rays 1 / 0 = in shadow or not), t, u, v, seed afterwards,
+// number of alpha draws counted.  Returns the number of traversal-stack overflows.
+uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t nrays, const float* org, const float* dir, const float* tmax, const uint32_t* seeds, uint32_t* outW,
+                   float* outTUV, uint32_t* outSeed, uint32_t* outDraws)
+{
+  Scene*             s = static_cast<Scene*>(p);
+  const DeviceScene& S = two ? s->dsTwo : s->dsFlat;
+  std::vector<float4> rayO(nrays), rayD(nrays), absorb(nrays), neeDir(nrays), hit(nrays);
+  for(uint32_t r = 0; r < nrays; ++r)
+  {
+    rayO[r]   = make_float4(org[3 * r], org[3 * r + 1], org[3 * r + 2], 0.f);
+    rayD[r]   = make_float4(dir[3 * r], dir[3 * r + 1], dir[3 * r + 2], __uint_as_float(seeds[r]));
+    neeDir[r] = make_float4(dir[3 * r], dir[3 * r + 1], dir[3 * r + 2], 1.f);
+    absorb[r] = make_float4(0.f, 0.f, 0.f, tmax ? tmax[r] : PT_INFINITY);
+  }
+  Counters total;
+  std::memset(&total, 0, sizeof(total));
+#pragma omp parallel
+  {
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+    Counters              cnt;
+    std::memset(&cnt, 0, sizeof(cnt));
+    RenderBuffers rb;
+    std::memset(&rb, 0, sizeof(rb));
+    rb.ps.rayO = rayO.data(); rb.ps.rayD = rayD.data(); rb.ps.absorb = absorb.data(); rb.ps.neeDir = neeDir.data(); rb.ps.hit = hit.data();
+    rb.counters = &cnt;
+#pragma omp for schedule(dynamic, 64)
+    for(long long r = 0; r < (long long)nrays; ++r)
+    {
+      const f3    o = xyz(rayO[r]), d = xyz(rayD[r]);
+      uint32_t    seed = seeds[r], draws = 0;
+      if(!exact)
+      {
+        if(kind == 0)
+        {
+          if(two) tail_closest<true>(S, rb, uint32_t(r), stack.data(), draws); else tail_closest<false>(S, rb, uint32_t(r), stack.data(), draws);
+          const float4 h = hit[r];
+          outW[r]        = __float_as_uint(h.y);   // flat: leaf slot; two-level: world index -- translated below
+          if(outW[r] != BVH_NONE && !two)
+            outW[r] = __float_as_uint(S.tris[outW[r]].p0w.w) & TRI_INDEX_MASK;
+          outTUV[3 * r] = h.x; outTUV[3 * r + 1] = h.z; outTUV[3 * r + 2] = h.w;
+          outSeed[r]    = __float_as_uint(rayD[r].w);
+        }
+        else
+        {
+          const bool sh = two ? tail_shadow<true>(S, rb, uint32_t(r), stack.data(), variant, seed, draws) : tail_shadow<false>(S, rb, uint32_t(r), stack.data(), variant, seed, draws);
+          outW[r]       = sh ? 1u : 0u;
+          outTUV[3 * r] = outTUV[3 * r + 1] = outTUV[3 * r + 2] = 0.f;
+          outSeed[r]    = seed;
+        }
+      }
+      else
+      {  // trace contract T5 / T6: candidates strictly in key order, an opaque one commits, a non-opaque one draws once
+        const uint32_t seed0 = seed;
+        const float    lim   = kind == 0 ? PT_INFINITY : absorb[r].w;
+        float          tPrev = 0.0f;
+        uint32_t       wPrev = 0xffffffffu;
+        RayHit         h;
+        bool           dummy, found = false;
+        for(;;)
+        {
+          if(two) traverse<TM_RAW_ALL, true>(S, o, d, lim, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt); else traverse<TM_RAW_ALL, false>(S, o, d, lim, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
+          if(h.slot == BVH_NONE)
+            break;
+          if((h.w >> 29) & TRI_OPAQUE)
+          {
+            found = true;
+            break;
+          }
+          ++draws;
+          if(alpha_test(S, h.slot, h.u, h.v, seed))
+          {
+            found = true;
+            break;
+          }
+          tPrev = h.t;
+          wPrev = h.w & TRI_INDEX_MASK;
+        }
+        if(kind == 0)
+        {
+          outW[r]       = found ? (h.w & TRI_INDEX_MASK) : BVH_NONE;
+          outTUV[3 * r] = found ? h.t : PT_INFINITY; outTUV[3 * r + 1] = found ? h.u : 0.f; outTUV[3 * r + 2] = found ? h.v : 0.f;
+          outSeed[r]    = seed;
+        }
+        else
+        {
+          outW[r]       = found ? 1u : 0u;
+          outTUV[3 * r] = outTUV[3 * r + 1] = outTUV[3 * r + 2] = 0.f;
+          outSeed[r]    = variant == PT_VARIANT_RTX ? seed0 : seed;
+        }
+      }
+      outDraws[r] = draws;
+    }
 #pragma omp critical
     total.stackOverflow += cnt.stackOverflow;
   }

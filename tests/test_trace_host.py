@@ -255,3 +255,91 @@ def test_degenerate_inputs():
     for mode in (0, 1, 2):
         assert (tr.candidates(mode, org, dirs)[0] == NONE).all()
     tr.close()
+
+
+# ---- stochastic alpha: the product's two-pass settle functions against the contract's key-ordered loop -------------------------------------
+class TracedScene(Traced):
+    """a full scene description (materials, textures): instance flags, alpha view, opacity maps and texel pool come from the product's own
+    host code (pt_capi.hip build_scene_records)"""
+
+    def __init__(self, scene: Scene):
+        self.L = harness()
+        self.L.th_create_scene.restype = C.c_void_p
+        self.L.th_create_scene.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self.L.th_settle.restype = C.c_uint32
+        self.L.th_settle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32] + [C.c_void_p] * 8
+        if scene.vertices is None:
+            scene.finalize(capi.pack_vertices)
+        d, keep = scene.desc()
+        err = C.create_string_buffer(256)
+        self.h = self.L.th_create_scene(C.byref(d), err, 256)
+        assert self.h, err.value
+        self.keep = keep
+        self.n = self.L.th_num_tris(self.h)
+
+    def settle(self, kind, two, exact, org, dirs, seeds, tmax=None, variant=0):
+        org, dirs = np.ascontiguousarray(org, np.float32), np.ascontiguousarray(dirs, np.float32)
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        n = len(org)
+        tm = None if tmax is None else np.ascontiguousarray(tmax, np.float32)
+        w, tuv, sd, dr = np.zeros(n, np.uint32), np.zeros((n, 3), np.float32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        over = self.L.th_settle(self.h, kind, two, exact, variant, n, org.ctypes.data, dirs.ctypes.data, tm.ctypes.data if tm is not None else None, seeds.ctypes.data,
+                                w.ctypes.data, tuv.ctypes.data, sd.ctypes.data, dr.ctypes.data)
+        assert over == 0
+        return w, tuv, sd, dr
+
+
+def scene_rays(tr, rng, n, eye_center, eye_spread):
+    k = n // 2
+    targets = rng.integers(0, tr.n, n)
+    pts = []
+    for w in targets:
+        tri, _ = tr.world_tri(w)
+        b = rng.dirichlet((1, 1, 1))
+        pts.append(tri[0:3] + b[1] * tri[3:6] + b[2] * tri[6:9])
+    pts = np.array(pts)
+    eye = np.asarray(eye_center) + rng.normal(0, 1, (k, 3)) * eye_spread
+    a, b = pts[:n - k], pts[rng.permutation(n)[:n - k]]
+    org = np.concatenate([eye, a + (b - a) * 1e-5])
+    dirs = np.concatenate([pts[:k] - eye, b - a])
+    dirs = dirs / np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-30)
+    return org.astype(np.float32), dirs.astype(np.float32)
+
+
+def _alpha_scenes():
+    yield "fuzz0", synth.fuzz_scene(0), (0, 0, 6), 3.0
+    yield "fuzz1", synth.fuzz_scene(1), (0, 0, 6), 3.0
+    yield "fuzz5", synth.fuzz_scene(5), (0, 0, 6), 3.0
+    yield "sponza-like", synth.sponza_like(target_tris=12000, tex_size=64), (0, 3, 0), 4.0   # foliage cards: MASK with power-of-two textures -> opacity maps
+
+
+@pytest.mark.parametrize("name,scene,eye,spread", list(_alpha_scenes()), ids=lambda x: x if isinstance(x, str) else None)
+def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
+    """trace contract T5 / T6 with stochastic alpha: the product's settle functions (pass A nearest certain hit, pass B count of the zero-
+    opacity candidates in front of it, draws consumed in bulk, exact fallback; opacity maps answering most evaluations) must return the hit,
+    the barycentrics AND the RNG state of the definition -- candidates strictly in key order, one draw per non-opaque candidate -- on the flat
+    and on the two-level structure, for closest-hit rays, bounded shadow rays and the RT-pipeline flavour of the shadow ray."""
+    tr = TracedScene(scene)
+    rng = np.random.default_rng(4242)
+    n = 6000
+    org, dirs = scene_rays(tr, rng, n, eye, spread)
+    seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    ref = tr.settle(0, 0, 1, org, dirs, seeds)                      # the definition, flat structure
+    assert (ref[0] != NONE).mean() > 0.5 and ref[3].sum() > n // 20, "the scene must exercise hits and alpha draws"
+    for two, exact in ((0, 0), (1, 0), (1, 1)):
+        got = tr.settle(0, two, exact, org, dirs, seeds)
+        same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
+        # (a ray may differ only through an ill-conditioned candidate, see test_walks_report_brute_force_candidates: none is expected at this size)
+        assert same.all(), f"{name}: closest-hit, two={two} exact={exact}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
+        if not exact:
+            assert np.array_equal(got[3], ref[3])                   # the alpha-test counter (pt_Stats.alphaTests) counts the same draws
+    tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
+    for variant in (0, 1):
+        ref = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
+        for two, exact in ((0, 0), (1, 0), (1, 1)):
+            got = tr.settle(1, two, exact, org, dirs, seeds, tmax, variant)
+            same = (got[0] == ref[0]) & (got[2] == ref[2])
+            assert same.all(), f"{name}: shadow variant {variant}, two={two} exact={exact}: {np.count_nonzero(~same)} rays differ"
+        if variant == 1:
+            assert np.array_equal(ref[2], seeds)                    # RT pipeline: the any-hit shader draws from a copy of the seed
+    tr.close()
