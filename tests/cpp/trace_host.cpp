@@ -123,10 +123,17 @@ extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long*
 
 namespace {
 
+struct Box {
+  float lo[3], hi[3];
+  bool  alpha;
+};
 struct Bvh {
   std::vector<TriRec>   tris;   // leaf order
   std::vector<WideNode> wide;   // node 0 = root
   float                 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  // the binary tree the wide nodes were collapsed from (th_step_model re-collapses it at other widths)
+  std::vector<uint32_t> cl, cr;
+  std::vector<Box>      leafBox, innerBox;
 };
 
 // pt_accel.hip tri_box: padded box of a record (p0, p0 + e1, p0 + e2)
@@ -145,10 +152,6 @@ void tri_box_h(const TriRec& r, float lo[3], float hi[3])
   }
 }
 
-struct Box {
-  float lo[3], hi[3];
-  bool  alpha;
-};
 float half_area_h(const Box& b)
 {
   const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -277,6 +280,7 @@ Bvh build_bvh(const std::vector<TriRec>& in)
     out.lo[a] = root.lo[a];
     out.hi[a] = root.hi[a];
   }
+  out.cl = cl; out.cr = cr; out.leafBox = leaf; out.innerBox = inner;
   return out;
 }
 
@@ -730,6 +734,156 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
     total.stackOverflow += cnt.stackOverflow;
   }
   return total.stackOverflow;
+}
+
+// DESIGN EXPERIMENT (tools/steps_experiment.py; nothing of the product runs here except tri_test): how many DEPENDENT memory round trips does a
+// closest-hit walk of the flat structure need per ray -- the quantity that bounds the trace stages -- for node width 4
+// (the product's layout) or 8, and with the triangles of a node's leaf children fetched together in one round trip instead of one per
+// triangle?  The binary tree of the flat structure is collapsed again at the requested width (same greedy rule as k_collapse) and walked
+// nearest-first with a plain slab test; a step = one node fetch, or one (batch of) triangle fetch(es).
+// out per ray: steps, nodes visited, triangles tested.
+void th_step_model(void* p, int width, int batchLeaves, uint32_t nrays, const float* org, const float* dir, const float* tmaxIn, uint32_t* out3)
+{
+  Scene*     s = static_cast<Scene*>(p);
+  const Bvh& b = s->flat;
+  const uint32_t n = uint32_t(b.tris.size());
+  struct WN { int cnt; Box box[8]; uint32_t ref[8]; };
+  std::vector<WN> nodes;
+  if(n >= 2)
+  {
+    struct Item { uint32_t b2, wide; };
+    std::vector<Item> queue{{0u, 0u}};
+    nodes.resize(1);
+    for(size_t qi = 0; qi < queue.size(); ++qi)
+    {
+      const Item it = queue[qi];
+      uint32_t   id[8];
+      int        cnt = 0;
+      id[cnt++] = b.cl[it.b2];
+      id[cnt++] = b.cr[it.b2];
+      while(cnt < width)
+      {
+        int   best = -1;
+        float bestA = -1.f;
+        for(int k = 0; k < cnt; ++k)
+          if(!(id[k] & BVH_LEAF) && half_area_h(b.innerBox[id[k]]) > bestA)
+          {
+            bestA = half_area_h(b.innerBox[id[k]]);
+            best  = k;
+          }
+        if(best < 0)
+          break;
+        const uint32_t node = id[best];
+        id[best]            = id[cnt - 1];
+        --cnt;
+        id[cnt++] = b.cl[node];
+        id[cnt++] = b.cr[node];
+      }
+      WN w;
+      w.cnt = cnt;
+      for(int k = 0; k < cnt; ++k)
+      {
+        if(id[k] & BVH_LEAF)
+        {
+          w.box[k] = b.leafBox[id[k] & ~BVH_LEAF];
+          w.ref[k] = id[k];
+        }
+        else
+        {
+          w.box[k] = b.innerBox[id[k]];
+          w.ref[k] = uint32_t(nodes.size());
+          nodes.emplace_back();
+          queue.push_back({id[k], w.ref[k]});
+        }
+      }
+      nodes[it.wide] = w;
+    }
+  }
+#pragma omp parallel for schedule(dynamic, 64)
+  for(long long r = 0; r < (long long)nrays; ++r)
+  {
+    const f3 o = f3{org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d = f3{dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
+    const float id3[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, o3[3] = {o.x, o.y, o.z};
+    float       best = tmaxIn ? tmaxIn[r] : 3.0e38f;
+    uint32_t    steps = 0, nn = 0, nt = 0;
+    auto        test_tri = [&](uint32_t slot) {
+      const TriRec& tr = b.tris[slot];
+      float         t, u, v;
+      ++nt;
+      if(tri_test(tr, __float_as_uint(tr.p0w.w) >> 29, o, d, t, u, v) && t > 0.f && t < best)
+        best = t;
+    };
+    if(n == 1)
+    {
+      test_tri(0);
+      steps = 1;
+    }
+    else if(n >= 2)
+    {
+      uint32_t stack[256];
+      int      sp = 0;
+      uint32_t cur = 0;
+      for(;;)
+      {
+        if(cur & BVH_LEAF)
+        {
+          ++steps;
+          test_tri(cur & ~BVH_LEAF);
+        }
+        else
+        {
+          ++steps;
+          ++nn;
+          const WN& w = nodes[cur];
+          float     tn[8];
+          uint32_t  rf[8];
+          int       nh = 0;
+          bool      anyLeaf = false;
+          for(int k = 0; k < w.cnt; ++k)
+          {
+            float t0 = 0.f, t1 = best;
+            for(int a = 0; a < 3; ++a)
+            {
+              const float ta = (w.box[k].lo[a] - o3[a]) * id3[a], tb = (w.box[k].hi[a] - o3[a]) * id3[a];
+              t0 = std::fmax(t0, std::fmin(ta, tb));
+              t1 = std::fmin(t1, std::fmax(ta, tb));
+            }
+            if(t0 * 0.9999996f <= t1 * 1.0000004f)
+            {
+              if(batchLeaves && (w.ref[k] & BVH_LEAF))
+              {
+                anyLeaf = true;
+                test_tri(w.ref[k] & ~BVH_LEAF);  // fetched together with the node's other hit leaves: one round trip (counted below)
+              }
+              else
+              {
+                tn[nh] = t0;
+                rf[nh] = w.ref[k];
+                ++nh;
+              }
+            }
+          }
+          if(anyLeaf)
+            ++steps;
+          // far-to-near onto the stack
+          for(int i = 0; i < nh; ++i)
+            for(int j = i + 1; j < nh; ++j)
+              if(tn[j] > tn[i])
+              {
+                std::swap(tn[i], tn[j]);
+                std::swap(rf[i], rf[j]);
+              }
+          for(int i = 0; i < nh && sp < 256; ++i)
+            if(!batchLeaves || tn[i] <= best)
+              stack[sp++] = rf[i];
+        }
+        if(sp == 0)
+          break;
+        cur = stack[--sp];
+      }
+    }
+    out3[3 * r] = steps; out3[3 * r + 1] = nn; out3[3 * r + 2] = nt;
+  }
 }
 
 }  // extern "C"
