@@ -113,13 +113,14 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 }
 #define PT_TRI_TEST_OVERRIDE th_tri_test_robust
 #endif
-#include "pt_settle.h"  // pt_trace.h + the per-ray settle functions k_tail runs (tail_closest, tail_shadow)
+#include "pt_shade.h"  // pt_settle.h (pt_trace.h + the per-ray settle functions k_tail runs) + the shading steps of a path (generate_ray, shade_path, ...)
 #include "../../include/pt_types.h"
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
 extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
 extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut, uint32_t* alphaMapsOut, uint32_t* texelsOut,
-                                      char* err, size_t errLen);
+                                      void* texRecsOut, char* err, size_t errLen);
+extern "C" int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel* out, float* out_integral, float* out_average);
 
 namespace {
 
@@ -307,6 +308,11 @@ struct Scene {
   AlphaMat                 alphaMat;
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
+  std::vector<TexRec>      texRecs;
+  std::vector<pt_GltfShadeMaterial> materials;
+  std::vector<pt_Light>    lights;
+  std::vector<float4>      env;
+  std::vector<pt_EnvAccel> envAccel;
   DeviceScene              dsFlat, dsTwo;
   double                   maxPadRatio = 0;
 };
@@ -455,6 +461,8 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   std::memset(&d, 0, sizeof(d));
   d.vertices = s->vertices.data(); d.indices = s->indices.data(); d.instances = s->inst.data();
   d.alphaMats = s->alphaMats.data(); d.alphaMaps = s->alphaMaps.data(); d.texels = s->texels.data();
+  d.materials = s->materials.empty() ? nullptr : s->materials.data(); d.lights = s->lights.empty() ? nullptr : s->lights.data();
+  d.texRecs = s->texRecs.empty() ? nullptr : s->texRecs.data();
   d.numTris = triTotal; d.numInstances = numInst;
   s->dsFlat           = d;
   s->dsFlat.wide      = s->flat.wide.data();
@@ -512,7 +520,7 @@ void* th_create(const float* vertices8, uint32_t numVerts, const uint32_t* indic
 void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
 {
   unsigned long long counts[5] = {0, 0, 0, 0, 0};
-  if(pt_debug_scene_records(d, counts, nullptr, nullptr, nullptr, nullptr, nullptr, err, errLen) != 0)
+  if(pt_debug_scene_records(d, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, err, errLen) != 0)
     return nullptr;
   Scene* s = new Scene();
   s->vertices.resize(size_t(d->numVertices) * 2);
@@ -522,8 +530,13 @@ void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
   s->alphaMats.resize(counts[1]);
   s->alphaMaps.resize(counts[2]);
   s->texels.resize(counts[3]);
+  s->texRecs.resize(d->numTextures ? d->numTextures : 1);
+  s->materials.assign(d->materials, d->materials + d->numMaterials);
+  s->lights.assign(d->lights, d->lights + d->numLights);
+  if(s->lights.empty())
+    s->lights.emplace_back();
   std::vector<float> pad(2 * counts[0] + 2);
-  if(pt_debug_scene_records(d, counts, s->inst.data(), pad.data(), s->alphaMats.data(), s->alphaMaps.data(), s->texels.data(), err, errLen) != 0)
+  if(pt_debug_scene_records(d, counts, s->inst.data(), pad.data(), s->alphaMats.data(), s->alphaMaps.data(), s->texels.data(), s->texRecs.data(), err, errLen) != 0)
   {
     delete s;
     return nullptr;
@@ -884,6 +897,117 @@ void th_step_model(void* p, int width, int batchLeaves, uint32_t nrays, const fl
     }
     out3[3 * r] = steps; out3[3 * r + 1] = nn; out3[3 * r + 2] = nt;
   }
+}
+
+// ---- whole frames with the product's shading source on the host ---------------------------------------------------------------------------
+// What k_generate / k_tail / k_accumulate do per lane (pt_shade.h, pt_settle.h), run as a loop over the path slots of one frame at a time:
+// camera ray, then per bounce closest hit -> shade_path -> shadow ray -> NEE add + Russian roulette, then the running mean.  Same tile / slot
+// layout as the device (32 x 32 pixel tiles of 16 8x8 blocks).  The caller compares the image with the oracle bit for bit.
+int th_set_env(void* p, const float* rgba, int w, int h, float* integral)
+{
+  Scene* s = static_cast<Scene*>(p);
+  s->env.resize(size_t(w) * h);
+  std::memcpy(s->env.data(), rgba, sizeof(float) * 4 * size_t(w) * h);
+  s->envAccel.resize(size_t(w) * h);
+  float avg = 0.f;
+  const int rc = pt_build_env_accel(rgba, w, h, s->envAccel.data(), integral, &avg);
+  for(DeviceScene* d : {&s->dsFlat, &s->dsTwo})
+  {
+    d->env = s->env.data(); d->envAccel = s->envAccel.data(); d->envW = w; d->envH = h;
+  }
+  return rc;
+}
+void th_set_camera(void* p, const pt_SceneCamera* cam, const pt_SunAndSky* ss)
+{
+  Scene* s = static_cast<Scene*>(p);
+  for(DeviceScene* d : {&s->dsFlat, &s->dsTwo})
+  {
+    d->camera = *cam;
+    d->sunsky = *ss;
+  }
+}
+// frames 0 .. frames-1 of `st` (st->frame is ignored) accumulated like the device does; out: row-major width x height x 4
+uint32_t th_render(void* p, int two, const pt_RtxState* stIn, int variant, int frames, float* out)
+{
+  Scene*             s = static_cast<Scene*>(p);
+  const DeviceScene& S = two ? s->dsTwo : s->dsFlat;
+  const int          W = stIn->size[0], H = stIn->size[1];
+  FrameParams        fp;
+  std::memset(&fp, 0, sizeof(fp));
+  fp.st = *stIn; fp.width = W; fp.height = H; fp.tilesX = (W + PT_TILE - 1) / PT_TILE; fp.tilesY = (H + PT_TILE - 1) / PT_TILE;
+  fp.rank = 0; fp.nranks = 1; fp.numLocalTiles = uint32_t(fp.tilesX) * fp.tilesY; fp.numSlots = fp.numLocalTiles * 1024u; fp.batch = 1; fp.variant = variant;
+  const uint32_t        n = fp.numSlots;
+  std::vector<float4>   st9[9];
+  for(auto& v : st9)
+    v.assign(n, make_float4(0, 0, 0, 0));
+  std::vector<float4>   frame(n, make_float4(0, 0, 0, 0));
+  std::vector<uint32_t> slotTile(fp.numLocalTiles);
+  for(uint32_t i = 0; i < fp.numLocalTiles; ++i)
+    slotTile[i] = i;
+  Counters total;
+  std::memset(&total, 0, sizeof(total));
+  RenderBuffers rb;
+  std::memset(&rb, 0, sizeof(rb));
+  rb.ps.rayO = st9[0].data(); rb.ps.rayD = st9[1].data(); rb.ps.thr = st9[2].data(); rb.ps.rad = st9[3].data(); rb.ps.absorb = st9[4].data();
+  rb.ps.neeDir = st9[5].data(); rb.ps.neeRad = st9[6].data(); rb.ps.hit = st9[7].data(); rb.ps.sum = st9[8].data();
+  rb.frame = frame.data(); rb.slotTile = slotTile.data();
+  for(int f = 0; f < frames; ++f)
+  {
+    fp.st.frame = f;
+    for(int smp = 0; smp < fp.st.maxSamples; ++smp)
+    {
+      fp.sample = smp;
+#pragma omp parallel
+      {
+        std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+        Counters              cnt;
+        std::memset(&cnt, 0, sizeof(cnt));
+        RenderBuffers lrb = rb;
+        lrb.counters      = &cnt;
+#pragma omp for schedule(dynamic, 256)
+        for(long long sl = 0; sl < (long long)n; ++sl)
+        {
+          const uint32_t slot = uint32_t(sl);
+          int            px, py;
+          if(!slot_pixel(fp, lrb.slotTile, slot, px, py))
+            continue;
+          generate_ray(S, lrb, fp, slot, 0u, px, py);
+          uint32_t nAlpha = 0;
+          for(int depth = 0; depth < fp.st.maxDepth; ++depth)
+          {
+            if(two) tail_closest<true>(S, lrb, slot, stack.data(), nAlpha); else tail_closest<false>(S, lrb, slot, stack.data(), nAlpha);
+            uint32_t  events = 0;
+            const int to     = shade_path<-1>(S, lrb, fp, slot, depth, events);
+            bool      survive = to == SHADE_TO_NEXT;
+            if(to == SHADE_TO_SHADOW)
+            {
+              uint32_t   seed;
+              const bool inShadow = two ? tail_shadow<true>(S, lrb, slot, stack.data(), variant, seed, nAlpha) : tail_shadow<false>(S, lrb, slot, stack.data(), variant, seed, nAlpha);
+              survive             = finish_bounce_core(lrb, slot, inShadow, seed) && depth != fp.st.maxDepth - 1;
+            }
+            if(!survive)
+              break;
+          }
+        }
+#pragma omp critical
+        total.stackOverflow += cnt.stackOverflow;
+      }
+#pragma omp parallel for schedule(static)
+      for(long long ps = 0; ps < (long long)n; ++ps)
+      {
+        int px, py;
+        if(slot_pixel(fp, rb.slotTile, uint32_t(ps), px, py))
+          accumulate_pixel(rb, fp, uint32_t(ps));
+      }
+    }
+  }
+  for(uint32_t slot = 0; slot < n; ++slot)
+  {  // k_untile
+    int px, py;
+    if(slot_pixel(fp, rb.slotTile, slot, px, py))
+      std::memcpy(out + (size_t(py) * W + px) * 4, &frame[slot], 16);
+  }
+  return total.stackOverflow;
 }
 
 }  // extern "C"

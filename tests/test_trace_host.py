@@ -343,3 +343,54 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
         if variant == 1:
             assert np.array_equal(ref[2], seeds)                    # RT pipeline: the any-hit shader draws from a copy of the seed
     tr.close()
+
+
+# ---- whole frames: the product's shading source on the host against the oracle ---------------------------------------------------------------
+def host_render(cfg, frames, two=0):
+    """cfg: tests.common.Config.  The frames k_generate / k_tail / k_accumulate would produce, computed by the same functions (pt_shade.h,
+    pt_settle.h, pt_trace.h, pt_bsdf.h, pt_surface.h, pt_sky.h) compiled for the host."""
+    tr = TracedScene(cfg.scene)
+    L = tr.L
+    L.th_set_env.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.th_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.th_render.restype = C.c_uint32
+    L.th_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    integral = C.c_float()
+    assert L.th_set_env(tr.h, cfg.env.ctypes.data, cfg.env.shape[1], cfg.env.shape[0], C.byref(integral)) == 0
+    L.th_set_camera(tr.h, C.byref(cfg.camera), C.byref(cfg.sunsky))
+    st = cfg.state(integral.value)
+    out = np.zeros((cfg.height, cfg.width, 4), np.float32)
+    assert L.th_render(tr.h, two, C.byref(st), cfg.variant, frames, out.ctypes.data) == 0
+    tr.close()
+    return out
+
+
+def _bits_equal(a, b):
+    an, bn = np.isnan(a), np.isnan(b)
+    return np.array_equal(an, bn) and np.array_equal(np.where(an, 0, a).view(np.uint32), np.where(bn, 0, b).view(np.uint32))
+
+
+@pytest.mark.parametrize("two", [0, 1])
+def test_host_build_of_the_shading_source_renders_the_oracles_frames(two):
+    """End to end without a GPU: camera ray, traversal with stochastic alpha, shading state, materials and textures, environment NEE through the
+    alias table, both BSDFs, punctual lights, sun & sky, Russian roulette, firefly clamp and the running mean -- the functions the HIP kernels
+    are made of, compiled by g++ -- give the CPU oracle's accumulation images BIT FOR BIT (the oracle is in turn bit-identical to the
+    reference's own shaders, tests/test_oracle_vs_ref.py).  On the GPU the same comparison is tests/test_gpu_parity.py."""
+    from tests.common import Config, render_oracle
+    env = synth.procedural_sky(128, 64)
+    # every material feature + punctual lights, both BSDFs, several samples per frame
+    for pbr in (0, 1):
+        cfg = Config(synth.feature_box(tex_size=32, lights=True), env, 64, 48, depth=6, pbr=pbr, max_samples=2)
+        assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), ("feature box", pbr)
+    # first-hit AOVs
+    for mode in (hd.eNormal, hd.eTexcoord, hd.eBaseColor, hd.eAlpha):
+        cfg = Config(synth.feature_box(tex_size=32), env, 64, 48, debug=mode)
+        assert _bits_equal(host_render(cfg, 1, two), render_oracle(cfg, 1)), mode
+    # adversarial geometry with MASK / BLEND soups, the RT-pipeline flavour, sun & sky instead of the environment map
+    ss = hd.default_sun_and_sky(); ss.in_use = 1
+    cfg = Config(synth.fuzz_scene(2), env, 96, 64, depth=5, variant=capi.PT_VARIANT_RTX, sunsky=ss)
+    assert _bits_equal(host_render(cfg, 3, two), render_oracle(cfg, 3)), "fuzz scene, RTX variant, sun & sky"
+    # an image that is not a multiple of the tile size, depth of field
+    sc = synth.fuzz_scene(4); sc.camera.aperture = 0.05
+    cfg = Config(sc, env, 50, 37, depth=4, hdr_multiplier=2.0)
+    assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), "odd size, depth of field"

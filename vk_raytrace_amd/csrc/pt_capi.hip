@@ -1798,9 +1798,10 @@ int pt_reset_stats(pt_context* c)
 // Test hook (not part of the ABI; tests/cpp/trace_host.cpp): the host-side records pt_set_scene derives from a scene description, copied into
 // caller arrays (no GPU involved).  Call with null outputs to get the counts: counts[0] instances, [1] materials, [2] opacity-map words,
 // [3] texels of the RGBA8 pool, [4] world triangles.  instOut: InstanceRec[counts[0]] (128 B each); padOut: 2 floats per instance
-// (TlasLeaf::padC0 / padC1 of the two-level walk); alphaMatsOut: AlphaMat[counts[1]] (64 B each); texelsOut: the pool in upload order.
+// (TlasLeaf::padC0 / padC1 of the two-level walk); alphaMatsOut: AlphaMat[counts[1]] (64 B each); texelsOut: the pool in upload order;
+// texRecsOut: TexRec[max(1, numTextures)] (32 B each).
 extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut,
-                                                                            uint32_t* alphaMapsOut, uint32_t* texelsOut, char* err, size_t errLen)
+                                                                            uint32_t* alphaMapsOut, uint32_t* texelsOut, void* texRecsOut, char* err, size_t errLen)
 {
   SceneRecords R;
   std::string  msg;
@@ -1824,6 +1825,8 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(con
     std::memcpy(alphaMatsOut, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size());
   if(alphaMapsOut)
     std::memcpy(alphaMapsOut, R.alphaMaps.data(), 4 * R.alphaMaps.size());
+  if(texRecsOut)
+    std::memcpy(texRecsOut, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size());
   if(texelsOut)
   {
     if(d->numTextures == 0)
