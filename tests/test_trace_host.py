@@ -394,3 +394,16 @@ def test_host_build_of_the_shading_source_renders_the_oracles_frames(two):
     sc = synth.fuzz_scene(4); sc.camera.aperture = 0.05
     cfg = Config(sc, env, 50, 37, depth=4, hdr_multiplier=2.0)
     assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), "odd size, depth of field"
+
+
+def test_host_build_renders_the_c3_stand_in_like_the_oracle():
+    """the bench scene (269 k triangles, alpha-tested foliage cards with opacity maps, HDR environment, Disney BSDF, depth 8) at a reduced
+    resolution, four frames: host build of the product's source == oracle, bit for bit, on both acceleration structures"""
+    from tests.common import Config, render_oracle
+    from vk_raytrace_amd import workloads
+    wl = workloads.c3_sponza(160, 90, 4, tex_size=64, env_w=256)
+    cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
+    ref = render_oracle(cfg, 4)
+    assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+    for two in (0, 1):
+        assert _bits_equal(host_render(cfg, 4, two), ref), two
