@@ -26,6 +26,11 @@ static inline int          __float_as_int(float f) { int i; std::memcpy(&i, &f, 
 static inline float        __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 template <class T>
 static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
+// a one-lane "wavefront" for the wave-level helpers of pt_machine.h (the ray supply is not used here; the per-lane state machine is)
+static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
+static inline int                __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline unsigned int       __builtin_amdgcn_readfirstlane(unsigned int x) { return x; }
+static const struct { unsigned x, y, z; } threadIdx = {0, 0, 0};
 
 #ifdef TH_ROBUST_T2
 // EXPERIMENT (tools/t2_robust_experiment.py; not the contract): T2 with a forward error bound.  The fp32 evaluation is kept whenever its verdict
@@ -114,6 +119,7 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 #define PT_TRI_TEST_OVERRIDE th_tri_test_robust
 #endif
 #include "pt_shade.h"  // pt_settle.h (pt_trace.h + the per-ray settle functions k_tail runs) + the shading steps of a path (generate_ray, shade_path, ...)
+#include "pt_machine.h"  // the resumable per-lane traversal of the persistent kernels (k_closest_p / k_shadow_p)
 #include "../../include/pt_types.h"
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
@@ -649,7 +655,9 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
 // The product's per-ray settle functions (pt_settle.h: what k_tail runs per lane) against the contract's exact loop, ray by ray.
 //   kind 0: closest-hit ray (T5), kind 1: shadow ray (T6, bounded by tmax[r]);  two: 0 flat structure, 1 two-level structure;
 //   exact 0: tail_closest / tail_shadow (pass A, pass B, consume_rejected_draws, fallback), exact 1: the key-ordered loop with one
-//   alpha_test per non-opaque candidate (k_closest_x / k_shadow_x = the definition).
+//   alpha_test per non-opaque candidate (k_closest_x / k_shadow_x = the definition), exact 2: the TRACE MACHINE of the persistent kernels
+//   (pt_machine.h lane_begin / lane_inner / lane_leaf / lane_pop / lane_begin_count driven like k_closest_p / k_shadow_p drive one lane; the
+//   few lines of their service round -- pass A -> pass B transition, bulk draws, hand-over to the exact loop -- are restated here).
 // out per ray: w (world triangle index of the hit, 0xffffffff none; for shadow rays 1 / 0 = in shadow or not), t, u, v, seed afterwards,
 // number of alpha draws counted.  Returns the number of traversal-stack overflows.
 uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t nrays, const float* org, const float* dir, const float* tmax, const uint32_t* seeds, uint32_t* outW,
@@ -681,7 +689,65 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
     {
       const f3    o = xyz(rayO[r]), d = xyz(rayD[r]);
       uint32_t    seed = seeds[r], draws = 0;
-      if(!exact)
+      bool machineFallback = false;
+      if(exact == 2)
+      {
+        TraceLane             L;
+        std::vector<uint32_t> spill(STACK_SPILL);
+        lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
+        for(;;)
+        {
+          while(!L.done)
+          {
+            if(!(L.cur & BVH_LEAF))
+            {
+              if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt); else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
+            }
+            if(!L.done && (L.cur & BVH_LEAF))
+            {
+              if(two) lane_leaf<false, true>(S, L, stack.data(), spill.data()); else lane_leaf<false, false>(S, L, stack.data(), spill.data());
+            }
+          }
+          // service round of k_closest_p / k_shadow_p for this lane
+          bool fallback = (L.flags & TF_SAW_FRAC) != 0;
+          if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
+          {
+            if(two) lane_begin_count<true>(L); else lane_begin_count<false>(L);
+            continue;
+          }
+          if(!fallback)
+          {
+            uint32_t nDraw = L.cnt;
+            if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
+              ++nDraw;
+            uint32_t s2 = seed;
+            if(consume_rejected_draws(s2, nDraw))
+            {
+              draws = nDraw;
+              if(kind == 0)
+              {
+                outW[r]       = L.bslot == BVH_NONE ? BVH_NONE : (L.bw & TRI_INDEX_MASK);
+                outTUV[3 * r] = L.bslot == BVH_NONE ? PT_INFINITY : L.bt; outTUV[3 * r + 1] = L.bslot == BVH_NONE ? 0.f : L.bu; outTUV[3 * r + 2] = L.bslot == BVH_NONE ? 0.f : L.bv;
+                outSeed[r]    = nDraw ? s2 : seed;
+              }
+              else
+              {
+                outW[r]       = L.bslot != BVH_NONE ? 1u : 0u;
+                outTUV[3 * r] = outTUV[3 * r + 1] = outTUV[3 * r + 2] = 0.f;
+                outSeed[r]    = variant == PT_VARIANT_RTX ? seed : s2;
+              }
+            }
+            else
+              fallback = true;
+          }
+          machineFallback = fallback;  // queueX / queueX2: the exact kernels take over (below)
+          break;
+        }
+      }
+      if(exact == 2 && !machineFallback)
+      {
+      }
+      else if(!exact)
       {
         if(kind == 0)
         {

@@ -316,7 +316,8 @@ def _alpha_scenes():
 @pytest.mark.parametrize("name,scene,eye,spread", list(_alpha_scenes()), ids=lambda x: x if isinstance(x, str) else None)
 def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
     """trace contract T5 / T6 with stochastic alpha: the product's settle functions (pass A nearest certain hit, pass B count of the zero-
-    opacity candidates in front of it, draws consumed in bulk, exact fallback; opacity maps answering most evaluations) must return the hit,
+    opacity candidates in front of it, draws consumed in bulk, exact fallback; opacity maps answering most evaluations) -- in the lock-step
+    form k_tail and the k_*_s kernels use (traverse<>) and in the resumable per-lane form of the persistent kernels (pt_machine.h) -- must return the hit,
     the barycentrics AND the RNG state of the definition -- candidates strictly in key order, one draw per non-opaque candidate -- on the flat
     and on the two-level structure, for closest-hit rays, bounded shadow rays and the RT-pipeline flavour of the shadow ray."""
     tr = TracedScene(scene)
@@ -326,17 +327,17 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
     seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
     ref = tr.settle(0, 0, 1, org, dirs, seeds)                      # the definition, flat structure
     assert (ref[0] != NONE).mean() > 0.5 and ref[3].sum() > n // 20, "the scene must exercise hits and alpha draws"
-    for two, exact in ((0, 0), (1, 0), (1, 1)):
+    for two, exact in ((0, 0), (1, 0), (1, 1), (0, 2), (1, 2)):   # exact = 2: the trace machine of the persistent kernels (pt_machine.h)
         got = tr.settle(0, two, exact, org, dirs, seeds)
         same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
         # (a ray may differ only through an ill-conditioned candidate, see test_walks_report_brute_force_candidates: none is expected at this size)
         assert same.all(), f"{name}: closest-hit, two={two} exact={exact}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
-        if not exact:
+        if exact != 1:
             assert np.array_equal(got[3], ref[3])                   # the alpha-test counter (pt_Stats.alphaTests) counts the same draws
     tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
     for variant in (0, 1):
         ref = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
-        for two, exact in ((0, 0), (1, 0), (1, 1)):
+        for two, exact in ((0, 0), (1, 0), (1, 1), (0, 2), (1, 2)):
             got = tr.settle(1, two, exact, org, dirs, seeds, tmax, variant)
             same = (got[0] == ref[0]) & (got[2] == ref[2])
             assert same.all(), f"{name}: shadow variant {variant}, two={two} exact={exact}: {np.count_nonzero(~same)} rays differ"
