@@ -992,8 +992,12 @@ void th_set_camera(void* p, const pt_SceneCamera* cam, const pt_SunAndSky* ss)
     d->sunsky = *ss;
   }
 }
-// frames 0 .. frames-1 of `st` (st->frame is ignored) accumulated like the device does; out: row-major width x height x 4
-uint32_t th_render(void* p, int two, const pt_RtxState* stIn, int variant, int frames, float* out)
+// frames 0 .. frames-1 of `st` (st->frame is ignored) accumulated like the device does; out: row-major width x height x 4.
+// rank / nranks: the image-tile shard of pt_set_shard (tiles with (tx + ty) % nranks == rank, in increasing order: pt_resize); only the pixels
+// of the rank's own tiles are written.
+uint32_t th_render_shard(void* p, int two, const pt_RtxState* stIn, int variant, int frames, int rank, int nranks, float* out);
+uint32_t th_render(void* p, int two, const pt_RtxState* stIn, int variant, int frames, float* out) { return th_render_shard(p, two, stIn, variant, frames, 0, 1, out); }
+uint32_t th_render_shard(void* p, int two, const pt_RtxState* stIn, int variant, int frames, int rank, int nranks, float* out)
 {
   Scene*             s = static_cast<Scene*>(p);
   const DeviceScene& S = two ? s->dsTwo : s->dsFlat;
@@ -1001,15 +1005,19 @@ uint32_t th_render(void* p, int two, const pt_RtxState* stIn, int variant, int f
   FrameParams        fp;
   std::memset(&fp, 0, sizeof(fp));
   fp.st = *stIn; fp.width = W; fp.height = H; fp.tilesX = (W + PT_TILE - 1) / PT_TILE; fp.tilesY = (H + PT_TILE - 1) / PT_TILE;
-  fp.rank = 0; fp.nranks = 1; fp.numLocalTiles = uint32_t(fp.tilesX) * fp.tilesY; fp.numSlots = fp.numLocalTiles * 1024u; fp.batch = 1; fp.variant = variant;
+  std::vector<uint32_t> slotTile;
+  for(int ty = 0; ty < fp.tilesY; ++ty)
+    for(int tx = 0; tx < fp.tilesX; ++tx)
+      if((tx + ty) % nranks == rank)
+        slotTile.push_back(uint32_t(ty * fp.tilesX + tx));
+  fp.rank = rank; fp.nranks = nranks; fp.numLocalTiles = uint32_t(slotTile.size()); fp.numSlots = fp.numLocalTiles * 1024u; fp.batch = 1; fp.variant = variant;
+  if(slotTile.empty())
+    return 0;
   const uint32_t        n = fp.numSlots;
   std::vector<float4>   st9[9];
   for(auto& v : st9)
     v.assign(n, make_float4(0, 0, 0, 0));
   std::vector<float4>   frame(n, make_float4(0, 0, 0, 0));
-  std::vector<uint32_t> slotTile(fp.numLocalTiles);
-  for(uint32_t i = 0; i < fp.numLocalTiles; ++i)
-    slotTile[i] = i;
   Counters total;
   std::memset(&total, 0, sizeof(total));
   RenderBuffers rb;

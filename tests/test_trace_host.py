@@ -347,21 +347,23 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
 
 
 # ---- whole frames: the product's shading source on the host against the oracle ---------------------------------------------------------------
-def host_render(cfg, frames, two=0):
+def host_render(cfg, frames, two=0, shard=None):
     """cfg: tests.common.Config.  The frames k_generate / k_tail / k_accumulate would produce, computed by the same functions (pt_shade.h,
-    pt_settle.h, pt_trace.h, pt_bsdf.h, pt_surface.h, pt_sky.h) compiled for the host."""
+    pt_settle.h, pt_trace.h, pt_bsdf.h, pt_surface.h, pt_sky.h) compiled for the host.  shard = (rank, nranks): only that rank's image tiles
+    (pt_set_shard), the other pixels stay zero."""
     tr = TracedScene(cfg.scene)
     L = tr.L
     L.th_set_env.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.th_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    L.th_render.restype = C.c_uint32
-    L.th_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.th_render_shard.restype = C.c_uint32
+    L.th_render_shard.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     integral = C.c_float()
     assert L.th_set_env(tr.h, cfg.env.ctypes.data, cfg.env.shape[1], cfg.env.shape[0], C.byref(integral)) == 0
     L.th_set_camera(tr.h, C.byref(cfg.camera), C.byref(cfg.sunsky))
     st = cfg.state(integral.value)
     out = np.zeros((cfg.height, cfg.width, 4), np.float32)
-    assert L.th_render(tr.h, two, C.byref(st), cfg.variant, frames, out.ctypes.data) == 0
+    rank, nranks = shard if shard is not None else (0, 1)
+    assert L.th_render_shard(tr.h, two, C.byref(st), cfg.variant, frames, rank, nranks, out.ctypes.data) == 0
     tr.close()
     return out
 
