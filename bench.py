@@ -7,25 +7,33 @@ accumulated into the RGBA32F framebuffer exactly like shaders/pathtrace.comp:122
 and environment are resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps 256 --warmup 8
+  python bench.py --gpus N ...          (self-launching: spawns one process per GPU on 127.0.0.1 and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 With N > 1 the image tiles are sharded over the ranks (vk_raytrace_amd/shard.py); the ranks do not communicate while rendering and
 the single framebuffer gather -- libptmi's own RCCL path, pt_gather_shards / pt_gather_finish -- happens after the timed loop (its time
-is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).
+is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).  `ranks_seen` is
+ncclCommCount of that communicator.  Every rank binds its GPU through pt_create BEFORE any rendezvous, so a box with fewer than N
+devices fails with pt_create's device-count message.
 
 After the timed region (never part of `value`), rank 0 measures what the JSON line's evidence fields need, all in this run:
   calibration        pt_measure_peaks: the VALU-issue and HBM-streaming ceilings of this box
   interactive        render + tonemap per frame (batch = 1, SampleExample's display loop)
-  serialised         one batch on a second context with one frame slot: standalone stage durations (HIP events, nothing overlapped)
-  roofline           the stage with the largest standalone time, algorithmic bytes per launch / its average launch duration vs 8 TB/s;
-                     `traffic` = measured HBM bytes per launch from profiles/r02_traffic.json (this round's PMC passes, tools/pmc_r02.sh)
+  serialised         one batch on a second context with one frame slot and the SAME launch policy as the timed run (k_tail included):
+                     standalone stage durations (HIP events on the launching stream, nothing overlapped)
+  roofline           the stage with the largest standalone time: `achieved` / `frac` = SURVEY.md 8(d) ALGORITHMIC bytes per launch / its average
+                     launch duration vs 8 TB/s (may exceed 1: most algorithmic bytes are served by L2 / Infinity Cache); `traffic` /
+                     `traffic_frac` = HBM bytes per launch from this round's PMC passes (profiles/r03_traffic.json, tools/pmc_r03.sh);
+                     `l2_*` = L2 requests of the same stage (profiles/r03_cache.json) against the 34.5 TB/s L2 ceiling
   hbm_measured       measured HBM bytes per sample x this run's rate
-  issue_roofline     VALU wave-instructions per sample (profiles/r02_valu.json, same PMC run) x this run's rate / the calibrated ceiling
-  cpu_baseline       the CPU oracle (kind "port") on a bounded sample of the same workload, N = 1 only
+  issue_roofline     VALU wave-instructions per sample (profiles/r03_valu.json, same PMC run) x this run's rate / the calibrated ceiling
+  cpu_baseline       oracle/_ref (the reference's own pathtrace.comp compiled for the host, kind "reference") and the CPU oracle (the
+                     restatement, `port_value`) on a bounded sample of the same workload, N = 1 only
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,6 +44,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch / HIP initialise (see vk_raytrace_amd/capi.py)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per XCD)")
+L2_LINE = 128          # bytes per L2 request (TCC cache line)
 
 
 def parse():
@@ -55,19 +65,78 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the serialised profiling pass (roofline fields become null)")
     ap.add_argument("--no-interactive", action="store_true", help="skip the frame-by-frame (render + tonemap) measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="target duration of the CPU baseline sample (split between the compiled reference and the port)")
     return ap.parse_args()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: one child per GPU with the environment torch.distributed.run would give it.  Rank 0's
+    stdout (the JSON line) is this process's stdout.  A child that fails ends the job: the others are stopped (by PID) and its exit code is ours."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"bench.py: rank {r} of {n} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
+def latest_profile(kind):
+    """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's)."""
+    for rnd in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{kind}.json")
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)), f"profiles/{rnd}_{kind}.json"
+            except Exception:
+                pass
+    return None, None
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world  # under a launcher the launcher's world size is the truth
+
+    from vk_raytrace_amd import capi, workloads
+    from vk_raytrace_amd.renderer import HipRenderer
+    from vk_raytrace_amd import shard
+    from vk_raytrace_amd import host_device as hd
+
+    # bind the GPU first: "device ordinal R out of range: K HIP device(s) visible" comes from pt_create, before any rendezvous can hang
+    r = HipRenderer()
+    r.setup(local_rank)
 
     dist = None
     torch = None
@@ -78,14 +147,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_dist:
+        import datetime
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from vk_raytrace_amd import capi, workloads
-    from vk_raytrace_amd.renderer import HipRenderer
-    from vk_raytrace_amd import shard
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
 
     t_setup = time.time()
     if args.workload == "c3":
@@ -97,21 +163,17 @@ def main():
     wl.scene.finalize(capi.pack_vertices)
     W, H = wl.width, wl.height
 
-    r = HipRenderer()
-    r.setup(local_rank)
     if args.accel == "two":
         r.set_accel_mode(capi.PT_ACCEL_TWO_LEVEL)
+    shard_rank, shard_n = rank, world
     if args.emulate_shard:
-        er, en = (int(x) for x in args.emulate_shard.split("/"))
-        r.set_shard(er, en)
+        shard_rank, shard_n = (int(x) for x in args.emulate_shard.split("/"))
         args.no_cpu_baseline = True
-    else:
-        r.set_shard(rank, world)
+    r.set_shard(shard_rank, shard_n)
     r.set_scene(wl.scene)
     integral, _ = r.set_env(wl.env)
     cam = capi.camera_lookat(wl.scene.camera, W / H, nb_lights=len(wl.scene.lights))
     r.set_camera(cam)
-    from vk_raytrace_amd import host_device as hd
     r.set_sunsky(hd.default_sun_and_sky())
     r.create((W, H))
     st = hd.default_rtx_state()
@@ -154,8 +216,10 @@ def main():
     stats = r.stats()
 
     # the one collective of the path (untimed, reported): libptmi's own RCCL gather behind the C ABI (pt_gather_shards / pt_gather_finish)
+    ranks_seen = 1
     if world > 1 or force_dist:
         gatherer = shard.NativeGather(rank, world, local_rank, dist)
+        ranks_seen = gatherer.ranks_seen()
         r.synchronize()
         if dist is not None:
             dist.barrier()
@@ -168,12 +232,12 @@ def main():
         img = r.read_accum()
         gather_ms = (time.perf_counter() - t0) * 1e3
 
+    RAY_KEYS = ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")
     if dist is not None:
         # whole-job counters
-        keys = ["closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups"]
-        v = torch.tensor([float(stats[k]) for k in keys], dtype=torch.float64, device=f"cuda:{local_rank}")
+        v = torch.tensor([float(stats[k]) for k in RAY_KEYS], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        for i, k in enumerate(keys):
+        for i, k in enumerate(RAY_KEYS):
             stats[k] = int(v[i].item())
 
     if rank != 0:
@@ -181,8 +245,11 @@ def main():
             dist.destroy_process_group()
         return
 
-    samples = W * H * args.steps
+    # pixels actually rendered by this job (an emulated shard renders one rank's tiles only)
+    job_pixels = W * H if not args.emulate_shard else int(stats["samples"] // max(1, args.steps))
+    samples = job_pixels * args.steps
     value = samples / elapsed / 1e6
+    is_file = getattr(wl, "note", "") == "gltf"
     out = {
         "metric": "Msamples/s on Sponza 1920x1080; per-pixel L2 vs ref at equal spp",
         "value": value,
@@ -195,15 +262,17 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "gltf" if is_file else "synthetic",
         "config": {"workload": wl.name, "triangles": wl.scene.num_triangles, "materials": len(wl.scene.materials), "textures": len(wl.scene.textures),
-                   "width": W, "height": H, "spp": args.steps, "max_depth": wl.depth, "bsdf": "disney", "env": f"{wl.env.shape[1]}x{wl.env.shape[0]} procedural HDR",
-                   "parallelism": f"image tiles {hd.TILE}x{hd.TILE} over {world} GPU(s), scene replicated"},
+                   "width": W, "height": H, "spp": args.steps, "max_depth": wl.depth, "bsdf": "disney" if wl.pbr_mode == 0 else "gltf", "env": f"{wl.env.shape[1]}x{wl.env.shape[0]} procedural HDR",
+                   "parallelism": f"image tiles {hd.TILE}x{hd.TILE} over {world} GPU(s), scene replicated" + (f"; this run = shard {args.emulate_shard} on one GPU" if args.emulate_shard else "")},
+        "ranks_seen": ranks_seen,
         "setup_s": t_setup,
         "gather_ms": gather_ms,
         "bvh_build_ms": stats["msBuildAccel"],
         "accel": {"mode": args.accel, "bytes": stats["bytesAccel"], "blas": stats["numBlas"], "tlas_nodes": stats["numTlasNodes"], "nodes": stats["numBvhNodes"]},
-        "rays": {k: stats[k] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")},
+        "batch": {"frames": stats["batchFrames"], "in_flight": stats["framesInFlight"]},
+        "rays": {k: stats[k] for k in RAY_KEYS},
         "image_mean": float(np.mean(img[..., :3])) if img is not None else None,
     }
 
@@ -216,7 +285,10 @@ def main():
             r.update_instances(nodes)
         out["accel"]["update_instances_ms"] = (time.perf_counter() - t0) * 1e3 / args.refit
 
-    # ---- CPU baseline (oracle == literal restatement of pathtrace.comp, kind "port") + algorithmic bytes ----
+    # ---- CPU baseline + algorithmic bytes ---------------------------------------------------------------------------------------------
+    # kind "reference": oracle/_ref/libref.so = shaders/pathtrace.comp:87-134 with everything it includes, compiled for the host by the committed
+    # recipe (oracle/ref_glue), dispatched over a bounded pixel sample on the host cores; what the Vulkan driver would supply (ray queries,
+    # texture filtering) is bound to the oracle's trace contract.  `port_value`: the oracle's own restatement on the same sample.
     alg = None
     if world == 1 and not args.no_cpu_baseline:
         from tests import orc
@@ -232,26 +304,45 @@ def main():
         ys = (blocks // bx)[:, None, None] * 8 + np.arange(8)[None, :, None]
         ok = (xs < W) & (ys < H)
         ids = (ys * W + xs)[np.broadcast_to(ok, (len(blocks), 8, 8))].astype(np.uint32)
-        acc = np.zeros((H, W, 4), np.float32)
         ost = hd.default_rtx_state()
         ost.size[0], ost.size[1] = W, H
         ost.maxDepth, ost.pbrMode, ost.maxSamples = wl.depth, wl.pbr_mode, 1
         ost.fireflyClampThreshold = 4.0 * integral
-        t0 = time.perf_counter()
-        frames = 0
-        while frames < 2 or (time.perf_counter() - t0 < args.cpu_seconds and frames < args.steps):
-            ost.frame = frames
-            o.render_frame(ost, acc, ids)
-            frames += 1
-        cpu_t = time.perf_counter() - t0
-        os_ = o.stats()
         cores = os.cpu_count()
         try:
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
-        out["cpu_baseline"] = {"value": len(ids) * frames / cpu_t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "sample": f"CPU oracle (restatement of pathtrace.comp, OpenMP), every 16th 8x8 pixel block of the same {W}x{H} workload ({len(ids)} pixels), frames 0..{frames - 1}, {cpu_t:.1f} s"}
+
+        def timed(render_frames, budget_s):
+            """frames of the sample per call inside ONE thread team (no fork / join per frame); the first call (lazy BVH build, page faults) is not timed"""
+            acc = np.zeros((H, W, 4), np.float32)
+            render_frames(ost, 0, 1, acc, ids)
+            per_call, done, t0 = 4, 1, time.perf_counter()
+            while done < 1 + per_call or (time.perf_counter() - t0 < budget_s and done < 1 + 64 * per_call):
+                render_frames(ost, done, per_call, acc, ids)
+                done += per_call
+            dt = time.perf_counter() - t0
+            return len(ids) * (done - 1) / dt / 1e6, done - 1, dt
+
+        port_v, port_f, port_t = timed(o.render_frames, args.cpu_seconds / 2)
+        os_ = o.stats()
+        base = {"value": port_v, "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": f"CPU oracle (restatement of pathtrace.comp, OpenMP, one thread team), every 16th 8x8 pixel block of the same {W}x{H} workload ({len(ids)} pixels), {port_f} frames, {port_t:.1f} s"}
+        try:
+            from tests import ref
+            if os.path.exists(ref.LIB_PATH):
+                rr = ref.Reference(wl.scene, wl.env, oracle=o)
+                rr.set_camera(cam)
+                rr.set_sunsky(hd.default_sun_and_sky())
+                ref_v, ref_f, ref_t = timed(rr.render_frames, args.cpu_seconds / 2)
+                base = {"value": ref_v, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                        "sample": f"oracle/_ref = the reference's shaders/pathtrace.comp compiled for the host (OpenMP, one invocation per pixel like vkCmdDispatch; ray queries and "
+                                  f"texture filtering bound to the oracle's trace contract), every 16th 8x8 pixel block of the same {W}x{H} workload ({len(ids)} pixels), {ref_f} frames, {ref_t:.1f} s",
+                        "port_value": port_v, "port_sample": base["sample"]}
+        except Exception as e:  # the compiled reference is optional evidence; the port above stands
+            base["reference_error"] = repr(e)
+        out["cpu_baseline"] = base
         cr, sr = max(1, os_["closestRays"]), max(1, os_["shadowRays"])
         alg = {
             "nodes_per_closest_ray": (os_["nodesVisited"] - os_["nodesShadow"]) / cr,
@@ -262,10 +353,21 @@ def main():
         }
     elif os.path.exists(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")):
         alg = json.load(open(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")))
+
+    # SURVEY.md 8(d) algorithmic bytes: reference-layout BVH2 visits x 32 B, triangle tests x 36 B, hit shading 348 B + 16 B per texture tap,
+    # any-hit evaluation 340 B, NEE lookup 80 B, miss 64 B, framebuffer 32 B per sample
+    def trace_bytes(closest, shadow, alpha_c, alpha_s):
+        return (closest * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + alpha_c * 340,
+                shadow * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36) + alpha_s * 340)
+
+    def shade_bytes(hits, misses, nee):
+        return hits * (348 + 16 * alg["tex_taps_per_hit"]) + nee * 80 + misses * 64
+
     if alg is not None:
         rays = out["rays"]
-        b_total = (rays["closestRays"] * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + rays["shadowRays"] * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36)
-                   + rays["shadedHits"] * (348 + 16 * alg["tex_taps_per_hit"]) + rays["alphaTests"] * 340 + rays["neeLookups"] * 80 + rays["misses"] * 64 + samples * 32)
+        fc = rays["closestRays"] / max(1, rays["closestRays"] + rays["shadowRays"])
+        bc, bs = trace_bytes(rays["closestRays"], rays["shadowRays"], rays["alphaTests"] * fc, rays["alphaTests"] * (1 - fc))
+        b_total = bc + bs + shade_bytes(rays["shadedHits"], rays["misses"], rays["neeLookups"]) + samples * 32
         out["alg_bytes_per_sample"] = b_total / samples
         out["alg_model"] = alg
 
@@ -285,28 +387,29 @@ def main():
         for _ in range(n_i):
             st.frame = frame; r.setPushContants(st); r.run(); r.tonemap(tm); frame += 1
         ti = time.perf_counter() - t0
-        out["interactive"] = {"value": W * H * n_i / ti / 1e6, "unit": "Msamples/s", "ms_per_frame": ti / n_i * 1e3, "frames": n_i,
+        out["interactive"] = {"value": job_pixels * n_i / ti / 1e6, "unit": "Msamples/s", "ms_per_frame": ti / n_i * 1e3, "frames": n_i,
                               "note": "render + pt_tonemap (RGBA8 read back to the host) per frame: batch = 1, like SampleExample's display loop"}
     # (3) standalone kernel durations: the timed loop overlaps four launch sequences on separate streams, so a HIP-event bracket there is not a
-    # kernel's own duration.  One batch is rendered again on a second context with ONE frame slot (PT_TUNE inflight=1): nothing overlaps,
-    # HIP events on the launching stream bracket each stage.
+    # kernel's own duration.  One batch is rendered again on a second context with ONE frame slot (PT_TUNE inflight=1) and otherwise the launch
+    # policy of the timed run (k_tail takes the late bounces): nothing overlaps, HIP events on the launching stream bracket each stage.
     serial = None
-    if not args.no_profile and not args.emulate_shard:
-        # tail=0: every bounce goes through the staged kernels, so that a stage's time and its rays belong together (the timed run hands the
-        # late, small bounces to the fused k_tail: stats["msTail"])
-        os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1,tail=0").lstrip(",")
+    if not args.no_profile:
+        os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1").lstrip(",")
         r2 = HipRenderer()
         r2.setup(local_rank)
-        r2.set_shard(rank, world)
+        if args.accel == "two":
+            r2.set_accel_mode(capi.PT_ACCEL_TWO_LEVEL)
+        r2.set_shard(shard_rank, shard_n)
         r2.set_scene(wl.scene)
         r2.set_env(wl.env)
         r2.set_camera(cam)
         r2.set_sunsky(hd.default_sun_and_sky())
         r2.create((W, H))
         nser = min(args.steps, 32)
-        for phase in range(2):  # warm-up batch, then the measured one
+        # three batches: the first two give the queue-size feedback its observation (it decides where k_tail takes over), the third is measured
+        for phase in range(3):
             r2.reset_stats()
-            r2.set_profiling(phase == 1)
+            r2.set_profiling(phase == 2)
             t0 = time.perf_counter()
             for f in range(nser):
                 st.frame = f; r2.setPushContants(st); r2.run()
@@ -315,70 +418,85 @@ def main():
         s2 = r2.stats()
         r2.set_profiling(False)
         r2.destroy()
-        nsamp = (W * H * nser) / max(1, world)  # samples of the measured batch on this GPU (image tiles are split evenly)
-        serial = {"frames": nser, "wall_ms": tser * 1e3, "launches_per_stage": int(s2["launchesTraceClosest"]),
-                  "stage_ms": {"generate": s2["msGenerate"], "closest": s2["msTraceClosest"], "shade": s2["msShade"], "shadow": s2["msTraceShadow"], "accumulate": s2["msAccumulate"]},
-                  "rays": {k: s2[k] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")}, "samples": nsamp}
+        nsamp = float(s2["samples"])
+        serial = {"frames": nser, "wall_ms": tser * 1e3, "launches_per_stage": int(s2["launchesTraceClosest"]), "launches_tail": int(s2["launchesTail"]),
+                  "stage_ms": {"generate": s2["msGenerate"], "closest": s2["msTraceClosest"], "shade": s2["msShade"], "shadow": s2["msTraceShadow"], "tail": s2["msTail"],
+                               "accumulate": s2["msAccumulate"]},
+                  "rays": {k: s2[k] for k in RAY_KEYS}, "rays_in_tail": {k: s2["tail" + k[0].upper() + k[1:]] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests")},
+                  "samples": nsamp}
         out["serialised"] = serial
 
-    # ---- roofline of the dominant kernel: chosen by its standalone time, priced on algorithmic bytes --------------------
+    # ---- roofline of the dominant stage: chosen by its standalone time, priced on algorithmic bytes ---------------------
     if alg is not None and serial is not None:
-        sr = serial["rays"]
+        sr, tl = serial["rays"], serial["rays_in_tail"]
+        st_c, st_s = sr["closestRays"] - tl["closestRays"], sr["shadowRays"] - tl["shadowRays"]           # rays of the staged kernels
+        st_a, tl_a = sr["alphaTests"] - tl["alphaTests"], tl["alphaTests"]
+        fa = st_c / max(1, st_c + st_s)
+        ft = tl["closestRays"] / max(1, tl["closestRays"] + tl["shadowRays"])
+        bc, bs = trace_bytes(st_c, st_s, st_a * fa, st_a * (1 - fa))
+        tc, ts = trace_bytes(tl["closestRays"], tl["shadowRays"], tl_a * ft, tl_a * (1 - ft))
+        st_hits, st_miss = sr["shadedHits"] - tl["shadedHits"], sr["misses"] - tl["misses"]
+        nb = max(1, serial["launches_per_stage"] // max(1, wl.depth)) if serial["launches_per_stage"] >= wl.depth else 1  # launch sequences of the measured batch
         stage_bytes = {
-            "closest": sr["closestRays"] * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + sr["alphaTests"] * 340 * (sr["closestRays"] / max(1, sr["closestRays"] + sr["shadowRays"])),
-            "shadow": sr["shadowRays"] * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36) + sr["alphaTests"] * 340 * (sr["shadowRays"] / max(1, sr["closestRays"] + sr["shadowRays"])),
-            "shade": sr["shadedHits"] * (348 + 16 * alg["tex_taps_per_hit"]) + sr["neeLookups"] * 80 + sr["misses"] * 64,
+            "closest": bc, "shadow": bs, "shade": shade_bytes(st_hits, st_miss, st_hits),
+            "tail": tc + ts + shade_bytes(tl["shadedHits"], tl["misses"], tl["shadedHits"]),
             "generate": 0.0,
-            "accumulate": serial["samples"] * 32.0,
+            # per sample the radiance handed over (16 B); per launch the running mean of the local framebuffer read and written ONCE (32 B per pixel)
+            "accumulate": serial["samples"] * 16.0 + serial["samples"] / max(1, serial["frames"]) * 32.0,
         }
-        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "generate": "k_generate", "accumulate": "k_accumulate"}
+        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate",
+                   "accumulate": "k_accumulate"}
         launches = max(1, serial["launches_per_stage"])
+        cache, cache_src = latest_profile("cache")
+        traffic_j, traffic_src = latest_profile("traffic")
         table = {}
         for k, ms in serial["stage_ms"].items():
-            n_l = launches if k in ("closest", "shade", "shadow") else max(1, launches // max(1, wl.depth))
-            table[k] = {"kernel": kernels[k], "ms": ms, "launches": n_l, "avg_launch_ms": ms / n_l, "alg_bytes": stage_bytes[k],
-                        "alg_GBps": (stage_bytes[k] / (ms * 1e-3) / 1e9) if ms > 0 else None}
+            n_l = launches if k in ("closest", "shade", "shadow") else max(1, serial["launches_tail"]) if k == "tail" else 1
+            row = {"kernel": kernels[k], "ms": ms, "launches": n_l, "avg_launch_ms": ms / n_l, "alg_bytes": stage_bytes[k],
+                   "alg_GBps": (stage_bytes[k] / (ms * 1e-3) / 1e9) if ms > 0 else None}
+            if traffic_j and traffic_j["hbm_bytes_per_sample"].get(k) is not None and ms > 0:
+                row["hbm_bytes"] = traffic_j["hbm_bytes_per_sample"][k] * serial["samples"]
+                row["hbm_GBps"] = row["hbm_bytes"] / (ms * 1e-3) / 1e9
+            if cache and cache.get("l2_requests_per_sample", {}).get(k) is not None and ms > 0:
+                row["l2_bytes"] = cache["l2_requests_per_sample"][k] * L2_LINE * serial["samples"]
+                row["l2_GBps"] = row["l2_bytes"] / (ms * 1e-3) / 1e9
+                row["l2_hit_rate"] = cache.get("l2_hit_rate", {}).get(k)
+            table[k] = row
         out["stages_serialised"] = table
-        dom = max(("closest", "shade", "shadow"), key=lambda k: serial["stage_ms"][k])
+        dom = max(("closest", "shade", "shadow", "tail"), key=lambda k: serial["stage_ms"][k])
         d = table[dom]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                per_sample = tj["hbm_bytes_per_sample"].get(dom)
-                traffic = per_sample * serial["samples"] / d["launches"] if per_sample else None
-                out["hbm_measured"] = {"bytes_per_sample": tj["hbm_bytes_per_sample"]["total"], "GBps": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9,
-                                       "frac": tj["hbm_bytes_per_sample"]["total"] * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
-                                       "source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r02.sh, gfx950 corrections) x this run's rate",
-                                       "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
-            except Exception:
-                traffic = None
-        # `achieved` is what the stage moves across the HBM interface (measured, PMC) per second of its own standalone run time; the
-        # algorithmic bytes (reference-layout BVH2 visits x 32 B, triangle tests x 36 B, material / texture / light records)
-        # are reported next to it -- most of them are served by L2 / Infinity Cache (the whole scene + BVH is ~115 MB), which is why the
-        # algorithmic rate can exceed the HBM peak while the interface is far from saturated.
-        ach = (traffic / (d["avg_launch_ms"] * 1e-3) / 1e9) if traffic else None
-        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": ach if ach is not None else d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ((ach if ach is not None else d["alg_GBps"]) / HBM_PEAK_GBS), "traffic": traffic,
-                           "achieved_basis": "measured HBM bytes per launch (profiles/r02_traffic.json) / standalone launch duration" if ach is not None else "algorithmic bytes / standalone launch duration",
-                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "alg_GBps": d["alg_GBps"], "alg_frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
-                           "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
-                           "note": "dominant stage = largest STANDALONE time (serialised pass of this run: one frame slot, nothing overlapped, HIP events on the launching stream; "
-                                   "profiles/r02_trace_batch.txt holds the rocprofv3 per-dispatch durations of the same kind of batch)"}
-    # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round,
-    # profiles/r02_valu.json); the rate is this run's; the ceiling is the one measured above on this box.
-    vpath = os.path.join(ROOT, "profiles", "r02_valu.json")
-    if args.workload == "c3" and os.path.exists(vpath):
+        traffic = d.get("hbm_bytes") / d["launches"] if d.get("hbm_bytes") else None
+        if traffic_j:
+            tot = traffic_j["hbm_bytes_per_sample"]["total"]
+            out["hbm_measured"] = {"bytes_per_sample": tot, "GBps": tot * samples / max(1, world) / elapsed / 1e9, "frac": tot * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
+                                   "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r03.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
+                                   "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
+        # `achieved` / `frac`: SURVEY.md 8(d) -- algorithmic bytes per launch over the stage's average standalone launch duration, against the HBM peak.
+        # The algorithmic bytes are reference-layout node / triangle / material records; most of them are served by L2 / Infinity Cache (scene + BVH
+        # ~115 MB), so this fraction can exceed 1 while the HBM interface (`traffic`, `traffic_frac`: PMC-measured bytes) is far from saturated;
+        # `l2_frac` prices the same stage's L2 requests against the L2 ceiling.
+        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
+                           "achieved_basis": "SURVEY 8(d) algorithmic bytes per launch / average standalone launch duration (HIP events on the launching stream, serialised pass of this run)",
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                           "traffic": traffic, "traffic_GBps": d.get("hbm_GBps"), "traffic_frac": d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None, "traffic_source": traffic_src,
+                           "l2_GBps": d.get("l2_GBps"), "l2_frac": d["l2_GBps"] / L2_PEAK_GBS if d.get("l2_GBps") else None, "l2_hit_rate": d.get("l2_hit_rate"), "l2_source": cache_src,
+                           "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
+                           "note": "dominant stage = largest STANDALONE time; frac > 1 means the algorithmic bytes are cache-served, traffic_frac is the HBM interface, l2_frac the L2"}
+    # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round); the rate is
+    # this run's; the ceiling is the one measured above on this box.
+    valu_j, valu_src = latest_profile("valu")
+    if args.workload == "c3" and valu_j:
         try:
-            per_sample = json.load(open(vpath))["valu_wave_instr_per_sample"]
+            per_sample = valu_j["valu_wave_instr_per_sample"]
             peak = out["calibration"]["valu_G_wave_instr_per_s"] * 1e9
             ach = per_sample * samples / elapsed / max(1, world)
             out["issue_roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU", "frac": ach / peak,
-                                     "valu_wave_instr_per_sample": per_sample, "source": "profiles/r02_valu.json x this run's rate / this run's calibration"}
+                                     "valu_wave_instr_per_sample": per_sample, "source": f"{valu_src} x this run's rate / this run's calibration"}
         except Exception:
             pass
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -36,7 +36,8 @@ typedef enum pt_Status {
   PT_ERR_NO_DEVICE = -2, /* no HIP device with that ordinal (or not gfx950) */
   PT_ERR_HIP       = -3, /* a HIP runtime call failed; see pt_last_error */
   PT_ERR_STATE     = -4, /* call order violated (e.g. render before build_accel) */
-  PT_ERR_OOM       = -5
+  PT_ERR_OOM       = -5,
+  PT_ERR_UNAVAILABLE = -6 /* an optional runtime library is missing (librccl.so for the pt_comm_* / pt_gather_* calls); see pt_comm_last_error */
 } pt_Status;
 
 
@@ -173,13 +174,19 @@ int pt_scatter_shards(pt_context* ctx, const void* gathered_dev, int nranks);
  *                         every rank pt_gather_shards(ctx, comm, 0); rank 0 pt_gather_finish(ctx), then pt_read_accum / pt_tonemap.
  *   one process, N GPUs : pt_comm_init_all; pt_comm_group_begin(); pt_gather_shards(ctx[i], comm[i], 0) for every i; pt_comm_group_end();
  *                         pt_gather_finish(ctx[0]).
- * The communicator's rank / size must equal pt_set_shard's. */
+ * The communicator's rank / size must equal pt_set_shard's.  Without librccl.so every call of this group returns PT_ERR_UNAVAILABLE
+ * (single-GPU hosts never need the library; libptmi.so is built without the RCCL headers).  Only the root allocates the gather buffer;
+ * pt_gather_finish on a context that did not enqueue a gather as root returns PT_ERR_STATE. */
 typedef struct pt_comm pt_comm;
 #define PT_COMM_ID_BYTES 128
 int pt_comm_get_unique_id(unsigned char id_out[PT_COMM_ID_BYTES]);
 int pt_comm_init_rank(int nranks, const unsigned char id[PT_COMM_ID_BYTES], int rank, int device_ordinal, pt_comm** out_comm);
 int pt_comm_init_all(int ndev, const int* device_ordinals, pt_comm** out_comms);
 int pt_comm_destroy(pt_comm* comm);
+/* ranks of the communicator as RCCL reports them (ncclCommCount): what a launcher prints to show that N processes really met */
+int pt_comm_count(pt_comm* comm, int* out_nranks);
+/* why the last pt_comm_* call of this thread's process failed (e.g. "librccl.so not found: ..."); never NULL */
+const char* pt_comm_last_error(void);
 int pt_comm_group_begin(void);
 int pt_comm_group_end(void);
 int pt_gather_shards(pt_context* ctx, pt_comm* comm, int root);

@@ -181,6 +181,43 @@ int orc_render_frame(orc_ctx* c, const pt_RtxState* state, float* accum, const u
   return 0;
 }
 
+// `nframes` consecutive frames (frame = first_frame ...) of the listed pixels inside ONE thread team (bench.py's cpu_baseline leg: a fork / join
+// of a few hundred threads per frame would be most of a small frame's time).  Per pixel the frames are folded in frame order, as always.
+int orc_render_frames(orc_ctx* c, const pt_RtxState* state, int first_frame, int nframes, float* accum, const uint32_t* pixel_ids, uint64_t n)
+{
+  const int W = state->size[0], H = state->size[1];
+  if(W <= 0 || H <= 0 || !accum || !pixel_ids)
+    return -1;
+  if(c->scene.sunsky.in_use != 1 && c->scene.env.empty())
+  {
+    c->err = "no environment set";
+    return -1;
+  }
+  const int nthreads = c->threads > 0 ? c->threads : omp_get_max_threads();
+  Stats     total;
+#pragma omp parallel num_threads(nthreads)
+  {
+    Stats mine;
+    for(int f = first_frame; f < first_frame + nframes; ++f)
+    {
+      pt_RtxState st = *state;
+      st.frame       = f;
+      Tracer tr(c->scene, st, c->variant);
+#pragma omp for schedule(dynamic, 16)
+      for(int64_t i = 0; i < (int64_t)n; ++i)
+      {
+        uint32_t id = pixel_ids[i];
+        tr.render_pixel(int(id % W), int(id / W), accum + size_t(id) * 4);
+      }  // (implicit barrier: frame f is complete for every pixel before f + 1 starts)
+      mine.add(tr.stats);
+    }
+#pragma omp critical
+    total.add(mine);
+  }
+  c->stats.add(total);
+  return 0;
+}
+
 // 12 uint64: samples closestRays shadowRays shadedHits misses alphaTests neeLookups nodesVisited trisTested texTaps nodesShadow trisShadow
 int orc_get_stats(orc_ctx* c, uint64_t* out)
 {

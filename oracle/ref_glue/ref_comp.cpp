@@ -100,6 +100,39 @@ int ref_render_frame(const pt_RtxState* st, float* accum, const uint32_t* pixel_
   return 0;
 }
 
+// The same dispatch for `nframes` consecutive frames (rtxState.frame = first_frame ...) inside ONE thread team: the CPU-baseline leg of bench.py
+// times this, and a fork / join of a few hundred threads per frame would be most of a small frame's time.  Frames stay ordered (the running
+// mean of pathtrace.comp:122-133 folds them in frame order per pixel): the push constant changes between two work-sharing loops, behind a barrier.
+int ref_render_frames(const pt_RtxState* st, int first_frame, int nframes, float* accum, const uint32_t* pixel_ids, uint64_t n, int threads)
+{
+  std::memcpy(&rtxState, st, sizeof(RtxState));
+  resultImage.px = accum;
+  resultImage.w  = st->size[0];
+  resultImage.h  = st->size[1];
+  const int     W     = st->size[0], H = st->size[1];
+  const int64_t total = pixel_ids ? (int64_t)n : (int64_t)W * H;
+  if(threads <= 0)
+    threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+  for(int f = first_frame; f < first_frame + nframes; ++f)
+  {
+#pragma omp single
+    rtxState.frame = f;  // (implicit barrier: every thread sees the new push constant)
+#pragma omp for schedule(dynamic, 16)
+    for(int64_t i = 0; i < total; ++i)
+    {
+      uint32_t id = pixel_ids ? pixel_ids[i] : (uint32_t)i;
+      gl_GlobalInvocationID.x  = id % (uint32_t)W;
+      gl_GlobalInvocationID.y  = id / (uint32_t)W;
+      gl_GlobalInvocationID.z  = 0;
+      gl_GlobalInvocationID.xy = uvec2(gl_GlobalInvocationID.x, gl_GlobalInvocationID.y);
+      g_clock                  = 0;
+      shader_main();
+    }
+  }
+  return 0;
+}
+
 // ---- function-level known answers straight from the reference's GLSL ------------------------------------------------------
 uint32_t ref_tea(uint32_t a, uint32_t b) { return tea(a, b); }                        // random.glsl:34-48
 void     ref_pcg_stream(uint32_t seed, uint32_t n, uint32_t* words, float* floats, uint32_t* state)

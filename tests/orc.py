@@ -153,6 +153,14 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(self.L.orc_last_error(self.ctx).decode())
 
+    def render_frames(self, state: hd.RtxState, first_frame, nframes, accum, pixel_ids):
+        """`nframes` consecutive frames of the listed pixels inside one OpenMP team (timed by bench.py's cpu_baseline leg)."""
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous
+        pixel_ids = np.ascontiguousarray(pixel_ids, np.uint32)
+        self.L.orc_render_frames.argtypes = [C.c_void_p, C.POINTER(hd.RtxState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+        if self.L.orc_render_frames(self.ctx, C.byref(state), int(first_frame), int(nframes), accum.ctypes.data, pixel_ids.ctypes.data, len(pixel_ids)) != 0:
+            raise RuntimeError(self.L.orc_last_error(self.ctx).decode())
+
     def render(self, state: hd.RtxState, frames, accum=None, first_frame=0):
         W, H = state.size[0], state.size[1]
         if accum is None:

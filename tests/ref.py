@@ -45,6 +45,7 @@ def lib():
         L.ref_set_camera.argtypes = [C.POINTER(hd.SceneCamera)]
         L.ref_set_sunsky.argtypes = [C.POINTER(hd.SunAndSky)]
         L.ref_render_frame.argtypes = [C.POINTER(hd.RtxState), P, P, C.c_uint64, C.c_int]
+        L.ref_render_frames.argtypes = [C.POINTER(hd.RtxState), C.c_int, C.c_int, P, P, C.c_uint64, C.c_int]
         L.ref_tea.argtypes = [C.c_uint32, C.c_uint32]
         L.ref_tea.restype = C.c_uint32
         L.ref_pcg_stream.argtypes = [C.c_uint32, C.c_uint32, P, P, P]
@@ -126,6 +127,14 @@ class Reference:
             state.frame = f
             (self.L.ref_rtx_render_frame if self.rtx else self.L.ref_render_frame)(C.byref(state), accum.ctypes.data, None if ids is None else ids.ctypes.data,
                                                                                     0 if ids is None else len(ids), threads)
+        return accum
+
+
+    def render_frames(self, state, first_frame, nframes, accum, pixel_ids, threads=0):
+        """pathtrace.comp for `nframes` consecutive frames of the listed pixels inside one OpenMP team (bench.py's cpu_baseline leg)."""
+        assert not self.rtx
+        ids = np.ascontiguousarray(pixel_ids, np.uint32)
+        self.L.ref_render_frames(C.byref(state), int(first_frame), int(nframes), accum.ctypes.data, ids.ctypes.data, len(ids), threads)
         return accum
 
 

@@ -1,0 +1,105 @@
+"""The native gather path (csrc/pt_comm.cpp: pt_comm_* / pt_gather_shards / pt_gather_finish) and bench.py's self-launching N-GPU mode.
+
+No GPU: what happens without librccl.so (every call answers PT_ERR_UNAVAILABLE with a message -- no crash, no half-open RCCL group) and how
+`bench.py --gpus N` fails on a host without devices (pt_create's message, not an argument error).
+GPU (1 device): the single-process flavour (pt_comm_init_all + pt_comm_group_begin / end) end to end with ndev = 1, the root-only gather
+buffer, and `bench.py --gpus 2` failing with pt_create's device-count message."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from vk_raytrace_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_MISSING = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from vk_raytrace_amd import capi, shard
+L = capi.lib()
+ident = (C.c_ubyte * 128)()
+rc = L.pt_comm_get_unique_id(ident)
+assert rc == capi.PT_ERR_UNAVAILABLE, rc
+msg = L.pt_comm_last_error().decode()
+assert "librccl" in msg and len(msg) > len("librccl.so not found: "), msg
+comm = C.c_void_p()
+assert L.pt_comm_init_rank(1, ident, 0, 0, C.byref(comm)) == capi.PT_ERR_UNAVAILABLE
+assert L.pt_comm_init_all(1, None, C.byref(comm)) == capi.PT_ERR_UNAVAILABLE
+assert L.pt_comm_group_begin() == capi.PT_ERR_UNAVAILABLE and L.pt_comm_group_end() == capi.PT_ERR_UNAVAILABLE
+assert L.pt_comm_get_unique_id(None) == capi.PT_ERR_INVALID          # a bad argument stays distinguishable from a missing library
+try:
+    shard.NativeGather(0, 1, 0)
+    raise SystemExit("NativeGather did not raise")
+except capi.PtError as e:
+    assert e.code == capi.PT_ERR_UNAVAILABLE and "librccl" in str(e), e
+print("ok")
+"""
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    env = dict(os.environ, PT_RCCL_LIB="/nonexistent/librccl.so.1")
+    p = subprocess.run([sys.executable, "-c", _MISSING % ROOT], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.returncode, p.stdout, p.stderr)
+
+
+def test_bench_self_launch_fails_with_the_device_message_without_devices():
+    """`python bench.py --gpus 2` needs no launcher; here (no GPU) both ranks fail in pt_create and the parent reports it and stops."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by test_bench_gpus_2_on_a_one_gpu_box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "no HIP device available" in p.stderr and "exited with code" in p.stderr, p.stderr[-2000:]
+    assert "must be launched through" not in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_on_a_one_gpu_box():
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "device ordinal 1 out of range: 1 HIP device(s) visible" in p.stderr, p.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_single_process_gather_with_one_device():
+    """pt_comm_init_all + pt_comm_group_begin / pt_gather_shards / pt_comm_group_end + pt_gather_finish: the flavour one process driving N GPUs
+    uses, here with N = 1 (everything but the peer-to-peer transfers runs).  The gathered image equals the plain read-back."""
+    from tests.common import Config, render_hip
+    from vk_raytrace_amd import synth
+    L = capi.lib()
+    cfg = Config(synth.feature_box(tex_size=32), synth.procedural_sky(128, 64), 200, 120)
+    img, r = render_hip(cfg, 3, return_obj=True)
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    rc = L.pt_comm_init_all(1, dev, C.byref(comm))
+    assert rc == capi.PT_OK, L.pt_comm_last_error()
+    n = C.c_int(0)
+    assert L.pt_comm_count(comm, C.byref(n)) == capi.PT_OK and n.value == 1
+    assert L.pt_gather_finish(r._ctx) == capi.PT_ERR_STATE           # nothing enqueued yet
+    assert L.pt_gather_shards(r._ctx, comm, 1) == capi.PT_ERR_INVALID  # root out of range: rejected before anything is allocated or grouped
+    assert L.pt_comm_group_begin() == capi.PT_OK
+    assert L.pt_gather_shards(r._ctx, comm, 0) == capi.PT_OK
+    assert L.pt_comm_group_end() == capi.PT_OK
+    assert L.pt_gather_finish(r._ctx) == capi.PT_OK
+    assert L.pt_gather_finish(r._ctx) == capi.PT_ERR_STATE           # consumed
+    got = r.read_accum()
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+    assert L.pt_comm_destroy(comm) == capi.PT_OK
+    r.destroy()
+    # two ranks that the context was not sharded for: the communicator check answers, and the RCCL group is closed again (a later call works)
+    comm = C.c_void_p()
+    assert L.pt_comm_init_all(1, dev, C.byref(comm)) == capi.PT_OK
+    img2, r2 = render_hip(cfg, 1, shard=(1, 2), return_obj=True)
+    assert L.pt_gather_shards(r2._ctx, comm, 0) == capi.PT_ERR_INVALID
+    assert L.pt_comm_group_begin() == capi.PT_OK and L.pt_comm_group_end() == capi.PT_OK
+    assert L.pt_comm_destroy(comm) == capi.PT_OK
+    r2.destroy()

@@ -273,3 +273,24 @@ def test_arithmetic_or_garbage_jpeg_is_rejected_with_a_message(tmp_path):
     data = b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00\xff\xd9"      # SOF9: arithmetic coding
     with pytest.raises(ValueError, match="not supported"):
         CppScene(_image_doc(tmp_path, data, "arith.jpg"))
+
+
+def test_asset_dir_loads_through_the_cpp_importer(tmp_path, monkeypatch):
+    """PT_ASSET_DIR (real assets are used when present): workloads.c3_sponza picks <dir>/Sponza.glb up through pt_gltf_load --
+    the importer a C++ host uses -- and the flat arrays are those of the scene that was exported."""
+    from vk_raytrace_amd import workloads
+    from vk_raytrace_amd.scene import GltfFileScene
+    src = synth.sponza_like(target_tris=3000, tex_size=8)
+    gltf.save_gltf(src, str(tmp_path / "Sponza.glb"))
+    monkeypatch.setenv("PT_ASSET_DIR", str(tmp_path))
+    wl = workloads.c3_sponza(64, 48, 2)
+    assert isinstance(wl.scene, GltfFileScene) and wl.note == "gltf" and "Sponza.glb" in wl.name
+    src.finalize(capi.pack_vertices)
+    d, _ = wl.scene.desc()
+    assert d.numVertices == len(src.vertices) and d.numIndices == len(src.indices)
+    got = np.ctypeslib.as_array(C.cast(d.vertices, C.POINTER(C.c_uint8)), (d.numVertices * 32,))
+    assert np.array_equal(got, src.vertices.view(np.uint8).reshape(-1))
+    assert wl.scene.num_triangles == src.num_triangles and len(wl.scene.materials) == len(src.materials) and len(wl.scene.textures) == len(src.textures)
+    assert np.allclose(wl.scene.camera.eye, src.camera.eye, atol=1e-6) and abs(wl.scene.camera.fov - src.camera.fov) < 1e-4
+    monkeypatch.setenv("PT_ASSET_IMPORTER", "python")
+    assert not isinstance(workloads.c3_sponza(64, 48, 2).scene, GltfFileScene)

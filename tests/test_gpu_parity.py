@@ -199,13 +199,108 @@ def test_c2_full_size_64spp():
     check_sparse(cfg, 64, 64)
 
 
-def test_c4_c5_full_size_sampled():
-    """C4 (the C3 scene at 3840x2160) and C5 (bistro-like, 3.8 M instanced triangles, 3840x2160): a few frames at full size against the
-    oracle on a sparse pixel sample (their 1024 / 4096 spp only repeat the per-frame arithmetic checked here)."""
-    wl = workloads.c3_sponza(3840, 2160, 1024, tex_size=256, env_w=1024)
-    check_sparse(Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0), 4, 1024)
-    wl = workloads.c5_bistro(tex_size=128)
-    check_sparse(Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0), 4, 1024)
+@pytest.mark.parametrize("which", ["c4", "c5"])
+def test_c4_c5_full_size_sampled(which):
+    """C4 (the C3 scene at 3840x2160) and C5 (bistro-like, 3.8 M instanced triangles, 1 793 instances, 3840x2160): a few frames at full size
+    against the oracle on a sparse pixel sample (their 1024 / 4096 spp only repeat the per-frame arithmetic checked here) -- on the flat
+    structure AND on the two-level structure (BLAS per prim-mesh + TLAS, the reference's shape, src/accelstruct.cpp:110-162), and the two
+    whole 4K images against each other."""
+    if which == "c4":
+        wl = workloads.c3_sponza(3840, 2160, 1024, tex_size=256, env_w=1024)
+    else:
+        wl = workloads.c5_bistro(tex_size=128)
+    cfg = Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0)
+    flat = check_sparse(cfg, 4, 1024)
+    two = render_hip(cfg, 4, accel=capi.PT_ACCEL_TWO_LEVEL)
+    check_sparse(cfg, 4, 1024, hip_image=two)
+    assert_identical(two, flat, f"{which}: two-level vs flat, 3840x2160 x 4 spp")
+
+
+def test_path_state_budget_shrinks_the_batch(env_small):
+    """pt_resize's path-state budget (PT_TUNE stateMB / stateGB, else 85 % of the free device memory): a budget far below one default batch
+    halves the batch and drops frame slots instead of failing, a repeated pt_resize arrives at the same batch, and the frames are unchanged."""
+    from vk_raytrace_amd.renderer import HipRenderer
+    cfg = Config(synth.feature_box(tex_size=32), env_small, 256, 192)
+    ref_img, r0 = render_hip(cfg, 12, return_obj=True)
+    full = r0.stats()
+    r0.destroy()
+    old = os.environ.get("PT_TUNE")
+    try:
+        # 256x192 -> 48 tiles x 1024 slots x 180 B = 8.8 MB per frame of the batch and slot: 20 MB is two frames on one slot
+        os.environ["PT_TUNE"] = "stateMB=20"
+        img, r = render_hip(cfg, 12, return_obj=True)
+        s = r.stats()
+        assert s["batchFrames"] * s["framesInFlight"] <= 2 and s["batchFrames"] < full["batchFrames"], (s["batchFrames"], s["framesInFlight"], full["batchFrames"])
+        r.create((128, 96)); r.create((256, 192)); r.create((200, 100)); r.create((256, 192))   # re-layouts: the budget counts what the slots already hold
+        assert r.stats()["batchFrames"] == s["batchFrames"]
+        r.destroy()
+        assert_identical(img, ref_img, "budgeted batch vs default batch")
+        os.environ["PT_TUNE"] = "stateMB=1"   # not even one frame on one slot: a clean PT_ERR_OOM from pt_resize, no crash
+        r = HipRenderer(); r.setup(0); r.set_scene(cfg.scene)
+        with pytest.raises(capi.PtError) as e:
+            r.create((1024, 768))
+        assert e.value.code == capi.PT_ERR_OOM
+        r.destroy()
+    finally:
+        if old is None:
+            os.environ.pop("PT_TUNE", None)
+        else:
+            os.environ["PT_TUNE"] = old
+
+
+def test_gltf_file_renders_like_the_scene_it_was_exported_from(tmp_path, monkeypatch, env_small):
+    """The real-asset path end to end: the C3 stand-in written as Sponza.glb, found through PT_ASSET_DIR, imported by libptmi's own C++ importer
+    (pt_gltf_load: the Scene::load of the drop-in, reference src/scene.cpp:56-155) and rendered -- bit-identical to the oracle on the imported
+    arrays and to the render of the synthetic scene itself (same camera)."""
+    from vk_raytrace_amd import gltf
+    from vk_raytrace_amd.scene import GltfFileScene
+    src = workloads.c3_sponza(320, 200, 4, tex_size=64, target_tris=40_000, env_w=256).scene
+    gltf.save_gltf(src, str(tmp_path / "Sponza.glb"))
+    monkeypatch.setenv("PT_ASSET_DIR", str(tmp_path))
+    wl = workloads.c3_sponza(320, 200, 4, env_w=256)
+    assert isinstance(wl.scene, GltfFileScene) and wl.scene.num_triangles == src.num_triangles
+    cfg = Config(wl.scene, env_small, 320, 200, depth=8)
+    h, o = check_frames(cfg, 4)
+    src.camera = wl.scene.camera   # the exporter writes the camera as a node transform: compare at the importer's camera
+    assert_identical(render_hip(Config(src, env_small, 320, 200, depth=8), 4), h, "synthetic scene vs its exported file")
+
+
+def test_sample_example_interactive_state_machine(env_small):
+    """SampleExample's frame counter and de-scaling (reference src/sample_example.cpp:183-199, :410-413, :528-557): a camera change restarts the
+    accumulation, a mouse drag renders at 1 / level of the region and shows it zoomed, releasing the button restarts at full size."""
+    from vk_raytrace_amd.renderer import SampleExample
+    app = SampleExample(0)
+    app.loadScene(synth.feature_box(tex_size=32))
+    app.loadEnvironmentHdr(env_small)
+    app.setRenderRegion(160, 120)
+    app.m_descalingLevel = 2
+    app.updateUniformBuffer()
+    for _ in range(3):
+        app.updateFrame(); app.renderScene()
+    assert app.m_rtxState.frame == 2
+    still = app.m_pRender.read_accum()
+    app.m_scene.camera.eye = (app.m_scene.camera.eye[0] + 0.25, app.m_scene.camera.eye[1], app.m_scene.camera.eye[2])
+    app.updateUniformBuffer(); app.updateFrame(); app.renderScene()
+    assert app.m_rtxState.frame == 0                                  # camera moved: resetFrame, then frame 0
+    moved = app.m_pRender.read_accum()
+    assert not np.array_equal(moved, still)
+    cfg = Config(app.m_scene, env_small, 160, 120)
+    assert_identical(moved, render_oracle(cfg, 1), "first frame after the camera change")
+    app.onMouseButton("lmb", True); app.onMouseMotion(5, 5)
+    assert app.m_descaling
+    app.updateFrame(); app.renderScene()
+    small = app.m_pRender.read_accum()
+    assert small.shape == (60, 80, 4) and tuple(app.m_rtxState.size) == (80, 60)
+    shown = app.drawPost()
+    assert shown.shape == (120, 160, 4) and abs(app.m_tonemapper.zoom - 0.5) < 1e-7
+    tm = hd.default_tonemapper(); tm.zoom = 0.5
+    assert np.array_equal(shown, orc.tonemap(tm, small, display_size=(160, 120)))
+    app.onMouseButton("lmb", False)
+    assert not app.m_descaling and app.m_rtxState.frame == -1      # released: full size again, accumulation restarted
+    app.updateFrame(); app.renderScene()
+    assert_identical(app.m_pRender.read_accum(), moved, "full-size frame 0 after the drag")
+    assert app.drawPost().shape == (120, 160, 4) and app.m_tonemapper.zoom == 1.0
+    app.destroy()
 
 
 def test_tonemap_matches_oracle(env_small):

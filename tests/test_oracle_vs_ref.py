@@ -380,3 +380,29 @@ def test_post_frag_descaling(level, ae):
     R.ref_tonemap(C.byref(tm), big.ctypes.data, W, H, a.ctypes.data)
     assert O.orc_tonemap_zoom(C.byref(tm), small.ctypes.data, w, h, W, H, None, b.ctypes.data) == 0
     same(a, b, "post.frag with zoom")
+
+
+def test_multi_frame_entry_points_equal_frame_by_frame():
+    """ref_render_frames / orc_render_frames (several frames inside one OpenMP team: what bench.py's cpu_baseline leg times) give exactly the
+    frames of the frame-by-frame entry points, and the compiled reference and the oracle agree on them."""
+    sc = synth.feature_box(tex_size=16)
+    env = synth.procedural_sky(64, 32)
+    cfg = Config(sc, env, 96, 64)
+    ids = np.arange(96 * 64, dtype=np.uint32)[::3].copy()
+    o = orc.Oracle()
+    o.set_scene(cfg.scene); integ, _ = o.set_env(cfg.env); o.set_camera(cfg.camera); o.set_sunsky(cfg.sunsky)
+    st = cfg.state(integ)
+    a = np.zeros((64, 96, 4), np.float32)
+    for f in range(5):
+        st.frame = f
+        o.render_frame(st, a, ids)
+    b = np.zeros_like(a)
+    o.render_frames(st, 0, 2, b, ids)
+    o.render_frames(st, 2, 3, b, ids)
+    same(a, b, "orc_render_frames")
+    r = ref.Reference(cfg.scene, cfg.env, oracle=o)
+    r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky)
+    c = np.zeros_like(a)
+    r.render_frames(st, 0, 5, c, ids, threads=3)
+    same(a, c, "ref_render_frames")
+    o.close()

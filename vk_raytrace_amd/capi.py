@@ -14,7 +14,7 @@ from . import host_device as hd
 PT_VARIANT_RAYQUERY, PT_VARIANT_RTX = 0, 1
 PT_ACCEL_FLAT, PT_ACCEL_TWO_LEVEL = 0, 1
 PT_FN = {"sin": 0, "cos": 1, "tan": 2, "asin": 3, "acos": 4, "atan2": 5, "exp": 6, "log": 7, "pow": 8}
-PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM = 0, -1, -2, -3, -4, -5
+PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM, PT_ERR_UNAVAILABLE = 0, -1, -2, -3, -4, -5, -6
 
 # PT_LIB: developer override used to compare builds of the same HIP library (tools/build_variants.sh); never a fallback
 LIB_PATH = os.environ.get("PT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptmi.so")
@@ -51,6 +51,8 @@ API = [
     ("pt_comm_init_rank", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     ("pt_comm_init_all", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     ("pt_comm_destroy", C.c_int, [_P]),
+    ("pt_comm_count", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("pt_comm_last_error", C.c_char_p, []),
     ("pt_comm_group_begin", C.c_int, []),
     ("pt_comm_group_end", C.c_int, []),
     ("pt_gather_shards", C.c_int, [_P, _P, C.c_int]),

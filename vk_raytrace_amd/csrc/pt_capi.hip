@@ -89,6 +89,7 @@ struct pt_context {
   DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
+  bool     gatherEnqueued = false;  // pt_gather_shards ran on this context as the root and pt_gather_finish has not consumed it yet
   StageTimers timers;
   pt_Stats    stats{};
   double      msBuild = 0;
@@ -468,6 +469,8 @@ void pt_timers_end(StageTimers* t, hipStream_t s, int stage)
   (void)hipEventRecord(t->pend[t->npend].b, s);
   if(stage == 1)
     t->launchesClosest++;
+  if(stage == 5)
+    t->launchesTail++;
   t->npend++;
   if(t->npend == t->cap && t->cap >= 8192)
     pt_timers_collect(t);  // bound the number of live events
@@ -508,7 +511,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   }
   if(device_ordinal < 0 || device_ordinal >= count)
   {
-    g_createError = "device ordinal out of range";
+    g_createError = "device ordinal " + std::to_string(device_ordinal) + " out of range: " + std::to_string(count) + " HIP device(s) visible to this process";
     return PT_ERR_NO_DEVICE;
   }
   hipDeviceProp_t prop;
@@ -527,9 +530,11 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     g_createError = "hipSetDevice failed";
     return PT_ERR_HIP;
   }
+  g_tuning = PtTuning{};  // every context starts from the defaults: a knob set for one context's creation does not leak into the next
   if(const char* tune = getenv("PT_TUNE"))
   {  // performance A/B knobs only
     int v;
+    if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) g_tuning.stateMB = v;
     if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) g_tuning.packetClosestBounces = v;
     if(const char* p = strstr(tune, "packetShadow=")) if(sscanf(p, "packetShadow=%d", &v) == 1) g_tuning.packetShadowBounces = v;
@@ -1147,11 +1152,26 @@ int pt_resize(pt_context* c, int width, int height)
   const size_t perPath = 9 * sizeof(float4) + 9 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
   {
-    size_t freeB = 0, totalB = 0;
-    (void)hipMemGetInfo(&freeB, &totalB);
-    double budget = g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : double(freeB) * 0.85;
-    while(c->batchMax > 1 && double(perPath) * double(c->numSlots ? c->numSlots : 1) * c->batchMax * c->inflight > budget)
+    // what is free now PLUS what the frame slots already hold (those buffers are re-used or released below): a repeated pt_resize at the same
+    // size must arrive at the same batch, not at half of it.  A failed query means "no cap" -- the retry loop below still shrinks on a failed allocation.
+    size_t freeB = 0, totalB = 0, held = 0;
+    const bool haveInfo = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
+    (void)hipGetLastError();
+    for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+    {
+      pt_context::FrameSlot& fs = c->slots[i];
+      for(DevBuf& bf : fs.dState) held += bf.bytes;
+      const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      for(const DevBuf* bf : q) held += bf->bytes;
+    }
+    const double budget = g_tuning.stateMB > 0 ? g_tuning.stateMB * 1e6 : g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
+    auto need = [&]() { return double(perPath) * double(c->numSlots ? c->numSlots : 1) * c->batchMax * c->inflight; };
+    while(c->batchMax > 1 && need() > budget)
       c->batchMax = (c->batchMax + 1) / 2;
+    while(c->inflight > 1 && need() > budget)
+      c->inflight = (c->inflight + 1) / 2;
+    if((g_tuning.stateMB > 0 || g_tuning.stateGB > 0) && need() > budget)  // an explicit cap that one frame on one slot exceeds (a cap derived
+      return c->fail(PT_ERR_OOM, "pt_resize: the path state of one %dx%d frame (%.0f bytes) exceeds the configured budget (%.0f bytes)", width, height, need(), budget);  // from the free memory is left to the allocations below)
   }
   for(;;)
   {
@@ -1700,11 +1720,13 @@ int pt_scatter_shards(pt_context* c, const void* gathered_dev, int nranks)
 }
 
 // internal hooks of pt_comm.cpp (hidden: not part of the ABI)
-__attribute__((visibility("hidden"))) int pt_comm_internal_shard(pt_context* c, void** shard, size_t* bytes, int* rank, int* nranks, void** gatherBuf, hipStream_t* stream, int* device)
+__attribute__((visibility("hidden"))) int pt_comm_internal_shard(pt_context* c, void** shard, size_t* bytes, int* rank, int* nranks, int root, void** gatherBuf, hipStream_t* stream, int* device)
 {
   CTX_CHECK(c);
   if(c->width == 0)
     return c->fail(PT_ERR_STATE, "pt_gather_shards before pt_resize");
+  if(root < 0 || root >= c->nranks)
+    return c->fail(PT_ERR_INVALID, "pt_gather_shards: root %d of %d ranks", root, c->nranks);
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, sync_all(c));  // the shard is complete; the gather is enqueued on the context's stream
   *shard  = c->dFrame.p;
@@ -1713,24 +1735,32 @@ __attribute__((visibility("hidden"))) int pt_comm_internal_shard(pt_context* c, 
   *nranks = c->nranks;
   *stream = c->stream;
   *device = c->device;
-  if(gatherBuf)
-  {
+  *gatherBuf       = nullptr;
+  c->gatherEnqueued = false;
+  if(c->rank == root)
+  {  // only the root holds the nranks x shard buffer (133 MB for a 4K image on 8 GPUs)
     int rc = dev_alloc(c, c->dGather, *bytes * size_t(c->nranks));
     if(rc != PT_OK)
       return rc;
-    *gatherBuf = c->dGather.p;
+    *gatherBuf        = c->dGather.p;
+    c->gatherEnqueued = true;
   }
   return PT_OK;
 }
-__attribute__((visibility("hidden"))) void pt_comm_internal_fail(pt_context* c, int code, const char* msg) { c->fail(code, "%s", msg); }
+__attribute__((visibility("hidden"))) void pt_comm_internal_fail(pt_context* c, int code, const char* msg)
+{
+  c->gatherEnqueued = false;
+  c->fail(code, "%s", msg);
+}
 
 int pt_gather_finish(pt_context* c)
 {
   CTX_CHECK(c);
-  if(!c->dGather.p)
-    return c->fail(PT_ERR_STATE, "pt_gather_finish without pt_gather_shards on the root");
+  if(!c->gatherEnqueued || !c->dGather.p)
+    return c->fail(PT_ERR_STATE, "pt_gather_finish without a pt_gather_shards that this context enqueued as the root");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->gatherEnqueued = false;
   return pt_scatter_shards(c, c->dGather.p, c->nranks);
 }
 
@@ -1763,11 +1793,16 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.msAccumulate = c->timers.ms[4];
   s.msTail       = c->timers.ms[5];
   s.launchesTraceClosest = c->timers.launchesClosest;
+  s.launchesTail         = c->timers.launchesTail;
+  s.tailClosestRays = k.tailClosestRays; s.tailShadowRays = k.tailShadowRays; s.tailShadedHits = k.tailShadedHits; s.tailMisses = k.tailMisses;
+  s.tailAlphaTests = k.tailAlphaTests;
   s.numTriangles = c->numTris;
   s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;
   s.msBuildAccel = c->msBuild;
   s.numBlas      = c->numBlas;
   s.numTlasNodes = c->numTlasNodes;
+  s.batchFrames    = uint32_t(c->batchMax);
+  s.framesInFlight = uint32_t(c->inflight);
   s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes;
   uint64_t bytes = 0;
   const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel,
@@ -1788,6 +1823,7 @@ int pt_reset_stats(pt_context* c)
   for(double& m : c->timers.ms)
     m = 0;
   c->timers.launchesClosest = 0;
+  c->timers.launchesTail    = 0;
   c->stats                  = pt_Stats{};
   HIP_TRY(c, hipMemset(c->dCounters.p, 0, sizeof(Counters)));
   return PT_OK;

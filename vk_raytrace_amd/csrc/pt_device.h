@@ -159,6 +159,7 @@ struct PathState {
 struct Counters {
   unsigned long long closestRays, shadowRays, shadedHits, misses, alphaTests, neeLookups, nodesVisited, trisTested;
   unsigned int       stackOverflow, _pad;
+  unsigned long long tailClosestRays, tailShadowRays, tailShadedHits, tailMisses, tailAlphaTests;  // the part of the totals above that k_tail traced / shaded
 };
 
 struct FrameParams {

@@ -111,6 +111,7 @@ struct PtTuning {
   int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of
                                    // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
   int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
+  int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
   int shadeSpecialised     = 0;    // k_shade<0 / 1>: the common case (no debug output, no sun & sky, no punctual lights) compiled per BSDF
   int sortClosest          = 0;    // bounce >= 1: the closest-hit queue is binned by (direction octant, origin cell) before it is traced, so that the 64 rays a
                                    // wave of the trace machine pulls together (and refills with) start in the same region with the same direction signs
@@ -163,7 +164,7 @@ struct StageTimers {
   bool       enabled = false;
   hipEvent_t ev[2] = {nullptr, nullptr};
   double     ms[6] = {0, 0, 0, 0, 0, 0};  // generate, closest, shade, shadow, accumulate, tail (k_tail: the late bounces of a launch sequence)
-  uint64_t   launchesClosest = 0;
+  uint64_t   launchesClosest = 0, launchesTail = 0;
   hipStream_t stream = nullptr;
   // pending (start,stop) pairs are resolved lazily to keep the stream asynchronous
   struct Pending { hipEvent_t a, b; int stage; };

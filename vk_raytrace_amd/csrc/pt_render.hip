@@ -828,6 +828,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBu
   wave_add(&rb.counters->misses, nMiss);
   wave_add(&rb.counters->shadedHits, nHit);
   wave_add(&rb.counters->neeLookups, nNee);
+  // the same again as "of which in the tail": per-stage byte / ray accounting of bench.py
+  wave_add(&rb.counters->tailClosestRays, nClosest);
+  wave_add(&rb.counters->tailShadowRays, nShadow);
+  wave_add(&rb.counters->tailAlphaTests, nAlpha);
+  wave_add(&rb.counters->tailMisses, nMiss);
+  wave_add(&rb.counters->tailShadedHits, nHit);
 }
 
 // ---- k_accumulate ---------------------------------------------------------------------------------------------

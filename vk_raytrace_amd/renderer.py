@@ -205,21 +205,30 @@ class HipRenderer(Renderer):
 
 
 class SampleExample:
-    """The headless slice of the reference's orchestrator (src/sample_example.{hpp,cpp})."""
+    """The headless slice of the reference's orchestrator (src/sample_example.{hpp,cpp}): scene / environment loading, the frame counter with its
+    camera-change detection, the de-scaling state machine of the mouse callbacks, renderScene and drawPost."""
 
     def __init__(self, device=0, renderer=None):
         self.m_rtxState = hd.default_rtx_state()       # sample_example.hpp:162-174
         self.m_sunAndSky = hd.default_sun_and_sky()    # sample_example.hpp:176-193
         self.m_tonemapper = hd.default_tonemapper()    # render_output.hpp:37-49
         self.m_maxFrames = 100000                      # sample_example.hpp:195
+        self.m_descaling = False                       # sample_example.hpp:197
+        self.m_descalingLevel = 1                      # sample_example.hpp:198
         self.m_pRender = renderer if renderer is not None else HipRenderer()
         self.m_pRender.setup(device)                   # sample_example.cpp:77-82
         self.m_scene = None
-        self.m_size = (0, 0)
+        self.m_size = (0, 0)                           # m_renderRegion.extent
+        self._refCamMatrix = None                      # updateFrame's `static glm::mat4 refCamMatrix` / `static float fov`
+        self._refFov = 0.0
+        self._inputs = {"lmb": False, "mmb": False, "rmb": False}  # AppBaseVk::m_inputs
         self.resetFrame()
 
-    # sample_example.cpp:90-98 loadScene + main.cpp:186-189
+    # sample_example.cpp:90-98 loadScene + main.cpp:186-189.  A path goes through libptmi's own importer (pt_gltf_load), like Scene::load.
     def loadScene(self, scene):
+        if isinstance(scene, (str, bytes, os.PathLike)):
+            from .scene import GltfFileScene
+            scene = GltfFileScene(os.fsdecode(scene))
         if scene.vertices is None:
             scene.finalize(capi.pack_vertices)
         self.m_scene = scene
@@ -240,30 +249,60 @@ class SampleExample:
         self.m_pRender.create(self.m_size)
         self.resetFrame()
 
-    # sample_example.cpp:168-178
+    def _render_size(self):
+        """sample_example.cpp:410-413: the size actually rendered (integer division by the de-scaling level while a mouse button is down)"""
+        if self.m_descaling:
+            return (max(1, self.m_size[0] // self.m_descalingLevel), max(1, self.m_size[1] // self.m_descalingLevel))
+        return self.m_size
+
+    # sample_example.cpp:168-178 (the aspect ratio is the render region's, whatever the de-scaling)
     def updateUniformBuffer(self):
         cam = capi.camera_lookat(self.m_scene.camera, self.m_size[0] / self.m_size[1], nb_lights=len(self.m_scene.lights))
         self.m_pRender.set_camera(cam)
         self.m_pRender.set_sunsky(self.m_sunAndSky)
 
-    # sample_example.cpp:183-199 (camera-change detection is the caller's resetFrame())
+    # sample_example.cpp:183-199: "If the camera matrix has changed, resets the frame otherwise, increments frame."  CameraManip.getMatrix() is
+    # the view matrix of (eye, center, up); comparing the three vectors it is computed from is the same predicate.
     def updateFrame(self):
+        c = self.m_scene.camera if self.m_scene is not None else None
+        m = None if c is None else (tuple(float(x) for x in c.eye), tuple(float(x) for x in c.center), tuple(float(x) for x in c.up))
+        f = 0.0 if c is None else float(c.fov)
+        if self._refCamMatrix != m or self._refFov != f:
+            self.resetFrame()
+            self._refCamMatrix, self._refFov = m, f
         if self.m_rtxState.frame < self.m_maxFrames:
             self.m_rtxState.frame += 1
 
     def resetFrame(self):  # sample_example.cpp:204-207
         self.m_rtxState.frame = -1
 
+    # sample_example.cpp:528-541 / :546-557 -- the de-scaling state machine of the window callbacks
+    def onMouseMotion(self, x=0, y=0):
+        if self._inputs["lmb"] or self._inputs["rmb"] or self._inputs["mmb"]:
+            self.m_descaling = True
+
+    def onMouseButton(self, button, pressed):
+        """button: "lmb" | "mmb" | "rmb"; pressed: GLFW_PRESS (True) / GLFW_RELEASE (False)"""
+        self._inputs[button] = bool(pressed)
+        if not (self._inputs["lmb"] or self._inputs["rmb"] or self._inputs["mmb"]) and not pressed and self.m_descaling:
+            self.m_descaling = False
+            self.resetFrame()
+
     # sample_example.cpp:390-429
     def renderScene(self):
         if self.m_rtxState.frame >= self.m_maxFrames:
             return
-        self.m_rtxState.size[0], self.m_rtxState.size[1] = self.m_size
+        size = self._render_size()
+        self.m_rtxState.size[0], self.m_rtxState.size[1] = size
         self.m_pRender.setPushContants(self.m_rtxState)
-        self.m_pRender.run(None, self.m_size, None, None)
+        self.m_pRender.run(None, size, None, None)
 
-    # sample_example.cpp:362-384 -> RenderOutput::run
+    # sample_example.cpp:362-384 -> RenderOutput::run; :378 `zoom = m_descaling ? 1.0f / m_descalingLevel : 1.0f`
     def drawPost(self):
+        if self.m_descaling:
+            self.m_tonemapper.zoom = 1.0 / self.m_descalingLevel
+            return self.m_pRender.tonemap(self.m_tonemapper, display_size=self.m_size)
+        self.m_tonemapper.zoom = 1.0
         return self.m_pRender.tonemap(self.m_tonemapper)
 
     def render(self, frames):

@@ -192,3 +192,58 @@ def rotate_z(a):
     m = np.eye(4, dtype=np.float32)
     m[0, 0], m[0, 1], m[1, 0], m[1, 1] = c, -s, s, c
     return m
+
+
+class GltfFileScene:
+    """A .gltf / .glb file imported by libptmi's own C++ importer (pt_gltf_load: the Scene::load of the drop-in, reference
+    src/scene.cpp:56-155) -- what a C++ host gets.  Same surface as `Scene` as far as the renderer, the oracle binding and bench.py use it
+    (desc(), camera, counts, node_array()); the flat arrays stay owned by the importer until close()."""
+
+    def __init__(self, path):
+        from . import capi
+        self.path = str(path)
+        self.name = self.path
+        self._L = capi.lib()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._L.pt_gltf_load(self.path.encode(), C.byref(self._h), err, 512)
+        if rc != capi.PT_OK:
+            raise ValueError(f"pt_gltf_load({self.path}): {err.value.decode()}")
+        d = self._L.pt_gltf_desc(self._h).contents
+        self._desc = d
+        self.vertices = True  # (Scene.finalize() has nothing to do: the importer packs the vertices itself)
+        self.prim_meshes = [tuple(int(x) for x in t) for t in
+                            np.frombuffer(C.string_at(d.primMeshes, d.numPrimMeshes * hd.primmesh_dtype.itemsize), hd.primmesh_dtype).tolist()]
+        self._nodes = np.frombuffer(C.string_at(d.nodes, d.numNodes * hd.node_dtype.itemsize), hd.node_dtype).copy()
+        self.nodes = [(np.asarray(n["worldMatrix"], np.float32).reshape(4, 4).T.copy(), int(n["primMesh"])) for n in self._nodes]
+        self.materials = list(np.frombuffer(C.string_at(d.materials, d.numMaterials * hd.material_dtype.itemsize), hd.material_dtype).copy())
+        self.lights = list(np.frombuffer(C.string_at(d.lights, d.numLights * hd.light_dtype.itemsize), hd.light_dtype).copy()) if d.numLights else []
+        self.textures = [None] * int(d.numTextures)
+        e, c, u = (np.zeros(3, np.float32) for _ in range(3))
+        f = C.c_float()
+        self._L.pt_gltf_camera(self._h, e.ctypes.data, c.ctypes.data, u.ctypes.data, C.byref(f))
+        self.camera = Camera(tuple(float(x) for x in e), tuple(float(x) for x in c), tuple(float(x) for x in u), float(f.value))
+
+    def finalize(self, pack_fn=None):
+        return self
+
+    @property
+    def num_triangles(self):
+        return sum(self.prim_meshes[pm][3] // 3 for _, pm in self.nodes)
+
+    def node_array(self):
+        return self._nodes.copy()
+
+    def desc(self):
+        return self._desc, (self,)
+
+    def close(self):
+        if self._h:
+            self._L.pt_gltf_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -74,19 +74,32 @@ class NativeGather:
         from . import capi
         self._C, self._capi, self._lib = C, capi, capi.lib()
         self.rank, self.nranks = rank, nranks
+        self.comm = None
+        if nranks > 1 and dist is None:
+            raise ValueError("more than one rank needs a torch.distributed process group to distribute the ncclUniqueId")
         ident = (C.c_ubyte * 128)()
-        if rank == 0 and self._lib.pt_comm_get_unique_id(ident) != capi.PT_OK:
-            raise capi.PtError(capi.PT_ERR_HIP, "pt_comm_get_unique_id (is librccl.so present?)")
+        rc = self._lib.pt_comm_get_unique_id(ident) if rank == 0 else capi.PT_OK
+        # rank 0's status travels with the id: if it failed (librccl.so missing, ...) EVERY rank raises instead of waiting in the broadcast
+        box = [(rc, bytes(ident), self._lib.pt_comm_last_error().decode() if rc != capi.PT_OK else "")]
         if nranks > 1:
-            if dist is None:
-                raise ValueError("more than one rank needs a torch.distributed process group to distribute the ncclUniqueId")
-            box = [bytes(ident)]
             dist.broadcast_object_list(box, src=0)
-            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
-        self.comm = C.c_void_p()
-        rc = self._lib.pt_comm_init_rank(nranks, ident, rank, device_ordinal, C.byref(self.comm))
+        rc, raw, why = box[0]
         if rc != capi.PT_OK:
-            raise capi.PtError(rc, "pt_comm_init_rank")
+            raise capi.PtError(rc, f"pt_comm_get_unique_id on rank 0: {why}")
+        ident = (C.c_ubyte * 128).from_buffer_copy(raw)
+        comm = C.c_void_p()
+        rc = self._lib.pt_comm_init_rank(nranks, ident, rank, device_ordinal, C.byref(comm))
+        if rc != capi.PT_OK:
+            raise capi.PtError(rc, "pt_comm_init_rank: " + self._lib.pt_comm_last_error().decode())
+        self.comm = comm
+
+    def ranks_seen(self):
+        """ncclCommCount of the communicator: the number of processes that really met."""
+        n = self._C.c_int(0)
+        rc = self._lib.pt_comm_count(self.comm, self._C.byref(n))
+        if rc != self._capi.PT_OK:
+            raise self._capi.PtError(rc, "pt_comm_count: " + self._lib.pt_comm_last_error().decode())
+        return n.value
 
     def gather(self, renderer):
         """Full RGBA32F image on rank 0, None elsewhere."""

@@ -34,8 +34,13 @@ def real_asset(name):
     for rel in (f"{name}.gltf", f"{name}.glb", f"{name}/{name}.gltf", f"{name}/glTF/{name}.gltf", f"{name}/glTF-Binary/{name}.glb"):
         p = os.path.join(root, rel)
         if os.path.exists(p):
-            from . import gltf
-            return gltf.load_gltf(p)
+            # libptmi's own importer (pt_gltf_load, csrc/pt_gltf.cpp): the path a C++ host takes; PT_ASSET_IMPORTER=python selects the
+            # Python importer (vk_raytrace_amd/gltf.py, its cross-check)
+            if os.environ.get("PT_ASSET_IMPORTER") == "python":
+                from . import gltf
+                return gltf.load_gltf(p)
+            from .scene import GltfFileScene
+            return GltfFileScene(p)
     return None
 
 
@@ -54,8 +59,8 @@ def c2_helmet(scale=1.0):
 def c3_sponza(width=1920, height=1080, spp=256, tex_size=1024, target_tris=262_267, env_w=2048):
     real = real_asset("Sponza")
     if real is not None:
-        return Workload(f"C3 Sponza (real asset from PT_ASSET_DIR, {real.num_triangles} tris) {width}x{height} {spp}spp depth8 Disney + HDR env",
-                        real, synth.procedural_sky(env_w, env_w // 2), width, height, spp, 8, 0)
+        return Workload(f"C3 Sponza (glTF file {getattr(real, 'path', 'from PT_ASSET_DIR')}, {real.num_triangles} tris) {width}x{height} {spp}spp depth8 Disney + HDR env",
+                        real, synth.procedural_sky(env_w, env_w // 2), width, height, spp, 8, 0, note="gltf")
     return Workload(f"C3 sponza-like (synthetic Crytek-Sponza stand-in, {target_tris} tris target) {width}x{height} {spp}spp depth8 Disney + HDR env",
                     synth.sponza_like(target_tris=target_tris, tex_size=tex_size), synth.procedural_sky(env_w, env_w // 2), width, height, spp, 8, 0)
 
