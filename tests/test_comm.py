@@ -78,6 +78,13 @@ def test_single_process_gather_with_one_device():
     L = capi.lib()
     cfg = Config(synth.feature_box(tex_size=32), synth.procedural_sky(128, 64), 200, 120)
     img, r = render_hip(cfg, 3, return_obj=True)
+    # the one-process-per-GPU flavour with a single rank first (what bench.py's N > 1 ranks do): unique id -> pt_comm_init_rank
+    from vk_raytrace_amd import shard
+    g = shard.NativeGather(0, 1, 0)
+    assert g.ranks_seen() == 1
+    got = g.gather(r)
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
+    g.close()
     comm = C.c_void_p()
     dev = (C.c_int * 1)(0)
     rc = L.pt_comm_init_all(1, dev, C.byref(comm))

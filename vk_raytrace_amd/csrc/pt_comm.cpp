@@ -50,6 +50,7 @@ bool load()
   Rccl&                       r = rccl();
   if(r.handle)
     return true;
+  setenv("NCCL_DEBUG", "WARN", 0);  // RCCL then names the failing call on stderr when something goes wrong (silent otherwise); never overrides the caller's setting
   // PT_RCCL_LIB: test hook (a name that cannot be opened exercises the "library missing" answers on a host that has RCCL)
   const char* forced = std::getenv("PT_RCCL_LIB");
   void*       h      = nullptr;
@@ -135,6 +136,7 @@ int pt_comm_init_rank(int nranks, const unsigned char id[PT_COMM_ID_BYTES], int 
   std::memcpy(&uid, id, sizeof(uid));
   rcclComm_t   c = nullptr;
   rcclResult_t r;
+  (void)hipGetLastError();  // RCCL reads the thread's sticky HIP error: a stale hipErrorNotReady of an event query must not become its "unhandled cuda error"
   if((r = rccl().CommInitRank(&c, nranks, uid, rank)) != 0)
     return fail(PT_ERR_HIP, "ncclCommInitRank", r);
   *out_comm = reinterpret_cast<pt_comm*>(c);
@@ -155,6 +157,7 @@ int pt_comm_init_all(int ndev, const int* device_ordinals, pt_comm** out_comms)
     return fail(PT_ERR_NO_DEVICE, msg);
   }
   rcclResult_t r;
+  (void)hipGetLastError();  // (see pt_comm_init_rank)
   if((r = rccl().CommInitAll(reinterpret_cast<rcclComm_t*>(out_comms), ndev, device_ordinals)) != 0)
     return fail(PT_ERR_HIP, "ncclCommInitAll", r);
   return PT_OK;
@@ -233,6 +236,7 @@ int pt_gather_shards(pt_context* ctx, pt_comm* comm, int root)
     return PT_ERR_HIP;
   const size_t count = bytes / sizeof(float);
   rcclResult_t r;
+  (void)hipGetLastError();  // (see pt_comm_init_rank)
   if((r = rccl().GroupStart()) != 0)
     return nccl_fail(ctx, "ncclGroupStart", r);
   int          firstErr = PT_OK;
