@@ -1,19 +1,18 @@
 // Packet traversal for coherent rays (the primary rays of an 8x8 pixel block = one wavefront).
 //
-// All 64 lanes walk ONE traversal: the node / triangle records are fetched with scalar loads into SGPRs (one fetch per
-// wave instead of one per lane, no per-lane address arithmetic, no vector-memory latency in the dependent chain), the
-// stack is a single wave-level array and the child order is decided once per wave on the scalar unit.  What stays per
-// lane is the arithmetic that defines the result: the slab tests against the lane's own ray and best-hit bound, the
-// ray/triangle test and the candidate rules of traverse<TM_CLOSEST> (pt_trace.h) -- so hits, alpha counts and flags
-// are those of the per-lane traversal (the trace contract is independent of the visiting order).
+// All 64 lanes walk ONE traversal of the 8-wide structure (pt_cwbvh.h): node and triangle records are fetched with scalar loads into SGPRs
+// (one fetch per wave instead of one per lane, no per-lane address arithmetic, no vector-memory latency in the dependent chain), the node /
+// triangle groups and the stack of postponed groups are wave-level (SGPRs + one LDS array), and the visiting order comes from the octant the
+// packet shares.  What stays per lane is the arithmetic that defines the result: the box tests against the lane's own ray and best-hit bound,
+// the ray/triangle test and the candidate rules of pass A (pt_trace.h lane_triangle<TM_CLOSEST>) -- so hits, alpha counts and flags are
+// those of the per-lane traversal (the trace contract is independent of the visiting order).  A child is visited when ANY lane hits its box.
 //
-// The fused slab test picks near / far planes by the sign of the ray direction; a packet shares that choice only if
-// all its lanes agree on the three signs.  The (rare) packets that do not -- the block containing the optical axis --
-// fall back to the per-lane traversal.
+// The octant order needs all lanes to agree on the three direction signs.  The (rare) packets that do not -- the block containing the
+// optical axis -- fall back to the per-lane traversal.
 #pragma once
 #include "pt_trace.h"
 
-#define PACKET_STACK 128  // wave-level stack entries (4-wide nodes push at most 3 per visit; overflow is counted like the per-lane one)
+#define PACKET_STACK 64  // wave-level stack entries (one per node visit at most: as deep as the tree; overflow is counted like the per-lane one)
 
 typedef float    pt_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t pt_u4v __attribute__((ext_vector_type(4)));
@@ -31,143 +30,116 @@ PT_DEV uint4 sloadu4(const void* base, uint32_t byteOff)
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// `valid`: the lane carries a ray.  wstack: PACKET_STACK dwords of LDS shared by the wave.  Returns false when the packet
+#define PK_UB(x, j) float(((x) >> (8 * (j))) & 0xffu)
+#define PK_CHILD(w, j)                                                                                                                                                      \
+  {                                                                                                                                                                         \
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(PK_UB(nx[w], j), sx, blx), __builtin_fmaf(PK_UB(ny[w], j), sy, bly)), fmaxf(__builtin_fmaf(PK_UB(nz[w], j), sz, blz), 0.0f)); \
+    const float tf = fminf(fminf(__builtin_fmaf(PK_UB(fx[w], j), sx, bhx), __builtin_fmaf(PK_UB(fy[w], j), sy, bhy)), fminf(__builtin_fmaf(PK_UB(fz[w], j), sz, bhz), lim));  \
+    if(__ballot(valid && tn <= tf))                                                                                                                                         \
+      hits |= ((bits[w] >> (8 * (j))) & 0xffu) << ((index[w] >> (8 * (j))) & 0xffu);                                                                                        \
+  }
+
+// `valid`: the lane carries a ray.  wstack: PACKET_STACK uint2 of LDS shared by the wave.  Returns false when the packet
 // is not sign-coherent (nothing was traversed; the caller runs the per-lane traversal instead).
-// SHADOW: any-hit semantics of traverse<TM_SHADOW> -- an opaque hit inside (0, tmax) ends the lane (`opaqueHit`), the bound stays
-// tmax because an opaque occluder may lie behind the nearest non-opaque candidate.
-template <bool SHADOW>
-PT_DEV bool traverse_packet(const DeviceScene& S, bool valid, f3 o, f3 d, float tmax, uint32_t* wstack, RayHit& best, bool& opaqueHit, Counters* counters)
+PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint2* wstack, RayHit& best, Counters* counters)
 {
-  const RayBox rb = make_raybox(o, d);
-  opaqueHit       = false;
+  TraceLane L;  // the per-lane part of the state: ray, best hit, alpha bookkeeping (groups / stack fields unused: they are wave-level here)
+  lane_begin(L, o, d, PT_INFINITY, false);
+  const BoxRay&            R  = L.R;
   const unsigned long long vm = __ballot(valid);
-  const unsigned long long sx = __ballot(valid && rb.idir.x < 0.0f), sy = __ballot(valid && rb.idir.y < 0.0f), sz = __ballot(valid && rb.idir.z < 0.0f);
-  if((sx != 0ull && sx != vm) || (sy != 0ull && sy != vm) || (sz != 0ull && sz != vm))
+  const unsigned long long sx_ = __ballot(valid && R.idir.x < 0.0f), sy_ = __ballot(valid && R.idir.y < 0.0f), sz_ = __ballot(valid && R.idir.z < 0.0f);
+  if((sx_ != 0ull && sx_ != vm) || (sy_ != 0ull && sy_ != vm) || (sz_ != 0ull && sz_ != vm))
     return false;
-  best.slot = BVH_NONE; best.t = tmax; best.w = 0xffffffffu; best.flags = 0; best.count = 0;
+  best.slot = BVH_NONE; best.t = PT_INFINITY; best.w = 0xffffffffu; best.flags = 0; best.count = 0;
   best.zeroMaxT = best.zeroMaxT2 = best.zeroMaxT3 = -1.0f;
   best.u = best.v = 0.0f;
   if(S.numTris == 0 || vm == 0ull)
     return true;
-  const uint32_t offX = sx ? 48u : 0u, offY = sy ? 48u : 0u, offZ = sz ? 48u : 0u;  // wave-uniform
+  const bool     negx = sx_ != 0ull, negy = sy_ != 0ull, negz = sz_ != 0ull;  // wave-uniform
+  const uint32_t octinv = 7u ^ ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u));
+  const uint32_t oct4   = octinv * 0x01010101u;
 
-  uint32_t cur = 0;
+  uint32_t ngx = 0u, ngy = (1u << (24u + octinv)) | 1u, tgx = 0u, tgy = 0u;  // wave-uniform groups: the root
   int      sp  = 0;
-#ifdef PT_HIST
-  uint32_t hInner = 0, hLeaf = 0;
-#endif
   for(;;)
   {
-#ifdef PT_HIST
-    if(cur & BVH_LEAF) ++hLeaf; else ++hInner;
-#endif
-    if(!(cur & BVH_LEAF))
+    if(tgy)
+    {  // up to two triangles of the group, both records in flight together
+      const uint32_t j0 = uint32_t(__builtin_ctz(tgy));
+      tgy &= tgy - 1u;
+      const bool     two = tgy != 0u;
+      const uint32_t j1  = two ? uint32_t(__builtin_ctz(tgy)) : j0;
+      tgy &= tgy - 1u;
+      const uint32_t s0 = (tgx + j0) * 48u, s1 = (tgx + j1) * 48u;
+      TriRec         a, b;
+      a.p0w = sload4(S.tris, s0); a.e1n = sload4(S.tris, s0 + 16u); a.e2p = sload4(S.tris, s0 + 32u);
+      b.p0w = sload4(S.tris, s1); b.e1n = sload4(S.tris, s1 + 16u); b.e2p = sload4(S.tris, s1 + 32u);
+      if(valid)
+        lane_triangle<TM_CLOSEST, false>(S, L, tgx + j0, a);
+      if(two && valid)
+        lane_triangle<TM_CLOSEST, false>(S, L, tgx + j1, b);
+      continue;
+    }
+    if(!(ngy & 0xff000000u))
     {
-      const uint32_t at = (cur & BVH_SLOT_MASK) << 7;
-      const float4   px = sload4(S.wide, at + offX), qx = sload4(S.wide, at + 48u - offX);
-      const float4   py = sload4(S.wide, at + 16u + offY), qy = sload4(S.wide, at + 64u - offY);
-      const float4   pz = sload4(S.wide, at + 32u + offZ), qz = sload4(S.wide, at + 80u - offZ);
-      const uint4    ch = sloadu4(S.wide, at + 96u);
-      const float    pxs[4] = {px.x, px.y, px.z, px.w}, qxs[4] = {qx.x, qx.y, qx.z, qx.w};
-      const float    pys[4] = {py.x, py.y, py.z, py.w}, qys[4] = {qy.x, qy.y, qy.z, qy.w};
-      const float    pzs[4] = {pz.x, pz.y, pz.z, pz.w}, qzs[4] = {qz.x, qz.y, qz.z, qz.w};
-      const uint32_t cc[4]  = {ch.x, ch.y, ch.z, ch.w};
-      float          key[4];   // wave-uniform ordering key: entry distance of the first lane that hits the child
-      uint32_t       cid[4];
-      int            nh = 0;
-#pragma unroll
-      for(int k = 0; k < 4; ++k)
+      if(sp == 0)
+        break;
+      const uint2 e = wstack[--sp];
+      const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+      if(!(ey & 0xff000000u))
       {
-        const float nr = fmaxf(fmaxf(__builtin_fmaf(pxs[k], rb.idir.x, rb.nlo.x), __builtin_fmaf(pys[k], rb.idir.y, rb.nlo.y)), fmaxf(__builtin_fmaf(pzs[k], rb.idir.z, rb.nlo.z), 0.0f)) * 0.9999996f;
-        const float fr = fminf(fminf(__builtin_fmaf(qxs[k], rb.idir.x, rb.nhi.x), __builtin_fmaf(qys[k], rb.idir.y, rb.nhi.y)), fminf(__builtin_fmaf(qzs[k], rb.idir.z, rb.nhi.z), SHADOW ? tmax : best.t)) * 1.0000004f;
-        const unsigned long long hm = (cc[k] != BVH_NONE) ? __ballot(valid && nr <= fr) : 0ull;
-        if(hm)
-        {
-          key[nh] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nr), __ffsll((long long)hm) - 1));
-          cid[nh] = cc[k];
-          ++nh;
-        }
-      }
-      if(nh)
-      {
-        // scalar insertion sort, nearest first (nh <= 4, all operands wave-uniform)
-#pragma unroll
-        for(int i = 1; i < 4; ++i)
-          for(int j = i; j > 0 && j < nh && key[j] < key[j - 1]; --j)
-          {
-            const float    tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
-            const uint32_t tc = cid[j]; cid[j] = cid[j - 1]; cid[j - 1] = tc;
-          }
-        for(int i = nh - 1; i >= 1; --i)
-        {
-          if(sp < PACKET_STACK)
-            wstack[sp++] = cid[i];
-          else if((threadIdx.x & 63) == 0)
-            atomicAdd(&counters->stackOverflow, 1u);
-        }
-        cur = cid[0];
+        tgx = ex;
+        tgy = ey;
         continue;
       }
+      ngx = ex;
+      ngy = ey;
     }
-    else
+    const uint32_t r    = 31u - uint32_t(__builtin_clz(ngy));
+    const uint32_t slot = (r - 24u) ^ octinv;
+    ngy &= ~(1u << r);
+    const uint32_t child = ngx + uint32_t(__builtin_popcount(ngy & ((1u << slot) - 1u) & 0xffu));
+    if(ngy & 0xff000000u)
     {
-      const uint32_t slot = cur & BVH_SLOT_MASK;
-      const float4   t0 = sload4(S.tris, slot * 48u), t1 = sload4(S.tris, slot * 48u + 16u), t2 = sload4(S.tris, slot * 48u + 32u);
-      TriRec         tr;
-      tr.p0w = t0; tr.e1n = t1; tr.e2p = t2;
-      const uint32_t wbits = __float_as_uint(t0.w);
-      const uint32_t flags = wbits >> 29;
-      const bool     opq   = (flags & TRI_OPAQUE) != 0;
-      float          t, u, v;
-      if(valid && tri_test(tr, flags, o, d, t, u, v) && t > 0.0f && t < tmax)
+      if(sp < PACKET_STACK)
       {
-        const uint32_t w = wbits & TRI_INDEX_MASK;
-        if(SHADOW && opq)
-        {
-          opaqueHit = true;
-          valid     = false;  // the lane leaves the packet
-        }
-        else if(best.slot == BVH_NONE || key_less(t, w, best.t, best.w & TRI_INDEX_MASK))
-        {
-          bool certain = opq;
-          if(!opq)
-          {
-            const float op = opacity_class(S, S.alphaRecs[slot], u, v);
-            certain        = op >= 1.0f;
-            if(!certain)
-            {
-              best.flags |= (op <= 0.0f) ? TF_SAW_ZERO : TF_SAW_FRAC;
-              if(op <= 0.0f)
-              {
-                best.count++;
-                note_zero_candidate(t, best.zeroMaxT, best.zeroMaxT2, best.zeroMaxT3);
-              }
-            }
-          }
-          if(certain)
-          {
-            best.t = t; best.u = u; best.v = v; best.slot = slot; best.w = wbits;
-          }
-        }
+        if((threadIdx.x & 63) == 0)
+          wstack[sp] = make_uint2(ngx, ngy);
+        ++sp;
       }
+      else if((threadIdx.x & 63) == 0)
+        atomicAdd(&counters->stackOverflow, 1u);
     }
-    if(sp == 0 || (SHADOW && __ballot(valid) == 0ull))
-      break;
-    cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
+    // ---- the node through scalar loads
+    const uint32_t at = child * uint32_t(CW_NODE_BYTES);
+    const uint4    h0 = sloadu4(S.wide, at), h1 = sloadu4(S.wide, at + 16u), q0 = sloadu4(S.wide, at + 32u), q1 = sloadu4(S.wide, at + 48u), q2 = sloadu4(S.wide, at + 64u);
+    const float sx = __uint_as_float((h0.w & 0xffu) << 23) * R.idir.x, sy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23) * R.idir.y, sz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23) * R.idir.z;
+    const float bx = (__uint_as_float(h0.x) - R.o.x) * R.idir.x, by = (__uint_as_float(h0.y) - R.o.y) * R.idir.y, bz = (__uint_as_float(h0.z) - R.o.z) * R.idir.z;
+    const float ex = (fabsf(bx) + 255.0f * fabsf(sx)) * 8.0e-7f, ey = (fabsf(by) + 255.0f * fabsf(sy)) * 8.0e-7f, ez = (fabsf(bz) + 255.0f * fabsf(sz)) * 8.0e-7f;
+    const float blx = bx - ex, bhx = bx + ex, bly = by - ey, bhy = by + ey, blz = bz - ez, bhz = bz + ez;
+    const uint32_t nx[2] = {negx ? q1.z : q0.x, negx ? q1.w : q0.y}, fx[2] = {negx ? q0.x : q1.z, negx ? q0.y : q1.w};
+    const uint32_t ny[2] = {negy ? q2.x : q0.z, negy ? q2.y : q0.w}, fy[2] = {negy ? q0.z : q2.x, negy ? q0.w : q2.y};
+    const uint32_t nz[2] = {negz ? q2.z : q1.x, negz ? q2.w : q1.y}, fz[2] = {negz ? q1.x : q2.z, negz ? q1.y : q2.w};
+    uint32_t       bits[2], index[2];
+#pragma unroll
+    for(int w = 0; w < 2; ++w)
+    {
+      const uint32_t meta  = w ? h1.w : h1.z;
+      const uint32_t inner = ((meta & (meta << 1)) & 0x10101010u) >> 4;
+      index[w]             = (meta ^ (oct4 & (inner * 0xffu))) & 0x1f1f1f1fu;
+      bits[w]              = (meta >> 5) & 0x07070707u;
+    }
+    const float lim  = L.bt;
+    uint32_t    hits = 0;
+    PK_CHILD(0, 0) PK_CHILD(0, 1) PK_CHILD(0, 2) PK_CHILD(0, 3) PK_CHILD(1, 0) PK_CHILD(1, 1) PK_CHILD(1, 2) PK_CHILD(1, 3)
+    ngx = h1.x & CW_CHILD_MASK;
+    ngy = (hits & 0xff000000u) | (h0.w >> 24);
+    tgx = h1.y;
+    tgy = hits & 0x00ffffffu;
   }
-#ifdef PT_HIST
-  if((threadIdx.x & 63) == 0)
-  {
-    atomicAdd(&g_hist[7][SHADOW ? 4 : 0], (unsigned long long)hInner); atomicAdd(&g_hist[7][SHADOW ? 5 : 1], (unsigned long long)hLeaf); atomicAdd(&g_hist[7][SHADOW ? 6 : 2], 1ull);
-    atomicAdd(&g_hist[7][SHADOW ? 7 : 3], (unsigned long long)__popcll(vm));
-  }
-#endif
+  best.slot = L.bslot; best.t = L.bt; best.u = L.bu; best.v = L.bv; best.w = L.bw; best.flags = L.flags; best.count = L.cnt;
+  best.zeroMaxT = L.zeroMaxT; best.zeroMaxT2 = L.zeroMaxT2; best.zeroMaxT3 = L.zeroMaxT3;
   return true;
 }
-
-PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint32_t* wstack, RayHit& best, Counters* counters)
-{
-  bool dummy;
-  return traverse_packet<false>(S, valid, o, d, PT_INFINITY, wstack, best, dummy, counters);
-}
-
+#undef PK_CHILD
+#undef PK_UB
