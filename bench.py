@@ -108,6 +108,29 @@ def self_launch(n):
     return rc
 
 
+def usable_cores():
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a container that sees 256 cores through
+    the affinity mask but is throttled to a few would otherwise run 256 spinning OpenMP threads on them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]       # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def latest_profile(kind):
     """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's)."""
     for rnd in ("r03", "r02"):
@@ -308,11 +331,21 @@ def main():
         ost.size[0], ost.size[1] = W, H
         ost.maxDepth, ost.pbrMode, ost.maxSamples = wl.depth, wl.pbr_mode, 1
         ost.fireflyClampThreshold = 4.0 * integral
-        cores = os.cpu_count()
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
+        # threads: what the scheduler / cgroup quota say, then a short probe (a box may show 256 cores and deliver a fraction: spinning
+        # OpenMP threads on throttled cores are slower than fewer threads) -- the fastest of {all, 64, 32, 16, 8} on two frames of the sample
+        cores, best_rate = usable_cores(), 0.0
+        probe_acc = np.zeros((H, W, 4), np.float32)
+        o.L.orc_set_threads(o.ctx, cores)
+        o.render_frames(ost, 0, 1, probe_acc, ids)  # (lazy BVH build of the oracle: not part of any timing)
+        for cand in sorted({c for c in (cores, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True):
+            o.L.orc_set_threads(o.ctx, cand)
+            t0 = time.perf_counter()
+            o.render_frames(ost, 1, 2, probe_acc, ids)
+            rate = 2 * len(ids) / (time.perf_counter() - t0)
+            if rate > best_rate * 1.05:
+                best_rate, threads = rate, cand
+        cores = threads
+        o.L.orc_set_threads(o.ctx, cores)
 
         def timed(render_frames, budget_s):
             """frames of the sample per call inside ONE thread team (no fork / join per frame); the first call (lazy BVH build, page faults) is not timed"""
@@ -335,7 +368,7 @@ def main():
                 rr = ref.Reference(wl.scene, wl.env, oracle=o)
                 rr.set_camera(cam)
                 rr.set_sunsky(hd.default_sun_and_sky())
-                ref_v, ref_f, ref_t = timed(rr.render_frames, args.cpu_seconds / 2)
+                ref_v, ref_f, ref_t = timed(lambda st_, f0, nf, acc, ids_: rr.render_frames(st_, f0, nf, acc, ids_, threads=cores), args.cpu_seconds / 2)
                 base = {"value": ref_v, "unit": "Msamples/s", "cores": cores, "kind": "reference",
                         "sample": f"oracle/_ref = the reference's shaders/pathtrace.comp compiled for the host (OpenMP, one invocation per pixel like vkCmdDispatch; ray queries and "
                                   f"texture filtering bound to the oracle's trace contract), every 16th 8x8 pixel block of the same {W}x{H} workload ({len(ids)} pixels), {ref_f} frames, {ref_t:.1f} s",

@@ -129,7 +129,7 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
 extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
-extern "C" int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut, uint32_t* numNodesOut, uint32_t* depthOut);
+extern "C" int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, uint32_t leafMax, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut, uint32_t* numNodesOut, uint32_t* depthOut);
 extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut, uint32_t* alphaMapsOut, uint32_t* texelsOut,
                                       void* texRecsOut, char* err, size_t errLen);
 extern "C" int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel* out, float* out_integral, float* out_average);
@@ -149,8 +149,8 @@ struct Bvh {
 
 // the per-thread traversal stack of the walks: LDS part and spill part, one "lane" (stride TRACE_BLOCK like on the device)
 struct HostStack {
-  std::vector<uint2> lds, spill;
-  HostStack() : lds(size_t(STACK_LDS) * TRACE_BLOCK), spill(size_t(STACK_SPILL) * TRACE_BLOCK) {}
+  std::vector<uint32_t> lds, spill;
+  HostStack() : lds(size_t(STACK_LDS_WORDS)), spill(size_t(STACK_SPILL_WORDS)) {}
   TStack view() { return TStack{lds.data(), spill.data()}; }
 };
 
@@ -176,8 +176,9 @@ float half_area_h(const Box& b)
   return dx * dy + dy * dz + dz * dx;
 }
 
-// records (edge form, flags in p0w.w >> 29) -> leaf order + 4-wide nodes (k_gather, k_refit, k_emit, k_collapse)
-Bvh build_bvh(const std::vector<TriRec>& in)
+// records (edge form, flags in p0w.w >> 29) -> leaf order + 8-wide nodes (k_gather, k_refit, k_emit, k_collapse8).  leafMax: triangles per leaf
+// child (CW_LEAF_MAX; 1 for the TLAS, whose "triangles" are instances)
+Bvh build_bvh(const std::vector<TriRec>& in, uint32_t leafMax = CW_LEAF_MAX)
 {
   Bvh            out;
   const uint32_t n = uint32_t(in.size());
@@ -252,7 +253,7 @@ Bvh build_bvh(const std::vector<TriRec>& in)
   std::vector<uint32_t> perm(n);
   uint32_t              numNodes = 0;
   out.wide.resize(cap);
-  if(pt_debug_cw_collapse(b2.data(), n, out.wide.data(), cap, perm.data(), &numNodes, &out.depth) != 0)
+  if(pt_debug_cw_collapse(b2.data(), n, leafMax, out.wide.data(), cap, perm.data(), &numNodes, &out.depth) != 0)
   {
     out.tris.clear();
     out.wide.clear();
@@ -418,7 +419,7 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
     prox.push_back(r);
   }
-  s->tlas = build_bvh(prox);
+  s->tlas = build_bvh(prox, 1u);
   for(const TriRec& r : s->tlas.tris)
   {
     const uint32_t id = __float_as_uint(r.p0w.w) & TRI_INDEX_MASK;
@@ -557,8 +558,9 @@ void th_world_tri(void* p, uint32_t w, float* out9, uint32_t* flags)
 
 // Invariants of an 8-wide quantised structure (pt_cwbvh.h), checked by walking it: which 0 flat, 1 TLAS.  For every node and child slot the
 // DECODED box (p + q 2^e, evaluated in double) must enclose everything below that child -- the padded boxes (k_gather's tri_box) of all its
-// triangles --, inner children are the consecutive nodes childBase + rank, the triangles of leaf children consecutive slots from triBase, every
-// leaf slot is referenced exactly once, empty slots carry no bits, amask tags exactly the children that hold non-opaque triangles.
+// triangles --, inner children are the consecutive nodes childBase + rank, the triangles of leaf children consecutive slots from triBase in
+// slot order, every leaf slot is referenced exactly once, empty slots are inverted and untagged, amask tags exactly the children that hold
+// non-opaque triangles, every plane is an integer of the 11-bit grid.
 // out: [0] violations, [1] nodes reached, [2] triangles reached, [3] depth, [4] children in total, [5] leaf children in total.
 void th_check_structure(void* p, int which, uint32_t* out6)
 {
@@ -580,25 +582,27 @@ void th_check_structure(void* p, int which, uint32_t* out6)
     ++nodes;
     maxDepth = std::max(maxDepth, depth);
     const CwNode& nd = b.wide[idx];
-    const uint32_t imask = nd.eimask >> 24, amask = nd.childBase >> 24;
-    uint32_t       rank = 0;
+    const uint32_t imask = nd.eimask >> 24, amask = nd.childBase >> 24, l1 = nd.leaves & 0xffu, l2 = (nd.leaves >> 8) & 0xffu;
+    uint32_t       rank = 0, triOff = 0;
+    if((imask & l1) || (l2 & ~l1))
+      ++bad;
     for(int k = 0; k < 8; ++k)
     {
-      const uint32_t meta = (nd.meta[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      auto           q    = [&](const uint32_t* w) { return double((w[k >> 2] >> (8 * (k & 3))) & 0xffu); };
+      auto           q    = [&](const uint16_t* w) { return double(cw_float_of_half(w[k])); };
       const double   step[3] = {std::ldexp(1.0, int(nd.eimask & 0xff) - 127), std::ldexp(1.0, int((nd.eimask >> 8) & 0xff) - 127), std::ldexp(1.0, int((nd.eimask >> 16) & 0xff) - 127)};
       const double   dlo[3] = {nd.p[0] + q(nd.qlox) * step[0], nd.p[1] + q(nd.qloy) * step[1], nd.p[2] + q(nd.qloz) * step[2]};
       const double   dhi[3] = {nd.p[0] + q(nd.qhix) * step[0], nd.p[1] + q(nd.qhiy) * step[1], nd.p[2] + q(nd.qhiz) * step[2]};
+      for(const uint16_t* w : {nd.qlox, nd.qloy, nd.qloz, nd.qhix, nd.qhiy, nd.qhiz})
+        if(cw_half_of_int(uint32_t(cw_float_of_half(w[k]))) != w[k] || cw_float_of_half(w[k]) > float(CW_GRID_MAX))
+          ++bad;  // every plane is an integer of the grid
       Content        c{{1e300, 1e300, 1e300}, {-1e300, -1e300, -1e300}, false};
       if((imask >> k) & 1u)
       {
-        if(meta != (0x20u | (24u + uint32_t(k))))
-          ++bad;
         c = visit((nd.childBase & CW_CHILD_MASK) + rank, depth + 1);
         ++rank;
         ++children;
       }
-      else if(meta == 0u)
+      else if(!((l1 >> k) & 1u))
       {
         if(dlo[0] <= dhi[0] && dlo[1] <= dhi[1] && dlo[2] <= dhi[2])
           ++bad;  // an empty slot must carry an inverted box
@@ -608,14 +612,12 @@ void th_check_structure(void* p, int which, uint32_t* out6)
       }
       else
       {
-        const uint32_t unary = meta >> 5, off = meta & 31u, count = unary == 1 ? 1 : unary == 3 ? 2 : unary == 7 ? 3 : 0;
-        if(count == 0 || off + count > 24)
-          ++bad;
+        const uint32_t count = ((l2 >> k) & 1u) ? 2u : 1u;
         ++children;
         ++leaves;
         for(uint32_t j = 0; j < count; ++j)
         {
-          const uint32_t slot = nd.triBase + off + j;
+          const uint32_t slot = nd.triBase + triOff + j;
           if(slot >= b.tris.size())
           {
             ++bad;
@@ -632,6 +634,7 @@ void th_check_structure(void* p, int which, uint32_t* out6)
           }
           c.alpha = c.alpha || !((__float_as_uint(b.tris[slot].p0w.w) >> 29) & TRI_OPAQUE);
         }
+        triOff += count;
       }
       for(int a = 0; a < 3; ++a)
         if(!(dlo[a] <= c.lo[a] && dhi[a] >= c.hi[a]))

@@ -980,14 +980,14 @@ __global__ void k_tlas_leaves(uint32_t n, const TriRec* __restrict__ leafOrder, 
 // counters: [0] items of the next level, [1] CwNodes allocated, [2] triangles placed.  perm[new leaf slot] = old (binary-tree order) leaf slot.
 // Inner children of a node take consecutive node ids, the triangles of its leaf children consecutive leaf slots: one atomic each per node.
 __global__ void k_collapse8(const BvhNode* __restrict__ b2, const CwItem* __restrict__ qin, uint32_t nIn, CwItem* __restrict__ qout, uint32_t* counters, uint32_t nodeCapacity,
-                            CwNode* __restrict__ out, uint32_t* __restrict__ perm)
+                            CwNode* __restrict__ out, uint32_t* __restrict__ perm, uint32_t leafMax)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= nIn)
     return;
   const CwItem it = qin[i];
   CwOpen       open[CW_WIDTH];
-  const int    n = cw_gather_children(b2, it.b2, open);
+  const int    n = cw_gather_children(b2, it.b2, open, leafMax);
   CwChild      ch[CW_WIDTH];
   uint32_t     nInner = 0, nTri = 0;
   float        nlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -998,7 +998,7 @@ __global__ void k_collapse8(const BvhNode* __restrict__ b2, const CwItem* __rest
       ch[c].lo[a] = open[c].lo[a]; ch[c].hi[a] = open[c].hi[a];
       nlo[a] = fminf(nlo[a], open[c].lo[a]); nhi[a] = fmaxf(nhi[a], open[c].hi[a]);
     }
-    const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= CW_LEAF_MAX;
+    const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= leafMax;
     ch[c].kind  = leaf ? open[c].count : 0u;
     ch[c].alpha = (open[c].ref & BVH_ALPHA) ? 1u : 0u;
     nInner += leaf ? 0u : 1u;
@@ -1309,7 +1309,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     while(nIn)
     {
       HIPCHK(hipMemcpyAsync(dCnt, cnt, 16, hipMemcpyHostToDevice, stream));
-      k_collapse8<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, cwCapacity, dCwOut, dPerm);
+      k_collapse8<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, cwCapacity, dCwOut, dPerm, dProxies ? 1u : uint32_t(CW_LEAF_MAX));  // (TLAS: one instance per leaf)
       HIPCHK(hipMemcpyAsync(cnt, dCnt, 16, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
       if(cnt[3] || cnt[1] > cwCapacity || cnt[2] > n)
@@ -1500,10 +1500,10 @@ done:
 // binary tree in the builder's format -- the same cw_* bodies (pt_cwbvh.h), plain counters instead of atomics, the same level-synchronous order.
 // nodesOut: `capacity` CwNodes; permOut[new leaf slot] = old leaf slot (numTris entries).  Returns 0, or -1 when a node cannot be encoded /
 // the capacity is exceeded.
-extern "C" __attribute__((visibility("default"))) int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut,
+extern "C" __attribute__((visibility("default"))) int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, uint32_t leafMax, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut,
                                                                           uint32_t* numNodesOut, uint32_t* depthOut)
 {
-  if(!b2 || !nodesOut || !permOut || numTris == 0 || capacity == 0)
+  if(!b2 || !nodesOut || !permOut || numTris == 0 || capacity == 0 || leafMax < 1 || leafMax > CW_LEAF_MAX)
     return -1;
   std::vector<CwItem> cur{CwItem{0u, 0u}}, next;
   uint32_t            numNodes = 1, numPlaced = 0, depth = 0;
@@ -1513,7 +1513,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_cw_collapse(const
     for(const CwItem& it : cur)
     {
       CwOpen    open[CW_WIDTH];
-      const int n = cw_gather_children(b2, it.b2, open);
+      const int n = cw_gather_children(b2, it.b2, open, leafMax);
       CwChild   ch[CW_WIDTH];
       uint32_t  nInner = 0, nTri = 0;
       float     nlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -1524,7 +1524,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_cw_collapse(const
           ch[c].lo[a] = open[c].lo[a]; ch[c].hi[a] = open[c].hi[a];
           nlo[a] = std::fmin(nlo[a], open[c].lo[a]); nhi[a] = std::fmax(nhi[a], open[c].hi[a]);
         }
-        const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= CW_LEAF_MAX;
+        const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= leafMax;
         ch[c].kind  = leaf ? open[c].count : 0u;
         ch[c].alpha = (open[c].ref & BVH_ALPHA) ? 1u : 0u;
         nInner += leaf ? 0u : 1u;

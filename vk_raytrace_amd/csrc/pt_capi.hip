@@ -1210,8 +1210,8 @@ int pt_resize(pt_context* c, int width, int height)
       for(DevBuf* bf : q)
         ok = ok && dev_alloc_quiet(*bf, 4 * n);
       ok = ok && dev_alloc_quiet(fs.dSortHist, sizeof(uint32_t) * SORT_BINS) && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
-      // traversal-stack levels beyond the LDS part: one slice per wavefront of a launch (109 MB per frame slot; only trees deeper than STACK_LDS touch it)
-      ok = ok && dev_alloc_quiet(fs.dSpill, sizeof(uint2) * size_t(PT_SPILL_WAVES) * STACK_SPILL * TRACE_BLOCK);
+      // traversal-stack levels beyond the LDS part: one slice per wavefront of a launch (86 MB per frame slot; only trees deeper than STACK_LDS touch it)
+      ok = ok && dev_alloc_quiet(fs.dSpill, sizeof(uint32_t) * size_t(PT_SPILL_WAVES) * STACK_SPILL_WORDS);
       if(ok)
         HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
     }
@@ -1261,7 +1261,7 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.sortKeys = (uint32_t*)fs.dSortKeys.p;
     fs.rb.sortHist = (uint32_t*)fs.dSortHist.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
-    fs.rb.spill    = (uint2*)fs.dSpill.p;
+    fs.rb.spill    = (uint32_t*)fs.dSpill.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
@@ -1510,9 +1510,9 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
   int rc;
   if((rc = dev_alloc(c, c->dPick, sizeof(pt_PickResult))) != PT_OK)
     return rc;
-  if((rc = dev_alloc(c, c->dPickSpill, sizeof(uint2) * size_t(STACK_SPILL) * TRACE_BLOCK)) != PT_OK)
+  if((rc = dev_alloc(c, c->dPickSpill, sizeof(uint32_t) * size_t(STACK_SPILL_WORDS))) != PT_OK)
     return rc;
-  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p, (Counters*)c->dCounters.p, (uint2*)c->dPickSpill.p);
+  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p, (Counters*)c->dCounters.p, (uint32_t*)c->dPickSpill.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dPick.p, sizeof(pt_PickResult), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

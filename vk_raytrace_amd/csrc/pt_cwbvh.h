@@ -1,27 +1,29 @@
-// The acceleration structure the traversal kernels walk: an 8-wide BVH with child boxes quantised to 8 bits per plane on a per-node grid
-// (after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017), laid out for gfx950.
+// The acceleration structure the traversal kernels walk: an 8-wide BVH whose child boxes are quantised to an 11-bit grid per node and stored as
+// fp16 integers (after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017 -- their 8-bit
+// planes and octant-ordered child slots, adapted to what is cheap on gfx950).
 //
 // Why (measured on the 4-wide fp32 layout of rounds 1-2, profiles/r03_valu.json / r03_cache.json): the trace kernels spend ~60 % of their wave
-// cycles parked on memory -- a wavefront waits for the slowest of its 64 lanes, and with 128 B per 4 children (10 MB of nodes for the 269 k
-// triangle stand-in against 4 MB of L2 per XCD) nearly every step has a lane that goes out to Infinity Cache / HBM.  Here one node visit
-// decides 8 children from 80 B (five aligned 16-byte loads per lane, 2 MB of nodes for the same scene), a node's hit leaf triangles are
-// fetched together, and a ray needs ~0.65x the dependent round trips (profiles/r02c_steps_experiment.txt).
+// cycles parked on memory -- a wavefront waits for the slowest of its 64 lanes -- and the rest on ~37 VALU instructions per child box.  Here
+// one node visit decides 8 children from 128 B (eight aligned 16-byte loads per lane, all in flight together; the 4-wide layout spent the same
+// bytes on 4 children), a ray needs ~0.65x the dependent round trips, and a plane costs ONE instruction: v_fma_mix_f32 reads the fp16 grid
+// coordinate straight out of a register half and multiplies it with the fp32 grid step (an 8-bit plane costs a conversion and an FMA;
+// first measured that way: 1.7x the VALU work per ray of the 4-wide layout and 10 % slower, profiles/r03c_variants_*.txt).
 //
-//   CwNode, 80 B:
+//   CwNode, 128 B:
 //     p[3]          fp32 origin of the node's quantisation grid (lower corner of the union of its children's boxes)
-//     e[3]          one exponent byte per axis: grid step 2^(e - 127); 255 steps cover the node's extent
+//     e[3]          one exponent byte per axis: grid step 2^(e - 127); 2047 steps cover the node's extent
 //     imask         bit k: child slot k is an inner node
 //     childBase     24 bits: index of the first inner child (the inner children of a node are consecutive nodes, in slot order)
 //                   | amask << 24: bit k: slot k holds non-opaque triangles (leaf) / its subtree does (inner) -- the alpha-only walks skip the rest
 //     triBase       leaf slot of the node's first triangle (the triangles of a node's leaf children are consecutive records, in slot order)
-//     meta[8]       per slot: empty 0x00; inner 0x20 | (24 + slot); leaf (unary triangle count: 1, 3, 7) << 5 | offset of its first triangle
-//     qlo/qhi[3][8] the child boxes on the grid: lower planes rounded down, upper planes rounded up (conservative by construction: the
-//                   builder checks p + q 2^e against the fp32 box in double precision)
+//     l1 | l2 << 8  bit k of l1: slot k is a leaf; of l2: that leaf holds two triangles (else one)
+//     qlo/qhi[3][8] the child boxes on the grid as fp16 integers 0 .. 2047: lower planes rounded down, upper planes rounded up (conservative
+//                   by construction: the builder checks p + q 2^e against the fp32 box in double precision); empty slots: inverted (2047, 0)
 //
 // Child slots are not arbitrary: a child is put into the slot whose sign pattern (bit 0 / 1 / 2 = x / y / z on the + side of the node centre)
 // matches where it lies, so that visiting the hit slots in increasing (slot XOR ray-direction signs) is a front-to-back order that costs no
-// sorting (cw_assign_slots).  The traversal (pt_trace.h) builds a 32-bit hit mask per visit -- bits 24..31: hit inner children at position
-// 24 + (slot ^ octinv), bits 0..23: hit triangles at their offset from triBase -- and pops the highest bit first.
+// sorting (cw_assign_slots) -- over ALL children, leaves and inner nodes alike: a leaf's triangles are tested when its turn comes, not before
+// nearer inner children (testing a node's leaves first cost 2x the triangle tests, tools/steps_experiment.py).
 //
 // The functions below are plain code of (inputs) -> (node) shared by the device builder (pt_accel.hip k_collapse8), its host emulation
 // (pt_debug_cw_collapse, used by the CPU tests) and nothing else.
@@ -37,11 +39,10 @@
 #endif
 
 #define CW_WIDTH 8
-#ifndef CW_LEAF_MAX
-#define CW_LEAF_MAX 3          // triangles per leaf child (3 x 8 = 24 triangle bits of the hit mask)
-#endif
+#define CW_LEAF_MAX 2          // triangles per leaf child (both records are fetched together)
+#define CW_GRID_MAX 2047       // largest grid coordinate (the fp16 integers 0 .. 2048 are exact)
 #define CW_EXP_MIN 27          // exponent byte floor (2^-100): ray-side products with it never underflow, so an inverted (empty) box can never test as hit
-#define CW_NODE_BYTES 80
+#define CW_NODE_BYTES 128
 #define CW_CHILD_MASK 0x00ffffffu
 
 struct CwNode {
@@ -49,17 +50,41 @@ struct CwNode {
   uint32_t eimask;     // e[0] | e[1] << 8 | e[2] << 16 | imask << 24
   uint32_t childBase;  // first inner child | amask << 24
   uint32_t triBase;
-  uint32_t meta[2];    // slots 0..3, 4..7 (byte k of the pair = slot k)
-  uint32_t qlox[2], qloy[2];
-  uint32_t qloz[2], qhix[2];
-  uint32_t qhiy[2], qhiz[2];
+  uint32_t leaves;     // l1 | l2 << 8
+  uint32_t _pad;
+  uint16_t qlox[8], qloy[8], qloz[8];  // fp16 bit patterns, slot k at [k]; 16 B per plane set: the ray's direction signs pick near / far by ADDRESS
+  uint16_t qhix[8], qhiy[8], qhiz[8];
 };
-static_assert(sizeof(CwNode) == CW_NODE_BYTES, "CwNode is five 16-byte loads");
+static_assert(sizeof(CwNode) == CW_NODE_BYTES, "CwNode is eight 16-byte loads");
+#define CW_OFF_QLO 32u  // byte offset of qlox; qloy, qloz follow at +16, +32
+#define CW_OFF_QHI 80u  // byte offset of qhix
+
+// fp16 bit pattern of the integer q (0 .. 2048): exact
+CW_FN uint16_t cw_half_of_int(uint32_t q)
+{
+  if(q == 0)
+    return 0;
+  int e = 0;
+  while((q >> (e + 1)) != 0)
+    ++e;
+  return uint16_t(((uint32_t(e) + 15u) << 10) | ((q << (10 - e)) & 0x3ffu));
+}
+// and back (normal, non-negative halves only: what the nodes hold)
+CW_FN float cw_float_of_half(uint32_t h)
+{
+  h &= 0xffffu;
+  if(h == 0)
+    return 0.0f;
+  const uint32_t bits = (((h >> 10) + 112u) << 23) | ((h & 0x3ffu) << 13);
+  float          f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
 
 // what a collapse step knows about one child of the node it emits
 struct CwChild {
   float    lo[3], hi[3];
-  uint32_t kind;      // 0: inner node, 1..CW_LEAF_MAX: leaf with that many triangles
+  uint32_t kind;      // 0: inner node, 1..leafMax: leaf with that many triangles
   uint32_t alpha;     // non-opaque triangles in it / below it
 };
 
@@ -100,14 +125,14 @@ CW_FN void cw_assign_slots(const CwChild* ch, int n, const float nlo[3], const f
   }
 }
 
-// Grid of one axis: origin p (fp32), exponent byte e with 2^(e-127) * 255 >= extent.  Quantisation runs in double so that "the decoded plane
+// Grid of one axis: origin p (fp32), exponent byte e with 2^(e-127) * 2047 >= extent.  Quantisation runs in double so that "the decoded plane
 // encloses the fp32 plane" is exact arithmetic, not an argument about rounding.
 CW_FN uint32_t cw_axis_exponent(float lo, float hi)
 {
   const double ext = double(hi) - double(lo);
   int          e   = CW_EXP_MIN;
-  // smallest e with 255 * 2^(e-127) >= ext
-  while(e < 254 && 255.0 * ldexp(1.0, e - 127) < ext)
+  // smallest e with 2047 * 2^(e-127) >= ext
+  while(e < 254 && double(CW_GRID_MAX) * ldexp(1.0, e - 127) < ext)
     ++e;
   return uint32_t(e);
 }
@@ -116,7 +141,7 @@ CW_FN uint32_t cw_quant_lo(float v, float p, uint32_t e)
   const double step = ldexp(1.0, int(e) - 127);
   double       q    = floor((double(v) - double(p)) / step);
   if(q < 0.0) q = 0.0;
-  if(q > 255.0) q = 255.0;
+  if(q > double(CW_GRID_MAX)) q = double(CW_GRID_MAX);
   while(q > 0.0 && double(p) + q * step > double(v))  // (never taken for finite inputs: floor is exact in double here; kept as the stated invariant)
     q -= 1.0;
   return uint32_t(q);
@@ -126,7 +151,7 @@ CW_FN uint32_t cw_quant_hi(float v, float p, uint32_t e)
   const double step = ldexp(1.0, int(e) - 127);
   double       q    = ceil((double(v) - double(p)) / step);
   if(q < 0.0) q = 0.0;
-  if(q > 255.0) q = 255.0;
+  if(q > double(CW_GRID_MAX)) q = double(CW_GRID_MAX);
   return uint32_t(q);
 }
 
@@ -150,12 +175,12 @@ CW_FN bool cw_encode_node(const CwChild* ch, int n, const int slotOf[CW_WIDTH], 
   for(int a = 0; a < 3; ++a)
   {
     e[a] = cw_axis_exponent(nlo[a], nhi[a]);
-    // the upper planes must fit into 255 steps counted from p: bump the exponent if rounding up overflows the byte
+    // the upper planes must fit into 2047 steps counted from p: bump the exponent if rounding up overflows the grid
     for(;;)
     {
       bool ok = true;
       for(int c = 0; c < n && ok; ++c)
-        ok = double(nlo[a]) + 255.0 * ldexp(1.0, int(e[a]) - 127) >= double(ch[c].hi[a]);
+        ok = double(nlo[a]) + double(CW_GRID_MAX) * ldexp(1.0, int(e[a]) - 127) >= double(ch[c].hi[a]);
       if(ok || e[a] >= 254)
         break;
       ++e[a];
@@ -164,17 +189,15 @@ CW_FN bool cw_encode_node(const CwChild* ch, int n, const int slotOf[CW_WIDTH], 
   CwNode nd;
   memset(&nd, 0, sizeof(nd));
   nd.p[0] = nlo[0]; nd.p[1] = nlo[1]; nd.p[2] = nlo[2];
-  uint8_t  qlo[3][CW_WIDTH], qhi[3][CW_WIDTH], meta[CW_WIDTH];
+  uint16_t* qlo[3] = {nd.qlox, nd.qloy, nd.qloz};
+  uint16_t* qhi[3] = {nd.qhix, nd.qhiy, nd.qhiz};
   for(int s = 0; s < CW_WIDTH; ++s)
-  {
-    meta[s] = 0;
     for(int a = 0; a < 3; ++a)
     {
-      qlo[a][s] = 255;  // inverted box: an empty slot is never hit (and if it were, its meta byte of 0 contributes no bits)
-      qhi[a][s] = 0;
+      qlo[a][s] = cw_half_of_int(CW_GRID_MAX);  // inverted box: an empty slot is never hit (and if it were, it is neither inner nor leaf: no work)
+      qhi[a][s] = cw_half_of_int(0);
     }
-  }
-  uint32_t imask = 0, amask = 0;
+  uint32_t imask = 0, amask = 0, l1 = 0, l2 = 0;
   int      childInSlot[CW_WIDTH];
   for(int s = 0; s < CW_WIDTH; ++s)
     childInSlot[s] = -1;
@@ -188,20 +211,21 @@ CW_FN bool cw_encode_node(const CwChild* ch, int n, const int slotOf[CW_WIDTH], 
       continue;
     for(int a = 0; a < 3; ++a)
     {
-      qlo[a][s] = uint8_t(cw_quant_lo(ch[c].lo[a], nlo[a], e[a]));
-      qhi[a][s] = uint8_t(cw_quant_hi(ch[c].hi[a], nlo[a], e[a]));
+      qlo[a][s] = cw_half_of_int(cw_quant_lo(ch[c].lo[a], nlo[a], e[a]));
+      qhi[a][s] = cw_half_of_int(cw_quant_hi(ch[c].hi[a], nlo[a], e[a]));
     }
     if(ch[c].alpha)
       amask |= 1u << s;
     if(ch[c].kind == 0)
     {
       imask |= 1u << s;
-      meta[s]      = uint8_t(0x20u | (24u + uint32_t(s)));
       innerRank[c] = nInner++;
     }
     else
     {
-      meta[s]      = uint8_t((((1u << ch[c].kind) - 1u) << 5) | nTri);
+      l1 |= 1u << s;
+      if(ch[c].kind == 2)
+        l2 |= 1u << s;
       triOffset[c] = nTri;
       nTri += ch[c].kind;
     }
@@ -209,13 +233,7 @@ CW_FN bool cw_encode_node(const CwChild* ch, int n, const int slotOf[CW_WIDTH], 
   nd.eimask    = e[0] | (e[1] << 8) | (e[2] << 16) | (imask << 24);
   nd.childBase = (childBase & CW_CHILD_MASK) | (amask << 24);
   nd.triBase   = triBase;
-  auto pack4 = [](const uint8_t* b) { return uint32_t(b[0]) | (uint32_t(b[1]) << 8) | (uint32_t(b[2]) << 16) | (uint32_t(b[3]) << 24); };
-  for(int w = 0; w < 2; ++w)
-  {
-    nd.meta[w] = pack4(meta + 4 * w);
-    nd.qlox[w] = pack4(qlo[0] + 4 * w); nd.qloy[w] = pack4(qlo[1] + 4 * w); nd.qloz[w] = pack4(qlo[2] + 4 * w);
-    nd.qhix[w] = pack4(qhi[0] + 4 * w); nd.qhiy[w] = pack4(qhi[1] + 4 * w); nd.qhiz[w] = pack4(qhi[2] + 4 * w);
-  }
+  nd.leaves    = l1 | (l2 << 8);
   *out = nd;
   return true;
 }
@@ -223,9 +241,10 @@ CW_FN bool cw_encode_node(const CwChild* ch, int n, const int slotOf[CW_WIDTH], 
 // ---- collapse: binary tree -> CwNodes ----------------------------------------------------------------------------------------------------
 // One work item = (binary node to open, CwNode id it becomes).  The binary tree is the builder's product (BvhNode: both child boxes in the
 // parent, child references with BVH_LEAF / BVH_ALPHA tags, d.z / d.w = number of triangles below the left / right child).
-//   1. open the child of largest surface area that is an inner binary node with more than CW_LEAF_MAX triangles, until 8 children;
+//   1. open the child of largest surface area that is an inner binary node with more than leafMax triangles, until 8 children;
 //   2. slots left over: open multi-triangle leaves-to-be (largest area first) -- a box test per triangle costs nothing extra in an 8-wide node;
-//   3. what remains inner with <= CW_LEAF_MAX triangles becomes ONE leaf child holding those triangles.
+//   3. what remains inner with <= leafMax triangles becomes ONE leaf child holding those triangles.
+// leafMax: CW_LEAF_MAX for triangles, 1 for the TLAS (a lane enters one instance at a time).
 struct CwItem {
   uint32_t b2;    // binary node (index into the BvhNode array)
   uint32_t node;  // CwNode it becomes
@@ -276,7 +295,7 @@ CW_FN int cw_leaf_slots(const BvhNode* b2, uint32_t ref, uint32_t* slots)
   return n;
 }
 // Gathers the (up to 8) children of work item `it`.  Returns their number.
-CW_FN int cw_gather_children(const BvhNode* b2, uint32_t b2node, CwOpen* ch)
+CW_FN int cw_gather_children(const BvhNode* b2, uint32_t b2node, CwOpen* ch, uint32_t leafMax)
 {
   int n = cw_open_children(b2, b2node, ch);
   for(int phase = 0; phase < 2; ++phase)
@@ -287,7 +306,7 @@ CW_FN int cw_gather_children(const BvhNode* b2, uint32_t b2node, CwOpen* ch)
       for(int k = 0; k < n; ++k)
       {
         const bool inner = !(ch[k].ref & BVH_LEAF);
-        if(inner && (phase == 0 ? ch[k].count > CW_LEAF_MAX : true))
+        if(inner && (phase == 0 ? ch[k].count > leafMax : true))
         {
           const float a = cw_half_area(ch[k]);
           if(a > bestA)

@@ -83,7 +83,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
 #define PT_PERSISTENT_WAVES (256u * 20u)
-#define PT_SPILL_WAVES 2048  // wavefronts of one launch that own a slice of a frame slot's traversal-stack spill area (STACK_SPILL x 64 entries each)
+#define PT_SPILL_WAVES 2048  // wavefronts of one launch that own a slice of a frame slot's traversal-stack spill area (STACK_SPILL_WORDS words each)
 
 struct RenderBuffers {
   PathState ps;
@@ -98,7 +98,7 @@ struct RenderBuffers {
   uint32_t* sortKeys;  // sort key of every entry of the queue being sorted
   uint32_t* sortHist;  // SORT_BINS bin counters -> bin offsets
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
-  uint2*    spill;     // traversal-stack entries beyond the LDS levels: [wave of the launch][level][lane] (pt_trace.h)
+  uint32_t* spill;     // traversal-stack entries beyond the LDS levels: [wave of the launch][word][level][lane] (pt_trace.h)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
   Counters* counters;
@@ -150,7 +150,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
 #define SORT_MAX_CELL_BITS 5
 #define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint2* spill);
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint32_t* spill);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles);
 // the offscreen image with its mip chain as the display pass samples it (level 0 = the image; src/render_output.cpp:188-193)

@@ -2,7 +2,7 @@
 //
 // All 64 lanes walk ONE traversal of the 8-wide structure (pt_cwbvh.h): node and triangle records are fetched with scalar loads into SGPRs
 // (one fetch per wave instead of one per lane, no per-lane address arithmetic, no vector-memory latency in the dependent chain), the node /
-// triangle groups and the stack of postponed groups are wave-level (SGPRs + one LDS array), and the visiting order comes from the octant the
+// group and the stack of postponed groups are wave-level (SGPRs + one LDS array), and the visiting order comes from the octant the
 // packet shares.  What stays per lane is the arithmetic that defines the result: the box tests against the lane's own ray and best-hit bound,
 // the ray/triangle test and the candidate rules of pass A (pt_trace.h lane_triangle<TM_CLOSEST>) -- so hits, alpha counts and flags are
 // those of the per-lane traversal (the trace contract is independent of the visiting order).  A child is visited when ANY lane hits its box.
@@ -30,20 +30,21 @@ PT_DEV uint4 sloadu4(const void* base, uint32_t byteOff)
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-#define PK_UB(x, j) float(((x) >> (8 * (j))) & 0xffu)
-#define PK_CHILD(w, j)                                                                                                                                                      \
-  {                                                                                                                                                                         \
-    const float tn = fmaxf(fmaxf(__builtin_fmaf(PK_UB(nx[w], j), sx, blx), __builtin_fmaf(PK_UB(ny[w], j), sy, bly)), fmaxf(__builtin_fmaf(PK_UB(nz[w], j), sz, blz), 0.0f)); \
-    const float tf = fminf(fminf(__builtin_fmaf(PK_UB(fx[w], j), sx, bhx), __builtin_fmaf(PK_UB(fy[w], j), sy, bhy)), fminf(__builtin_fmaf(PK_UB(fz[w], j), sz, bhz), lim));  \
-    if(__ballot(valid && tn <= tf))                                                                                                                                         \
-      hits |= ((bits[w] >> (8 * (j))) & 0xffu) << ((index[w] >> (8 * (j))) & 0xffu);                                                                                        \
+#define PK_CHILD(k)                                                                                                                                            \
+  {                                                                                                                                                            \
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(cw_plane(cw_word(nx, (k) >> 1), (k) & 1), sx, blx), __builtin_fmaf(cw_plane(cw_word(ny, (k) >> 1), (k) & 1), sy, bly)), \
+                           fmaxf(__builtin_fmaf(cw_plane(cw_word(nz, (k) >> 1), (k) & 1), sz, blz), 0.0f));                                                    \
+    const float tf = fminf(fminf(__builtin_fmaf(cw_plane(cw_word(fx, (k) >> 1), (k) & 1), sx, bhx), __builtin_fmaf(cw_plane(cw_word(fy, (k) >> 1), (k) & 1), sy, bhy)), \
+                           fminf(__builtin_fmaf(cw_plane(cw_word(fz, (k) >> 1), (k) & 1), sz, bhz), lim));                                                     \
+    if(__ballot(valid && tn <= tf))                                                                                                                            \
+      hits |= 1u << (k);                                                                                                                                       \
   }
 
-// `valid`: the lane carries a ray.  wstack: PACKET_STACK uint2 of LDS shared by the wave.  Returns false when the packet
+// `valid`: the lane carries a ray.  wstack: PACKET_STACK x 3 words of LDS shared by the wave.  Returns false when the packet
 // is not sign-coherent (nothing was traversed; the caller runs the per-lane traversal instead).
-PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint2* wstack, RayHit& best, Counters* counters)
+PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d, uint32_t* wstack, RayHit& best, Counters* counters)
 {
-  TraceLane L;  // the per-lane part of the state: ray, best hit, alpha bookkeeping (groups / stack fields unused: they are wave-level here)
+  TraceLane L;  // the per-lane part of the state: ray, best hit, alpha bookkeeping (group / stack fields unused: they are wave-level here)
   lane_begin(L, o, d, PT_INFINITY, false);
   const BoxRay&            R  = L.R;
   const unsigned long long vm = __ballot(valid);
@@ -57,54 +58,48 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
     return true;
   const bool     negx = sx_ != 0ull, negy = sy_ != 0ull, negz = sz_ != 0ull;  // wave-uniform
   const uint32_t octinv = 7u ^ ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u));
-  const uint32_t oct4   = octinv * 0x01010101u;
+  const uint32_t ox = negx ? 48u : 0u, oy = negy ? 48u : 0u, oz = negz ? 48u : 0u;
 
-  uint32_t ngx = 0u, ngy = (1u << (24u + octinv)) | 1u, tgx = 0u, tgy = 0u;  // wave-uniform groups: the root
-  int      sp  = 0;
+  uint32_t gx = 0u | (1u << (24u + octinv)), gy = 0u, gz = 1u;  // the wave-uniform group: the root
+  int      sp = 0;
   for(;;)
   {
-    if(tgy)
-    {  // up to two triangles of the group, both records in flight together
-      const uint32_t j0 = uint32_t(__builtin_ctz(tgy));
-      tgy &= tgy - 1u;
-      const bool     two = tgy != 0u;
-      const uint32_t j1  = two ? uint32_t(__builtin_ctz(tgy)) : j0;
-      tgy &= tgy - 1u;
-      const uint32_t s0 = (tgx + j0) * 48u, s1 = (tgx + j1) * 48u;
+    if(!(gx >> 24))
+    {
+      if(sp == 0)
+        break;
+      --sp;
+      gx = __builtin_amdgcn_readfirstlane(wstack[3 * sp]);
+      gy = __builtin_amdgcn_readfirstlane(wstack[3 * sp + 1]);
+      gz = __builtin_amdgcn_readfirstlane(wstack[3 * sp + 2]);
+    }
+    const uint32_t r    = 31u - uint32_t(__builtin_clz(gx));
+    const uint32_t slot = (r - 24u) ^ octinv;
+    gx &= ~(1u << r);
+    if((gz >> (8u + slot)) & 1u)
+    {  // a leaf: one or two triangles, both records in flight together
+      const uint32_t below = (1u << slot) - 1u;
+      const uint32_t first = gy + uint32_t(__builtin_popcount((gz >> 8) & below & 0xffu)) + uint32_t(__builtin_popcount((gz >> 16) & below & 0xffu));
+      const bool     two   = ((gz >> (16u + slot)) & 1u) != 0u;
+      const uint32_t s0 = first * 48u, s1 = (first + (two ? 1u : 0u)) * 48u;
       TriRec         a, b;
       a.p0w = sload4(S.tris, s0); a.e1n = sload4(S.tris, s0 + 16u); a.e2p = sload4(S.tris, s0 + 32u);
       b.p0w = sload4(S.tris, s1); b.e1n = sload4(S.tris, s1 + 16u); b.e2p = sload4(S.tris, s1 + 32u);
       if(valid)
-        lane_triangle<TM_CLOSEST, false>(S, L, tgx + j0, a);
+        lane_triangle<TM_CLOSEST, false>(S, L, first, a);
       if(two && valid)
-        lane_triangle<TM_CLOSEST, false>(S, L, tgx + j1, b);
+        lane_triangle<TM_CLOSEST, false>(S, L, first + 1u, b);
       continue;
     }
-    if(!(ngy & 0xff000000u))
-    {
-      if(sp == 0)
-        break;
-      const uint2 e = wstack[--sp];
-      const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
-      if(!(ey & 0xff000000u))
-      {
-        tgx = ex;
-        tgy = ey;
-        continue;
-      }
-      ngx = ex;
-      ngy = ey;
-    }
-    const uint32_t r    = 31u - uint32_t(__builtin_clz(ngy));
-    const uint32_t slot = (r - 24u) ^ octinv;
-    ngy &= ~(1u << r);
-    const uint32_t child = ngx + uint32_t(__builtin_popcount(ngy & ((1u << slot) - 1u) & 0xffu));
-    if(ngy & 0xff000000u)
+    const uint32_t child = (gx & CW_CHILD_MASK) + uint32_t(__builtin_popcount(gz & ((1u << slot) - 1u) & 0xffu));
+    if(gx >> 24)
     {
       if(sp < PACKET_STACK)
       {
         if((threadIdx.x & 63) == 0)
-          wstack[sp] = make_uint2(ngx, ngy);
+        {
+          wstack[3 * sp] = gx; wstack[3 * sp + 1] = gy; wstack[3 * sp + 2] = gz;
+        }
         ++sp;
       }
       else if((threadIdx.x & 63) == 0)
@@ -112,34 +107,26 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
     }
     // ---- the node through scalar loads
     const uint32_t at = child * uint32_t(CW_NODE_BYTES);
-    const uint4    h0 = sloadu4(S.wide, at), h1 = sloadu4(S.wide, at + 16u), q0 = sloadu4(S.wide, at + 32u), q1 = sloadu4(S.wide, at + 48u), q2 = sloadu4(S.wide, at + 64u);
+    const uint4    h0 = sloadu4(S.wide, at), h1 = sloadu4(S.wide, at + 16u);
+    const uint4    nx = sloadu4(S.wide, at + CW_OFF_QLO + ox), fx = sloadu4(S.wide, at + CW_OFF_QHI - ox);
+    const uint4    ny = sloadu4(S.wide, at + CW_OFF_QLO + 16u + oy), fy = sloadu4(S.wide, at + CW_OFF_QHI + 16u - oy);
+    const uint4    nz = sloadu4(S.wide, at + CW_OFF_QLO + 32u + oz), fz = sloadu4(S.wide, at + CW_OFF_QHI + 32u - oz);
     const float sx = __uint_as_float((h0.w & 0xffu) << 23) * R.idir.x, sy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23) * R.idir.y, sz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23) * R.idir.z;
     const float bx = (__uint_as_float(h0.x) - R.o.x) * R.idir.x, by = (__uint_as_float(h0.y) - R.o.y) * R.idir.y, bz = (__uint_as_float(h0.z) - R.o.z) * R.idir.z;
-    const float ex = (fabsf(bx) + 255.0f * fabsf(sx)) * 8.0e-7f, ey = (fabsf(by) + 255.0f * fabsf(sy)) * 8.0e-7f, ez = (fabsf(bz) + 255.0f * fabsf(sz)) * 8.0e-7f;
+    const float gmax = float(CW_GRID_MAX);
+    const float ex = (fabsf(bx) + gmax * fabsf(sx)) * 8.0e-7f, ey = (fabsf(by) + gmax * fabsf(sy)) * 8.0e-7f, ez = (fabsf(bz) + gmax * fabsf(sz)) * 8.0e-7f;
     const float blx = bx - ex, bhx = bx + ex, bly = by - ey, bhy = by + ey, blz = bz - ez, bhz = bz + ez;
-    const uint32_t nx[2] = {negx ? q1.z : q0.x, negx ? q1.w : q0.y}, fx[2] = {negx ? q0.x : q1.z, negx ? q0.y : q1.w};
-    const uint32_t ny[2] = {negy ? q2.x : q0.z, negy ? q2.y : q0.w}, fy[2] = {negy ? q0.z : q2.x, negy ? q0.w : q2.y};
-    const uint32_t nz[2] = {negz ? q2.z : q1.x, negz ? q2.w : q1.y}, fz[2] = {negz ? q1.x : q2.z, negz ? q1.y : q2.w};
-    uint32_t       bits[2], index[2];
-#pragma unroll
-    for(int w = 0; w < 2; ++w)
-    {
-      const uint32_t meta  = w ? h1.w : h1.z;
-      const uint32_t inner = ((meta & (meta << 1)) & 0x10101010u) >> 4;
-      index[w]             = (meta ^ (oct4 & (inner * 0xffu))) & 0x1f1f1f1fu;
-      bits[w]              = (meta >> 5) & 0x07070707u;
-    }
     const float lim  = L.bt;
     uint32_t    hits = 0;
-    PK_CHILD(0, 0) PK_CHILD(0, 1) PK_CHILD(0, 2) PK_CHILD(0, 3) PK_CHILD(1, 0) PK_CHILD(1, 1) PK_CHILD(1, 2) PK_CHILD(1, 3)
-    ngx = h1.x & CW_CHILD_MASK;
-    ngy = (hits & 0xff000000u) | (h0.w >> 24);
-    tgx = h1.y;
-    tgy = hits & 0x00ffffffu;
+    PK_CHILD(0) PK_CHILD(1) PK_CHILD(2) PK_CHILD(3) PK_CHILD(4) PK_CHILD(5) PK_CHILD(6) PK_CHILD(7)
+    const uint32_t kinds = (h0.w >> 24) | ((h1.z & 0xffffu) << 8);
+    hits &= (kinds | (kinds >> 8)) & 0xffu;
+    gx = (h1.x & CW_CHILD_MASK) | (cw_visit_order(hits, octinv) << 24);
+    gy = h1.y;
+    gz = kinds;
   }
   best.slot = L.bslot; best.t = L.bt; best.u = L.bu; best.v = L.bv; best.w = L.bw; best.flags = L.flags; best.count = L.cnt;
   best.zeroMaxT = L.zeroMaxT; best.zeroMaxT2 = L.zeroMaxT2; best.zeroMaxT3 = L.zeroMaxT3;
   return true;
 }
 #undef PK_CHILD
-#undef PK_UB

@@ -164,7 +164,7 @@ template <bool HEAT, bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
-  __shared__ uint2 stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   uint32_t*        C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t   count = C[cntIn];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 #endif
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
 {
-  __shared__ uint2    wstack[PACKET_STACK];
+  __shared__ uint32_t wstack[PACKET_STACK * STACK_WORDS];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0, nRays = 0, nAlpha = 0;
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
 {
-  __shared__ uint2 stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   const TStack     st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
   const uint32_t   count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
@@ -344,6 +344,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceSce
   __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups
   uint32_t*      C     = rb.counts + depth * CNT_STRIDE;
   const uint32_t count = C[CNT_IN];
+  if(blockIdx.x * SHADE_BLOCK >= count)
+    return;  // the grid covers every path slot of the batch; from bounce 1 on most of its workgroups lie beyond the queue
   if(threadIdx.x < 5)
     sCnt[threadIdx.x] = 0;
   __syncthreads();
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
                                                                              int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
-  __shared__ uint2    stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -497,7 +499,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
-  __shared__ uint2 stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   const TStack     st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
   uint32_t*        C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t   count = C[CNT_X_SHADOW];
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int depth0)
 {
-  __shared__ uint2 stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   uint32_t*        C     = rb.counts + depth0 * CNT_STRIDE;
   const uint32_t   count = C[CNT_IN];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * TRACE_BLOCK >= count)
@@ -689,7 +691,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
 
 // ---- ray picker (src/sample_example.cpp:468-511; nvvk::RayPickerKHR shoots a flag-less ray: no culling, no any-hit) ------------------
 template <bool TWO>
-__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters, uint2* spill)
+__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters, uint32_t* spill)
 {
   const f2 d         = f2{pickX * 2.0f - 1.0f, pickY * 2.0f - 1.0f};
   const f4 origin    = mat4_mul(cam.viewInverse, f4{0, 0, 0, 1});
@@ -699,7 +701,7 @@ __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float p
   const f3 o = xyz(origin), dir = xyz(direction);
   // nearest triangle in key order (t, world index), no culling: one BVH traversal (the 64 lanes of the wave walk the same ray; a pick is a
   // rare query, what matters is that it does not scale with the triangle count: 3.8 M records per click on C5 with the old brute force)
-  __shared__ uint2 stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stack[STACK_LDS_WORDS];
   const TStack     st{stack + threadIdx.x, spill_column(spill, 0u)};
   RayHit           h;
   traverse<TM_PICK, TWO>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, st, h, counters);
@@ -1070,7 +1072,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     st.fn();
 }
 
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint2* spill)
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint32_t* spill)
 {
   pt_SceneCamera cam = scene.camera;
   std::memcpy(cam.viewInverse, viewInv, sizeof(cam.viewInverse));

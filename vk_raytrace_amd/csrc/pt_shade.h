@@ -100,9 +100,10 @@ PT_DEV void generate_ray(const DeviceScene& S, const RenderBuffers& rb, const Fr
 
   rb.ps.rayO[slot]   = make_float4(org.x, org.y, org.z, 0.f);
   rb.ps.rayD[slot]   = make_float4(dir.x, dir.y, dir.z, __uint_as_float(seed));
-  rb.ps.thr[slot]    = make_float4(1.f, 1.f, 1.f, 1.f);
-  rb.ps.rad[slot]    = make_float4(0.f, 0.f, 0.f, 0.f);
-  rb.ps.absorb[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // throughput = 1, radiance = 0, absorption = 0 (pathtrace.glsl:201-203) are not written: shade_path knows them at depth 0 (48 B per sample
+  // that would be written here and read back there).  Without a single bounce nobody else writes the radiance the accumulate step reads.
+  if(st.maxDepth == 0)
+    rb.ps.rad[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- environment (shaders/env_sampling.glsl:38-135) ---------------------------------------------------------
@@ -181,8 +182,9 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   const f3           rdir = xyz(dw);
   uint32_t           seed = __float_as_uint(dw.w);
   const float4       hit  = rb.ps.hit[slot];
-  f3                 radiance   = xyz(rb.ps.rad[slot]);
-  f3                 throughput = xyz(rb.ps.thr[slot]);
+  // depth 0: the initial values of pathtrace.glsl:201-203, which generate_ray therefore does not store (the same floats either way)
+  f3                 radiance   = depth == 0 ? splat3(0.0f) : xyz(rb.ps.rad[slot]);
+  f3                 throughput = depth == 0 ? splat3(1.0f) : xyz(rb.ps.thr[slot]);
   const int          dbg        = MODE >= 0 ? PT_DEBUG_NONE : st.debugging_mode;
 
   // ---- miss: environment (pathtrace.glsl:204-228) ----
@@ -262,7 +264,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
     return SHADE_DONE;
   }
 
-  f3 absorption = xyz(rb.ps.absorb[slot]);
+  f3 absorption = depth == 0 ? splat3(0.0f) : xyz(rb.ps.absorb[slot]);
   if(dot3(sf.normal, sf.ffnormal) > 0.0f)
     absorption = splat3(0.0f);
   radiance += sf.emission * throughput;

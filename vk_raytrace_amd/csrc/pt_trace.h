@@ -21,27 +21,27 @@
 // (ALPHA_BLEND) lies in front of the certain hit, it falls back to the exact key-ordered loop
 // (TM_RAW_*).  All three routes produce identical hits and identical RNG states.
 //
-// The walk (round 3): 8-wide nodes with quantised child boxes (pt_cwbvh.h).  One node visit = five 16-byte loads per lane, all in flight
-// together, and decides 8 children; the hit children are NOT sorted: the builder placed them in octant order, so the hit mask's highest bit
-// is the next child to visit.  What a lane carries between steps is
-//   a node group      (first inner child, hit bits 31..24 | inner-child mask)   -- the still unvisited hit children of the last node visited
-//   a triangle group  (first triangle, 24 hit bits)                              -- the triangles of its hit leaf children
-// and a stack of postponed groups: a node visit pushes at most ONE entry (the remainder of the group it came from), so the stack is as deep
-// as the tree, not 7x that.  The first STACK_LDS entries of every lane live in LDS laid out [level][lane] (8-byte entries: 64 lanes x 8 B =
-// two conflict-free bank rows), deeper entries go to a per-wavefront area in global memory (same layout) -- no scratch memory, no register
-// array with a dynamic index.  Overflow beyond STACK_LDS + STACK_SPILL is counted in Counters::stackOverflow and reported by every call that
-// hands results to the host.
+// The walk (round 3): 8-wide nodes with child boxes on an 11-bit grid (pt_cwbvh.h).  One node visit = eight 16-byte loads per lane, all in flight
+// together, one v_fma_mix_f32 per plane, and decides 8 children; the hit children are NOT sorted: the builder placed them in octant order, so
+// after an XOR-permutation of the 8 hit bits with the ray's direction signs the highest bit is the next child to visit -- leaf or inner.
+// What a lane carries between steps is ONE group of three words
+//   first inner child | hit bits 31..24,   first triangle,   inner mask | leaf mask << 8 | two-triangle-leaf mask << 16
+// = the still unvisited hit children of the last node visited, and a stack of postponed groups: a node visit pushes at most ONE entry (the
+// remainder of the group it came from), so the stack is as deep as the tree, not 7x that.  The first STACK_LDS entries of every lane live in
+// LDS laid out [word][level][lane] (conflict free), deeper entries go to a per-wavefront area in global memory (same layout) -- no scratch
+// memory, no register array with a dynamic index.  Overflow beyond STACK_TOTAL is counted in Counters::stackOverflow and reported by every
+// call that hands results to the host.
 //
-// One step of a lane (lane_step) = up to two triangle tests of its triangle group (their six 16-byte loads in flight together), then -- if
-// that emptied the group -- one node visit.  The lock-step walks (traverse<>: exact fallback, ray picker, k_tail) and the refilling trace
-// machine of the persistent kernels (pt_render.hip) are the same per-lane code; only who calls lane_step differs.
+// One step of a lane (lane_step) = if the next child of its group is a leaf, that leaf's one or two triangles (both records in flight
+// together); then, if the next child is an inner node, that node's visit.  The lock-step walks (traverse<>: exact fallback, ray picker,
+// k_tail) and the refilling trace machine of the persistent kernels (pt_render.hip) are the same per-lane code; only who calls lane_step differs.
 #pragma once
 #include "pt_surface.h"
 #include "pt_cwbvh.h"
 
 #define TRACE_BLOCK 64
 #ifndef STACK_LDS
-#define STACK_LDS 12
+#define STACK_LDS 8
 #endif
 #define STACK_TOTAL 64
 #define STACK_SPILL (STACK_TOTAL - STACK_LDS)
@@ -128,16 +128,27 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
 #endif
 
 // ---- traversal stack ------------------------------------------------------------------------------------------------------------------
+// Entries are three words, stored as three planes of [level][lane] words: every access is 64 consecutive dwords (one conflict-free bank row).
+#define STACK_WORDS 3
 struct TStack {
-  uint2* lds;    // this lane's column of the wavefront's LDS stack: entry k at lds[k * TRACE_BLOCK]
-  uint2* spill;  // this lane's column of the wavefront's global spill area (entries STACK_LDS ..): entry k at spill[(k - STACK_LDS) * TRACE_BLOCK]; may be null
+  uint32_t* lds;    // this lane's column of the wavefront's LDS stack: word w of entry k at lds[(w * STACK_LDS + k) * TRACE_BLOCK]
+  uint32_t* spill;  // this lane's column of the wavefront's global spill area: word w of entry k >= STACK_LDS at spill[(w * STACK_SPILL + k - STACK_LDS) * TRACE_BLOCK]; may be null
 };
-PT_DEV void stack_push(const TStack& s, int& sp, uint32_t x, uint32_t y, Counters* counters)
+PT_DEV void stack_push(const TStack& s, int& sp, uint32_t x, uint32_t y, uint32_t z, Counters* counters)
 {
   if(sp < STACK_LDS)
-    s.lds[sp * TRACE_BLOCK] = make_uint2(x, y);
+  {
+    s.lds[(0 * STACK_LDS + sp) * TRACE_BLOCK] = x;
+    s.lds[(1 * STACK_LDS + sp) * TRACE_BLOCK] = y;
+    s.lds[(2 * STACK_LDS + sp) * TRACE_BLOCK] = z;
+  }
   else if(sp < STACK_TOTAL && s.spill)
-    s.spill[(sp - STACK_LDS) * TRACE_BLOCK] = make_uint2(x, y);
+  {
+    const int k = sp - STACK_LDS;
+    s.spill[(0 * STACK_SPILL + k) * TRACE_BLOCK] = x;
+    s.spill[(1 * STACK_SPILL + k) * TRACE_BLOCK] = y;
+    s.spill[(2 * STACK_SPILL + k) * TRACE_BLOCK] = z;
+  }
   else
   {
     atomicAdd(&counters->stackOverflow, 1u);  // entry dropped (flagged; pt_get_stats / pt_synchronize report it)
@@ -145,26 +156,42 @@ PT_DEV void stack_push(const TStack& s, int& sp, uint32_t x, uint32_t y, Counter
   }
   ++sp;
 }
-PT_DEV uint2 stack_pop(const TStack& s, int& sp)
+PT_DEV void stack_pop(const TStack& s, int& sp, uint32_t& x, uint32_t& y, uint32_t& z)
 {
   --sp;
-  return sp < STACK_LDS ? s.lds[sp * TRACE_BLOCK] : s.spill[(sp - STACK_LDS) * TRACE_BLOCK];
+  if(sp < STACK_LDS)
+  {
+    x = s.lds[(0 * STACK_LDS + sp) * TRACE_BLOCK];
+    y = s.lds[(1 * STACK_LDS + sp) * TRACE_BLOCK];
+    z = s.lds[(2 * STACK_LDS + sp) * TRACE_BLOCK];
+  }
+  else
+  {
+    const int k = sp - STACK_LDS;
+    x = s.spill[(0 * STACK_SPILL + k) * TRACE_BLOCK];
+    y = s.spill[(1 * STACK_SPILL + k) * TRACE_BLOCK];
+    z = s.spill[(2 * STACK_SPILL + k) * TRACE_BLOCK];
+  }
 }
-// the wavefront's spill area of a launch: (wave slot, level, lane)
-PT_DEV uint2* spill_column(uint2* spillBase, uint32_t waveSlot) { return spillBase ? spillBase + (size_t(waveSlot) * STACK_SPILL) * TRACE_BLOCK + (threadIdx.x & 63u) : nullptr; }
+#define STACK_LDS_WORDS (STACK_WORDS * STACK_LDS * TRACE_BLOCK)       // uint32_t per wavefront in LDS
+#define STACK_SPILL_WORDS (STACK_WORDS * STACK_SPILL * TRACE_BLOCK)   // uint32_t per wavefront in the global spill area
+// the wavefront's spill area of a launch: (wave slot, word, level, lane)
+PT_DEV uint32_t* spill_column(uint32_t* spillBase, uint32_t waveSlot) { return spillBase ? spillBase + size_t(waveSlot) * STACK_SPILL_WORDS + (threadIdx.x & 63u) : nullptr; }
 
 // ---- per-ray constants of the box tests -------------------------------------------------------------------------------------------------
-// A child plane sits at p + q 2^e; its ray parameter is t = q s + b with s = 2^e idir and b = (p - o) idir (one FMA per plane once s and b are
-// known for the node).  The box test is not part of the bit-exact contract (results are BVH independent), it only has to be conservative:
-// fl(b) is off by at most 2^-23 |b| (difference and product rounded), the FMA by 2^-24 |t|, idir itself by 2^-24 relative, and |t| <= |b| +
-// 255 |s|, so biasing b by E = (|b| + 255 |s|) * 8e-7 towards "hit" (b - E for near planes, b + E for far planes) covers all of it twice over
-// -- that is 1e-6 of the node's own extent, nothing against the 1/255 of the quantisation.  |d| components below 1e-18 are clamped so that
-// idir stays finite (a ray moves < 1 ulp along such an axis over any representable distance).
+// A child plane sits at p + q 2^e; its ray parameter is t = q s + b with s = 2^e idir and b = (p - o) idir: one v_fma_mix_f32 per plane once s
+// and b are known for the node (q is read as fp16 out of a register half, s and b are fp32, the result is fp32 with one rounding).  The box test
+// is not part of the bit-exact contract (results are BVH independent), it only has to be conservative: fl(b) is off by at most 2^-23 |b|
+// (difference and product rounded), the FMA by 2^-24 |t|, idir itself by 2^-24 relative, and |t| <= |b| + 2047 |s|, so biasing b by
+// E = (|b| + 2047 |s|) * 8e-7 towards "hit" (b - E for near planes, b + E for far planes) covers all of it twice over -- that is 1e-6 of the
+// node's own extent, nothing against the 1/2047 of the quantisation.  The sign of idir says which plane of a slab is the near one: near and
+// far planes are fetched from sign-dependent offsets inside the node (no per-axis min / max, no select).  |d| components below 1e-18 are
+// clamped so that idir stays finite (a ray moves < 1 ulp along such an axis over any representable distance).
 struct BoxRay {
   f3       o;       // ray origin in the space of the nodes being tested (world; object space inside an instance of the two-level structure)
   f3       idir;
   float    eps;     // extra plane padding (two-level structure: rounding of the ray transform, enter_instance); 0 in world space
-  uint32_t oct4;    // octinv * 0x01010101, octinv = 7 ^ (direction sign bits): hit inner children go to bit 24 + (slot ^ octinv), highest bit first
+  uint32_t octinv;  // 7 ^ (direction sign bits): hit child `slot` goes to bit 24 + (slot ^ octinv) of the group, highest bit first
 };
 PT_DEV BoxRay make_boxray(f3 o, f3 d)
 {
@@ -173,64 +200,85 @@ PT_DEV BoxRay make_boxray(f3 o, f3 d)
   rb.o    = o;
   rb.idir = f3{1.0f / dx, 1.0f / dy, 1.0f / dz};
   rb.eps  = 0.0f;
-  const uint32_t oct = (rb.idir.x < 0.0f ? 1u : 0u) | (rb.idir.y < 0.0f ? 2u : 0u) | (rb.idir.z < 0.0f ? 4u : 0u);
-  rb.oct4 = (7u ^ oct) * 0x01010101u;
+  rb.octinv = 7u ^ ((rb.idir.x < 0.0f ? 1u : 0u) | (rb.idir.y < 0.0f ? 2u : 0u) | (rb.idir.z < 0.0f ? 4u : 0u));
   return rb;
 }
 
-// One node visit: the 32-bit hit mask of node `idx` against [0, lim] (bits 31..24 inner children in visiting order, bits 23..0 triangles) and
-// the header fields the groups need.  alphaOnly: only children tagged in amask (pass B and the non-opaque walks never need an opaque subtree).
+// fp16 grid coordinate of child `k` (0..7) out of the plane set's four words
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 pt_h2v __attribute__((ext_vector_type(2)));
+PT_DEV float cw_plane(uint32_t word, int hi)
+{
+  const pt_h2v h = __builtin_bit_cast(pt_h2v, word);
+  return float(hi ? h.y : h.x);  // folds into v_fma_mix_f32's op_sel
+}
+#else
+PT_DEV float cw_plane(uint32_t word, int hi) { return cw_float_of_half(hi ? (word >> 16) : word); }
+#endif
+PT_DEV uint32_t cw_word(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// One node visit: the hit children of node `idx` against [0, lim] in SLOT order (bit k = slot k; lane_step permutes them into visiting order)
+// and the header fields the group needs.  alphaOnly: only children tagged in amask (pass B and the non-opaque walks never need an opaque subtree).
 struct NodeHit {
-  uint32_t hits, childBase, triBase, imask, amask;
+  uint32_t hits, childBase, triBase, kinds, alphaHits;  // kinds: inner mask | leaf mask << 8 | two-triangle-leaf mask << 16
+  uint32_t nearest;                                     // slot of the hit child with the smallest entry distance, 8: none
 };
-#define CW_UB(x, j) float(((x) >> (8 * (j))) & 0xffu)
-#define CW_CHILD(w, j)                                                                                                                                                      \
-  {                                                                                                                                                                         \
-    const float tn = fmaxf(fmaxf(__builtin_fmaf(CW_UB(nx[w], j), sx, blx), __builtin_fmaf(CW_UB(ny[w], j), sy, bly)), fmaxf(__builtin_fmaf(CW_UB(nz[w], j), sz, blz), 0.0f)); \
-    const float tf = fminf(fminf(__builtin_fmaf(CW_UB(fx[w], j), sx, bhx), __builtin_fmaf(CW_UB(fy[w], j), sy, bhy)), fminf(__builtin_fmaf(CW_UB(fz[w], j), sz, bhz), lim));  \
-    hits |= (tn <= tf) ? (((bits[w] >> (8 * (j))) & 0xffu) << ((index[w] >> (8 * (j))) & 0xffu)) : 0u;                                                                     \
+#define CW_CHILD(k)                                                                                                                                            \
+  {                                                                                                                                                            \
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(cw_plane(cw_word(nx, (k) >> 1), (k) & 1), sx, blx), __builtin_fmaf(cw_plane(cw_word(ny, (k) >> 1), (k) & 1), sy, bly)), \
+                           fmaxf(__builtin_fmaf(cw_plane(cw_word(nz, (k) >> 1), (k) & 1), sz, blz), 0.0f));                                                    \
+    const float tf = fminf(fminf(__builtin_fmaf(cw_plane(cw_word(fx, (k) >> 1), (k) & 1), sx, bhx), __builtin_fmaf(cw_plane(cw_word(fy, (k) >> 1), (k) & 1), sy, bhy)), \
+                           fminf(__builtin_fmaf(cw_plane(cw_word(fz, (k) >> 1), (k) & 1), sz, bhz), lim));                                                     \
+    /* the sign bit of tf - tn says "missed"; the 8 bits are shifted together with one v_alignbit_b32 each (children 7 .. 0: child k ends at bit k) */           \
+    const float gap = tf - tn;                                                                                                                                 \
+    miss            = (miss << 1) | (__float_as_uint(gap) >> 31);                                                                                              \
+    const bool nearer = gap >= 0.0f && tn < tnear;                                                                                                             \
+    tnear   = nearer ? tn : tnear;                                                                                                                             \
+    nearest = nearer ? uint32_t(k) : nearest;                                                                                                                  \
   }
 PT_DEV NodeHit cw_test_node(const CwNode* __restrict__ nodes, uint32_t idx, const BoxRay& R, float lim, bool alphaOnly)
 {
   const char*    nb = reinterpret_cast<const char*>(nodes);
   const uint32_t at = idx * uint32_t(CW_NODE_BYTES);  // 32-bit byte offsets (the node array is < 4 GB)
-  const uint4    h0 = *reinterpret_cast<const uint4*>(nb + at), h1 = *reinterpret_cast<const uint4*>(nb + (at + 16u)), q0 = *reinterpret_cast<const uint4*>(nb + (at + 32u)),
-              q1 = *reinterpret_cast<const uint4*>(nb + (at + 48u)), q2 = *reinterpret_cast<const uint4*>(nb + (at + 64u));
+  // near / far plane sets by the direction sign, chosen by ADDRESS
+  const uint32_t ox = R.idir.x < 0.0f ? 48u : 0u, oy = R.idir.y < 0.0f ? 48u : 0u, oz = R.idir.z < 0.0f ? 48u : 0u;
+  const uint4    h0 = *reinterpret_cast<const uint4*>(nb + at), h1 = *reinterpret_cast<const uint4*>(nb + (at + 16u));
+  const uint4    nx = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QLO + ox)), fx = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QHI - ox));
+  const uint4    ny = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QLO + 16u + oy)), fy = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QHI + 16u - oy));
+  const uint4    nz = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QLO + 32u + oz)), fz = *reinterpret_cast<const uint4*>(nb + (at + CW_OFF_QHI + 32u - oz));
   NodeHit        nh;
   nh.childBase = h1.x & CW_CHILD_MASK;
-  nh.amask     = h1.x >> 24;
   nh.triBase   = h1.y;
-  nh.imask     = h0.w >> 24;
+  nh.kinds     = (h0.w >> 24) | ((h1.z & 0xffffu) << 8);
+  const uint32_t amask = h1.x >> 24;
   // per-axis grid step and origin in ray parameters
   const float sx = __uint_as_float((h0.w & 0xffu) << 23) * R.idir.x, sy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23) * R.idir.y, sz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23) * R.idir.z;
   const float bx = (__uint_as_float(h0.x) - R.o.x) * R.idir.x, by = (__uint_as_float(h0.y) - R.o.y) * R.idir.y, bz = (__uint_as_float(h0.z) - R.o.z) * R.idir.z;
-  const float ex = __builtin_fmaf(fabsf(R.idir.x), R.eps, (fabsf(bx) + 255.0f * fabsf(sx)) * 8.0e-7f), ey = __builtin_fmaf(fabsf(R.idir.y), R.eps, (fabsf(by) + 255.0f * fabsf(sy)) * 8.0e-7f),
-              ez = __builtin_fmaf(fabsf(R.idir.z), R.eps, (fabsf(bz) + 255.0f * fabsf(sz)) * 8.0e-7f);
+  const float gmax = float(CW_GRID_MAX);
+  const float ex = __builtin_fmaf(fabsf(R.idir.x), R.eps, (fabsf(bx) + gmax * fabsf(sx)) * 8.0e-7f), ey = __builtin_fmaf(fabsf(R.idir.y), R.eps, (fabsf(by) + gmax * fabsf(sy)) * 8.0e-7f),
+              ez = __builtin_fmaf(fabsf(R.idir.z), R.eps, (fabsf(bz) + gmax * fabsf(sz)) * 8.0e-7f);
   const float blx = bx - ex, bhx = bx + ex, bly = by - ey, bhy = by + ey, blz = bz - ez, bhz = bz + ez;
-  // near / far planes by the direction sign (q0: qlox, qloy; q1: qloz, qhix; q2: qhiy, qhiz)
-  const bool     negx = R.idir.x < 0.0f, negy = R.idir.y < 0.0f, negz = R.idir.z < 0.0f;
-  const uint32_t nx[2] = {negx ? q1.z : q0.x, negx ? q1.w : q0.y}, fx[2] = {negx ? q0.x : q1.z, negx ? q0.y : q1.w};
-  const uint32_t ny[2] = {negy ? q2.x : q0.z, negy ? q2.y : q0.w}, fy[2] = {negy ? q0.z : q2.x, negy ? q0.w : q2.y};
-  const uint32_t nz[2] = {negz ? q2.z : q1.x, negz ? q2.w : q1.y}, fz[2] = {negz ? q1.x : q2.z, negz ? q1.y : q2.w};
-  // per child: the bits it contributes and where (inner: 1 bit at 24 + (slot ^ octinv); leaf: its triangles' bits at their offset)
-  uint32_t bits[2], index[2];
-  const uint32_t am = alphaOnly ? nh.amask : 0xffu;
-#pragma unroll
-  for(int w = 0; w < 2; ++w)
-  {
-    const uint32_t meta  = w ? h1.w : h1.z;
-    const uint32_t inner = ((meta & (meta << 1)) & 0x10101010u) >> 4;                         // 0x01 in the bytes of inner children
-    index[w]             = (meta ^ (R.oct4 & (inner * 0xffu))) & 0x1f1f1f1fu;
-    const uint32_t keep  = (((am >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u;             // bit k of the nibble -> byte k
-    bits[w]              = ((meta >> 5) & 0x07070707u) & (keep * 0xffu);
-  }
-  uint32_t hits = 0;
-  CW_CHILD(0, 0) CW_CHILD(0, 1) CW_CHILD(0, 2) CW_CHILD(0, 3) CW_CHILD(1, 0) CW_CHILD(1, 1) CW_CHILD(1, 2) CW_CHILD(1, 3)
-  nh.hits = hits;
+  // children that count: inner or leaf (an empty slot's inverted box can never), and for the alpha-only walks only the tagged ones
+  const uint32_t valid = (nh.kinds | (nh.kinds >> 8)) & (alphaOnly ? amask : 0xffu) & 0xffu;
+  uint32_t    miss = 0, nearest = 0;
+  float       tnear = 3.0e38f;
+  CW_CHILD(7) CW_CHILD(6) CW_CHILD(5) CW_CHILD(4) CW_CHILD(3) CW_CHILD(2) CW_CHILD(1) CW_CHILD(0)
+  const uint32_t hits = ~miss & valid;
+  nh.alphaHits = hits & amask;
+  nh.hits      = hits;
+  nh.nearest   = ((hits >> nearest) & 1u) ? nearest : 8u;  // (8: none -- nothing hit, or the nearest box belongs to a child that does not count)
   return nh;
 }
 #undef CW_CHILD
-#undef CW_UB
+
+// the 8 hit bits from slot order into visiting order: bit k -> bit k ^ octinv (three conditional swaps of neighbours, pairs, nibbles)
+PT_DEV uint32_t cw_visit_order(uint32_t m, uint32_t octinv)
+{
+  m = (octinv & 1u) ? (((m & 0x55u) << 1) | ((m >> 1) & 0x55u)) : m;
+  m = (octinv & 2u) ? (((m & 0x33u) << 2) | ((m >> 2) & 0x33u)) : m;
+  m = (octinv & 4u) ? (((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu)) : m;
+  return m;
+}
 
 // ---- two-level walk (TLAS over instances, one object-space BLAS per prim-mesh; reference: src/accelstruct.cpp:110-162) -----------
 // A lane is either at TLAS level (InstCtx::inst == BVH_NONE: world-space ray constants, groups index DeviceScene::tlas / tlasLeaves) or inside
@@ -290,8 +338,9 @@ struct TraceLane {
   float    tmax;           // exclusive upper bound on t (TM_COUNT: the limit key's t, inclusive for ties)
   float    bt, bu, bv;     // best hit so far (pass A: best CERTAIN hit)
   uint32_t bslot, bw;
-  uint32_t ngx, ngy;       // node group: first inner child | hit bits 31..24, inner-child mask 7..0 (no hit bits: nothing to visit)
-  uint32_t tgx, tgy;       // triangle group: first triangle (two-level, TLAS level: first TlasLeaf), 24 hit bits
+  uint32_t gx, gy, gz;     // the group: first inner child | hit bits 31..24 (visiting order), first triangle (two-level, TLAS level: first TlasLeaf),
+                           // inner mask | leaf mask << 8 | two-triangle-leaf mask << 16 (slot order) | (slot + 1) << 24 of the child to take
+                           // BEFORE the hit bits: the nearest hit child of the node just visited.  Nothing pending, no hit bits: group exhausted.
   int      sp;
   uint32_t flags, cnt, wLimit;
   float    zeroMaxT, zeroMaxT2, zeroMaxT3;  // pass A: the three largest t among the zero-opacity candidates seen
@@ -299,7 +348,7 @@ struct TraceLane {
   uint32_t wPrev;
   int      pass;           // TM_MACHINE: 0 = pass A (nearest certain hit), 1 = pass B (count zero-opacity candidates in front of it)
   bool     done;
-  bool     sawAlpha;       // a visited node had children tagged non-opaque (shadow rays: without one, the first certain hit is final -- see lane_step)
+  bool     sawAlpha;       // a box tagged non-opaque was hit (shadow rays: without one, the first certain hit is final -- see lane_triangle)
   bool     anyEnds;        // shadow ray: the first certain hit may end the walk when no non-opaque geometry was met (nothing can consume a draw)
   InstCtx  ic;             // two-level instantiations only: the instance the lane is inside of
   uint32_t steps;          //   and the loop-iteration guard
@@ -308,21 +357,20 @@ struct TraceLane {
 #endif
 };
 
-PT_DEV void lane_root(TraceLane& L)
+// a group whose only child is "inner child 0 of base `node`" = that node, pending as the nearest
+PT_DEV void lane_enter_node(TraceLane& L, uint32_t node)
 {
-  // a group whose only hit child is "inner child 0 of base 0" = node 0, at the bit the ray's octant gives slot 0
-  L.ngx = 0u;
-  L.ngy = (1u << (24u + (L.R.oct4 & 7u))) | 1u;
-  L.tgx = 0u;
-  L.tgy = 0u;
-  L.sp  = 0;
+  L.gx = node;
+  L.gy = 0u;
+  L.gz = 1u | (1u << 24);
 }
 PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
 {
   L.o = o; L.d = d;
   L.R = make_boxray(o, d);
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
-  lane_root(L);
+  lane_enter_node(L, 0u);
+  L.sp = 0;
   L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.done = emptyScene; L.zeroMaxT = -1.0f; L.zeroMaxT2 = -1.0f; L.zeroMaxT3 = -1.0f;
   L.tPrev = 0.0f; L.wPrev = 0xffffffffu; L.sawAlpha = false; L.anyEnds = false;
   L.ic = InstCtx{BVH_NONE, 0, 0u}; L.steps = 0;
@@ -342,11 +390,12 @@ PT_DEV void lane_begin_count(TraceLane& L)
     L.ic.inst = BVH_NONE;
     L.R       = make_boxray(L.o, L.d);
   }
-  lane_root(L);
+  lane_enter_node(L, 0u);
+  L.sp = 0;
   L.flags = 0; L.cnt = 0; L.pass = 1; L.done = false;
 }
 
-// One triangle of the lane's triangle group under the candidate rules of `mode`.
+// One triangle of a leaf under the candidate rules of `mode`.
 template <int MODE, bool TWO>
 PT_DEV void lane_triangle(const DeviceScene& S, TraceLane& L, uint32_t slot, TriRec tr)
 {
@@ -407,10 +456,10 @@ PT_DEV void lane_triangle(const DeviceScene& S, TraceLane& L, uint32_t slot, Tri
       if(certain)
       {
         L.bt = t; L.bu = u; L.bv = v; L.bslot = slot; L.bw = wbits;
-        // Shadow rays (T6: the nearest certain hit ends the ray, zero-opacity candidates in front of it consume draws): as long as no visited
-        // node had a child tagged non-opaque, no candidate anywhere along the ray can consume a draw and ANY certain hit gives the same
-        // verdict and the same RNG state as the nearest one -- the reference's own gl_RayFlagsTerminateOnFirstHitEXT (traceray_rq.glsl:157).
-        // Sound because unvisited nodes are descendants of visited ones: a subtree without the tag holds opaque triangles only.
+        // Shadow rays (T6: the nearest certain hit ends the ray, zero-opacity candidates in front of it consume draws): as long as the ray has
+        // hit no box tagged non-opaque, no candidate anywhere along it can consume a draw and ANY certain hit gives the same verdict and the
+        // same RNG state as the nearest one -- the reference's own gl_RayFlagsTerminateOnFirstHitEXT (traceray_rq.glsl:157).  Sound because
+        // the boxes a ray has not been tested against lie inside boxes it hit: an untagged box holds opaque triangles only.
         if(L.anyEnds && !L.sawAlpha)
           L.done = true;
       }
@@ -418,8 +467,25 @@ PT_DEV void lane_triangle(const DeviceScene& S, TraceLane& L, uint32_t slot, Tri
   }
 }
 
-// One step of the walk: up to two triangles of the lane's triangle group, then -- if the group is empty -- one node visit (of the next hit
-// child of the lane's node group, or of a group popped from the stack).  Sets L.done when nothing is left.
+// Visiting order of a group: first the pending nearest child (exact: smallest entry distance of the node's hit children), then the other hit
+// children in octant order (highest hit bit first).  Going to the nearest child first is what makes the bound shrink early: octant order
+// alone tested 2x the triangles of a nearest-first walk (tools/steps_experiment.py).
+PT_DEV bool group_has_next(const TraceLane& L) { return ((L.gx >> 24) | (L.gz >> 24)) != 0u; }
+PT_DEV uint32_t group_next_slot(const TraceLane& L)
+{
+  const uint32_t pending = L.gz >> 24;
+  return pending ? pending - 1u : (((31u - uint32_t(__clz(int(L.gx)))) - 24u) ^ L.R.octinv);
+}
+PT_DEV void group_drop_next(TraceLane& L)
+{
+  if(L.gz >> 24)
+    L.gz &= 0x00ffffffu;
+  else
+    L.gx &= ~(1u << (31u - uint32_t(__clz(int(L.gx)))));
+}
+
+// One step of the walk: the next child of the lane's group if it is a leaf (its one or two triangles), then the next child if it is an inner
+// node (its visit); an exhausted group is replaced from the stack.  Sets L.done when nothing is left.
 template <int MODE, bool TWO>
 PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const TStack& st, Counters* counters)
 {
@@ -431,43 +497,38 @@ PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const TStack& st, Coun
     L.done = true;
     return;
   }
-  // ---- triangles
-  if(L.tgy)
+  // ---- a leaf, if it is the group's next child
+  if(group_has_next(L))
   {
-    if(TWO && L.ic.inst == BVH_NONE)
-    {  // TLAS level: the group's members are instances.  Enter the first; what is left at this level waits on the stack.
-      const uint32_t j = uint32_t(__ffs(int(L.tgy))) - 1u;
-      const TlasLeaf tl = S.tlasLeaves[L.tgx + j];
-      L.tgy &= L.tgy - 1u;
-      if(L.tgy)
-        stack_push(st, L.sp, L.tgx, L.tgy, counters);
-      if(L.ngy & 0xff000000u)
-        stack_push(st, L.sp, L.ngx, L.ngy, counters);
-      L.ic  = InstCtx{tl.inst, L.sp, tl.wflags};
-      L.R   = enter_instance(S, tl, L.o, L.d);
-      L.ngx = tl.nodeBase;                                  // "inner child 0 of base nodeBase" = the BLAS root
-      L.ngy = (1u << (24u + (L.R.oct4 & 7u))) | 1u;
-      L.tgy = 0u;
-    }
-    else
+    const uint32_t slot = group_next_slot(L);
+    if((L.gz >> (8u + slot)) & 1u)
     {
-      const uint32_t j0  = uint32_t(__ffs(int(L.tgy))) - 1u;
-      L.tgy &= L.tgy - 1u;
-      const bool     two = L.tgy != 0u;
-      const uint32_t j1  = two ? uint32_t(__ffs(int(L.tgy))) - 1u : j0;
-      L.tgy &= L.tgy - 1u;  // (0 stays 0)
-      const TriRec a = S.tris[L.tgx + j0], b = S.tris[L.tgx + j1];  // six 16-byte loads in flight together
-      lane_triangle<MODE, TWO>(S, L, L.tgx + j0, a);
-      if(two && !L.done)
-        lane_triangle<MODE, TWO>(S, L, L.tgx + j1, b);
-      if(L.done)
-        return;
+      group_drop_next(L);
+      const uint32_t below = (1u << slot) - 1u;
+      const uint32_t first = L.gy + uint32_t(__popc((L.gz >> 8) & below & 0xffu)) + uint32_t(__popc((L.gz >> 16) & below & 0xffu));
+      if(TWO && L.ic.inst == BVH_NONE)
+      {  // TLAS level: the leaf is an instance.  What is left of the group waits on the stack.
+        const TlasLeaf tl = S.tlasLeaves[first];
+        if(L.gx >> 24)
+          stack_push(st, L.sp, L.gx, L.gy, L.gz, counters);
+        L.ic = InstCtx{tl.inst, L.sp, tl.wflags};
+        L.R  = enter_instance(S, tl, L.o, L.d);
+        lane_enter_node(L, tl.nodeBase);  // the BLAS root
+      }
+      else
+      {
+        const bool   two = ((L.gz >> (16u + slot)) & 1u) != 0u;
+        const TriRec a = S.tris[first], b = S.tris[first + (two ? 1u : 0u)];  // six 16-byte loads in flight together
+        lane_triangle<MODE, TWO>(S, L, first, a);
+        if(two && !L.done)
+          lane_triangle<MODE, TWO>(S, L, first + 1u, b);
+        if(L.done)
+          return;
+      }
     }
   }
-  if(L.tgy)
-    return;
-  // ---- node
-  if(!(L.ngy & 0xff000000u))
+  // ---- an exhausted group is replaced from the stack
+  if(!group_has_next(L))
   {
     if(TWO && L.ic.inst != BVH_NONE && L.sp == L.ic.spBase)
     {  // the instance's subtree is exhausted: back to TLAS level.  The world-space constants are recomputed rather than kept
@@ -480,32 +541,25 @@ PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const TStack& st, Coun
       L.done = true;
       return;
     }
-    const uint2 e = stack_pop(st, L.sp);
-    if(!(e.y & 0xff000000u))
-    {  // a postponed triangle group (two-level: the rest of an instance group)
-      L.tgx = e.x;
-      L.tgy = e.y;
-      return;
-    }
-    L.ngx = e.x;
-    L.ngy = e.y;
+    stack_pop(st, L.sp, L.gx, L.gy, L.gz);
   }
-  const uint32_t r    = 31u - uint32_t(__clz(int(L.ngy)));
-  const uint32_t slot = (r - 24u) ^ (L.R.oct4 & 7u);
-  L.ngy &= ~(1u << r);
-  const uint32_t child = L.ngx + uint32_t(__popc(L.ngy & ((1u << slot) - 1u) & 0xffu));
-  if(L.ngy & 0xff000000u)
-    stack_push(st, L.sp, L.ngx, L.ngy, counters);
+  // ---- an inner node, if it is the group's next child
+  const uint32_t slot = group_next_slot(L);
+  if(!((L.gz >> slot) & 1u))
+    return;  // a leaf: the next step takes it
+  group_drop_next(L);
+  const uint32_t child = (L.gx & CW_CHILD_MASK) + uint32_t(__popc(L.gz & ((1u << slot) - 1u) & 0xffu));
+  if(L.gx >> 24)
+    stack_push(st, L.sp, L.gx, L.gy, L.gz, counters);
 #ifdef PT_STATS
   ++L.nNodes;
 #endif
   const float   lim = mode == TM_COUNT ? L.tmax : L.bt;
   const NodeHit nh  = cw_test_node((TWO && L.ic.inst == BVH_NONE) ? S.tlas : S.wide, child, L.R, lim, alphaOnly);
-  L.ngx = nh.childBase;
-  L.ngy = (nh.hits & 0xff000000u) | nh.imask;
-  L.tgx = nh.triBase;
-  L.tgy = nh.hits & 0x00ffffffu;
-  L.sawAlpha = L.sawAlpha || nh.amask != 0u;
+  L.gx = nh.childBase | (cw_visit_order(nh.hits & ~(1u << nh.nearest), L.R.octinv) << 24);  // (1 << 8 for "none" clears nothing)
+  L.gy = nh.triBase;
+  L.gz = nh.kinds | (nh.nearest < 8u ? (nh.nearest + 1u) << 24 : 0u);
+  L.sawAlpha = L.sawAlpha || nh.alphaHits != 0u;
 }
 
 // The lock-step form: one ray per lane until it is done.
