@@ -7,10 +7,10 @@ cd $REPO
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.txt
 for S in 20 96; do
   echo "== steps $S"
-  STEPS=$S BENCH_FLAGS="--no-profile --no-interactive" bash tools/variants_bench.sh old4wide default w4 w6 2>&1 | tee -a $OUT/variants_$S.txt
+  STEPS=$S BENCH_FLAGS="--no-profile --no-interactive" bash tools/variants_bench.sh old4wide default w4 2>&1 | tee -a $OUT/variants_$S.txt
 done
-timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_comm.py::test_single_process_gather_with_one_device 2>&1 | tail -15 > $OUT/gputest.txt; tail -15 $OUT/gputest.txt
-for E in "" "NCCL_DEBUG=WARN" "NCCL_DEBUG=INFO"; do
+
+for E in; do
   echo "== comm test with [$E]"
   env $E timeout 200 python -m pytest tests/test_comm.py -m gpu -q -x -s -k single_process 2>&1 | grep -v "^$" | tail -25 | tee -a $OUT/comm.txt
 done

@@ -85,10 +85,15 @@ PT_DEV bool traverse_packet_closest(const DeviceScene& S, bool valid, f3 o, f3 d
       TriRec         a, b;
       a.p0w = sload4(S.tris, s0); a.e1n = sload4(S.tris, s0 + 16u); a.e2p = sload4(S.tris, s0 + 32u);
       b.p0w = sload4(S.tris, s1); b.e1n = sload4(S.tris, s1 + 16u); b.e2p = sload4(S.tris, s1 + 32u);
-      if(valid)
-        lane_triangle<TM_CLOSEST, false>(S, L, first, a);
-      if(two && valid)
-        lane_triangle<TM_CLOSEST, false>(S, L, first + 1u, b);
+#pragma unroll 1
+      for(uint32_t j = 0;; ++j)
+      {  // (one copy of the triangle code: see lane_step)
+        if(valid)
+          lane_triangle<TM_CLOSEST, false>(S, L, first + j, a);
+        if(!two || j == 1u)
+          break;
+        a = b;
+      }
       continue;
     }
     const uint32_t child = (gx & CW_CHILD_MASK) + uint32_t(__builtin_popcount(gz & ((1u << slot) - 1u) & 0xffu));

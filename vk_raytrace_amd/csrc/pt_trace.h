@@ -518,10 +518,18 @@ PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const TStack& st, Coun
       else
       {
         const bool   two = ((L.gz >> (16u + slot)) & 1u) != 0u;
-        const TriRec a = S.tris[first], b = S.tris[first + (two ? 1u : 0u)];  // six 16-byte loads in flight together
-        lane_triangle<MODE, TWO>(S, L, first, a);
-        if(two && !L.done)
-          lane_triangle<MODE, TWO>(S, L, first + 1u, b);
+        TriRec       a = S.tris[first];
+        const TriRec b = S.tris[first + (two ? 1u : 0u)];  // six 16-byte loads in flight together
+        // ONE copy of the triangle code (it contains the any-hit evaluation with its texture filtering: twice inlined it doubled the
+        // kernels to ~40 KB each, against an instruction cache that the shade kernel's waves on the same CUs compete for)
+#pragma unroll 1
+        for(uint32_t j = 0;; ++j)
+        {
+          lane_triangle<MODE, TWO>(S, L, first + j, a);
+          if(!two || j == 1u || L.done)
+            break;
+          a = b;
+        }
         if(L.done)
           return;
       }
