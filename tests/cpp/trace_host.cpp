@@ -1,16 +1,15 @@
 // CPU harness around the PRODUCT's traversal source (test infrastructure; built and used by tests/test_trace_host.py only).
 //
-// vk_raytrace_amd/csrc/pt_trace.h -- traverse<MODE, TWO>, lane_step, cw_test_node, make_boxray, enter_instance, world_tri, tri_test -- is plain
+// vk_raytrace_amd/csrc/pt_trace.h -- traverse<MODE, TWO>, wide_node_step, make_raybox, enter_instance, world_tri, tri_test -- is plain
 // inline C++ apart from a handful of intrinsics, so it is compiled here for the host (g++, -ffp-contract=off like the device build) and run
 // against a brute-force loop over every world triangle with the same tri_test.  What the GPU parity tests can only show through images is
 // checked ray by ray without a GPU: the flat walk and the two-level walk (TLAS + object-space BLASes, per-instance box padding from
 // pt_capi.hip's two_level_pad) must report exactly the candidates brute force reports -- every candidate along the ray, in key order.
 //
-// The acceleration structures are assembled on the host in the product's formats (TriRec, CwNode, TlasLeaf).  Topology comes from the
-// product's device builder run through its host emulation (pt_debug_sahdev_topology in libptmi.so), the 8-wide quantised nodes from the
-// product's collapse run through ITS host emulation (pt_debug_cw_collapse: the cw_* bodies of pt_cwbvh.h that k_collapse8 runs); leaf boxes,
-// the binary nodes, the vertex form of BLAS leaves and the TLAS proxies restate pt_accel.hip (k_gather's tri_box, k_refit, k_emit,
-// k_blas_vertex_form, k_instance_proxies) -- they only have to be valid structures of that format, the code under test is the walk.
+// The acceleration structures are assembled on the host in the product's formats (TriRec, WideNode, TlasLeaf).  Topology comes from the
+// product's device builder run through its host emulation (pt_debug_sahdev_topology in libptmi.so); boxes, the 4-wide collapse, the vertex
+// form of BLAS leaves and the TLAS proxies restate pt_accel.hip (k_gather's tri_box, k_collapse, k_blas_vertex_form, k_instance_proxies)
+// -- they only have to be valid structures of that format, the code under test is the walk.
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime.h>  // vector types; nothing is launched
 #include <algorithm>
@@ -18,7 +17,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <functional>
 #include <vector>
 
 // the device intrinsics pt_trace.h and the headers it includes use
@@ -32,9 +30,6 @@ static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int                __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline unsigned int       __builtin_amdgcn_readfirstlane(unsigned int x) { return x; }
-static inline int                __ffs(int x) { return __builtin_ffs(x); }
-static inline int                __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
-static inline int                __popc(unsigned int x) { return __builtin_popcount(x); }
 static const struct { unsigned x, y, z; } threadIdx = {0, 0, 0};
 
 #ifdef TH_ROBUST_T2
@@ -129,7 +124,6 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
 extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
-extern "C" int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, uint32_t leafMax, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut, uint32_t* numNodesOut, uint32_t* depthOut);
 extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut, uint32_t* alphaMapsOut, uint32_t* texelsOut,
                                       void* texRecsOut, char* err, size_t errLen);
 extern "C" int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel* out, float* out_integral, float* out_average);
@@ -141,17 +135,12 @@ struct Box {
   bool  alpha;
 };
 struct Bvh {
-  std::vector<TriRec> tris;   // leaf order of the 8-wide nodes
-  std::vector<CwNode> wide;   // node 0 = root
-  uint32_t            depth = 0;
-  float               lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-};
-
-// the per-thread traversal stack of the walks: LDS part and spill part, one "lane" (stride TRACE_BLOCK like on the device)
-struct HostStack {
-  std::vector<uint32_t> lds, spill;
-  HostStack() : lds(size_t(STACK_LDS_WORDS)), spill(size_t(STACK_SPILL_WORDS)) {}
-  TStack view() { return TStack{lds.data(), spill.data()}; }
+  std::vector<TriRec>   tris;   // leaf order
+  std::vector<WideNode> wide;   // node 0 = root
+  float                 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  // the binary tree the wide nodes were collapsed from (th_step_model re-collapses it at other widths)
+  std::vector<uint32_t> cl, cr;
+  std::vector<Box>      leafBox, innerBox;
 };
 
 // pt_accel.hip tri_box: padded box of a record (p0, p0 + e1, p0 + e2)
@@ -176,9 +165,8 @@ float half_area_h(const Box& b)
   return dx * dy + dy * dz + dz * dx;
 }
 
-// records (edge form, flags in p0w.w >> 29) -> leaf order + 8-wide nodes (k_gather, k_refit, k_emit, k_collapse8).  leafMax: triangles per leaf
-// child (CW_LEAF_MAX; 1 for the TLAS, whose "triangles" are instances)
-Bvh build_bvh(const std::vector<TriRec>& in, uint32_t leafMax = CW_LEAF_MAX)
+// records (edge form, flags in p0w.w >> 29) -> leaf order + 4-wide nodes (k_gather, k_refit, k_emit, k_collapse)
+Bvh build_bvh(const std::vector<TriRec>& in)
 {
   Bvh            out;
   const uint32_t n = uint32_t(in.size());
@@ -220,51 +208,78 @@ Bvh build_bvh(const std::vector<TriRec>& in, uint32_t leafMax = CW_LEAF_MAX)
       inner[k].alpha = a.alpha || b.alpha;
     }
   }
-  // binary nodes in the builder's format (k_emit): both child boxes in the parent, tagged references, triangles below each child
-  std::vector<uint32_t> cnt(n > 1 ? n - 1 : 1, 1u);
-  if(n >= 2)
-    for(uint32_t k = n - 1; k-- > 0;)
-      cnt[k] = ((cl[k] & BVH_LEAF) ? 1u : cnt[cl[k]]) + ((cr[k] & BVH_LEAF) ? 1u : cnt[cr[k]]);
   auto child_ref = [&](uint32_t r) -> uint32_t {
     if(r & BVH_LEAF)
       return BVH_LEAF | (r & ~BVH_LEAF) | (leaf[r & ~BVH_LEAF].alpha ? BVH_ALPHA : 0u);
-    return r | (inner[r].alpha ? BVH_ALPHA : 0u);
+    return r;
   };
-  std::vector<BvhNode> b2(n > 1 ? n - 1 : 1);
-  if(n == 1)
+  // collapse (k_collapse): per wide node, open the inner child of largest area until 4 children
+  struct Item { uint32_t b2, wide; };
+  std::vector<Item> queue{{0u, 0u}};
+  out.wide.resize(1);
+  for(size_t qi = 0; qi < queue.size(); ++qi)
   {
-    const Box& b = leaf[0];
-    b2[0].a = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
-    b2[0].b = make_float4(b.hi[1], b.hi[2], FLT_MAX, FLT_MAX);
-    b2[0].c = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-    b2[0].d = make_uint4(child_ref(BVH_LEAF | 0u), BVH_NONE, 1u, 0u);
-  }
-  else
-    for(uint32_t k = 0; k + 1 < n; ++k)
+    const Item it = queue[qi];
+    uint32_t   id[4];
+    int        cnt = 0;
+    if(n == 1)
+      id[cnt++] = BVH_LEAF | 0u;
+    else
     {
-      const Box &a = ref_box(cl[k]), &b = ref_box(cr[k]);
-      b2[k].a = make_float4(a.lo[0], a.lo[1], a.lo[2], a.hi[0]);
-      b2[k].b = make_float4(a.hi[1], a.hi[2], b.lo[0], b.lo[1]);
-      b2[k].c = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
-      b2[k].d = make_uint4(child_ref(cl[k]), child_ref(cr[k]), (cl[k] & BVH_LEAF) ? 1u : cnt[cl[k]], (cr[k] & BVH_LEAF) ? 1u : cnt[cr[k]]);
+      id[cnt++] = cl[it.b2];
+      id[cnt++] = cr[it.b2];
+      while(cnt < 4)
+      {
+        int   best = -1;
+        float bestA = -1.f;
+        for(int k = 0; k < cnt; ++k)
+          if(!(id[k] & BVH_LEAF))
+          {
+            const float a = half_area_h(inner[id[k]]);
+            if(a > bestA)
+            {
+              bestA = a;
+              best  = k;
+            }
+          }
+        if(best < 0)
+          break;
+        const uint32_t node = id[best];
+        id[best]            = id[cnt - 1];
+        --cnt;
+        id[cnt++] = cl[node];
+        id[cnt++] = cr[node];
+      }
     }
-  // the product's collapse to 8-wide quantised nodes (host emulation of k_collapse8) + the leaf permutation it asks for (k_permute_leaves)
-  const uint32_t        cap = n / 2u + 2u;
-  std::vector<uint32_t> perm(n);
-  uint32_t              numNodes = 0;
-  out.wide.resize(cap);
-  if(pt_debug_cw_collapse(b2.data(), n, leafMax, out.wide.data(), cap, perm.data(), &numNodes, &out.depth) != 0)
-  {
-    out.tris.clear();
-    out.wide.clear();
-    return out;
-  }
-  out.wide.resize(numNodes);
-  {
-    std::vector<TriRec> ordered(n);
-    for(uint32_t i = 0; i < n; ++i)
-      ordered[i] = out.tris[perm[i]];
-    out.tris.swap(ordered);
+    WideNode w;
+    std::memset(&w, 0, sizeof(w));
+    float*    mnx = &w.minx[0].x; float* mny = &w.miny[0].x; float* mnz = &w.minz[0].x;
+    float*    mxx = &w.maxx[0].x; float* mxy = &w.maxy[0].x; float* mxz = &w.maxz[0].x;
+    uint32_t* ch  = &w.child[0].x;
+    for(int k = 0; k < 4; ++k)
+    {
+      if(k < cnt)
+      {
+        const Box& b = ref_box(id[k]);
+        mnx[k] = b.lo[0]; mny[k] = b.lo[1]; mnz[k] = b.lo[2]; mxx[k] = b.hi[0]; mxy[k] = b.hi[1]; mxz[k] = b.hi[2];
+        if(id[k] & BVH_LEAF)
+          ch[k] = child_ref(id[k]);
+        else
+        {
+          const uint32_t wid = uint32_t(out.wide.size());
+          out.wide.emplace_back();
+          queue.push_back({id[k], wid});
+          ch[k] = wid | (inner[id[k]].alpha ? BVH_ALPHA : 0u);
+        }
+      }
+      else
+      {
+        mnx[k] = mny[k] = mnz[k] = FLT_MAX;
+        mxx[k] = mxy[k] = mxz[k] = -FLT_MAX;
+        ch[k]                    = BVH_NONE;
+      }
+    }
+    out.wide[it.wide] = w;
   }
   const Box& root = n >= 2 ? inner[0] : leaf[0];
   for(int a = 0; a < 3; ++a)
@@ -272,6 +287,7 @@ Bvh build_bvh(const std::vector<TriRec>& in, uint32_t leafMax = CW_LEAF_MAX)
     out.lo[a] = root.lo[a];
     out.hi[a] = root.hi[a];
   }
+  out.cl = cl; out.cr = cr; out.leafBox = leaf; out.innerBox = inner;
   return out;
 }
 
@@ -291,7 +307,7 @@ struct Scene {
   // two-level
   std::vector<TriRec>      blasTris;
   std::vector<AlphaRec>    blasAlpha;
-  std::vector<CwNode>      blasWide;
+  std::vector<WideNode>    blasWide;
   Bvh                      tlas;
   std::vector<TlasLeaf>    tlasLeaves;
   std::vector<AlphaRec>    flatAlpha;
@@ -385,10 +401,12 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
       s->blasTris.push_back(r);
       s->blasAlpha.push_back(alpha_record(*s, I, k));
     }
-    for(CwNode w : b.wide)
-    {  // global bases (k_blas_rebase)
-      w.childBase = (((w.childBase & CW_CHILD_MASK) + nodeBase) & CW_CHILD_MASK) | (w.childBase & ~CW_CHILD_MASK);
-      w.triBase += slotBase;
+    for(WideNode w : b.wide)
+    {  // global references (k_blas_rebase)
+      uint32_t* ch = &w.child[0].x;
+      for(int k = 0; k < 4; ++k)
+        if(ch[k] != BVH_NONE)
+          ch[k] = (ch[k] & ~BVH_SLOT_MASK) | ((ch[k] & BVH_SLOT_MASK) + ((ch[k] & BVH_LEAF) ? slotBase : nodeBase));
       s->blasWide.push_back(w);
     }
     nodeBaseOf[I.primMesh] = nodeBase;
@@ -419,7 +437,7 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
     prox.push_back(r);
   }
-  s->tlas = build_bvh(prox, 1u);
+  s->tlas = build_bvh(prox);
   for(const TriRec& r : s->tlas.tris)
   {
     const uint32_t id = __float_as_uint(r.p0w.w) & TRI_INDEX_MASK;
@@ -556,107 +574,6 @@ void th_world_tri(void* p, uint32_t w, float* out9, uint32_t* flags)
   *flags = __float_as_uint(r.p0w.w) >> 29;
 }
 
-// Invariants of an 8-wide quantised structure (pt_cwbvh.h), checked by walking it: which 0 flat, 1 TLAS.  For every node and child slot the
-// DECODED box (p + q 2^e, evaluated in double) must enclose everything below that child -- the padded boxes (k_gather's tri_box) of all its
-// triangles --, inner children are the consecutive nodes childBase + rank, the triangles of leaf children consecutive slots from triBase in
-// slot order, every leaf slot is referenced exactly once, empty slots are inverted and untagged, amask tags exactly the children that hold
-// non-opaque triangles, every plane is an integer of the 11-bit grid.
-// out: [0] violations, [1] nodes reached, [2] triangles reached, [3] depth, [4] children in total, [5] leaf children in total.
-void th_check_structure(void* p, int which, uint32_t* out6)
-{
-  Scene*     s = static_cast<Scene*>(p);
-  const Bvh& b = which == 0 ? s->flat : s->tlas;
-  std::memset(out6, 0, 6 * sizeof(uint32_t));
-  if(b.wide.empty())
-    return;
-  std::vector<uint32_t> seen(b.tris.size(), 0u);
-  struct Content { double lo[3], hi[3]; bool alpha; };
-  uint32_t bad = 0, nodes = 0, tris = 0, maxDepth = 0, children = 0, leaves = 0;
-  std::function<Content(uint32_t, uint32_t)> visit = [&](uint32_t idx, uint32_t depth) -> Content {
-    Content all{{1e300, 1e300, 1e300}, {-1e300, -1e300, -1e300}, false};
-    if(idx >= b.wide.size())
-    {
-      ++bad;
-      return all;
-    }
-    ++nodes;
-    maxDepth = std::max(maxDepth, depth);
-    const CwNode& nd = b.wide[idx];
-    const uint32_t imask = nd.eimask >> 24, amask = nd.childBase >> 24, l1 = nd.leaves & 0xffu, l2 = (nd.leaves >> 8) & 0xffu;
-    uint32_t       rank = 0, triOff = 0;
-    if((imask & l1) || (l2 & ~l1))
-      ++bad;
-    for(int k = 0; k < 8; ++k)
-    {
-      auto           q    = [&](const uint16_t* w) { return double(cw_float_of_half(w[k])); };
-      const double   step[3] = {std::ldexp(1.0, int(nd.eimask & 0xff) - 127), std::ldexp(1.0, int((nd.eimask >> 8) & 0xff) - 127), std::ldexp(1.0, int((nd.eimask >> 16) & 0xff) - 127)};
-      const double   dlo[3] = {nd.p[0] + q(nd.qlox) * step[0], nd.p[1] + q(nd.qloy) * step[1], nd.p[2] + q(nd.qloz) * step[2]};
-      const double   dhi[3] = {nd.p[0] + q(nd.qhix) * step[0], nd.p[1] + q(nd.qhiy) * step[1], nd.p[2] + q(nd.qhiz) * step[2]};
-      for(const uint16_t* w : {nd.qlox, nd.qloy, nd.qloz, nd.qhix, nd.qhiy, nd.qhiz})
-        if(cw_half_of_int(uint32_t(cw_float_of_half(w[k]))) != w[k] || cw_float_of_half(w[k]) > float(CW_GRID_MAX))
-          ++bad;  // every plane is an integer of the grid
-      Content        c{{1e300, 1e300, 1e300}, {-1e300, -1e300, -1e300}, false};
-      if((imask >> k) & 1u)
-      {
-        c = visit((nd.childBase & CW_CHILD_MASK) + rank, depth + 1);
-        ++rank;
-        ++children;
-      }
-      else if(!((l1 >> k) & 1u))
-      {
-        if(dlo[0] <= dhi[0] && dlo[1] <= dhi[1] && dlo[2] <= dhi[2])
-          ++bad;  // an empty slot must carry an inverted box
-        if((amask >> k) & 1u)
-          ++bad;
-        continue;
-      }
-      else
-      {
-        const uint32_t count = ((l2 >> k) & 1u) ? 2u : 1u;
-        ++children;
-        ++leaves;
-        for(uint32_t j = 0; j < count; ++j)
-        {
-          const uint32_t slot = nd.triBase + triOff + j;
-          if(slot >= b.tris.size())
-          {
-            ++bad;
-            continue;
-          }
-          ++seen[slot];
-          ++tris;
-          float lo[3], hi[3];
-          tri_box_h(b.tris[slot], lo, hi);
-          for(int a = 0; a < 3; ++a)
-          {
-            c.lo[a] = std::min(c.lo[a], double(lo[a]));
-            c.hi[a] = std::max(c.hi[a], double(hi[a]));
-          }
-          c.alpha = c.alpha || !((__float_as_uint(b.tris[slot].p0w.w) >> 29) & TRI_OPAQUE);
-        }
-        triOff += count;
-      }
-      for(int a = 0; a < 3; ++a)
-        if(!(dlo[a] <= c.lo[a] && dhi[a] >= c.hi[a]))
-          ++bad;
-      if(c.alpha != (((amask >> k) & 1u) != 0u))
-        ++bad;
-      for(int a = 0; a < 3; ++a)
-      {
-        all.lo[a] = std::min(all.lo[a], c.lo[a]);
-        all.hi[a] = std::max(all.hi[a], c.hi[a]);
-      }
-      all.alpha = all.alpha || c.alpha;
-    }
-    return all;
-  };
-  visit(0u, 1u);
-  for(uint32_t v : seen)
-    if(v != 1u)
-      ++bad;
-  out6[0] = bad; out6[1] = nodes; out6[2] = tris; out6[3] = maxDepth; out6[4] = children; out6[5] = leaves;
-}
-
 // Every candidate of every ray in key order (t, world index), at most maxCand per ray: mode 0 brute force over all world triangles with the
 // product's tri_test, 1 the flat walk, 2 the two-level walk -- traverse<TM_RAW_ALL> restarted behind the previous candidate, exactly what the
 // exact fallback kernels (k_closest_x / k_shadow_x) do.  outW / outT: nrays x maxCand (0xffffffff: no further candidate).  Returns the
@@ -668,9 +585,8 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
   std::memset(&total, 0, sizeof(total));
 #pragma omp parallel
   {
-    HostStack hs;
-    const TStack stack = hs.view();
-    Counters  cnt;
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+    Counters              cnt;
     std::memset(&cnt, 0, sizeof(cnt));
 #pragma omp for schedule(dynamic, 64)
     for(long long r = 0; r < (long long)nrays; ++r)
@@ -700,10 +616,11 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
         else
         {
           RayHit h;
+          bool   dummy;
           if(mode == 1)
-            traverse<TM_RAW_ALL, false>(s->dsFlat, o, d, tmax, tPrev, wPrev, 0u, stack, h, &cnt);
+            traverse<TM_RAW_ALL, false>(s->dsFlat, o, d, tmax, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
           else
-            traverse<TM_RAW_ALL, true>(s->dsTwo, o, d, tmax, tPrev, wPrev, 0u, stack, h, &cnt);
+            traverse<TM_RAW_ALL, true>(s->dsTwo, o, d, tmax, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
           if(h.slot != BVH_NONE)
           {
             bt = h.t;
@@ -739,7 +656,7 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
 //   kind 0: closest-hit ray (T5), kind 1: shadow ray (T6, bounded by tmax[r]);  two: 0 flat structure, 1 two-level structure;
 //   exact 0: tail_closest / tail_shadow (pass A, pass B, consume_rejected_draws, fallback), exact 1: the key-ordered loop with one
 //   alpha_test per non-opaque candidate (k_closest_x / k_shadow_x = the definition), exact 2: the TRACE MACHINE of the persistent kernels
-//   (pt_trace.h lane_begin / lane_step<TM_MACHINE> / lane_begin_count driven like k_closest_p / k_shadow_p drive one lane; the
+//   (pt_machine.h lane_begin / lane_inner / lane_leaf / lane_pop / lane_begin_count driven like k_closest_p / k_shadow_p drive one lane; the
 //   few lines of their service round -- pass A -> pass B transition, bulk draws, hand-over to the exact loop -- are restated here).
 // out per ray: w (world triangle index of the hit, 0xffffffff none; for shadow rays 1 / 0 = in shadow or not), t, u, v, seed afterwards,
 // number of alpha draws counted.  Returns the number of traversal-stack overflows.
@@ -760,9 +677,8 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
   std::memset(&total, 0, sizeof(total));
 #pragma omp parallel
   {
-    HostStack hs;
-    const TStack stack = hs.view();
-    Counters  cnt;
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+    Counters              cnt;
     std::memset(&cnt, 0, sizeof(cnt));
     RenderBuffers rb;
     std::memset(&rb, 0, sizeof(rb));
@@ -776,14 +692,21 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       bool machineFallback = false;
       if(exact == 2)
       {
-        TraceLane L;
+        TraceLane             L;
+        std::vector<uint32_t> spill(STACK_SPILL);
         lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
-        L.anyEnds = kind != 0;  // k_shadow_p
         for(;;)
         {
           while(!L.done)
           {
-            if(two) lane_step<TM_MACHINE, true>(S, L, stack, &cnt); else lane_step<TM_MACHINE, false>(S, L, stack, &cnt);
+            if(!(L.cur & BVH_LEAF))
+            {
+              if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt); else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
+            }
+            if(!L.done && (L.cur & BVH_LEAF))
+            {
+              if(two) lane_leaf<false, true>(S, L, stack.data(), spill.data()); else lane_leaf<false, false>(S, L, stack.data(), spill.data());
+            }
           }
           // service round of k_closest_p / k_shadow_p for this lane
           bool fallback = (L.flags & TF_SAW_FRAC) != 0;
@@ -828,7 +751,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       {
         if(kind == 0)
         {
-          if(two) tail_closest<true>(S, rb, uint32_t(r), stack, draws); else tail_closest<false>(S, rb, uint32_t(r), stack, draws);
+          if(two) tail_closest<true>(S, rb, uint32_t(r), stack.data(), draws); else tail_closest<false>(S, rb, uint32_t(r), stack.data(), draws);
           const float4 h = hit[r];
           outW[r]        = __float_as_uint(h.y);   // flat: leaf slot; two-level: world index -- translated below
           if(outW[r] != BVH_NONE && !two)
@@ -838,7 +761,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
         }
         else
         {
-          const bool sh = two ? tail_shadow<true>(S, rb, uint32_t(r), stack, variant, seed, draws) : tail_shadow<false>(S, rb, uint32_t(r), stack, variant, seed, draws);
+          const bool sh = two ? tail_shadow<true>(S, rb, uint32_t(r), stack.data(), variant, seed, draws) : tail_shadow<false>(S, rb, uint32_t(r), stack.data(), variant, seed, draws);
           outW[r]       = sh ? 1u : 0u;
           outTUV[3 * r] = outTUV[3 * r + 1] = outTUV[3 * r + 2] = 0.f;
           outSeed[r]    = seed;
@@ -851,10 +774,10 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
         float          tPrev = 0.0f;
         uint32_t       wPrev = 0xffffffffu;
         RayHit         h;
-        bool           found = false;
+        bool           dummy, found = false;
         for(;;)
         {
-          if(two) traverse<TM_RAW_ALL, true>(S, o, d, lim, tPrev, wPrev, 0u, stack, h, &cnt); else traverse<TM_RAW_ALL, false>(S, o, d, lim, tPrev, wPrev, 0u, stack, h, &cnt);
+          if(two) traverse<TM_RAW_ALL, true>(S, o, d, lim, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt); else traverse<TM_RAW_ALL, false>(S, o, d, lim, tPrev, wPrev, 0u, stack.data(), h, dummy, &cnt);
           if(h.slot == BVH_NONE)
             break;
           if((h.w >> 29) & TRI_OPAQUE)
@@ -892,39 +815,153 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
   return total.stackOverflow;
 }
 
-// Work per ray of the product's walk on the flat structure (tools/steps_experiment.py): lane_step calls (each = at most one dependent round of
-// triangle fetches + one node fetch), node visits, triangle tests -- the quantities that bound the trace stages.
-// kind 0: closest-hit ray, 1: shadow ray bounded by tmaxIn[r].  Needs a -DPT_STATS build of this harness (TraceLane::nNodes / nTris).
+// DESIGN EXPERIMENT (tools/steps_experiment.py; nothing of the product runs here except tri_test): how many DEPENDENT memory round trips does a
+// closest-hit walk of the flat structure need per ray -- the quantity that bounds the trace stages -- for node width 4
+// (the product's layout) or 8, and with the triangles of a node's leaf children fetched together in one round trip instead of one per
+// triangle?  The binary tree of the flat structure is collapsed again at the requested width (same greedy rule as k_collapse) and walked
+// nearest-first with a plain slab test; a step = one node fetch, or one (batch of) triangle fetch(es).
 // out per ray: steps, nodes visited, triangles tested.
-void th_step_counts(void* p, int kind, uint32_t nrays, const float* org, const float* dir, const float* tmaxIn, uint32_t* out3)
+void th_step_model(void* p, int width, int batchLeaves, uint32_t nrays, const float* org, const float* dir, const float* tmaxIn, uint32_t* out3)
 {
-  Scene* s = static_cast<Scene*>(p);
-#pragma omp parallel
+  Scene*     s = static_cast<Scene*>(p);
+  const Bvh& b = s->flat;
+  const uint32_t n = uint32_t(b.tris.size());
+  struct WN { int cnt; Box box[8]; uint32_t ref[8]; };
+  std::vector<WN> nodes;
+  if(n >= 2)
   {
-    HostStack    hs;
-    const TStack stack = hs.view();
-    Counters     cnt;
-    std::memset(&cnt, 0, sizeof(cnt));
-#pragma omp for schedule(dynamic, 64)
-    for(long long r = 0; r < (long long)nrays; ++r)
+    struct Item { uint32_t b2, wide; };
+    std::vector<Item> queue{{0u, 0u}};
+    nodes.resize(1);
+    for(size_t qi = 0; qi < queue.size(); ++qi)
     {
-      const f3  o = f3{org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d = f3{dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
-      TraceLane L;
-      lane_begin(L, o, d, (kind && tmaxIn) ? tmaxIn[r] : PT_INFINITY, s->dsFlat.numTris == 0);
-      L.anyEnds      = kind != 0;
-      uint32_t steps = 0;
-      while(!L.done)
+      const Item it = queue[qi];
+      uint32_t   id[8];
+      int        cnt = 0;
+      id[cnt++] = b.cl[it.b2];
+      id[cnt++] = b.cr[it.b2];
+      while(cnt < width)
       {
-        lane_step<TM_CLOSEST, false>(s->dsFlat, L, stack, &cnt);
-        ++steps;
+        int   best = -1;
+        float bestA = -1.f;
+        for(int k = 0; k < cnt; ++k)
+          if(!(id[k] & BVH_LEAF) && half_area_h(b.innerBox[id[k]]) > bestA)
+          {
+            bestA = half_area_h(b.innerBox[id[k]]);
+            best  = k;
+          }
+        if(best < 0)
+          break;
+        const uint32_t node = id[best];
+        id[best]            = id[cnt - 1];
+        --cnt;
+        id[cnt++] = b.cl[node];
+        id[cnt++] = b.cr[node];
       }
-      out3[3 * r] = steps;
-#ifdef PT_STATS
-      out3[3 * r + 1] = L.nNodes; out3[3 * r + 2] = L.nTris;
-#else
-      out3[3 * r + 1] = out3[3 * r + 2] = 0;
-#endif
+      WN w;
+      w.cnt = cnt;
+      for(int k = 0; k < cnt; ++k)
+      {
+        if(id[k] & BVH_LEAF)
+        {
+          w.box[k] = b.leafBox[id[k] & ~BVH_LEAF];
+          w.ref[k] = id[k];
+        }
+        else
+        {
+          w.box[k] = b.innerBox[id[k]];
+          w.ref[k] = uint32_t(nodes.size());
+          nodes.emplace_back();
+          queue.push_back({id[k], w.ref[k]});
+        }
+      }
+      nodes[it.wide] = w;
     }
+  }
+#pragma omp parallel for schedule(dynamic, 64)
+  for(long long r = 0; r < (long long)nrays; ++r)
+  {
+    const f3 o = f3{org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d = f3{dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
+    const float id3[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, o3[3] = {o.x, o.y, o.z};
+    float       best = tmaxIn ? tmaxIn[r] : 3.0e38f;
+    uint32_t    steps = 0, nn = 0, nt = 0;
+    auto        test_tri = [&](uint32_t slot) {
+      const TriRec& tr = b.tris[slot];
+      float         t, u, v;
+      ++nt;
+      if(tri_test(tr, __float_as_uint(tr.p0w.w) >> 29, o, d, t, u, v) && t > 0.f && t < best)
+        best = t;
+    };
+    if(n == 1)
+    {
+      test_tri(0);
+      steps = 1;
+    }
+    else if(n >= 2)
+    {
+      uint32_t stack[256];
+      int      sp = 0;
+      uint32_t cur = 0;
+      for(;;)
+      {
+        if(cur & BVH_LEAF)
+        {
+          ++steps;
+          test_tri(cur & ~BVH_LEAF);
+        }
+        else
+        {
+          ++steps;
+          ++nn;
+          const WN& w = nodes[cur];
+          float     tn[8];
+          uint32_t  rf[8];
+          int       nh = 0;
+          bool      anyLeaf = false;
+          for(int k = 0; k < w.cnt; ++k)
+          {
+            float t0 = 0.f, t1 = best;
+            for(int a = 0; a < 3; ++a)
+            {
+              const float ta = (w.box[k].lo[a] - o3[a]) * id3[a], tb = (w.box[k].hi[a] - o3[a]) * id3[a];
+              t0 = std::fmax(t0, std::fmin(ta, tb));
+              t1 = std::fmin(t1, std::fmax(ta, tb));
+            }
+            if(t0 * 0.9999996f <= t1 * 1.0000004f)
+            {
+              if(batchLeaves && (w.ref[k] & BVH_LEAF))
+              {
+                anyLeaf = true;
+                test_tri(w.ref[k] & ~BVH_LEAF);  // fetched together with the node's other hit leaves: one round trip (counted below)
+              }
+              else
+              {
+                tn[nh] = t0;
+                rf[nh] = w.ref[k];
+                ++nh;
+              }
+            }
+          }
+          if(anyLeaf)
+            ++steps;
+          // far-to-near onto the stack
+          for(int i = 0; i < nh; ++i)
+            for(int j = i + 1; j < nh; ++j)
+              if(tn[j] > tn[i])
+              {
+                std::swap(tn[i], tn[j]);
+                std::swap(rf[i], rf[j]);
+              }
+          for(int i = 0; i < nh && sp < 256; ++i)
+            if(!batchLeaves || tn[i] <= best)
+              stack[sp++] = rf[i];
+        }
+        if(sp == 0)
+          break;
+        cur = stack[--sp];
+      }
+    }
+    out3[3 * r] = steps; out3[3 * r + 1] = nn; out3[3 * r + 2] = nt;
   }
 }
 
@@ -996,9 +1033,8 @@ uint32_t th_render_shard(void* p, int two, const pt_RtxState* stIn, int variant,
       fp.sample = smp;
 #pragma omp parallel
       {
-        HostStack hs;
-        const TStack stack = hs.view();
-        Counters  cnt;
+        std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+        Counters              cnt;
         std::memset(&cnt, 0, sizeof(cnt));
         RenderBuffers lrb = rb;
         lrb.counters      = &cnt;
@@ -1013,14 +1049,14 @@ uint32_t th_render_shard(void* p, int two, const pt_RtxState* stIn, int variant,
           uint32_t nAlpha = 0;
           for(int depth = 0; depth < fp.st.maxDepth; ++depth)
           {
-            if(two) tail_closest<true>(S, lrb, slot, stack, nAlpha); else tail_closest<false>(S, lrb, slot, stack, nAlpha);
+            if(two) tail_closest<true>(S, lrb, slot, stack.data(), nAlpha); else tail_closest<false>(S, lrb, slot, stack.data(), nAlpha);
             uint32_t  events = 0;
             const int to     = shade_path<-1>(S, lrb, fp, slot, depth, events);
             bool      survive = to == SHADE_TO_NEXT;
             if(to == SHADE_TO_SHADOW)
             {
               uint32_t   seed;
-              const bool inShadow = two ? tail_shadow<true>(S, lrb, slot, stack, variant, seed, nAlpha) : tail_shadow<false>(S, lrb, slot, stack, variant, seed, nAlpha);
+              const bool inShadow = two ? tail_shadow<true>(S, lrb, slot, stack.data(), variant, seed, nAlpha) : tail_shadow<false>(S, lrb, slot, stack.data(), variant, seed, nAlpha);
               survive             = finish_bounce_core(lrb, slot, inShadow, seed) && depth != fp.st.maxDepth - 1;
             }
             if(!survive)

@@ -1,8 +1,7 @@
-"""CPU measurement (no GPU): work per ray of the product's walk (pt_trace.h lane_step on the 8-wide quantised structure, host build of the
-same source) over the C3 stand-in's flat structure: lane_step calls -- each is at most one round of triangle fetches plus one node fetch, the
-dependent memory round trips that bound the trace stages --, node visits and triangle tests, for camera rays, random
-bounce rays and shadow rays.  profiles/r02c_steps_experiment.txt holds the same rays on the 4-wide fp32 layout of round 2 (24.9 / 25.9 / 26.3
-steps per ray) and the model that predicted 0.65x for 8-wide nodes with batched leaves.
+"""CPU experiment (no GPU): dependent memory round trips per ray of a closest-hit walk over the C3 stand-in's flat structure -- the quantity that
+bounds the trace stages (a stage lasts as long as its slowest ray, a chain of node / triangle fetches) -- for the product's
+4-wide nodes with one triangle per step (what the kernels do today), with the hit leaf children of a node fetched together, and for 8-wide nodes.
+Uses the binary tree the device builder produces (host emulation) and the test harness tests/cpp/trace_host.cpp (th_step_model).
    python tools/steps_experiment.py [rays]"""
 import ctypes as C
 import os
@@ -19,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 wl = workloads.c3_sponza(tex_size=64)
 tr = T.TracedScene(wl.scene)
 L = tr.L
-L.th_step_counts.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+L.th_step_model.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 rng = np.random.default_rng(1)
 cam = wl.scene.camera
 eye = np.array(cam.eye, np.float64)
@@ -41,15 +40,16 @@ o1 = p1 + d1 * 1e-3
 sun = np.array([np.cos(np.radians(45)) * np.sin(np.radians(30)), np.sin(np.radians(45)), np.cos(np.radians(45)) * np.cos(np.radians(30))])
 ds = np.repeat(sun[None], len(p1), 0)
 os_ = p1 + ds * 1e-3
-classes = [("primary (camera)", o0, d0, 0), ("bounce (random direction from a surface point)", o1, d1, 0), ("shadow (towards the sun from a surface point)", os_, ds, 1)]
-sizes = np.zeros(4, np.uint32)
-L.th_sizes(tr.h, sizes.ctypes.data)
-print(f"C3 stand-in, {tr.n} triangles, {sizes[0]} 8-wide nodes ({sizes[0] * 80 / 1e6:.1f} MB); {n} rays per class")
-for name, o, d, kind in classes:
+classes = [("primary (camera)", o0, d0), ("bounce (random direction from a surface point)", o1, d1), ("shadow (towards the sun from a surface point)", os_, ds)]
+print(f"C3 stand-in, {tr.n} triangles; {n} rays per class")
+for name, o, d in classes:
     o32, d32 = np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
-    out = np.zeros((len(o32), 3), np.uint32)
-    tmax = np.full(len(o32), 1e30, np.float32)
-    L.th_step_counts(tr.h, kind, len(o32), o32.ctypes.data, d32.ctypes.data, tmax.ctypes.data, out.ctypes.data)
-    st = out[:, 0].astype(np.float64)
-    print(f"   {name:50s} steps/ray mean {st.mean():6.1f}  p99 {np.percentile(st, 99):6.0f}  max {st.max():5.0f}   nodes {out[:, 1].mean():6.1f}  triangles {out[:, 2].mean():5.1f}")
+    print(name)
+    base = None
+    for width, batch, label in ((4, 0, "4-wide, one triangle per step (today)"), (4, 1, "4-wide, a node's hit leaves in one step"), (8, 0, "8-wide, one triangle per step"), (8, 1, "8-wide, a node's hit leaves in one step")):
+        out = np.zeros((len(o32), 3), np.uint32)
+        L.th_step_model(tr.h, width, batch, len(o32), o32.ctypes.data, d32.ctypes.data, None, out.ctypes.data)
+        st = out[:, 0].astype(np.float64)
+        base = base or st.mean()
+        print(f"   {label:42s} steps/ray mean {st.mean():6.1f} ({st.mean() / base:4.2f}x)  p99 {np.percentile(st, 99):6.0f}  max {st.max():5.0f}   nodes {out[:, 1].mean():6.1f}  triangles {out[:, 2].mean():5.1f}")
 tr.close()

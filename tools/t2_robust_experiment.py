@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 robust = os.path.join(ROOT, "tests", "cpp", "_build", "libtracehost_robust.so")
 T.harness()  # builds the contract's flavour
 lib_dir = os.path.dirname(capi.LIB_PATH)
-subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DTH_ROBUST_T2", "-Wno-attributes",
+subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DSTACK_LDS=24", "-DTH_ROBUST_T2", "-Wno-attributes",
                        "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "vk_raytrace_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), T.SRC,
                        "-L" + lib_dir, "-l:libptmi.so", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", robust])
 names = ["camera", "surface", "axis", "far"]

@@ -1,7 +1,7 @@
 // Device acceleration-structure build for gfx950.  Replaces AccelStructure::create of the reference
 // (src/accelstruct.cpp:55-162: one BLAS per prim-mesh + one TLAS instance per node, built by the Vulkan driver).
 //
-// pt_accel_build: ONE hierarchy over a set of primitives, as 8-wide quantised nodes (CwNode, pt_cwbvh.h) over leaf-ordered records (TriRec):
+// pt_accel_build: ONE hierarchy over a set of primitives, as 4-wide nodes (WideNode) over leaf-ordered records (TriRec):
 //   k_world_tris   instance transforms applied in fp32 (trace contract T1) -> TriRec + centroid   (or ready-made records: dProxies)
 //   topology       device binned SAH (default, pt_sahdev.h) | host SAH (cross-check) | PLOC | Karras radix tree (k_morton, radix sort, k_hierarchy)
 //   k_gather       records in leaf order + padded leaf boxes
@@ -24,7 +24,6 @@
 #include "pt_device.h"
 #include "pt_internal.h"
 #include "pt_sahdev.h"
-#include "pt_cwbvh.h"
 
 namespace {
 
@@ -367,11 +366,7 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ childL, const uint32
 // into a new inner node; the array is compacted; repeat until one cluster is left.  Unlike the radix tree of Karras 2012 (k_hierarchy) the
 // topology follows the surface-area heuristic locally, which is what makes the host SAH builder's trees fast to trace.
 // Ties in area are broken by (i xor j): a symmetric key, so runs of identical boxes still pair up as buddies instead of forming one merge per round.
-PT_DEV float half_area(float4 lo, float4 hi)
-{
-  float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-  return dx * dy + dy * dz + dz * dx;
-}
+PT_DEV float half_area(float4 lo, float4 hi);
 PT_DEV float union_half_area(float4 alo, float4 ahi, float4 blo, float4 bhi)
 {
   float dx = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), dy = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), dz = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
@@ -797,34 +792,8 @@ PT_DEV uint32_t leaf_ref(const TriRec* __restrict__ tris, uint32_t leaf)
   return BVH_LEAF | slot | ((flags & TRI_OPAQUE) ? 0u : BVH_ALPHA);
 }
 
-// Triangles below every inner node (bottom-up, the arrival protocol of k_refit): the collapse to 8-wide nodes turns a subtree of at most
-// CW_LEAF_MAX triangles into one leaf child.
-__global__ void k_counts(int n, const uint32_t* __restrict__ childL, const uint32_t* __restrict__ childR, const uint32_t* __restrict__ parentOfInner,
-                         const uint32_t* __restrict__ parentOfLeaf, uint32_t* cnt, unsigned int* arrive)
-{
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  uint32_t cur = parentOfLeaf[i];
-  while(cur != BVH_NONE)
-  {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned int prev = __hip_atomic_fetch_add(&arrive[cur], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if(prev == 0)
-      return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const uint32_t l = childL[cur], r = childR[cur];
-    const uint32_t cl = (l & BVH_LEAF) ? 1u : __hip_atomic_load(&cnt[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t cr = (r & BVH_LEAF) ? 1u : __hip_atomic_load(&cnt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&cnt[cur], cl + cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cur = parentOfInner[cur];
-  }
-}
-
 __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const uint32_t* __restrict__ childR, const float4* __restrict__ leafLo,
-                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, const TriRec* __restrict__ tris,
-                       const uint32_t* __restrict__ cnt, BvhNode* __restrict__ out)
+                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, const TriRec* __restrict__ tris, BvhNode* __restrict__ out)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= numInner)
@@ -838,9 +807,7 @@ __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const 
   nd.a   = make_float4(llo.x, llo.y, llo.z, lhi.x);
   nd.b   = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
   nd.c   = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
-  // d.z / d.w: triangles below the left / right child
-  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : (l | (llo.w > 0.f ? BVH_ALPHA : 0u)), (r & BVH_LEAF) ? leaf_ref(tris, r) : (r | (rlo.w > 0.f ? BVH_ALPHA : 0u)),
-                      (l & BVH_LEAF) ? 1u : cnt[l], (r & BVH_LEAF) ? 1u : cnt[r]);
+  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : (l | (llo.w > 0.f ? BVH_ALPHA : 0u)), (r & BVH_LEAF) ? leaf_ref(tris, r) : (r | (rlo.w > 0.f ? BVH_ALPHA : 0u)), 0u, 0u);
   out[i] = nd;
 }
 
@@ -851,7 +818,7 @@ __global__ void k_single_leaf(const float4* leafLo, const float4* leafHi, const 
   nd.a   = make_float4(lo.x, lo.y, lo.z, hi.x);
   nd.b   = make_float4(hi.y, hi.z, FLT_MAX, FLT_MAX);
   nd.c   = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-  nd.d   = make_uint4(leaf_ref(tris, BVH_LEAF), BVH_NONE, 1u, 0u);
+  nd.d   = make_uint4(leaf_ref(tris, BVH_LEAF), BVH_NONE, 0u, 0u);
   out[0] = nd;
 }
 
@@ -902,15 +869,19 @@ __global__ void k_blas_vertex_form(uint32_t n, TriRec* __restrict__ tris, const 
   r.e2p   = make_float4(v2.x, v2.y, v2.z, 0.f);
   tris[i] = r;
 }
-// node / triangle bases of a BLAS from local to global indices (nodes: + nodeBase, leaf slots: + slotBase), tags kept
-__global__ void k_blas_rebase(uint32_t numNodes, CwNode* __restrict__ nodes, uint32_t nodeBase, uint32_t slotBase)
+// child references of a BLAS from local to global indices (nodes: + nodeBase, leaf slots: + slotBase), tags kept
+__global__ void k_blas_rebase(uint32_t numWide, WideNode* __restrict__ wide, uint32_t nodeBase, uint32_t slotBase)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= numNodes)
+  if(i >= numWide)
     return;
-  const uint32_t cb  = nodes[i].childBase;
-  nodes[i].childBase = (((cb & CW_CHILD_MASK) + nodeBase) & CW_CHILD_MASK) | (cb & ~CW_CHILD_MASK);
-  nodes[i].triBase += slotBase;
+  for(int q = 0; q < PT_WIDE_Q; ++q)
+  {
+    uint32_t* ch = &wide[i].child[q].x;
+    for(int k = 0; k < 4; ++k)
+      if(ch[k] != BVH_NONE)
+        ch[k] = (ch[k] & ~BVH_SLOT_MASK) | ((ch[k] & BVH_SLOT_MASK) + ((ch[k] & BVH_LEAF) ? slotBase : nodeBase));
+  }
 }
 
 // World box of an instance = exact bounds of its T1 world triangles (the same xform_point the leaf test applies, so the box encloses every
@@ -976,69 +947,89 @@ __global__ void k_tlas_leaves(uint32_t n, const TriRec* __restrict__ leafOrder, 
   out[i]     = l;
 }
 
-// ---- collapse the binary tree to 8-wide quantised nodes (pt_cwbvh.h; level-synchronous, one thread per node) ------------------------------
-// counters: [0] items of the next level, [1] CwNodes allocated, [2] triangles placed.  perm[new leaf slot] = old (binary-tree order) leaf slot.
-// Inner children of a node take consecutive node ids, the triangles of its leaf children consecutive leaf slots: one atomic each per node.
-__global__ void k_collapse8(const BvhNode* __restrict__ b2, const CwItem* __restrict__ qin, uint32_t nIn, CwItem* __restrict__ qout, uint32_t* counters, uint32_t nodeCapacity,
-                            CwNode* __restrict__ out, uint32_t* __restrict__ perm, uint32_t leafMax)
+// ---- collapse BVH2 -> wide BVH (level-synchronous; one thread per wide node) -------------------------------------
+struct CollapseItem {
+  uint32_t b2;    // binary node to expand
+  uint32_t wide;  // wide node it becomes
+};
+PT_DEV float half_area(float4 lo, float4 hi)
+{
+  float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* __restrict__ qin, uint32_t nIn, CollapseItem* __restrict__ qout, uint32_t* counters /* [0]=nOut [1]=wideCount */,
+                           WideNode* __restrict__ out)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= nIn)
     return;
-  const CwItem it = qin[i];
-  CwOpen       open[CW_WIDTH];
-  const int    n = cw_gather_children(b2, it.b2, open, leafMax);
-  CwChild      ch[CW_WIDTH];
-  uint32_t     nInner = 0, nTri = 0;
-  float        nlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for(int c = 0; c < n; ++c)
-  {
-    for(int a = 0; a < 3; ++a)
+  const CollapseItem it = qin[i];
+  uint32_t           id[PT_BVH_WIDTH];
+  float4             lo[PT_BVH_WIDTH], hi[PT_BVH_WIDTH];
+  int                n = 0;
+  auto               push_children = [&](uint32_t node) {
+    const BvhNode nd = b2[node & BVH_SLOT_MASK];
+    id[n] = nd.d.x; lo[n] = make_float4(nd.a.x, nd.a.y, nd.a.z, 0.f); hi[n] = make_float4(nd.a.w, nd.b.x, nd.b.y, 0.f); ++n;
+    if(nd.d.y != BVH_NONE)
     {
-      ch[c].lo[a] = open[c].lo[a]; ch[c].hi[a] = open[c].hi[a];
-      nlo[a] = fminf(nlo[a], open[c].lo[a]); nhi[a] = fmaxf(nhi[a], open[c].hi[a]);
+      id[n] = nd.d.y; lo[n] = make_float4(nd.b.z, nd.b.w, nd.c.x, 0.f); hi[n] = make_float4(nd.c.y, nd.c.z, nd.c.w, 0.f); ++n;
     }
-    const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= leafMax;
-    ch[c].kind  = leaf ? open[c].count : 0u;
-    ch[c].alpha = (open[c].ref & BVH_ALPHA) ? 1u : 0u;
-    nInner += leaf ? 0u : 1u;
-    nTri += leaf ? open[c].count : 0u;
-  }
-  int slotOf[CW_WIDTH];
-  cw_assign_slots(ch, n, nlo, nhi, slotOf);
-  const uint32_t childBase = nInner ? atomicAdd(&counters[1], nInner) : 0u;
-  const uint32_t triBase   = nTri ? atomicAdd(&counters[2], nTri) : 0u;
-  uint32_t       innerRank[CW_WIDTH], triOffset[CW_WIDTH];
-  CwNode         nd;
-  if(!cw_encode_node(ch, n, slotOf, childBase, triBase, &nd, innerRank, triOffset) || childBase + nInner > nodeCapacity)
+  };
+  push_children(it.b2);
+  while(n < PT_BVH_WIDTH)
   {
-    atomicAdd(&counters[3], 1u);  // non-finite boxes or a node array that is too small: the build fails
-    return;
+    int   best = -1;
+    float bestA = -1.f;
+    for(int k = 0; k < n; ++k)
+      if(!(id[k] & BVH_LEAF))
+      {
+        float a = half_area(lo[k], hi[k]);
+        if(a > bestA)
+        {
+          bestA = a;
+          best  = k;
+        }
+      }
+    if(best < 0)
+      break;
+    const uint32_t node = id[best];
+    // replace slot `best` by the first child, append the second
+    id[best] = id[n - 1]; lo[best] = lo[n - 1]; hi[best] = hi[n - 1];
+    --n;
+    push_children(node);
   }
-  out[it.node] = nd;
-  const uint32_t qi = nInner ? atomicAdd(&counters[0], nInner) : 0u;
-  for(int c = 0; c < n; ++c)
+  WideNode w;
+  for(int q = 0; q < PT_WIDE_Q; ++q)
   {
-    if(ch[c].kind == 0u)
-      qout[qi + innerRank[c]] = CwItem{open[c].ref & BVH_SLOT_MASK, childBase + innerRank[c]};
-    else
+    float* mnx = &w.minx[q].x; float* mny = &w.miny[q].x; float* mnz = &w.minz[q].x;
+    float* mxx = &w.maxx[q].x; float* mxy = &w.maxy[q].x; float* mxz = &w.maxz[q].x;
+    uint32_t* ch = &w.child[q].x;
+    for(int k = 0; k < 4; ++k)
     {
-      uint32_t  slots[CW_LEAF_MAX];
-      const int k = cw_leaf_slots(b2, open[c].ref, slots);
-      for(int j = 0; j < k && j < CW_LEAF_MAX; ++j)
-        perm[triBase + triOffset[c] + uint32_t(j)] = slots[j];
+      int c = q * 4 + k;
+      if(c < n)
+      {
+        mnx[k] = lo[c].x; mny[k] = lo[c].y; mnz[k] = lo[c].z; mxx[k] = hi[c].x; mxy[k] = hi[c].y; mxz[k] = hi[c].z;
+        if(id[c] & BVH_LEAF)
+          ch[k] = id[c];
+        else
+        {
+          uint32_t wid = atomicAdd(&counters[1], 1u);
+          uint32_t qi  = atomicAdd(&counters[0], 1u);
+          qout[qi]     = CollapseItem{id[c] & BVH_SLOT_MASK, wid};
+          ch[k]        = wid | (id[c] & BVH_ALPHA);  // inner reference: wide node index + "subtree holds non-opaque triangles"
+        }
+      }
+      else
+      {
+        mnx[k] = mny[k] = mnz[k] = FLT_MAX;
+        mxx[k] = mxy[k] = mxz[k] = -FLT_MAX;
+        ch[k]                    = BVH_NONE;
+      }
     }
+    w.pad[q] = make_uint4(0, 0, 0, 0);
   }
-}
-// leaf records from binary-tree order into the order the 8-wide nodes address them in
-__global__ void k_permute_leaves(uint32_t n, const uint32_t* __restrict__ perm, const TriRec* __restrict__ in, TriRec* __restrict__ out, const AlphaRec* __restrict__ alphaIn,
-                                 AlphaRec* __restrict__ alphaOut)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  out[i]      = in[perm[i]];
-  alphaOut[i] = alphaIn[perm[i]];
+  out[it.wide] = w;
 }
 
 }  // namespace
@@ -1059,12 +1050,10 @@ __global__ void k_permute_leaves(uint32_t n, const uint32_t* __restrict__ perm, 
 // structure is built over one "diagonal" record per instance (p0 = box min, e1 = box extent, e2 = 0: its bounding box is the instance's box).
 // scratch (may be null): temporaries come out of the caller's arena instead of one device allocation each (a scene of hundreds of BLASes).
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, CwNode* dCwOut, uint32_t cwCapacity, uint32_t* numCwOut, uint32_t* depthOut, char* err, size_t errLen,
-                   const TriRec* dProxies, PtScratch* scratch)
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen, const TriRec* dProxies,
+                   PtScratch* scratch)
 {
-  *numCwOut = 0;
-  if(depthOut)
-    *depthOut = 0;
+  *numWideOut = 0;
   if(numTris == 0)
     return 0;
   PtScratch  localScratch;
@@ -1074,9 +1063,8 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   const int      B          = 256;
   const uint32_t G          = (n + B - 1) / B;
 
-  TriRec *  dUnsorted = nullptr, *dTrisB2 = nullptr;            // records in input order / in binary-tree leaf order (the final order comes out of the collapse)
-  AlphaRec *dAlphaUnsorted = nullptr, *dAlphaB2 = nullptr;
-  uint32_t *dPerm = nullptr, *dSubCount = nullptr;
+  TriRec*   dUnsorted = nullptr;
+  AlphaRec* dAlphaUnsorted = nullptr;
   float4 *  dCen = nullptr, *dLeafLo = nullptr, *dLeafHi = nullptr, *dNodeLo = nullptr, *dNodeHi = nullptr;
   uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr, *dHist = nullptr, *dBounds = nullptr;
   uint32_t *dChildL = nullptr, *dChildR = nullptr, *dParI = nullptr, *dParL = nullptr;
@@ -1086,10 +1074,6 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
 
   HIPCHK(sc.get((void**)&dUnsorted, sizeof(TriRec) * size_t(n)));
   HIPCHK(sc.get((void**)&dAlphaUnsorted, sizeof(AlphaRec) * size_t(n)));
-  HIPCHK(sc.get((void**)&dTrisB2, sizeof(TriRec) * size_t(n)));
-  HIPCHK(sc.get((void**)&dAlphaB2, sizeof(AlphaRec) * size_t(n)));
-  HIPCHK(sc.get((void**)&dPerm, 4 * size_t(n)));
-  HIPCHK(sc.get((void**)&dSubCount, 4 * size_t(n)));
   HIPCHK(sc.get((void**)&dCen, sizeof(float4) * size_t(n)));
   HIPCHK(sc.get((void**)&dLeafLo, sizeof(float4) * size_t(n)));
   HIPCHK(sc.get((void**)&dLeafHi, sizeof(float4) * size_t(n)));
@@ -1220,7 +1204,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     }
     // after 4 passes the sorted data is back in A
   }
-  k_gather<<<G, B, 0, stream>>>(n, dValsA, dUnsorted, dTrisB2, dAlphaUnsorted, dAlphaB2, dLeafLo, dLeafHi);
+  k_gather<<<G, B, 0, stream>>>(n, dValsA, dUnsorted, dTrisOut, dAlphaUnsorted, dAlphaOut, dLeafLo, dLeafHi);
   if(ploc)
   {
     // PLOC rounds; the cluster count comes back to the host between rounds (the build is not on the timed path).  A round merges at least the
@@ -1273,7 +1257,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   }
   if(n == 1)
   {
-    k_single_leaf<<<1, 1, 0, stream>>>(dLeafLo, dLeafHi, dTrisB2, dNodesOut);
+    k_single_leaf<<<1, 1, 0, stream>>>(dLeafLo, dLeafHi, dTrisOut, dNodesOut);
   }
   else
   {
@@ -1286,53 +1270,36 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
       (void)hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream);
       k_rotate<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
     }
-    (void)hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream);
-    k_counts<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dSubCount, dArrive);
-    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisB2, dSubCount, dNodesOut);
+    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(stream));
 
-  // ---- collapse to the 8-wide quantised layout, one level per launch (the queue sizes come back to the host between levels; the build is
-  // not on the timed path).  The number of levels is the depth of the structure = the bound of the traversal stack.
+  // ---- collapse to the wide layout, one BVH level per launch (the queue sizes come back to the host between levels;
+  // the build is not on the timed path)
   {
-    CwItem*   dQ[2] = {nullptr, nullptr};
-    uint32_t* dCnt  = nullptr;
-    HIPCHK(sc.get((void**)&dQ[0], sizeof(CwItem) * size_t(n)));
-    HIPCHK(sc.get((void**)&dQ[1], sizeof(CwItem) * size_t(n)));
-    HIPCHK(sc.get((void**)&dCnt, 16));
-    CwItem   first{0u, 0u};
-    uint32_t cnt[4] = {0u, 1u, 0u, 0u};  // next-queue size, nodes allocated (root = 0), triangles placed, failures
+    CollapseItem* dQ[2] = {nullptr, nullptr};
+    uint32_t*     dCnt  = nullptr;
+    HIPCHK(sc.get((void**)&dQ[0], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(sc.get((void**)&dQ[1], sizeof(CollapseItem) * size_t(n)));
+    HIPCHK(sc.get((void**)&dCnt, 8));
+    CollapseItem first{0u, 0u};
+    uint32_t     cnt[2] = {0u, 1u};  // next-queue size, wide nodes allocated (root = 0)
     HIPCHK(hipMemcpyAsync(dQ[0], &first, sizeof(first), hipMemcpyHostToDevice, stream));
-    uint32_t nIn = 1, depth = 0;
+    uint32_t nIn = 1;
     int      cur = 0;
-    while(nIn)
+    bool     ok  = true;
+    while(nIn && ok)
     {
-      HIPCHK(hipMemcpyAsync(dCnt, cnt, 16, hipMemcpyHostToDevice, stream));
-      k_collapse8<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, cwCapacity, dCwOut, dPerm, dProxies ? 1u : uint32_t(CW_LEAF_MAX));  // (TLAS: one instance per leaf)
-      HIPCHK(hipMemcpyAsync(cnt, dCnt, 16, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(dCnt, cnt, 8, hipMemcpyHostToDevice, stream));
+      k_collapse<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, dWideOut);
+      HIPCHK(hipMemcpyAsync(cnt, dCnt, 8, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
-      if(cnt[3] || cnt[1] > cwCapacity || cnt[2] > n)
-      {
-        snprintf(err, errLen, "collapse to 8-wide nodes failed (%u nodes of %u, %u triangles of %u, %u bad boxes)", cnt[1], cwCapacity, cnt[2], n, cnt[3]);
-        goto fail;
-      }
       nIn    = cnt[0];
       cnt[0] = 0;
       cur ^= 1;
-      ++depth;
     }
-    if(cnt[2] != n)
-    {
-      snprintf(err, errLen, "collapse to 8-wide nodes placed %u of %u triangles", cnt[2], n);
-      goto fail;
-    }
-    *numCwOut = cnt[1];
-    if(depthOut)
-      *depthOut = depth;
-    k_permute_leaves<<<G, B, 0, stream>>>(n, dPerm, dTrisB2, dTrisOut, dAlphaB2, dAlphaOut);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(stream));
+    *numWideOut = cnt[1];
   }
 
   sc.release();
@@ -1346,7 +1313,7 @@ fail:
 // ---- two-level structure: the builds -------------------------------------------------------------------------------------------------
 // Every BLAS is an ordinary pt_accel_build over ONE pseudo-instance with the identity transform (object space), written at its bases in the
 // shared arrays; then its leaf records are turned into vertex form and its references made global.
-int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, CwNode* dWide,
+int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
                   char* err, size_t errLen)
 {
   if(numBlas == 0)
@@ -1401,7 +1368,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
     if(!ok)
       snprintf(msg, sizeof(msg), "BLAS build: out of device memory");
     // temporaries of one build: < 640 B per triangle (pt_accel_build's lists + the SAH builder's bins); whatever does not fit is allocated singly
-    const size_t arenaBytes = size_t(maxTris) * 768 + (size_t(1) << 20);
+    const size_t arenaBytes = size_t(maxTris) * 640 + (size_t(1) << 20);
     if(ok && hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
       arena.cap = arenaBytes;
     else
@@ -1416,13 +1383,12 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
         break;
       PtBlasDesc&    d = blas[b];
       const uint32_t n = d.triCount;
-      if(pt_accel_build(ws, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, pt_cw_capacity(n), &d.numWide, &d.depth, msg,
-                        sizeof(msg), nullptr, &arena) != 0)
+      if(pt_accel_build(ws, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, msg, sizeof(msg), nullptr, &arena) != 0)
       {
         ok = false;
         break;
       }
-      if(d.numWide == 0 || d.numWide > pt_cw_capacity(n))
+      if(d.numWide == 0 || d.numWide > std::max(1u, n - 1))
       {
         snprintf(msg, sizeof(msg), "BLAS %u: %u wide nodes for %u triangles", b, d.numWide, n);
         ok = false;
@@ -1461,7 +1427,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
 }
 
 int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
-                  const float4* dVertices, const uint32_t* dIndices, CwNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, uint32_t* depthOut, char* err, size_t errLen)
+                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen)
 {
   *numWideOut = 0;
   if(numActive == 0)
@@ -1478,7 +1444,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
     goto done;
   }
   k_instance_proxies<<<n, 256, 0, stream>>>(dActive, dInst, dVertices, dIndices, dProx);
-  if(pt_accel_build(stream, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, pt_cw_capacity(n), numWideOut, depthOut, err, errLen, dProx, nullptr) != 0)
+  if(pt_accel_build(stream, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, numWideOut, err, errLen, dProx, nullptr) != 0)
     goto done;
   k_tlas_leaves<<<(n + 255) / 256, 256, 0, stream>>>(n, dLeafOrder, dInst, dInstNodeBase, dInstPad, dLeavesOut);
   if(hipMemcpyAsync(rootOut, dNodes, sizeof(BvhNode), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -1494,73 +1460,4 @@ done:
     if(q)
       (void)hipFree(q);
   return rc;
-}
-
-// Test hook (not part of the ABI; tests/cpp/trace_host.cpp, tests/test_cwbvh.py): the collapse of k_collapse8 run sequentially on the host over a
-// binary tree in the builder's format -- the same cw_* bodies (pt_cwbvh.h), plain counters instead of atomics, the same level-synchronous order.
-// nodesOut: `capacity` CwNodes; permOut[new leaf slot] = old leaf slot (numTris entries).  Returns 0, or -1 when a node cannot be encoded /
-// the capacity is exceeded.
-extern "C" __attribute__((visibility("default"))) int pt_debug_cw_collapse(const BvhNode* b2, uint32_t numTris, uint32_t leafMax, CwNode* nodesOut, uint32_t capacity, uint32_t* permOut,
-                                                                          uint32_t* numNodesOut, uint32_t* depthOut)
-{
-  if(!b2 || !nodesOut || !permOut || numTris == 0 || capacity == 0 || leafMax < 1 || leafMax > CW_LEAF_MAX)
-    return -1;
-  std::vector<CwItem> cur{CwItem{0u, 0u}}, next;
-  uint32_t            numNodes = 1, numPlaced = 0, depth = 0;
-  while(!cur.empty())
-  {
-    next.clear();
-    for(const CwItem& it : cur)
-    {
-      CwOpen    open[CW_WIDTH];
-      const int n = cw_gather_children(b2, it.b2, open, leafMax);
-      CwChild   ch[CW_WIDTH];
-      uint32_t  nInner = 0, nTri = 0;
-      float     nlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, nhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-      for(int c = 0; c < n; ++c)
-      {
-        for(int a = 0; a < 3; ++a)
-        {
-          ch[c].lo[a] = open[c].lo[a]; ch[c].hi[a] = open[c].hi[a];
-          nlo[a] = std::fmin(nlo[a], open[c].lo[a]); nhi[a] = std::fmax(nhi[a], open[c].hi[a]);
-        }
-        const bool leaf = (open[c].ref & BVH_LEAF) || open[c].count <= leafMax;
-        ch[c].kind  = leaf ? open[c].count : 0u;
-        ch[c].alpha = (open[c].ref & BVH_ALPHA) ? 1u : 0u;
-        nInner += leaf ? 0u : 1u;
-        nTri += leaf ? open[c].count : 0u;
-      }
-      int slotOf[CW_WIDTH];
-      cw_assign_slots(ch, n, nlo, nhi, slotOf);
-      const uint32_t childBase = nInner ? numNodes : 0u, triBase = nTri ? numPlaced : 0u;
-      numNodes += nInner;
-      numPlaced += nTri;
-      uint32_t innerRank[CW_WIDTH], triOffset[CW_WIDTH];
-      CwNode   nd;
-      if(numNodes > capacity || numPlaced > numTris || it.node >= capacity || !cw_encode_node(ch, n, slotOf, childBase, triBase, &nd, innerRank, triOffset))
-        return -1;
-      nodesOut[it.node] = nd;
-      const size_t q0 = next.size();
-      next.resize(q0 + nInner);
-      for(int c = 0; c < n; ++c)
-      {
-        if(ch[c].kind == 0u)
-          next[q0 + innerRank[c]] = CwItem{open[c].ref & BVH_SLOT_MASK, childBase + innerRank[c]};
-        else
-        {
-          uint32_t  slots[CW_LEAF_MAX];
-          const int k = cw_leaf_slots(b2, open[c].ref, slots);
-          for(int j = 0; j < k && j < CW_LEAF_MAX; ++j)
-            permOut[triBase + triOffset[c] + uint32_t(j)] = slots[j];
-        }
-      }
-    }
-    cur.swap(next);
-    ++depth;
-  }
-  if(numPlaced != numTris)
-    return -1;
-  if(numNodesOut) *numNodesOut = numNodes;
-  if(depthOut) *depthOut = depth;
-  return 0;
 }

@@ -16,8 +16,6 @@
 #include <vector>
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
-#include "pt_cwbvh.h"
-#include "pt_trace.h"  // STACK_TOTAL / STACK_SPILL: the traversal-stack bound the builds are checked against
 
 namespace {
 std::string g_createError;
@@ -36,8 +34,6 @@ struct pt_context {
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
-  uint32_t tlasDepth = 0, blasDepth = 0;
-  uint32_t accelDepth = 0;  // levels of the structure the kernels walk (two-level: TLAS levels + the deepest BLAS + the postponed instance group): the stack bound
   // two-level acceleration structure (pt_set_accel_mode): dWide / dTris / dAlphaRecs hold the concatenated BLASes, dTlas the instance hierarchy
   int      accelMode = PT_ACCEL_FLAT;
   DevBuf   dTlas, dTlasLeaves, dInstTriBase, dActive, dInstNodeBase, dInstPad;
@@ -60,7 +56,7 @@ struct pt_context {
   // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
   // running-mean accumulate is ordered across frames (events).
   struct FrameSlot {
-    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dQueueT, dSortKeys, dSortHist, dCounts, dSpill;
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dQueueT, dSortKeys, dSortHist, dCounts;
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
@@ -90,7 +86,7 @@ struct pt_context {
   uint64_t  launchSeq    = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
   DevBuf   dFrame, dSlotTile, dCounters;
-  DevBuf   dPick, dPickSpill;
+  DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
   bool     gatherEnqueued = false;  // pt_gather_shards ran on this context as the root and pt_gather_finish has not consumed it yet
@@ -248,7 +244,8 @@ void refresh_scene_ptrs(pt_context* c)
   s.lights       = (const pt_Light*)c->dLights.p;
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
   s.texels       = (const uint32_t*)c->dTexels.p;
-  s.wide         = (const CwNode*)c->dWide.p;
+  s.bvh          = (const BvhNode*)c->dBvh.p;
+  s.wide         = (const WideNode*)c->dWide.p;
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
@@ -258,7 +255,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.numTris      = c->numTris;
   s.numInstances = c->numInstances;
   const bool two = c->accelMode == PT_ACCEL_TWO_LEVEL && c->haveAccel;
-  s.tlas         = two ? (const CwNode*)c->dTlas.p : nullptr;
+  s.tlas         = two ? (const WideNode*)c->dTlas.p : nullptr;
   s.tlasLeaves   = two ? (const TlasLeaf*)c->dTlasLeaves.p : nullptr;
   s.instTriBase  = two ? (const uint32_t*)c->dInstTriBase.p : nullptr;
   s.twoLevel     = two ? 1u : 0u;
@@ -372,17 +369,14 @@ int build_tlas(pt_context* c)
   if((rc = upload(c, c->dInstTriBase, triBase.data(), 4 * triBase.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dInstPad, pad.data(), 4 * pad.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dInstNodeBase, c->hInstNodeBase.empty() ? &none : c->hInstNodeBase.data(), 4 * std::max<size_t>(1, c->hInstNodeBase.size()))) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dTlas, sizeof(CwNode) * size_t(pt_cw_capacity(c->numActive)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dTlas, sizeof(WideNode) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dTlasLeaves, sizeof(TlasLeaf) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
   auto    t0 = std::chrono::steady_clock::now();
   char    msg[256];
   BvhNode root{};
   if(pt_tlas_build(c->stream, (const InstanceRec*)c->dInstances.p, (const uint32_t*)c->dActive.p, c->numActive, (const uint32_t*)c->dInstNodeBase.p, (const float*)c->dInstPad.p,
-                   (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (CwNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, &c->tlasDepth, msg, sizeof(msg)) != 0)
+                   (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (WideNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "TLAS build: %s", msg);
-  c->accelDepth = c->tlasDepth + c->blasDepth + 2;  // + the rest of an instance group and of the TLAS node group postponed while inside an instance
-  if(c->accelDepth > STACK_TOTAL)
-    return c->fail(PT_ERR_INVALID, "two-level structure is %u levels deep (TLAS %u + BLAS %u); the traversal stack holds %d", c->accelDepth, c->tlasDepth, c->blasDepth, STACK_TOTAL);
   c->msBuildTlas = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for(int k = 0; k < 3; ++k)
     c->scene.boundsMin[k] = c->scene.boundsInvExt[k] = 0.f;
@@ -413,33 +407,29 @@ int build_two_level(pt_context* c)
       d.flags = I.flags & ~TRI_FLIP; d.materialIndex = I.materialIndex;
       d.slotBase = uint32_t(slots); d.nodeBase = uint32_t(nodes);
       slots += I.triCount;
-      nodes += pt_cw_capacity(I.triCount);
+      nodes += std::max(1u, I.triCount - 1);
       it = blasOf.emplace(I.primMesh, uint32_t(blas.size())).first;
       blas.push_back(d);
     }
     c->hInstNodeBase[i] = blas[it->second].nodeBase;
   }
-  if(slots > BVH_SLOT_MASK || nodes > CW_CHILD_MASK)
+  if(slots > BVH_SLOT_MASK || nodes > BVH_SLOT_MASK)
     return c->fail(PT_ERR_INVALID, "two-level structure: %llu distinct triangles exceed the reference range", (unsigned long long)slots);
   int rc;
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(std::max<uint64_t>(1, slots)))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(std::max<uint64_t>(1, slots)))) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dWide, sizeof(CwNode) * size_t(std::max<uint64_t>(1, nodes)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dWide, sizeof(WideNode) * size_t(std::max<uint64_t>(1, nodes)))) != PT_OK) return rc;
   dev_free(c->dBvh);  // the binary nodes are a build temporary here
   auto t0 = std::chrono::steady_clock::now();
   char msg[256];
   if(pt_blas_build(c->stream, blas.data(), uint32_t(blas.size()), (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p,
-                   (CwNode*)c->dWide.p, msg, sizeof(msg)) != 0)
+                   (WideNode*)c->dWide.p, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel (two-level): %s", msg);
   c->numBlas      = uint32_t(blas.size());
   c->numBvhNodes  = uint32_t(nodes);
   c->numWideNodes = 0;
-  c->blasDepth = 0;
   for(const PtBlasDesc& d : blas)
-  {
     c->numWideNodes += d.numWide;
-    c->blasDepth = std::max(c->blasDepth, d.depth);
-  }
   if((rc = build_tlas(c)) != PT_OK)
     return rc;
   HIP_TRY(c, sync_all(c));
@@ -545,8 +535,12 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   {  // performance A/B knobs only
     int v;
     if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) g_tuning.stateMB = v;
+    if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) g_tuning.packetClosestBounces = v;
+    if(const char* p = strstr(tune, "packetShadow=")) if(sscanf(p, "packetShadow=%d", &v) == 1) g_tuning.packetShadowBounces = v;
+    if(const char* p = strstr(tune, "minPacket=")) if(sscanf(p, "minPacket=%d", &v) == 1) g_tuning.minPacket = v;
     if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) g_tuning.packetWaves = v;
+    if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
     if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) g_tuning.persistentWaves = v;
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
@@ -608,7 +602,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dPickSpill, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -617,7 +611,7 @@ int pt_destroy(pt_context* c)
   {
     for(DevBuf& b : fs.dState)
       dev_free(b);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys, &fs.dSortHist, &fs.dCounts, &fs.dSpill};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys, &fs.dSortHist, &fs.dCounts};
     for(DevBuf* b : q)
       dev_free(*b);
     if(fs.accumDone)
@@ -920,16 +914,14 @@ int pt_build_accel(pt_context* c)
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dBvh, sizeof(BvhNode) * size_t(c->numBvhNodes))) != PT_OK) return rc;
-  if(pt_cw_capacity(c->numTris) > CW_CHILD_MASK)
-    return c->fail(PT_ERR_INVALID, "pt_build_accel: %u triangles exceed the 24-bit node range of the flat structure (use PT_ACCEL_TWO_LEVEL)", c->numTris);
-  if((rc = dev_alloc(c, c->dWide, sizeof(CwNode) * size_t(pt_cw_capacity(c->numTris)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dWide, sizeof(WideNode) * size_t(c->numBvhNodes))) != PT_OK) return rc;
   auto t0 = std::chrono::steady_clock::now();
   char msg[256];
   // the builder's ~30 temporaries come out of one arena (one allocation and one free instead of thirty each: 3-5 ms of a 15 ms build); whatever
   // does not fit -- or everything, if the arena cannot be had -- is allocated singly
   PtScratch arena;
   {
-    const size_t want = size_t(c->numTris) * 768 + (size_t(1) << 20);
+    const size_t want = size_t(c->numTris) * 640 + (size_t(1) << 20);
     if(hipMalloc((void**)&arena.base, want) == hipSuccess)
       arena.cap = want;
     else
@@ -939,8 +931,7 @@ int pt_build_accel(pt_context* c)
     }
   }
   const int brc = pt_accel_build(c->stream, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
-                                 (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p, (BvhNode*)c->dBvh.p, (CwNode*)c->dWide.p, pt_cw_capacity(c->numTris), &c->numWideNodes, &c->accelDepth, msg,
-                                 sizeof(msg), nullptr, &arena);
+                                 (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p, (BvhNode*)c->dBvh.p, (WideNode*)c->dWide.p, &c->numWideNodes, msg, sizeof(msg), nullptr, &arena);
   arena.release();
   if(arena.base)
     (void)hipFree(arena.base);
@@ -959,21 +950,6 @@ int pt_build_accel(pt_context* c)
     BvhNode root;
     HIP_TRY(c, hipMemcpy(&root, c->dBvh.p, sizeof(root), hipMemcpyDeviceToHost));
     bounds_from_root(c, root, c->numTris > 1 && root.d.y != BVH_NONE);
-  }
-  dev_free(c->dBvh);  // the binary tree was a build product: the kernels walk the 8-wide nodes only
-  if(c->accelDepth > STACK_TOTAL)
-    return c->fail(PT_ERR_INVALID, "acceleration structure is %u levels deep; the traversal stack holds %d", c->accelDepth, STACK_TOTAL);
-  if(c->numWideNodes && size_t(c->numWideNodes) * 2 < pt_cw_capacity(c->numTris))
-  {  // the node array was sized for the worst case: keep what the build used
-    DevBuf exact;
-    if(dev_alloc_quiet(exact, sizeof(CwNode) * size_t(c->numWideNodes)))
-    {
-      HIP_TRY(c, hipMemcpy(exact.p, c->dWide.p, sizeof(CwNode) * size_t(c->numWideNodes), hipMemcpyDeviceToDevice));
-      dev_free(c->dWide);
-      c->dWide = exact;
-    }
-    else
-      (void)hipGetLastError();
   }
   c->haveAccel = true;
   refresh_scene_ptrs(c);
@@ -1210,8 +1186,6 @@ int pt_resize(pt_context* c, int width, int height)
       for(DevBuf* bf : q)
         ok = ok && dev_alloc_quiet(*bf, 4 * n);
       ok = ok && dev_alloc_quiet(fs.dSortHist, sizeof(uint32_t) * SORT_BINS) && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
-      // traversal-stack levels beyond the LDS part: one slice per wavefront of a launch (86 MB per frame slot; only trees deeper than STACK_LDS touch it)
-      ok = ok && dev_alloc_quiet(fs.dSpill, sizeof(uint32_t) * size_t(PT_SPILL_WAVES) * STACK_SPILL_WORDS);
       if(ok)
         HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
     }
@@ -1261,7 +1235,6 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.sortKeys = (uint32_t*)fs.dSortKeys.p;
     fs.rb.sortHist = (uint32_t*)fs.dSortHist.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
-    fs.rb.spill    = (uint32_t*)fs.dSpill.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
@@ -1510,9 +1483,7 @@ int pt_pick(pt_context* c, float pick_x, float pick_y, const float* view_inverse
   int rc;
   if((rc = dev_alloc(c, c->dPick, sizeof(pt_PickResult))) != PT_OK)
     return rc;
-  if((rc = dev_alloc(c, c->dPickSpill, sizeof(uint32_t) * size_t(STACK_SPILL_WORDS))) != PT_OK)
-    return rc;
-  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p, (Counters*)c->dCounters.p, (uint32_t*)c->dPickSpill.p);
+  pt_launch_pick(c->stream, c->scene, pick_x, pick_y, view_inverse, proj_inverse, (pt_PickResult*)c->dPick.p, (Counters*)c->dCounters.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dPick.p, sizeof(pt_PickResult), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1826,7 +1797,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.tailClosestRays = k.tailClosestRays; s.tailShadowRays = k.tailShadowRays; s.tailShadedHits = k.tailShadedHits; s.tailMisses = k.tailMisses;
   s.tailAlphaTests = k.tailAlphaTests;
   s.numTriangles = c->numTris;
-  s.numBvhNodes  = c->numWideNodes;
+  s.numBvhNodes  = PT_BVH_WIDTH == 2 ? c->numBvhNodes : c->numWideNodes;
   s.msBuildAccel = c->msBuild;
   s.numBlas      = c->numBlas;
   s.numTlasNodes = c->numTlasNodes;

@@ -59,13 +59,23 @@ struct AlphaMat {
 #define ALPHA_ST_ZERO 1u    // opacity <= 0 everywhere
 #define ALPHA_ST_ONE 2u     // opacity >= 1 everywhere
 
-// The nodes the kernels walk: 8-wide, child boxes quantised to 8 bits per plane (80 B per node; pt_cwbvh.h), collapsed on the device from the
-// binary tree above.
-struct CwNode;
+// Wide node (PT_BVH_WIDTH = 4 or 8 children), collapsed on device from the binary LBVH by surface area.  The
+// traversal is bound by dependent memory round trips, not ALU, so fewer / fatter steps win: one node fetch
+// (W/4 * 7 aligned 16-byte loads, all in flight together) decides W children.  SoA inside the node.
+#ifndef PT_BVH_WIDTH
+#define PT_BVH_WIDTH 4
+#endif
+#define PT_WIDE_Q (PT_BVH_WIDTH / 4)
+struct WideNode {
+  float4 minx[PT_WIDE_Q], miny[PT_WIDE_Q], minz[PT_WIDE_Q];
+  float4 maxx[PT_WIDE_Q], maxy[PT_WIDE_Q], maxz[PT_WIDE_Q];
+  uint4  child[PT_WIDE_Q];   // bit31: leaf -> TriRec slot; BVH_NONE: empty slot (its box is inverted)
+  uint4  pad[PT_WIDE_Q];     // pads the node to 128 B (W=4) / 256 B (W=8)
+};
 
 // ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
 // One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
-// the instances' world boxes.  DeviceScene::wide / tris / alphaRecs then hold the concatenated BLASes (node and triangle bases
+// the instances' world boxes.  DeviceScene::wide / tris / alphaRecs then hold the concatenated BLASes (child references and leaf slots
 // are global indices into them), DeviceScene::tlas the instance hierarchy.  A BLAS leaf record keeps the three OBJECT-space vertex
 // positions (p0w.xyz, e1n.xyz, e2p.xyz; p0w.w = primitive index): the triangle test transforms them with the instance matrix exactly as
 // trace contract T1 does and runs in world space, so hits are bit-identical to the flat structure; only the box tests happen in object space.
@@ -111,7 +121,8 @@ struct DeviceScene {
   const pt_Light*             lights;
   const TexRec*               texRecs;
   const uint32_t*             texels;  // RGBA8 pool
-  const CwNode*               wide;  // the 8-wide quantised nodes (flat structure: over all world triangles; two-level: the concatenated BLASes)
+  const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
+  const WideNode*             wide;  // collapsed wide BVH
   const TriRec*               tris;
   const AlphaRec*             alphaRecs;  // leaf order, parallel to tris
   const AlphaMat*             alphaMats;  // one per material
@@ -126,7 +137,7 @@ struct DeviceScene {
   float                       boundsMin[3];     // world bounds of the triangles (ray-sort keys: origin cell)
   float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
   // two-level mode (null / 0 otherwise)
-  const CwNode*               tlas;         // instance hierarchy; its triangle groups index tlasLeaves
+  const WideNode*             tlas;         // instance hierarchy; its leaf references index tlasLeaves
   const TlasLeaf*             tlasLeaves;
   const uint32_t*             instTriBase;  // InstanceRec::triBase of every instance, compact (world triangle index -> instance)
   uint32_t                    twoLevel;

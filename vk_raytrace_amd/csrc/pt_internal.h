@@ -42,29 +42,22 @@ struct PtScratch {
     off      = 0;
   }
 };
-// dNodesOut: the binary tree (max(1, numTris - 1) BvhNodes, a build product the collapse reads; node 0 = root: its two child boxes are the world bounds);
-// dCwOut: the 8-wide quantised nodes the kernels walk (pt_cwbvh.h), cwCapacity = pt_cw_capacity(numTris) of them; depthOut: levels of that tree.
 int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
-                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, struct CwNode* dCwOut, uint32_t cwCapacity, uint32_t* numCwOut, uint32_t* depthOut, char* err, size_t errLen,
+                   TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen,
                    const TriRec* dProxies = nullptr, PtScratch* scratch = nullptr);
-// Upper bound of the 8-wide nodes over n triangles: every node but the root stands for a binary subtree of more than CW_LEAF_MAX (3) triangles; nodes
-// without inner children hold >= 4 triangles (<= n / 4 of them), nodes with inner children are full (8 children) and every chain of them consumes
-// >= 7 triangles per node.  n / 2 + 2 covers both with room to spare; pt_build_accel shrinks the array to what was used.
-inline uint32_t pt_cw_capacity(uint32_t n) { return n / 2u + 2u; }
 // Two-level structure (reference: src/accelstruct.cpp:110-162).  One BLAS per prim-mesh in object space ...
 struct PtBlasDesc {
   uint32_t primMesh, vertexOffset, firstIndex, triCount, flags;  // flags: TRI_OPAQUE / TRI_NOCULL of the mesh's material (no TRI_FLIP: that is per instance)
   int32_t  materialIndex;
-  uint32_t slotBase, nodeBase;  // where its leaf records / 8-wide nodes start in the shared arrays (pt_cw_capacity(triCount) nodes reserved from nodeBase)
-  uint32_t numWide;             // out: nodes used
-  uint32_t depth;               // out: levels of its tree
+  uint32_t slotBase, nodeBase;  // where its leaf records / wide nodes start in the shared arrays (nodeBase + max(1, triCount - 1) nodes reserved)
+  uint32_t numWide;             // out: wide nodes used
 };
-int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, struct CwNode* dWide,
+int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
                   char* err, size_t errLen);
 // ... and one TLAS over the world boxes of the `numActive` non-empty instances listed in dActive (exact bounds of the T1 world triangles).
 // dInstNodeBase[inst]: root node of the instance's BLAS; dInstPad[2 * inst + {0,1}]: TlasLeaf::padC0 / padC1.  rootOut: the binary root (world bounds).
 int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
-                  const float4* dVertices, const uint32_t* dIndices, struct CwNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, uint32_t* depthOut, char* err, size_t errLen);
+                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen);
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
 // Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):
@@ -83,7 +76,6 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
 #define PT_PERSISTENT_WAVES (256u * 20u)
-#define PT_SPILL_WAVES 2048  // wavefronts of one launch that own a slice of a frame slot's traversal-stack spill area (STACK_SPILL_WORDS words each)
 
 struct RenderBuffers {
   PathState ps;
@@ -98,7 +90,6 @@ struct RenderBuffers {
   uint32_t* sortKeys;  // sort key of every entry of the queue being sorted
   uint32_t* sortHist;  // SORT_BINS bin counters -> bin offsets
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
-  uint32_t* spill;     // traversal-stack entries beyond the LDS levels: [wave of the launch][word][level][lane] (pt_trace.h)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
   Counters* counters;
@@ -106,8 +97,13 @@ struct RenderBuffers {
 // Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
 // the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
 struct PtTuning {
+  int simpleClosestBounces = 1;   // bounces whose closest-hit stage uses the lock-step kernel (coherent primary rays: 82 % lane utilisation)
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
+  int packetShadowBounces  = 0;    // bounces whose shadow rays first go through the packet kernel.  Off: measured slower on C3 (1173 vs 1287
+                                   // Msamples/s at 1, 851 at 2) -- unoccluded any-hit rays cannot prune, so a packet walks the union of 64 full-length rays
+  int minPacket            = 16;   // lanes that must share the majority direction signs for a shadow packet to be walked
   int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
+  int simpleShadowBounces  = 0;   // shadow rays differ 10x in length: always on the refilling machine
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
   int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
@@ -150,7 +146,7 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
 #define SORT_MAX_CELL_BITS 5
 #define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint32_t* spill);
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
 void pt_launch_scatter_tiles(hipStream_t stream, const float4* gathered, int nranks, int maxTilesPerRank, int tilesX, int tilesY, const uint32_t* tileLocalIndex, float4* fullTiles);
 // the offscreen image with its mip chain as the display pass samples it (level 0 = the image; src/render_output.cpp:188-193)

@@ -18,6 +18,7 @@
 //                   (pathtrace.glsl:327-338); trace machine                                       queueS -> queue[out]
 //   k_closest_x / k_shadow_x   one ray per lane, exact key-ordered alpha loop, on the (normally almost empty) queues of
 //                   rays the two-pass scheme cannot settle
+//   k_closest_s / k_shadow_s / k_shadow_k   lock-step and packet variants selectable through PT_TUNE (bit-identical results)
 //   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean over the frames of the batch, in frame order
 //                   (pathtrace.comp:122-133)
 //
@@ -151,12 +152,12 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
     atomicAdd(ctr, (unsigned long long)v);
 }
 
-// Persistent wavefronts on the trace machine (pt_machine.h, pt_trace.h lane_step).  The loop alternates between
+// Persistent wavefronts on the trace machine (pt_machine.h).  The loop alternates between
 //   service: lanes whose ray has finished settle it (pass A -> pass B transition, RNG draws, hit record) and every
 //            idle lane pulls the next ray from the queue;
 //   run:     the traversal steps, executed until fewer than `minRun` lanes are still traversing (or, once the
 //            queue is empty, until all are done).
-// Settling rays outside the run loop keeps the hot loop to the triangle tests and the node visit; a finished lane
+// Settling rays outside the run loop keeps the hot loop to the node step and the triangle test; a finished lane
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
 // HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
 // instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
@@ -164,19 +165,24 @@ template <bool HEAT, bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
-  uint32_t*        C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t   count = C[cntIn];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t            spill[STACK_SPILL];
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[cntIn];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves, so that each still refills its lanes a few times
-  const TStack     st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
-  TraceLane        L;
-  RaySupply        rs;
+  uint32_t*           lds   = stack + threadIdx.x;
+  TraceLane           L;
+  RaySupply           rs;
   // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
   rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
-  uint32_t         pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
-  bool             alive = false;
-  lane_begin(L, f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 1.f}, 0.f, true);
+  uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
+  bool                alive = false;
+  L.done                    = true;
+  L.cur                     = 0;
+#ifdef PT_HIST
+  unsigned long long hIter = 0, hInner = 0, hLeaf = 0, hService = 0, hBoth = 0, hInnerIt = 0, hLeafIt = 0;
+#endif
   for(;;)
   {
     // ---- service
@@ -207,10 +213,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
           enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
         if(HEAT)
           rb.ps.rayO[pslot].w += heat_ns(heatT0);
-#ifdef PT_STATS
-        atomicAdd(&rb.counters->nodesVisited, (unsigned long long)L.nNodes);
-        atomicAdd(&rb.counters->trisTested, (unsigned long long)L.nTris);
-#endif
         alive = false;
       }
     }
@@ -230,27 +232,100 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       break;
     // ---- run
     const int target = rs.more ? minRun : 1;
+#ifdef PT_HIST
+    ++hService;
+#endif
     while(__popcll(__ballot(!L.done)) >= target)
     {
-      if(!L.done)
-        lane_step<TM_MACHINE, TWO>(S, L, st, rb.counters);
+#ifdef PT_HIST
+      const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
+#endif
+      if(!L.done && !(L.cur & BVH_LEAF))
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
+#ifdef PT_HIST
+      const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
+      ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
+#endif
+      if(!L.done && (L.cur & BVH_LEAF))
+        lane_leaf<false, TWO>(S, L, lds, spill);
     }
   }
+#ifdef PT_HIST
+  if((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&g_hist[5][0], hIter); atomicAdd(&g_hist[5][1], hInner); atomicAdd(&g_hist[5][2], hLeaf); atomicAdd(&g_hist[5][3], hService);
+    atomicAdd(&g_hist[5][4], hBoth); atomicAdd(&g_hist[5][5], hInnerIt); atomicAdd(&g_hist[5][6], hLeafIt);
+  }
+#endif
   wave_add(&rb.counters->closestRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Simple variant: one ray per lane for the lifetime of the wave (lock-step traversal: for coherent rays every
+// node fetch is a broadcast), pass A + pass B inline, exact fallback through queueX.
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  const bool          valid = i < C[CNT_IN];
+  uint32_t            slot = 0, nAlpha = 0;
+  bool                fallback = false;
+  if(valid)
+  {
+    slot                = queueIn[i];
+    const f3       o    = xyz(rb.ps.rayO[slot]);
+    const float4   dw   = rb.ps.rayD[slot];
+    const f3       d    = xyz(dw);
+    const uint32_t seed = __float_as_uint(dw.w);
+    RayHit         h;
+    bool           dummy;
+    traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+    fallback       = (h.flags & TF_SAW_FRAC) != 0;
+    const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+    uint32_t   nDraw = h.count;
+    if(passB)
+    {
+      RayHit c;
+      traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                         rb.counters);
+      fallback = (c.flags & TF_SAW_FRAC) != 0;
+      nDraw    = c.count;
+    }
+    if(!fallback)
+    {
+      if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+        ++nDraw;
+      uint32_t s2 = seed;
+      if(consume_rejected_draws(s2, nDraw))
+      {
+        store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
+        if(nDraw)
+          rb.ps.rayD[slot].w = __uint_as_float(s2);
+        nAlpha = nDraw;
+      }
+      else
+        fallback = true;
+    }
+  }
+  wave_add(&rb.counters->closestRays, valid ? 1u : 0u);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+  if(fallback)
+    enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
 }
 
 // Packet kernel for coherent rays (bounce 0, pt_packet.h): persistent wavefronts walk the queue 64 rays (one 8x8 pixel block)
 // at a time with ONE traversal per wave.  Rays it cannot settle on the spot -- packets whose lanes disagree on a direction
 // sign, rays that need pass B or the exact fallback -- are staged in LDS and appended to queueR, which the refilling trace
-// machine (k_closest_p) then redoes per lane.  Keeping those paths out of this kernel keeps its register budget small: the packet
+// machine (k_closest_p) then redoes per lane.  Keeping those paths out of this kernel keeps it at ~64 VGPRs: the packet
 // traversal is a serial chain of scalar loads, so it lives on resident waves, not on instruction throughput.
 #ifndef PT_PACKET_WAVES
 #define PT_PACKET_WAVES 8
 #endif
 __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
 {
-  __shared__ uint32_t wstack[PACKET_STACK * STACK_WORDS];
+  __shared__ uint32_t wstack[PACKET_STACK];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0, nRays = 0, nAlpha = 0;
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
@@ -306,9 +381,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_x(DeviceScene S, RenderBuffers rb, int bounce)
 {
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
-  const TStack     st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
-  const uint32_t   count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  const uint32_t      count = rb.counts[bounce * CNT_STRIDE + CNT_X_CLOSEST];
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
   {
     const uint32_t slot = rb.queueX[i];
@@ -319,9 +393,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     float          tPrev = 0.0f;
     uint32_t       wPrev = 0xffffffffu;
     RayHit         h;
+    bool           dummy;
     for(;;)
     {
-      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, st, h, rb.counters);
+      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
       if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
         break;
       atomicAdd(&rb.counters->alphaTests, 1ull);
@@ -405,28 +480,32 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
 }
 
 // Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
-// zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p).  A ray that never met non-opaque geometry
-// ends at its first certain hit (pt_trace.h lane_triangle: nothing could have consumed a draw).
+// zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
 template <bool HEAT, bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
+  uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[cntIn];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves, so that each still refills its lanes a few times
-  const TStack        st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
+  uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
   // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
   rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
-  lane_begin(L, f3{0.f, 0.f, 0.f}, f3{0.f, 0.f, 1.f}, 0.f, true);
+  L.done                    = true;
+  L.cur                     = 0;
+#ifdef PT_HIST
+  unsigned long long hIter = 0, hInner = 0, hLeaf = 0, hService = 0, hBoth = 0, hInnerIt = 0, hLeafIt = 0;
+#endif
   for(;;)
   {
     // ---- service (see k_closest_p)
@@ -460,10 +539,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
           survivor = finish_bounce_core(rb, pslot, inShadow, seed) && !lastBounce;
         if(HEAT)
           rb.ps.rayO[pslot].w += heat_ns(heatT0);
-#ifdef PT_STATS
-        atomicAdd(&rb.counters->nodesVisited, (unsigned long long)L.nNodes);
-        atomicAdd(&rb.counters->trisTested, (unsigned long long)L.nTris);
-#endif
         alive = false;
       }
     }
@@ -474,8 +549,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       pslot = queueIn[qi];
       seed  = __float_as_uint(rb.ps.rayD[pslot].w);
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
-      L.anyEnds = true;
-      alive     = true;
+      alive = true;
       ++nRays;
       if(HEAT)
         heatT0 = uint32_t(wall_clock64());
@@ -484,25 +558,178 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       break;
     // ---- run
     const int target = rs.more ? minRun : 1;
+#ifdef PT_HIST
+    ++hService;
+#endif
     while(__popcll(__ballot(!L.done)) >= target)
     {
-      if(!L.done)
-        lane_step<TM_MACHINE, TWO>(S, L, st, rb.counters);
+#ifdef PT_HIST
+      const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
+#endif
+      if(!L.done && !(L.cur & BVH_LEAF))
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
+#ifdef PT_HIST
+      const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
+      ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
+#endif
+      if(!L.done && (L.cur & BVH_LEAF))
+        lane_leaf<false, TWO>(S, L, lds, spill);
     }
   }
+#ifdef PT_HIST
+  if((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&g_hist[6][0], hIter); atomicAdd(&g_hist[6][1], hInner); atomicAdd(&g_hist[6][2], hLeaf); atomicAdd(&g_hist[6][3], hService);
+    atomicAdd(&g_hist[6][4], hBoth); atomicAdd(&g_hist[6][5], hInnerIt); atomicAdd(&g_hist[6][6], hLeafIt);
+  }
+#endif
   stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Packet kernel for shadow rays (pt_packet.h).  The next-event rays of one 8x8 pixel block start at neighbouring surface points
+// and -- whenever one bright light dominates the environment's alias table, i.e. any map with a sun -- nearly all point the same
+// way, so they walk the BVH together.  Per packet the lanes that share the majority's direction signs take the packet traversal;
+// the others, and every ray that needs pass B or the exact fallback, go to queueR2 and are settled per lane by k_shadow_p.
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_shadow_k(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant, int minPacket)
+{
+  __shared__ uint32_t wstack[PACKET_STACK];
+  __shared__ uint32_t stageR[STAGE_CAP], stageN[STAGE_CAP];
+  uint32_t            nR = 0, nN = 0, nRays = 0, nAlpha = 0;
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_SHADOW];
+#pragma unroll 1
+  for(uint32_t base = blockIdx.x * TRACE_BLOCK; base < count; base += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t i     = base + threadIdx.x;
+    const bool     valid = i < count;
+    uint32_t       slot = 0, seed = 0;
+    f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
+    float          maxDist = 0.f;
+    if(valid)
+    {
+      slot    = rb.queueS[i];
+      seed    = __float_as_uint(rb.ps.rayD[slot].w);
+      o       = xyz(rb.ps.rayO[slot]);
+      d       = xyz(rb.ps.neeDir[slot]);
+      maxDist = rb.ps.absorb[slot].w;
+    }
+    // the sign pattern most lanes share
+    const uint32_t           pat = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    unsigned long long       bestMask = 0ull;
+#pragma unroll
+    for(uint32_t q = 0; q < 8; ++q)
+    {
+      const unsigned long long m = __ballot(valid && pat == q);
+      if(__popcll(m) > __popcll(bestMask))
+        bestMask = m;
+    }
+    const bool inPacket = __popcll(bestMask) >= minPacket && ((bestMask >> (threadIdx.x & 63)) & 1ull);
+    RayHit     h;
+    bool       inShadow = false;
+    bool       unusedOpaque;
+    const bool packet   = traverse_packet<false>(S, inPacket, o, d, maxDist, wstack, h, unusedOpaque, rb.counters);
+    bool       redo     = valid && !(inPacket && packet);
+    bool       survivor = false;
+    if(valid && !redo)
+    {
+      {
+        redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
+        if(!redo)
+        {
+          uint32_t nDraw = h.count;
+          if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+            ++nDraw;
+          uint32_t s2 = seed;
+          if(consume_rejected_draws(s2, nDraw))
+          {
+            seed     = variant == PT_VARIANT_RTX ? seed : s2;
+            inShadow = h.slot != BVH_NONE;
+            nAlpha += nDraw;
+          }
+          else
+            redo = true;
+        }
+      }
+      if(!redo)
+      {
+        ++nRays;
+        survivor = finish_bounce_core(rb, slot, inShadow, seed) && !lastBounce;
+      }
+    }
+    stage_push(stageR, nR, redo, slot, rb.queueR2, &C[CNT_REDO_SHADOW]);
+    stage_push(stageN, nN, survivor, slot, queueOut, &C[CNT_STRIDE + CNT_IN]);
+  }
+  stage_flush(stageR, nR, rb.queueR2, &C[CNT_REDO_SHADOW]);
+  stage_flush(stageN, nN, queueOut, &C[CNT_STRIDE + CNT_IN]);
+  wave_add(&rb.counters->shadowRays, nRays);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Simple variant of the shadow stage (one ray per lane).
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  const bool          valid = i < C[CNT_SHADOW];
+  uint32_t            slot = 0, nAlpha = 0, seed = 0;
+  bool                fallback = false, inShadow = false;
+  if(valid)
+  {
+    slot                   = rb.queueS[i];
+    seed                   = __float_as_uint(rb.ps.rayD[slot].w);
+    const f3       o       = xyz(rb.ps.rayO[slot]);
+    const f3       d       = xyz(rb.ps.neeDir[slot]);
+    const float    maxDist = rb.ps.absorb[slot].w;
+    bool           dummy;
+    RayHit         h;
+    traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+    {
+      fallback       = (h.flags & TF_SAW_FRAC) != 0;
+      const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
+      uint32_t   nDraw = h.count;
+      if(passB)
+      {
+        RayHit c;
+        traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
+                           rb.counters);
+        fallback = (c.flags & TF_SAW_FRAC) != 0;
+        nDraw    = c.count;
+      }
+      if(!fallback)
+      {
+        if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
+          ++nDraw;
+        uint32_t s2 = seed;
+        if(consume_rejected_draws(s2, nDraw))
+        {
+          seed     = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
+          inShadow = h.slot != BVH_NONE;
+          nAlpha   = nDraw;
+        }
+        else
+          fallback = true;
+      }
+    }
+  }
+  wave_add(&rb.counters->shadowRays, valid ? 1u : 0u);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+  if(fallback)
+    enqueue(rb.queueX2, &C[CNT_X_SHADOW], slot);
+  else if(valid)
+    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
 {
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
-  const TStack     st{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
-  uint32_t*        C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t   count = C[CNT_X_SHADOW];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
+  const uint32_t      count = C[CNT_X_SHADOW];
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
   {
     const uint32_t slot    = rb.queueX2[i];
@@ -511,13 +738,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     const f3       o       = xyz(rb.ps.rayO[slot]);
     const f3       d       = xyz(rb.ps.neeDir[slot]);
     const float    maxDist = rb.ps.absorb[slot].w;
-    bool           inShadow = false;
+    bool           inShadow = false, dummy;
     RayHit         h;
     float          tPrev = 0.0f;
     uint32_t       wPrev = 0xffffffffu;
     for(;;)
     {
-      traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, st, h, rb.counters);
+      traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
       if(h.slot == BVH_NONE)
         break;
       if((h.w >> 29) & TRI_OPAQUE)
@@ -550,12 +777,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 template <bool TWO>
 __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int depth0)
 {
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
-  uint32_t*        C     = rb.counts + depth0 * CNT_STRIDE;
-  const uint32_t   count = C[CNT_IN];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C     = rb.counts + depth0 * CNT_STRIDE;
+  const uint32_t      count = C[CNT_IN];
   if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * TRACE_BLOCK >= count)
     return;
-  const TStack     lds{stack + threadIdx.x, spill_column(rb.spill, blockIdx.x)};
+  uint32_t* lds = stack + threadIdx.x;
   RaySupply rs;
   rs.chunk       = 64;
   uint32_t slot  = 0, nClosest = 0, nShadow = 0, nAlpha = 0, nMiss = 0, nHit = 0, nNee = 0;
@@ -691,7 +918,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
 
 // ---- ray picker (src/sample_example.cpp:468-511; nvvk::RayPickerKHR shoots a flag-less ray: no culling, no any-hit) ------------------
 template <bool TWO>
-__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters, uint32_t* spill)
+__global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float pickY, pt_SceneCamera cam, pt_PickResult* out, Counters* counters)
 {
   const f2 d         = f2{pickX * 2.0f - 1.0f, pickY * 2.0f - 1.0f};
   const f4 origin    = mat4_mul(cam.viewInverse, f4{0, 0, 0, 1});
@@ -701,10 +928,10 @@ __global__ void __launch_bounds__(64) k_pick(DeviceScene S, float pickX, float p
   const f3 o = xyz(origin), dir = xyz(direction);
   // nearest triangle in key order (t, world index), no culling: one BVH traversal (the 64 lanes of the wave walk the same ray; a pick is a
   // rare query, what matters is that it does not scale with the triangle count: 3.8 M records per click on C5 with the old brute force)
-  __shared__ uint32_t stack[STACK_LDS_WORDS];
-  const TStack     st{stack + threadIdx.x, spill_column(spill, 0u)};
-  RayHit           h;
-  traverse<TM_PICK, TWO>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, st, h, counters);
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  RayHit              h;
+  bool                dummy;
+  traverse<TM_PICK, TWO>(S, o, dir, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, counters);
   const float    bt = h.t, bu = h.u, bv = h.v;
   const uint32_t bs = h.slot;
   if(threadIdx.x != 0)
@@ -966,7 +1193,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
   const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
-  const uint32_t gridTrace = std::min(wavesAll < pw ? wavesAll : pw, uint32_t(PT_SPILL_WAVES));  // (every trace wave owns a slice of the spill area)
+  const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage, no k_tail
   for(int s = 0; s < fp.st.maxSamples; ++s)
@@ -987,7 +1214,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost three latency floors
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 5);
-          k_tail<TWO><<<std::min(wavesAll, uint32_t(PT_SPILL_WAVES)), TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
+          k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
           pt_timers_end(tm, stream, 5);
         }, false});
         break;
@@ -1006,6 +1233,8 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
           k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
           k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
         }
+        else if(depth < g_tuning.simpleClosestBounces)
+          k_closest_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
         else
           k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
@@ -1026,15 +1255,26 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       steps.push_back(PtStep{[=]() {
         pt_timers_begin(tm, stream, 3);
         const uint32_t* shadowIn = rb.queueS;
-        if(g_tuning.sortShadow)
+        if(g_tuning.sortShadow && depth >= g_tuning.simpleShadowBounces && depth >= g_tuning.packetShadowBounces)
         {
           sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
           shadowIn = rb.queueT;
         }
         if(heat)
           k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        else if(depth < g_tuning.simpleShadowBounces)
+          k_shadow_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         else
-          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        {
+          if(!TWO && depth < g_tuning.packetShadowBounces)
+          {
+            const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+            k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
+            k_shadow_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
+          }
+          else
+            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        }
         k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         pt_timers_end(tm, stream, 3);
       }, false});
@@ -1072,15 +1312,15 @@ void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderB
     st.fn();
 }
 
-void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters, uint32_t* spill)
+void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters)
 {
   pt_SceneCamera cam = scene.camera;
   std::memcpy(cam.viewInverse, viewInv, sizeof(cam.viewInverse));
   std::memcpy(cam.projInverse, projInv, sizeof(cam.projInverse));
   if(scene.twoLevel)
-    k_pick<true><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters, spill);
+    k_pick<true><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
   else
-    k_pick<false><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters, spill);
+    k_pick<false><<<1, 64, 0, stream>>>(scene, px, py, cam, dOut, counters);
 }
 
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor)
@@ -1122,3 +1362,20 @@ void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double
   (void)hipMemsetAsync(out3, 0, 3 * sizeof(double), stream);
   k_mean<<<256, 256, 0, stream>>>(rowMajor, n, out3);
 }
+
+#ifdef PT_HIST
+// measurement build only: copies (and optionally clears) the traversal histograms of pt_trace.h
+extern "C" __attribute__((visibility("default"))) int pt_debug_hist(unsigned long long* out, int reset)
+{
+  if(hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(g_hist)) != hipSuccess)
+    return -1;
+  if(reset)
+  {
+    static unsigned long long zero[8][40];
+    if(hipMemcpyToSymbol(HIP_SYMBOL(g_hist), zero, sizeof(zero)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+

@@ -1,6 +1,6 @@
 // Settling ONE ray per lane: the closest-hit ray (trace contract T5) and the shadow ray (T6) of a path, from the path state in HBM to the hit
 // record / the verdict, through the two-pass stochastic alpha of pt_trace.h with its exact key-ordered fallback.  These are the bodies k_tail
-// runs per lane (pt_render.hip); the exact-fallback kernels k_closest_x / k_shadow_x spell their last step out per stage.
+// runs per lane (pt_render.hip); the lock-step kernels k_closest_s / k_closest_x / k_shadow_s / k_shadow_x spell the same steps out per stage.
 // Plain inline functions of (scene, path state, slot): tests/cpp/trace_host.cpp compiles them for the host and holds them, ray by ray, to
 // the contract's exact loop -- hits AND the RNG state afterwards (tests/test_trace_host.py).
 #pragma once
@@ -19,21 +19,22 @@ PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, ui
 
 // the closest-hit ray of a path: hit record -> rb.ps.hit[slot], RNG state after the alpha draws -> rb.ps.rayD[slot].w
 template <bool TWO>
-PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, const TStack& stack, uint32_t& nAlpha)
+PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, uint32_t* stack, uint32_t& nAlpha)
 {
   const f3       o    = xyz(rb.ps.rayO[slot]);
   const float4   dw   = rb.ps.rayD[slot];
   const f3       d    = xyz(dw);
   uint32_t       seed = __float_as_uint(dw.w);
   RayHit         h;
-  traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack, h, rb.counters);
+  bool           dummy;
+  traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack, h, dummy, rb.counters);
   bool       fallback = (h.flags & TF_SAW_FRAC) != 0;
   const bool passB    = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
   uint32_t   nDraw    = h.count;
   if(passB)
   {
     RayHit c;
-    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, rb.counters);
+    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, dummy, rb.counters);
     fallback = (c.flags & TF_SAW_FRAC) != 0;
     nDraw    = c.count;
   }
@@ -56,7 +57,7 @@ PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t
   uint32_t wPrev = 0xffffffffu;
   for(;;)
   {
-    traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack, h, rb.counters);
+    traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
     if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
       break;
     ++nAlpha;
@@ -71,22 +72,23 @@ PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t
 
 // the shadow ray of a path (k_shadow_s / k_shadow_x): returns inShadow, `seed` = the path's seed afterwards
 template <bool TWO>
-PT_DEV bool tail_shadow(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, const TStack& stack, int variant, uint32_t& seed, uint32_t& nAlpha)
+PT_DEV bool tail_shadow(const DeviceScene& S, const RenderBuffers& rb, uint32_t slot, uint32_t* stack, int variant, uint32_t& seed, uint32_t& nAlpha)
 {
   seed                   = __float_as_uint(rb.ps.rayD[slot].w);
   const uint32_t seed0   = seed;
   const f3       o       = xyz(rb.ps.rayO[slot]);
   const f3       d       = xyz(rb.ps.neeDir[slot]);
   const float    maxDist = rb.ps.absorb[slot].w;
+  bool           dummy;
   RayHit         h;
-  traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack, h, rb.counters);
+  traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack, h, dummy, rb.counters);
   bool       fallback = (h.flags & TF_SAW_FRAC) != 0;
   const bool passB    = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
   uint32_t   nDraw    = h.count;
   if(passB)
   {
     RayHit c;
-    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, rb.counters);
+    traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack, c, dummy, rb.counters);
     fallback = (c.flags & TF_SAW_FRAC) != 0;
     nDraw    = c.count;
   }
@@ -108,7 +110,7 @@ PT_DEV bool tail_shadow(const DeviceScene& S, const RenderBuffers& rb, uint32_t 
   uint32_t wPrev    = 0xffffffffu;
   for(;;)
   {
-    traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack, h, rb.counters);
+    traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
     if(h.slot == BVH_NONE)
       break;
     if((h.w >> 29) & TRI_OPAQUE)
