@@ -11,10 +11,14 @@ and environment are resident in HBM before the timed region starts.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 With N > 1 the image tiles are sharded over the ranks (vk_raytrace_amd/shard.py); the ranks do not communicate while rendering and
-the single framebuffer gather -- libptmi's own RCCL path, pt_gather_shards / pt_gather_finish -- happens after the timed loop (its time
-is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).  `ranks_seen` is
+the single framebuffer gather -- libptmi's own RCCL path over xGMI, pt_gather_shards / pt_gather_finish -- happens after the timed loop (its
+time is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).  `ranks_seen` is
 ncclCommCount of that communicator.  Every rank binds its GPU through pt_create BEFORE any rendezvous, so a box with fewer than N
-devices fails with pt_create's device-count message.
+devices fails with pt_create's device-count message.  The control plane (rendezvous of the launcher's ranks, barriers around the timed
+region, the MAX of the ranks' times, handing out the ncclUniqueId) is vk_raytrace_amd/rendezvous.py -- a Unix-domain socket between the
+ranks of this node; a rank imports nothing of torch, because the PyTorch wheel's bundled HIP / RCCL libraries break the system RCCL that
+libptmi opens (rendezvous.py).  Device work and the data-path collective are libptmi's; pt_synchronize is the device synchronisation that
+brackets the timed region.
 
 After the timed region (never part of `value`), rank 0 measures what the JSON line's evidence fields need, all in this run:
   calibration        pt_measure_peaks: the VALU-issue and HBM-streaming ceilings of this box
@@ -161,20 +165,11 @@ def main():
     r = HipRenderer()
     r.setup(local_rank)
 
+    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"  # exercise the group / RCCL plumbing with one rank
     dist = None
-    torch = None
-    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"  # exercise the torch.distributed / RCCL plumbing with one rank
-    if force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_dist:
-        import datetime
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+        from vk_raytrace_amd.rendezvous import LocalGroup
+        dist = LocalGroup(rank, world)  # control plane only (see the module docstring)
 
     t_setup = time.time()
     if args.workload == "c3":
@@ -206,9 +201,8 @@ def main():
     t_setup = time.time() - t_setup
 
     def sync():
-        r.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
+        r.synchronize()  # pt_synchronize: every stream of the context has drained (the device-side bracket of the timed region)
+        if dist is not None:
             dist.barrier()
 
     frame = 0
@@ -228,14 +222,11 @@ def main():
         r.run()
         frame += 1
     r.synchronize()
-    if torch is not None:
-        torch.cuda.synchronize()
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dist.all_reduce([elapsed], "max")[0]
     stats = r.stats()
 
     # the one collective of the path (untimed, reported): libptmi's own RCCL gather behind the C ABI (pt_gather_shards / pt_gather_finish)
@@ -258,14 +249,14 @@ def main():
     RAY_KEYS = ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")
     if dist is not None:
         # whole-job counters
-        v = torch.tensor([float(stats[k]) for k in RAY_KEYS], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        v = dist.all_reduce([float(stats[k]) for k in RAY_KEYS], "sum")
         for i, k in enumerate(RAY_KEYS):
-            stats[k] = int(v[i].item())
+            stats[k] = int(v[i])
 
     if rank != 0:
         if dist is not None:
-            dist.destroy_process_group()
+            dist.barrier()  # rank 0 may still be reading the gathered image
+            dist.close()
         return
 
     # pixels actually rendered by this job (an emulated shard renders one rank's tiles only)
@@ -531,7 +522,8 @@ def main():
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.close()
 
 
 if __name__ == "__main__":

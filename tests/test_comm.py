@@ -40,6 +40,18 @@ print("ok")
 """
 
 
+def _visible_devices():
+    """HIP devices this process can create contexts on, asked through libptmi itself (torch.cuda must not be initialised next to it: capi.lib())"""
+    L, n = capi.lib(), 0
+    while n < 64:
+        ctx = C.c_void_p()
+        if L.pt_create(n, C.byref(ctx)) != capi.PT_OK:
+            break
+        L.pt_destroy(ctx)
+        n += 1
+    return n
+
+
 def test_missing_rccl_is_an_error_code_not_a_crash():
     env = dict(os.environ, PT_RCCL_LIB="/nonexistent/librccl.so.1")
     p = subprocess.run([sys.executable, "-c", _MISSING % ROOT], env=env, capture_output=True, text=True, timeout=120)
@@ -48,8 +60,7 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
 
 def test_bench_self_launch_fails_with_the_device_message_without_devices():
     """`python bench.py --gpus 2` needs no launcher; here (no GPU) both ranks fail in pt_create and the parent reports it and stops."""
-    import torch
-    if torch.cuda.is_available():
+    if _visible_devices() > 0:
         pytest.skip("a GPU is present: covered by test_bench_gpus_2_on_a_one_gpu_box")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
@@ -60,8 +71,7 @@ def test_bench_self_launch_fails_with_the_device_message_without_devices():
 
 @pytest.mark.gpu
 def test_bench_gpus_2_on_a_one_gpu_box():
-    import torch
-    if torch.cuda.device_count() != 1:
+    if _visible_devices() != 1:
         pytest.skip("needs exactly one visible device")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
@@ -110,3 +120,31 @@ def test_single_process_gather_with_one_device():
     assert L.pt_comm_group_begin() == capi.PT_OK and L.pt_comm_group_end() == capi.PT_OK
     assert L.pt_comm_destroy(comm) == capi.PT_OK
     r2.destroy()
+
+
+_GROUP = r"""
+import sys
+sys.path.insert(0, %r)
+from vk_raytrace_amd.rendezvous import LocalGroup
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+g = LocalGroup(rank, world, key=sys.argv[3], timeout=60)
+g.barrier()
+assert g.all_reduce([rank + 1.0, -rank], "max") == [float(world), 0.0]
+assert g.all_reduce([rank + 1.0, 2.0], "sum") == [world * (world + 1) / 2.0, 2.0 * world]
+blob = bytes(range(128)) if rank == 1 %% world else b"junk"
+assert g.broadcast_bytes(blob, 1 %% world) == bytes(range(128))
+for _ in range(50):
+    g.barrier()
+g.close()
+print("ok", rank)
+"""
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_local_group_control_plane(world, tmp_path):
+    """vk_raytrace_amd/rendezvous.py: the torch-free control plane of bench.py's ranks (barrier, MAX / SUM all-reduce, byte broadcast)."""
+    procs = [subprocess.Popen([sys.executable, "-c", _GROUP % ROOT, str(r), str(world), f"test{os.getpid()}_{world}"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in reversed(range(world))]  # rank 0 (the server) starts last: the peers wait for it
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and out.startswith("ok"), (out, err)

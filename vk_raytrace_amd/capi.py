@@ -94,7 +94,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C vk_raytrace_amd/csrc` "
                               "(or __graft_entry__.build()); the HIP library is the only implementation")
-        L = C.CDLL(LIB_PATH)
+        # RTLD_DEEPBIND: libptmi.so resolves hip* against ITS OWN dependency (/opt/rocm's libamdhip64), whatever else the process has loaded.
+        # PyTorch-ROCm wheels bundle a second HIP / HSA runtime; without deep binding the import order decides which runtime libptmi talks to,
+        # and two initialised runtimes in one process do not coexist ("No HIP GPUs are available", RCCL "unhandled cuda error").  With it the
+        # library, and the RCCL it opens the same way (csrc/pt_comm.cpp), always share one runtime; a process that uses libptmi must simply not
+        # initialise torch.cuda (bench.py's ranks use torch.distributed over gloo for the control plane only).
+        L = C.CDLL(LIB_PATH, mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND)
         for name, res, args in API:
             fn = getattr(L, name)  # AttributeError if the ABI and the header ever disagree
             fn.restype = res

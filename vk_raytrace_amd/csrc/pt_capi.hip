@@ -535,12 +535,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   {  // performance A/B knobs only
     int v;
     if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) g_tuning.stateMB = v;
-    if(const char* p = strstr(tune, "simpleClosest=")) if(sscanf(p, "simpleClosest=%d", &v) == 1) g_tuning.simpleClosestBounces = v;
     if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) g_tuning.packetClosestBounces = v;
-    if(const char* p = strstr(tune, "packetShadow=")) if(sscanf(p, "packetShadow=%d", &v) == 1) g_tuning.packetShadowBounces = v;
-    if(const char* p = strstr(tune, "minPacket=")) if(sscanf(p, "minPacket=%d", &v) == 1) g_tuning.minPacket = v;
     if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) g_tuning.packetWaves = v;
-    if(const char* p = strstr(tune, "simpleShadow=")) if(sscanf(p, "simpleShadow=%d", &v) == 1) g_tuning.simpleShadowBounces = v;
     if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
     if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) g_tuning.persistentWaves = v;
     if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;

@@ -50,14 +50,15 @@ bool load()
   Rccl&                       r = rccl();
   if(r.handle)
     return true;
-  setenv("NCCL_DEBUG", "WARN", 0);  // RCCL then names the failing call on stderr when something goes wrong (silent otherwise); never overrides the caller's setting
   // PT_RCCL_LIB: test hook (a name that cannot be opened exercises the "library missing" answers on a host that has RCCL)
   const char* forced = std::getenv("PT_RCCL_LIB");
   void*       h      = nullptr;
   std::string why;
   for(const char* name : {forced ? forced : "librccl.so.1", forced ? forced : "librccl.so", forced ? forced : "/opt/rocm/lib/librccl.so.1"})
   {
-    if((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+    // RTLD_DEEPBIND: RCCL must talk to the HIP runtime this library is linked against (its own DT_NEEDED libamdhip64), not to a second runtime a
+    // host process may have loaded globally (PyTorch wheels bundle one): device pointers and streams of one runtime mean nothing to the other
+    if((h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND)))
       break;
     const char* e = dlerror();  // read ONCE: glibc clears the message on read
     if(why.empty())

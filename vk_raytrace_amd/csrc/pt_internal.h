@@ -97,13 +97,8 @@ struct RenderBuffers {
 // Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
 // the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
 struct PtTuning {
-  int simpleClosestBounces = 1;   // bounces whose closest-hit stage uses the lock-step kernel (coherent primary rays: 82 % lane utilisation)
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
-  int packetShadowBounces  = 0;    // bounces whose shadow rays first go through the packet kernel.  Off: measured slower on C3 (1173 vs 1287
-                                   // Msamples/s at 1, 851 at 2) -- unoccluded any-hit rays cannot prune, so a packet walks the union of 64 full-length rays
-  int minPacket            = 16;   // lanes that must share the majority direction signs for a shadow packet to be walked
   int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
-  int simpleShadowBounces  = 0;   // shadow rays differ 10x in length: always on the refilling machine
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
   int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic

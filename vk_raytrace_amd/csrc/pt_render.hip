@@ -18,7 +18,6 @@
 //                   (pathtrace.glsl:327-338); trace machine                                       queueS -> queue[out]
 //   k_closest_x / k_shadow_x   one ray per lane, exact key-ordered alpha loop, on the (normally almost empty) queues of
 //                   rays the two-pass scheme cannot settle
-//   k_closest_s / k_shadow_s / k_shadow_k   lock-step and packet variants selectable through PT_TUNE (bit-identical results)
 //   k_accumulate    firefly clamp (pathtrace.glsl:379-384) + running mean over the frames of the batch, in frame order
 //                   (pathtrace.comp:122-133)
 //
@@ -259,60 +258,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 #endif
   wave_add(&rb.counters->closestRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
-}
-
-// Simple variant: one ray per lane for the lifetime of the wave (lock-step traversal: for coherent rays every
-// node fetch is a broadcast), pass A + pass B inline, exact fallback through queueX.
-template <bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_s(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
-{
-  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
-  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  const bool          valid = i < C[CNT_IN];
-  uint32_t            slot = 0, nAlpha = 0;
-  bool                fallback = false;
-  if(valid)
-  {
-    slot                = queueIn[i];
-    const f3       o    = xyz(rb.ps.rayO[slot]);
-    const float4   dw   = rb.ps.rayD[slot];
-    const f3       d    = xyz(dw);
-    const uint32_t seed = __float_as_uint(dw.w);
-    RayHit         h;
-    bool           dummy;
-    traverse<TM_CLOSEST, TWO>(S, o, d, PT_INFINITY, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-    fallback       = (h.flags & TF_SAW_FRAC) != 0;
-    const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
-    uint32_t   nDraw = h.count;
-    if(passB)
-    {
-      RayHit c;
-      traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? PT_INFINITY : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
-                         rb.counters);
-      fallback = (c.flags & TF_SAW_FRAC) != 0;
-      nDraw    = c.count;
-    }
-    if(!fallback)
-    {
-      if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
-        ++nDraw;
-      uint32_t s2 = seed;
-      if(consume_rejected_draws(s2, nDraw))
-      {
-        store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
-        if(nDraw)
-          rb.ps.rayD[slot].w = __uint_as_float(s2);
-        nAlpha = nDraw;
-      }
-      else
-        fallback = true;
-    }
-  }
-  wave_add(&rb.counters->closestRays, valid ? 1u : 0u);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-  if(fallback)
-    enqueue(rb.queueX, &C[CNT_X_CLOSEST], slot);
 }
 
 // Packet kernel for coherent rays (bounce 0, pt_packet.h): persistent wavefronts walk the queue 64 rays (one 8x8 pixel block)
@@ -586,141 +531,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
-}
-
-// Packet kernel for shadow rays (pt_packet.h).  The next-event rays of one 8x8 pixel block start at neighbouring surface points
-// and -- whenever one bright light dominates the environment's alias table, i.e. any map with a sun -- nearly all point the same
-// way, so they walk the BVH together.  Per packet the lanes that share the majority's direction signs take the packet traversal;
-// the others, and every ray that needs pass B or the exact fallback, go to queueR2 and are settled per lane by k_shadow_p.
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_shadow_k(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant, int minPacket)
-{
-  __shared__ uint32_t wstack[PACKET_STACK];
-  __shared__ uint32_t stageR[STAGE_CAP], stageN[STAGE_CAP];
-  uint32_t            nR = 0, nN = 0, nRays = 0, nAlpha = 0;
-  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      count = C[CNT_SHADOW];
-#pragma unroll 1
-  for(uint32_t base = blockIdx.x * TRACE_BLOCK; base < count; base += gridDim.x * TRACE_BLOCK)
-  {
-    const uint32_t i     = base + threadIdx.x;
-    const bool     valid = i < count;
-    uint32_t       slot = 0, seed = 0;
-    f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
-    float          maxDist = 0.f;
-    if(valid)
-    {
-      slot    = rb.queueS[i];
-      seed    = __float_as_uint(rb.ps.rayD[slot].w);
-      o       = xyz(rb.ps.rayO[slot]);
-      d       = xyz(rb.ps.neeDir[slot]);
-      maxDist = rb.ps.absorb[slot].w;
-    }
-    // the sign pattern most lanes share
-    const uint32_t           pat = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    unsigned long long       bestMask = 0ull;
-#pragma unroll
-    for(uint32_t q = 0; q < 8; ++q)
-    {
-      const unsigned long long m = __ballot(valid && pat == q);
-      if(__popcll(m) > __popcll(bestMask))
-        bestMask = m;
-    }
-    const bool inPacket = __popcll(bestMask) >= minPacket && ((bestMask >> (threadIdx.x & 63)) & 1ull);
-    RayHit     h;
-    bool       inShadow = false;
-    bool       unusedOpaque;
-    const bool packet   = traverse_packet<false>(S, inPacket, o, d, maxDist, wstack, h, unusedOpaque, rb.counters);
-    bool       redo     = valid && !(inPacket && packet);
-    bool       survivor = false;
-    if(valid && !redo)
-    {
-      {
-        redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
-        if(!redo)
-        {
-          uint32_t nDraw = h.count;
-          if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
-            ++nDraw;
-          uint32_t s2 = seed;
-          if(consume_rejected_draws(s2, nDraw))
-          {
-            seed     = variant == PT_VARIANT_RTX ? seed : s2;
-            inShadow = h.slot != BVH_NONE;
-            nAlpha += nDraw;
-          }
-          else
-            redo = true;
-        }
-      }
-      if(!redo)
-      {
-        ++nRays;
-        survivor = finish_bounce_core(rb, slot, inShadow, seed) && !lastBounce;
-      }
-    }
-    stage_push(stageR, nR, redo, slot, rb.queueR2, &C[CNT_REDO_SHADOW]);
-    stage_push(stageN, nN, survivor, slot, queueOut, &C[CNT_STRIDE + CNT_IN]);
-  }
-  stage_flush(stageR, nR, rb.queueR2, &C[CNT_REDO_SHADOW]);
-  stage_flush(stageN, nN, queueOut, &C[CNT_STRIDE + CNT_IN]);
-  wave_add(&rb.counters->shadowRays, nRays);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-}
-
-// Simple variant of the shadow stage (one ray per lane).
-template <bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_s(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int variant)
-{
-  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
-  uint32_t*           C = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-  const bool          valid = i < C[CNT_SHADOW];
-  uint32_t            slot = 0, nAlpha = 0, seed = 0;
-  bool                fallback = false, inShadow = false;
-  if(valid)
-  {
-    slot                   = rb.queueS[i];
-    seed                   = __float_as_uint(rb.ps.rayD[slot].w);
-    const f3       o       = xyz(rb.ps.rayO[slot]);
-    const f3       d       = xyz(rb.ps.neeDir[slot]);
-    const float    maxDist = rb.ps.absorb[slot].w;
-    bool           dummy;
-    RayHit         h;
-    traverse<TM_CLOSEST, TWO>(S, o, d, maxDist, 0.0f, 0xffffffffu, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-    {
-      fallback       = (h.flags & TF_SAW_FRAC) != 0;
-      const bool passB = !fallback && (h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count);
-      uint32_t   nDraw = h.count;
-      if(passB)
-      {
-        RayHit c;
-        traverse<TM_COUNT, TWO>(S, o, d, h.slot == BVH_NONE ? maxDist : h.t, 0.0f, 0xffffffffu, h.slot == BVH_NONE ? 0u : (h.w & TRI_INDEX_MASK), stack + threadIdx.x, c, dummy,
-                           rb.counters);
-        fallback = (c.flags & TF_SAW_FRAC) != 0;
-        nDraw    = c.count;
-      }
-      if(!fallback)
-      {
-        if(h.slot != BVH_NONE && !((h.w >> 29) & TRI_OPAQUE))
-          ++nDraw;
-        uint32_t s2 = seed;
-        if(consume_rejected_draws(s2, nDraw))
-        {
-          seed     = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
-          inShadow = h.slot != BVH_NONE;
-          nAlpha   = nDraw;
-        }
-        else
-          fallback = true;
-      }
-    }
-  }
-  wave_add(&rb.counters->shadowRays, valid ? 1u : 0u);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-  if(fallback)
-    enqueue(rb.queueX2, &C[CNT_X_SHADOW], slot);
-  else if(valid)
-    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
 }
 
 // Exact fallback for shadow rays (trace contract T6 with the key-ordered alpha loop).
@@ -1233,8 +1043,6 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
           k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
           k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
         }
-        else if(depth < g_tuning.simpleClosestBounces)
-          k_closest_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth);
         else
           k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
@@ -1255,26 +1063,15 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       steps.push_back(PtStep{[=]() {
         pt_timers_begin(tm, stream, 3);
         const uint32_t* shadowIn = rb.queueS;
-        if(g_tuning.sortShadow && depth >= g_tuning.simpleShadowBounces && depth >= g_tuning.packetShadowBounces)
+        if(g_tuning.sortShadow)
         {
           sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
           shadowIn = rb.queueT;
         }
         if(heat)
           k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-        else if(depth < g_tuning.simpleShadowBounces)
-          k_shadow_s<TWO><<<wavesAll, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         else
-        {
-          if(!TWO && depth < g_tuning.packetShadowBounces)
-          {
-            const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-            k_shadow_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant, g_tuning.minPacket);
-            k_shadow_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR2, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_REDO_SHADOW, CNT_CHUNK_REDO_SHADOW);
-          }
-          else
-            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-        }
+          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
         k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         pt_timers_end(tm, stream, 3);
       }, false});

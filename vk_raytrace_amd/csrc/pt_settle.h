@@ -1,6 +1,6 @@
 // Settling ONE ray per lane: the closest-hit ray (trace contract T5) and the shadow ray (T6) of a path, from the path state in HBM to the hit
 // record / the verdict, through the two-pass stochastic alpha of pt_trace.h with its exact key-ordered fallback.  These are the bodies k_tail
-// runs per lane (pt_render.hip); the lock-step kernels k_closest_s / k_closest_x / k_shadow_s / k_shadow_x spell the same steps out per stage.
+// runs per lane (pt_render.hip); the exact-fallback kernels k_closest_x / k_shadow_x spell the same steps out per stage.
 // Plain inline functions of (scene, path state, slot): tests/cpp/trace_host.cpp compiles them for the host and holds them, ray by ray, to
 // the contract's exact loop -- hits AND the RNG state afterwards (tests/test_trace_host.py).
 #pragma once

@@ -5,7 +5,7 @@ PT_TILE x PT_TILE tiles and rank r renders the tiles with (tx + ty) % nranks == 
 interleave: sky and interior tiles are spread evenly).  Seeds depend on the global pixel index only
 (shaders/pathtrace.comp:97), so every pixel is bit-identical to a single-GPU render.  Nothing is
 exchanged while rendering; at the end ONE gather of the accumulated framebuffer shards goes to rank 0
-(RCCL over xGMI when the backend is "nccl"; each peer's shard travels on its own point-to-point link).
+(RCCL over xGMI, natively behind the C ABI: each peer's shard travels on its own point-to-point link).
 """
 import numpy as np
 
@@ -37,53 +37,28 @@ def local_pixel_ids(width, height, rank, nranks):
     return np.concatenate(ids).astype(np.uint32) if ids else np.zeros(0, np.uint32)
 
 
-class _DevArray:
-    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, nfloats):
-        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
-def gather_framebuffer(renderer, rank, nranks, device, force=False):
-    """The single collective of the path: gathers every rank's shard on rank 0 and lets libptmi place
-    the tiles (pt_scatter_shards).  Returns the full RGBA32F image on rank 0, None elsewhere."""
-    renderer.synchronize()
-    if nranks == 1 and not force:
-        return renderer.read_accum()
-    import torch
-    import torch.distributed as dist
-
-    ptr, nbytes, _, _ = renderer.local_shard()
-    local = torch.as_tensor(_DevArray(ptr, nbytes // 4), device=device)
-    gathered = torch.empty((nranks, nbytes // 4), dtype=torch.float32, device=device) if rank == 0 else None
-    dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-    if rank != 0:
-        return None
-    torch.cuda.synchronize(device)
-    renderer.scatter_shards(gathered.data_ptr(), nranks)
-    return renderer.read_accum()
-
-
 class NativeGather:
     """The gather through libptmi's own RCCL path (pt_comm_* / pt_gather_shards / pt_gather_finish, csrc/pt_comm.cpp) -- what a C++ host
-    calls; torch is used for nothing but handing rank 0's ncclUniqueId to the other processes.  `gather_framebuffer` above is the same
-    exchange through torch.distributed and serves as its cross-check."""
+    calls.  The group (vk_raytrace_amd/rendezvous.py) is used for nothing but handing rank 0's ncclUniqueId to the other processes; no
+    torch is involved (rendezvous.py explains why it must not be)."""
 
-    def __init__(self, rank, nranks, device_ordinal, dist=None):
+    def __init__(self, rank, nranks, device_ordinal, group=None):
+        """group: a rendezvous.LocalGroup (or anything with broadcast_bytes(data, src)) that reaches every rank; only needed for nranks > 1"""
         import ctypes as C
+        import struct
         from . import capi
         self._C, self._capi, self._lib = C, capi, capi.lib()
         self.rank, self.nranks = rank, nranks
         self.comm = None
-        if nranks > 1 and dist is None:
-            raise ValueError("more than one rank needs a torch.distributed process group to distribute the ncclUniqueId")
+        if nranks > 1 and group is None:
+            raise ValueError("more than one rank needs a group to distribute the ncclUniqueId")
         ident = (C.c_ubyte * 128)()
         rc = self._lib.pt_comm_get_unique_id(ident) if rank == 0 else capi.PT_OK
-        # rank 0's status travels with the id: if it failed (librccl.so missing, ...) EVERY rank raises instead of waiting in the broadcast
-        box = [(rc, bytes(ident), self._lib.pt_comm_last_error().decode() if rc != capi.PT_OK else "")]
+        # rank 0's status travels with the id: if it failed (librccl.so missing, ...) EVERY rank raises instead of waiting for the others
+        msg = struct.pack("<i", rc) + bytes(ident) + (self._lib.pt_comm_last_error() if rc != capi.PT_OK else b"")
         if nranks > 1:
-            dist.broadcast_object_list(box, src=0)
-        rc, raw, why = box[0]
+            msg = group.broadcast_bytes(msg, 0)
+        rc, raw, why = struct.unpack("<i", msg[:4])[0], msg[4:132], msg[132:].decode(errors="replace")
         if rc != capi.PT_OK:
             raise capi.PtError(rc, f"pt_comm_get_unique_id on rank 0: {why}")
         ident = (C.c_ubyte * 128).from_buffer_copy(raw)
