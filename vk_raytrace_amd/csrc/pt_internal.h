@@ -100,7 +100,9 @@ struct PtTuning {
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
   int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
   int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
-  int persistentWaves      = 2048; // persistent kernels: waves per launch (several frames' launches share the GPU)
+  int persistentWaves      = 5120; // persistent kernels: waves per launch = what the chip holds at 5 waves / SIMD.  2048 (round 1-2: "several frames'
+                                   // launches share the GPU") left SIMDs short of waves whenever fewer than four launch sequences overlapped:
+                                   // 1395 -> 1515 Msamples/s at 96 steps, 4096 .. 8192 within 1 % (profiles/r03h_tune_96.txt, r03i_launch_policy_sweep.txt)
   int chunk                = 64;   // rays a persistent wave reserves per queue atomic
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
   int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of

@@ -51,7 +51,8 @@ namespace {
 #define PT_TRACE_WAVES_TWO 4  // two-level instantiations: object-space ray constants + instance context are live on top of the flat state (128 VGPRs)
 #endif
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 3
+#define PT_SHADE_WAVES 4  // 128 VGPRs.  The first bounce's shade launch streams ~700 B per path and is HBM-bound: a fourth wave per SIMD keeps more
+                          // loads in flight (+5 % on the 96-step bench against 3 waves / 137 VGPRs, profiles/r03h_*)
 #endif
 constexpr int SHADE_BLOCK = 256;
 

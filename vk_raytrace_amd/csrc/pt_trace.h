@@ -88,6 +88,82 @@ PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta <
 #ifdef PT_TRI_TEST_OVERRIDE
 // host experiments only (tests/cpp/trace_host.cpp -DTH_ROBUST_T2): a candidate replacement of T2 under evaluation takes the place of the contract's
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v) { return PT_TRI_TEST_OVERRIDE(tr, flags, o, d, t, u, v); }
+#elif defined(PT_ROBUST_T2)
+// MEASUREMENT BUILD ONLY (tools/build_variants.sh robust "-DPT_ROBUST_T2"): the candidate replacement of T2 that closes the
+// "accidental grazing hit" exception -- fp32 Moeller-Trumbore kept whenever a forward error bound shows that neither its verdict nor its t can
+// be a rounding artefact, the same formulas in fp64 otherwise (IEEE on every side, so still bit-reproducible).  Validated on the CPU harness
+// (profiles/r02c_t2_robust_experiment.txt: walks == brute force on all 240 000 adversarial rays); this build measures what it costs on the GPU,
+// where one ambiguous lane sends the whole wavefront through the fp64 branch.  Not the contract: oracle, _ref driver and goldens use T2 above.
+PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
+{
+  const f3    e1 = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
+  const f3    pv = cross3(d, e2);
+  const float det = dot3(e1, pv);
+  const f3    tv = o - p0;
+  const f3    qv = cross3(tv, e1);
+  const float nu = dot3(tv, pv), nv = dot3(d, qv), nt = dot3(e2, qv);
+  const f3    apv = f3{fabsf(d.y) * fabsf(e2.z) + fabsf(d.z) * fabsf(e2.y), fabsf(d.z) * fabsf(e2.x) + fabsf(d.x) * fabsf(e2.z), fabsf(d.x) * fabsf(e2.y) + fabsf(d.y) * fabsf(e2.x)};
+  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
+  const f3    aqv = f3{atv.y * fabsf(e1.z) + atv.z * fabsf(e1.y), atv.z * fabsf(e1.x) + atv.x * fabsf(e1.z), atv.x * fabsf(e1.y) + atv.y * fabsf(e1.x)};
+  const float k   = 8.0f * 5.9604645e-8f;
+  const float edet = k * (fabsf(e1.x) * apv.x + fabsf(e1.y) * apv.y + fabsf(e1.z) * apv.z);
+  const float eu   = k * (atv.x * apv.x + atv.y * apv.y + atv.z * apv.z);
+  const float ev   = k * (fabsf(d.x) * aqv.x + fabsf(d.y) * aqv.y + fabsf(d.z) * aqv.z);
+  const float et   = k * (fabsf(e2.x) * aqv.x + fabsf(e2.y) * aqv.y + fabsf(e2.z) * aqv.z);
+  const float adet = fabsf(det);
+  bool        sure = adet > 4.0f * edet;
+  if(sure)
+  {
+    const float s  = det < 0.0f ? -1.0f : 1.0f;
+    const float su = nu * s, sv = nv * s;
+    const bool  inside  = su > eu && sv > ev && (adet - su - sv) > (eu + ev + edet);
+    const bool  outside = su < -eu || sv < -ev || (su + sv - adet) > (eu + ev + edet);
+    const bool  tOk     = et <= 4.0e-6f * fabsf(nt);
+    sure = outside || (inside && tOk);
+  }
+  if(sure)
+  {
+    if(det == 0.0f)
+      return false;
+    if(!(flags & TRI_NOCULL))
+    {
+      const bool front = (flags & TRI_FLIP) ? (det < 0.0f) : (det > 0.0f);
+      if(!front)
+        return false;
+    }
+    const float inv = 1.0f / det;
+    u = nu * inv;
+    if(u < 0.0f || u > 1.0f)
+      return false;
+    v = nv * inv;
+    if(v < 0.0f || u + v > 1.0f)
+      return false;
+    t = nt * inv;
+    return true;
+  }
+  const double E1[3] = {e1.x, e1.y, e1.z}, E2[3] = {e2.x, e2.y, e2.z}, D[3] = {d.x, d.y, d.z}, TV[3] = {double(o.x) - p0.x, double(o.y) - p0.y, double(o.z) - p0.z};
+  const double PV[3] = {D[1] * E2[2] - D[2] * E2[1], D[2] * E2[0] - D[0] * E2[2], D[0] * E2[1] - D[1] * E2[0]};
+  const double DET   = E1[0] * PV[0] + E1[1] * PV[1] + E1[2] * PV[2];
+  if(DET == 0.0)
+    return false;
+  if(!(flags & TRI_NOCULL))
+  {
+    const bool front = (flags & TRI_FLIP) ? (DET < 0.0) : (DET > 0.0);
+    if(!front)
+      return false;
+  }
+  const double U = (TV[0] * PV[0] + TV[1] * PV[1] + TV[2] * PV[2]) / DET;
+  if(U < 0.0 || U > 1.0)
+    return false;
+  const double QV[3] = {TV[1] * E1[2] - TV[2] * E1[1], TV[2] * E1[0] - TV[0] * E1[2], TV[0] * E1[1] - TV[1] * E1[0]};
+  const double V     = (D[0] * QV[0] + D[1] * QV[1] + D[2] * QV[2]) / DET;
+  if(V < 0.0 || U + V > 1.0)
+    return false;
+  u = float(U);
+  v = float(V);
+  t = float((E2[0] * QV[0] + E2[1] * QV[1] + E2[2] * QV[2]) / DET);
+  return true;
+}
 #else
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
 {
