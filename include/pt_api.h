@@ -158,6 +158,19 @@ int pt_tonemap(pt_context* ctx, const pt_Tonemapper* tm, uint8_t* rgba8_out);
  * there).  With disp == accumulation size and zoom == 1 it is pt_tonemap. */
 int pt_tonemap_zoom(pt_context* ctx, const pt_Tonemapper* tm, int disp_width, int disp_height, uint8_t* rgba8_out);
 
+/* The display pass without a host stall (the reference's display loop keeps several frames in flight: src/main.cpp:201-264 only waits for a
+ * free swapchain image in prepareFrame() :213 and queues the frame with submitFrame() :261 -- the host never waits for the frame it just
+ * recorded).
+ * pt_tonemap_begin enqueues pt_tonemap_zoom's work behind the frames rendered so far and returns; frames rendered afterwards overlap it (their
+ * accumulate step waits until the pass has read the accumulation image).  pt_tonemap_end blocks until the OLDEST image begun is in host memory
+ * and copies it to rgba8_out (the size given to its pt_tonemap_begin).  At most PT_DISPLAY_RING (4) images may be pending
+ * (PT_ERR_STATE beyond, and for pt_tonemap_end with none pending); pt_tonemap_pending returns how many are.  The images are bit-identical to
+ * what pt_tonemap_zoom returns at the same point of the frame sequence.  A traversal-stack overflow is reported by the next synchronising
+ * call (pt_synchronize, pt_tonemap, pt_read_accum), not by pt_tonemap_end. */
+int pt_tonemap_begin(pt_context* ctx, const pt_Tonemapper* tm, int disp_width, int disp_height);
+int pt_tonemap_end(pt_context* ctx, uint8_t* rgba8_out);
+int pt_tonemap_pending(pt_context* ctx);
+
 /* Device-side view of the local shard for the RCCL gather: pointer to [maxTilesPerRank][PT_TILE*PT_TILE][4]
  * floats (owned tiles first, in increasing global tile id; padding zero). */
 int pt_local_shard(pt_context* ctx, void** device_ptr, size_t* bytes, int* num_local_tiles, int* max_tiles_per_rank);

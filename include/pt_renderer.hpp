@@ -110,6 +110,10 @@ public:
   void tonemap(const pt_Tonemapper& tm, uint8_t* rgba8) { check(pt_tonemap(m_ctx, &tm, rgba8)); }
   // while SampleExample de-scales (m_descaling, src/sample_example.cpp:410-413): viewport of dispW x dispH from the reduced-size render
   void tonemapZoom(const pt_Tonemapper& tm, int dispW, int dispH, uint8_t* rgba8) { check(pt_tonemap_zoom(m_ctx, &tm, dispW, dispH, rgba8)); }
+  // the display pass with frames in flight (main.cpp:213 prepareFrame / :261 submitFrame): begin after every frame, end returns the oldest image
+  void tonemapBegin(const pt_Tonemapper& tm, int dispW, int dispH) { check(pt_tonemap_begin(m_ctx, &tm, dispW, dispH)); }
+  void tonemapEnd(uint8_t* rgba8) { check(pt_tonemap_end(m_ctx, rgba8)); }
+  int  tonemapPending() const { return pt_tonemap_pending(m_ctx); }
 
   bool               ok() const { return m_status == PT_OK; }
   int                status() const { return m_status; }

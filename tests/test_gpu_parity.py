@@ -303,6 +303,64 @@ def test_sample_example_interactive_state_machine(env_small):
     app.destroy()
 
 
+def test_pipelined_display_equals_the_synchronous_loop(env_small):
+    """pt_tonemap_begin / pt_tonemap_end (frames in flight behind the display pass, reference src/main.cpp:213,261): the image sequence of a
+    display loop that never waits for the frame it just issued -- including a camera change that restarts the accumulation and a de-scaled
+    stretch -- is, image by image, the sequence of the loop that waits after every frame; the ring's limits are errors, not hangs."""
+    from vk_raytrace_amd.renderer import SampleExample
+
+    def loop(in_flight):
+        app = SampleExample(0)
+        app.loadScene(synth.feature_box(tex_size=32))
+        app.loadEnvironmentHdr(env_small)
+        app.setRenderRegion(160, 120)
+        app.m_descalingLevel = 2
+        app.m_framesInFlight = in_flight
+        app.m_tonemapper.autoExposure = 1
+        app.updateUniformBuffer()
+        shown = []
+        for i in range(14):
+            if i == 5:
+                app.m_scene.camera.eye = (app.m_scene.camera.eye[0] + 0.25, app.m_scene.camera.eye[1], app.m_scene.camera.eye[2])
+                app.updateUniformBuffer()
+            if i == 8:
+                app.onMouseButton("lmb", True); app.onMouseMotion(5, 5)
+            if i == 11:
+                app.onMouseButton("lmb", False)
+            app.updateFrame(); app.renderScene()
+            img = app.drawPost()
+            if img is not None:
+                shown.append(img)
+        shown += app.flushDisplay()
+        accum = app.m_pRender.read_accum()
+        app.destroy()
+        return shown, accum
+
+    want, accum0 = loop(0)
+    assert len(want) == 14
+    for k in (1, 2, 3):
+        got, accum = loop(k)
+        assert len(got) == 14
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape and np.array_equal(a, b), (k, i)
+        assert_identical(accum, accum0, f"accumulation image after the pipelined loop ({k} in flight)")
+    from vk_raytrace_amd.renderer import HipRenderer
+    cfg = Config(synth.feature_box(tex_size=32), env_small, 64, 48)
+    _, r = render_hip(cfg, 1, return_obj=True)
+    tm = hd.default_tonemapper()
+    with pytest.raises(RuntimeError, match="without a pending"):
+        r.tonemap_end()
+    for _ in range(4):
+        r.tonemap_begin(tm)
+    with pytest.raises(RuntimeError, match="waiting for pt_tonemap_end"):
+        r.tonemap_begin(tm)
+    ref = r.tonemap(tm)                     # the synchronous pass does not disturb the ring
+    assert r.tonemap_pending() == 4
+    for _ in range(4):
+        assert np.array_equal(r.tonemap_end(), ref)
+    r.destroy()
+
+
 def test_tonemap_matches_oracle(env_small):
     """post.frag incl. dithering, global and local auto-exposure on the vkCmdBlitImage mip chain (odd sizes: 150 -> 75 -> 37 ...), and the
     de-scaled preview (Tonemapper.zoom): RGBA8 output identical to the oracle's."""

@@ -45,6 +45,9 @@ API = [
     ("pt_write_accum", C.c_int, [_P, _P]),
     ("pt_tonemap", C.c_int, [_P, C.POINTER(hd.Tonemapper), _P]),
     ("pt_tonemap_zoom", C.c_int, [_P, C.POINTER(hd.Tonemapper), C.c_int, C.c_int, _P]),
+    ("pt_tonemap_begin", C.c_int, [_P, C.POINTER(hd.Tonemapper), C.c_int, C.c_int]),
+    ("pt_tonemap_end", C.c_int, [_P, _P]),
+    ("pt_tonemap_pending", C.c_int, [_P]),
     ("pt_local_shard", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("pt_scatter_shards", C.c_int, [_P, _P, C.c_int]),
     ("pt_comm_get_unique_id", C.c_int, [_P]),

@@ -89,6 +89,15 @@ struct pt_context {
   DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
+  // pipelined display (pt_tonemap_begin / pt_tonemap_end): a ring of pinned host images, each with the event that says its copy has landed
+  // and the event after which the accumulation image may be written again (the untile pass has read it)
+  struct DisplaySlot {
+    uint8_t*   host  = nullptr;
+    size_t     bytes = 0, used = 0;
+    hipEvent_t done = nullptr, read = nullptr;
+  };
+  DisplaySlot display[PT_DISPLAY_RING];
+  uint64_t    displayHead = 0, displayTail = 0;  // oldest image not collected yet / next one to fill
   bool     gatherEnqueued = false;  // pt_gather_shards ran on this context as the root and pt_gather_finish has not consumed it yet
   StageTimers timers;
   pt_Stats    stats{};
@@ -625,6 +634,15 @@ int pt_destroy(pt_context* c)
     (void)hipEventDestroy(c->timers.pend[i].b);
   }
   free(c->timers.pend);
+  for(auto& ds : c->display)
+  {
+    if(ds.host)
+      (void)hipHostFree(ds.host);
+    if(ds.done)
+      (void)hipEventDestroy(ds.done);
+    if(ds.read)
+      (void)hipEventDestroy(ds.read);
+  }
   (void)hipStreamDestroy(c->stream);
   delete c;
   return PT_OK;
@@ -1616,9 +1634,12 @@ int pt_fpmath_eval(pt_context* c, int fn, uint64_t n, const float* a, const floa
   return done(rc);
 }
 
-int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH, uint8_t* out)
+}  // extern "C"
+// The display pass enqueued on the context's stream, ending with the copy of the RGBA8 image to `out` (host memory; the caller synchronises).
+// readDone: recorded once the accumulation image has been read, and made the event the next frame's accumulate step waits for -- frames
+// rendered after this call may then overlap the rest of the pass.
+static int enqueue_tonemap(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH, uint8_t* out, hipEvent_t readDone)
 {
-  CTX_CHECK(c);
   if(!tm || !out)
     return c->fail(PT_ERR_INVALID, "pt_tonemap: null");
   if(c->width == 0)
@@ -1629,6 +1650,11 @@ int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH
   int rc = untile_to_rowmajor(c);
   if(rc != PT_OK)
     return rc;
+  if(readDone)
+  {
+    HIP_TRY(c, hipEventRecord(readDone, c->stream));
+    c->lastAccum = readDone;
+  }
   // level 0: the accumulation image itself, or a viewport-sized image with it in the corner; levels 1.. only with auto-exposure
   // (src/sample_example.cpp:423-427 generates the chain only then)
   MipView mv{};
@@ -1663,6 +1689,15 @@ int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH
   pt_launch_tonemap(c->stream, mv, *tm, (uint32_t*)c->dRgba8.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->dRgba8.p, 4 * size_t(dispW) * dispH, hipMemcpyDeviceToHost, c->stream));
+  return PT_OK;
+}
+extern "C" {
+int pt_tonemap_zoom(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH, uint8_t* out)
+{
+  CTX_CHECK(c);
+  int rc = enqueue_tonemap(c, tm, dispW, dispH, out, nullptr);
+  if(rc != PT_OK)
+    return rc;
   HIP_TRY(c, sync_all(c));
   return check_traversal(c);
 }
@@ -1670,6 +1705,56 @@ int pt_tonemap(pt_context* c, const pt_Tonemapper* tm, uint8_t* out)
 {
   CTX_CHECK(c);
   return pt_tonemap_zoom(c, tm, c->width, c->height, out);
+}
+
+int pt_tonemap_begin(pt_context* c, const pt_Tonemapper* tm, int dispW, int dispH)
+{
+  CTX_CHECK(c);
+  if(c->displayTail - c->displayHead >= PT_DISPLAY_RING)
+    return c->fail(PT_ERR_STATE, "pt_tonemap_begin: %d images are waiting for pt_tonemap_end", PT_DISPLAY_RING);
+  if(dispW <= 0 || dispH <= 0 || dispW > 32768 || dispH > 32768)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap_begin: viewport %dx%d", dispW, dispH);
+  HIP_TRY(c, hipSetDevice(c->device));
+  pt_context::DisplaySlot& ds    = c->display[c->displayTail % PT_DISPLAY_RING];
+  const size_t             bytes = 4 * size_t(dispW) * dispH;
+  if(ds.bytes < bytes)
+  {
+    if(ds.host)
+      (void)hipHostFree(ds.host);
+    ds.host  = nullptr;
+    ds.bytes = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&ds.host, bytes, hipHostMallocDefault));
+    ds.bytes = bytes;
+  }
+  if(!ds.done)
+    HIP_TRY(c, hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
+  if(!ds.read)
+    HIP_TRY(c, hipEventCreateWithFlags(&ds.read, hipEventDisableTiming));
+  int rc = enqueue_tonemap(c, tm, dispW, dispH, ds.host, ds.read);
+  if(rc != PT_OK)
+    return rc;
+  HIP_TRY(c, hipEventRecord(ds.done, c->stream));
+  ds.used = bytes;
+  c->displayTail++;
+  return PT_OK;
+}
+int pt_tonemap_pending(pt_context* c)
+{
+  return c ? int(c->displayTail - c->displayHead) : 0;
+}
+int pt_tonemap_end(pt_context* c, uint8_t* out)
+{
+  CTX_CHECK(c);
+  if(!out)
+    return c->fail(PT_ERR_INVALID, "pt_tonemap_end: null");
+  if(c->displayHead == c->displayTail)
+    return c->fail(PT_ERR_STATE, "pt_tonemap_end without a pending pt_tonemap_begin");
+  HIP_TRY(c, hipSetDevice(c->device));
+  pt_context::DisplaySlot& ds = c->display[c->displayHead % PT_DISPLAY_RING];
+  HIP_TRY(c, hipEventSynchronize(ds.done));
+  std::memcpy(out, ds.host, ds.used);
+  c->displayHead++;
+  return PT_OK;
 }
 
 int pt_local_shard(pt_context* c, void** device_ptr, size_t* bytes, int* num_local_tiles, int* max_tiles_per_rank)

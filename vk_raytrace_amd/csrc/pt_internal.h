@@ -75,6 +75,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 #define CNT_CHUNK_TAIL 10         // path-supply chunk counter of k_tail (the bounce it starts at)
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
+#define PT_DISPLAY_RING 4  // images pt_tonemap_begin may have in flight before pt_tonemap_end collects the oldest
 #define PT_PERSISTENT_WAVES (256u * 20u)
 
 struct RenderBuffers {

@@ -51,6 +51,7 @@ class HipRenderer(Renderer):
         super().__init__()
         self._lib = capi.lib()
         self._ctx = None
+        self._display_sizes = []  # viewports of the images begun with tonemap_begin and not collected yet
         self._keep = None
         self.size = (0, 0)
         self.env_integral = 1.0
@@ -173,6 +174,25 @@ class HipRenderer(Renderer):
             self._check(self._lib.pt_tonemap_zoom(self._ctx, C.byref(tm), w, h, out.ctypes.data))
         return out
 
+    def tonemap_begin(self, tm: hd.Tonemapper, display_size=None):
+        """pt_tonemap_begin: the display pass enqueued behind the frames rendered so far; later frames overlap it.  tonemap_end() returns the
+        oldest image begun (at most 4 may be pending)."""
+        w, h = display_size or self.size
+        self._check(self._lib.pt_tonemap_begin(self._ctx, C.byref(tm), w, h))
+        self._display_sizes.append((w, h))
+
+    def tonemap_pending(self):
+        return int(self._lib.pt_tonemap_pending(self._ctx))
+
+    def tonemap_end(self):
+        if not self._display_sizes:
+            self._check(self._lib.pt_tonemap_end(self._ctx, np.empty(4, np.uint8).ctypes.data))  # reports the error
+        w, h = self._display_sizes[0]
+        out = np.empty((h, w, 4), np.uint8)
+        self._check(self._lib.pt_tonemap_end(self._ctx, out.ctypes.data))
+        self._display_sizes.pop(0)
+        return out
+
     def measure_peaks(self):
         """pt_measure_peaks: VALU issue and HBM streaming ceilings measured on this device (dict)"""
         p = hd.Peaks()
@@ -215,6 +235,7 @@ class SampleExample:
         self.m_maxFrames = 100000                      # sample_example.hpp:195
         self.m_descaling = False                       # sample_example.hpp:197
         self.m_descalingLevel = 1                      # sample_example.hpp:198
+        self.m_framesInFlight = 0                      # display images the host lets the GPU run behind (drawPost); the reference's swapchain ring
         self.m_pRender = renderer if renderer is not None else HipRenderer()
         self.m_pRender.setup(device)                   # sample_example.cpp:77-82
         self.m_scene = None
@@ -299,11 +320,25 @@ class SampleExample:
 
     # sample_example.cpp:362-384 -> RenderOutput::run; :378 `zoom = m_descaling ? 1.0f / m_descalingLevel : 1.0f`
     def drawPost(self):
+        """The display pass (SampleExample::drawPost, src/sample_example.cpp:396-431).  m_framesInFlight = 0: the RGBA8 image of the frame just
+        rendered (the host waits for it).  m_framesInFlight = k > 0: the pass is enqueued and the image of the frame rendered k calls ago is
+        returned (None for the first k calls) -- the host never waits for the frame it just issued, like the reference's loop around
+        prepareFrame / submitFrame (src/main.cpp:213,261); flushDisplay() returns what is still in flight."""
+        size = None
         if self.m_descaling:
             self.m_tonemapper.zoom = 1.0 / self.m_descalingLevel
-            return self.m_pRender.tonemap(self.m_tonemapper, display_size=self.m_size)
-        self.m_tonemapper.zoom = 1.0
-        return self.m_pRender.tonemap(self.m_tonemapper)
+            size = self.m_size
+        else:
+            self.m_tonemapper.zoom = 1.0
+        if self.m_framesInFlight <= 0:
+            return self.m_pRender.tonemap(self.m_tonemapper, display_size=size)
+        self.m_pRender.tonemap_begin(self.m_tonemapper, display_size=size)
+        if self.m_pRender.tonemap_pending() > min(self.m_framesInFlight, 3):
+            return self.m_pRender.tonemap_end()
+        return None
+
+    def flushDisplay(self):
+        return [self.m_pRender.tonemap_end() for _ in range(self.m_pRender.tonemap_pending())]
 
     def render(self, frames):
         """`frames` iterations of the reference's main loop body (src/main.cpp:201-264)."""
