@@ -265,6 +265,8 @@ typedef struct pt_Stats {
   uint64_t tailMisses;
   uint64_t tailAlphaTests;
   uint64_t launchesTail;     /* launches of the fused late-bounce kernel (with profiling enabled, like launchesTraceClosest) */
+  uint64_t numMergedTriangles; /* two-level mode: triangles of the prim-meshes instantiated once, kept in ONE world-space bottom-level structure
+                                  (counted as one of numBlas); equal to numTriangles when the scene has no repeated mesh -- the flat kernels then run on it */
 } pt_Stats;
 
 /* pt_measure_peaks: ceilings measured on the device */

@@ -355,6 +355,9 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
   return ar;
 }
 
+static int g_mergeSingles = 1;  // PT_TUNE mergeSingles (pt_internal.h): the product's default
+extern "C" void th_set_merge_singles(int on) { g_mergeSingles = on; }
+
 // flat + two-level structures over s->inst (already filled), pads per instance
 static void build_structures(Scene* s, const std::vector<float>& padC0, const std::vector<float>& padC1, uint32_t numPrimMeshes)
 {
@@ -375,12 +378,51 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   s->flatAlpha.assign(std::max<size_t>(1, s->flat.tris.size()), AlphaRec{});
   for(size_t i = 0; i < s->flat.tris.size(); ++i)
     s->flatAlpha[i] = alpha_record(*s, s->inst[__float_as_uint(s->flat.tris[i].e1n.w)], __float_as_uint(s->flat.tris[i].e2p.w));
-  // ---- two-level: one object-space BLAS per prim-mesh that is instantiated (pt_capi.hip build_two_level / pt_accel.hip pt_blas_build)
+  // ---- two-level: the prim-meshes instantiated once share one world-space structure at slot 0 / node 0 (pt_capi.hip build_merged /
+  // pt_accel.hip pt_merged_build) ...
+  std::vector<char> isMerged(numInst, 0);
+  bool              haveMerged = false;
+  float             mlo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mhi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if(g_mergeSingles)
+  {
+    std::vector<uint32_t> uses(numPrimMeshes, 0);
+    for(uint32_t i = 0; i < numInst; ++i)
+      if(s->inst[i].triCount)
+        uses[s->inst[i].primMesh]++;
+    std::vector<TriRec> mw;
+    for(uint32_t i = 0; i < numInst; ++i)
+      if(s->inst[i].triCount && uses[s->inst[i].primMesh] == 1)
+      {
+        isMerged[i] = 1;
+        for(uint32_t k = 0; k < s->inst[i].triCount; ++k)
+          mw.push_back(world_record(*s, s->inst[i], i, k, s->inst[i].triBase + k));
+      }
+    if(!mw.empty())
+    {
+      haveMerged = true;
+      Bvh b      = build_bvh(mw);
+      for(const TriRec& r : b.tris)
+      {
+        s->blasTris.push_back(r);
+        s->blasAlpha.push_back(alpha_record(*s, s->inst[__float_as_uint(r.e1n.w)], __float_as_uint(r.e2p.w)));
+        float lo[3], hi[3];
+        tri_box_h(r, lo, hi);  // the root box of the structure is the union of its padded leaf boxes
+        for(int a = 0; a < 3; ++a)
+        {
+          mlo[a] = std::fmin(mlo[a], lo[a]);
+          mhi[a] = std::fmax(mhi[a], hi[a]);
+        }
+      }
+      for(const WideNode& w : b.wide)
+        s->blasWide.push_back(w);  // slot base and node base are 0: the references are already global
+    }
+  }
+  // ... and one object-space BLAS per other prim-mesh that is instantiated (pt_capi.hip build_two_level / pt_accel.hip pt_blas_build)
   std::vector<int64_t> nodeBaseOf(numPrimMeshes, -1);
   for(uint32_t i = 0; i < numInst; ++i)
   {
     const InstanceRec& I = s->inst[i];
-    if(I.triCount == 0 || nodeBaseOf[I.primMesh] >= 0)
+    if(I.triCount == 0 || isMerged[i] || nodeBaseOf[I.primMesh] >= 0)
       continue;
     InstanceRec P = I;  // the pseudo-instance: identity transform, no TRI_FLIP
     P.objectToWorld.r0 = make_float4(1, 0, 0, 0); P.objectToWorld.r1 = make_float4(0, 1, 0, 0); P.objectToWorld.r2 = make_float4(0, 0, 1, 0);
@@ -418,7 +460,7 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   for(uint32_t i = 0; i < numInst; ++i)
   {
     const InstanceRec& I = s->inst[i];
-    if(I.triCount == 0)
+    if(I.triCount == 0 || isMerged[i])
       continue;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for(uint32_t j = 0; j < 3 * I.triCount; ++j)
@@ -437,12 +479,26 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
     prox.push_back(r);
   }
+  if(haveMerged)
+  {  // the merged structure's proxy (pt_tlas_build): its root box
+    TriRec r;
+    r.p0w = make_float4(mlo[0], mlo[1], mlo[2], __uint_as_float(TRI_INDEX_MASK));
+    r.e1n = make_float4(mhi[0] - mlo[0], mhi[1] - mlo[1], mhi[2] - mlo[2], 0.f);
+    r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
+    prox.push_back(r);
+  }
   s->tlas = build_bvh(prox);
   for(const TriRec& r : s->tlas.tris)
   {
     const uint32_t id = __float_as_uint(r.p0w.w) & TRI_INDEX_MASK;
     TlasLeaf       l;
     std::memset(&l, 0, sizeof(l));
+    if(id == TRI_INDEX_MASK)
+    {
+      l.inst = PT_INST_MERGED;
+      s->tlasLeaves.push_back(l);
+      continue;
+    }
     l.inst     = id;
     l.nodeBase = uint32_t(nodeBaseOf[s->inst[id].primMesh]);
     l.wflags   = s->inst[id].triBase | (s->inst[id].flags << 29);

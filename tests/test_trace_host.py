@@ -56,9 +56,11 @@ def harness():
 
 
 class Traced:
-    def __init__(self, scene: Scene, flags):
-        """flags: per node TRI_OPAQUE | TRI_NOCULL bits"""
+    def __init__(self, scene: Scene, flags, merge_singles=True):
+        """flags: per node TRI_OPAQUE | TRI_NOCULL bits.  merge_singles: the two-level structure keeps the prim-meshes instantiated once in one
+        world-space structure (the product's default, PT_TUNE mergeSingles) or gives every prim-mesh its own object-space BLAS"""
         self.L = harness()
+        self.L.th_set_merge_singles(1 if merge_singles else 0)
         if scene.vertices is None:
             scene.finalize(capi.pack_vertices)
         v = np.ascontiguousarray(scene.vertices)
@@ -71,6 +73,7 @@ class Traced:
         for p, (vo, vc, fi, ic, _) in enumerate(scene.prim_meshes):
             bound[p] = np.abs(v["position"][vo:vo + vc]).max() if vc else 0.0
         self.h = self.L.th_create(v.ctypes.data, len(v), idx.ctypes.data, len(idx), inst, len(inst), bound.ctypes.data, len(bound))
+        self.L.th_set_merge_singles(1)
         assert self.h, "th_create failed"
         self.keep = (v, idx, inst, bound)
         self.n = self.L.th_num_tris(self.h)
@@ -147,6 +150,12 @@ def instanced_scene(seed, n_nodes=160, far=False):
     mtx = translate(*(np.array([0.5, 0.5, 0.5]) + off))
     sc.add_node(pms[1], mtx); flags.append(OPAQUE | NOCULL)
     sc.add_node(pms[1], mtx); flags.append(OPAQUE | NOCULL)
+    # prim-meshes with ONE instance each (the two-level structure keeps these in its merged world-space structure): rotated + non-uniformly
+    # scaled, mirrored, and one overlapping the coincident pair above
+    once = [sc.add_prim_mesh(p, n, uv, i, m, tangents=t) for (p, n, uv, i, t) in (synth.uv_sphere(0.7, 12, 6), synth.box((1.1, 0.6, 0.9), sub=2), synth.grid(4, 4, (-1, 0, 1), (2, 0, 0), (0, 0, -2)))]
+    sc.add_node(once[0], translate(*(np.array([-2.0, 1.0, 3.0]) + off)) @ rotate_y(0.7) @ rotate_x(1.9) @ scale(1.5, 0.4, 2.2)); flags.append(OPAQUE)
+    sc.add_node(once[1], translate(*(np.array([0.6, 0.4, 0.5]) + off)) @ rotate_z(0.3) @ scale(-1.0, 1.0, 1.0)); flags.append(OPAQUE | NOCULL)
+    sc.add_node(once[2], translate(*(np.array([1.0, -2.0, -1.0]) + off)) @ rotate_x(0.4) @ scale(3.0, 1.0, 3.0)); flags.append(OPAQUE | NOCULL)
     return sc, np.array(flags), off
 
 
@@ -197,10 +206,10 @@ def compare(tr, org, dirs, what, max_cand=6):
     return total, accidental
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_walks_report_brute_force_candidates(seed):
+@pytest.mark.parametrize("seed,merge", [(0, True), (1, True), (2, True), (3, True), (0, False), (3, False)])
+def test_walks_report_brute_force_candidates(seed, merge):
     sc, flags, off = instanced_scene(seed)
-    tr = Traced(sc, flags)
+    tr = Traced(sc, flags, merge_singles=merge)
     rng = np.random.default_rng(100 + seed)
     org, dirs = rays_for(tr, rng, off, 6000)
     total, accidental = compare(tr, org, dirs, f"scene {seed}")

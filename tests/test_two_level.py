@@ -102,9 +102,10 @@ def env_small():
     return synth.procedural_sky(256, 128)
 
 
-@pytest.fixture(params=["tail=0", "tail=65536"])
+@pytest.fixture(params=["tail=0", "tail=65536", "tail=65536,mergeSingles=0"])
 def tail_policy(request):
-    """staged kernels vs the fused tail kernel (see tests/test_gpu_parity.py)"""
+    """staged kernels vs the fused tail kernel (see tests/test_gpu_parity.py); mergeSingles=0: every prim-mesh gets its own object-space BLAS
+    (by default the ones instantiated once share a world-space structure, and a scene made only of those runs the flat kernels on it)"""
     old = os.environ.get("PT_TUNE")
     os.environ["PT_TUNE"] = request.param
     yield request.param
@@ -218,6 +219,14 @@ def test_update_instances(env_small, accel, tail_policy):
     assert not np.array_equal(moved, first)
     _assert_identical(moved, render_oracle(cfg, 3), "after the update")
     build_ms = r.stats()["msBuildAccel"]
+    sc.nodes[:] = original
+    r.update_instances(sc)
+    assert np.array_equal(frames().view(np.uint32), first.view(np.uint32))
+    # the ground is the one prim-mesh with a single instance: in two-level mode it lives in the merged world-space structure, which is rebuilt
+    m0, p0 = sc.nodes[0]
+    sc.nodes[0] = (translate(0.5, -0.4, 1.0) @ rotate_y(0.3) @ rotate_x(0.05) @ m0, p0)
+    r.update_instances(sc)
+    _assert_identical(frames(), render_oracle(cfg, 3), "after moving the singly instantiated ground")
     sc.nodes[:] = original
     r.update_instances(sc)
     assert np.array_equal(frames().view(np.uint32), first.view(np.uint32))

@@ -930,13 +930,24 @@ __global__ void __launch_bounds__(256) k_instance_proxies(const uint32_t* __rest
   }
 }
 __global__ void k_tlas_leaves(uint32_t n, const TriRec* __restrict__ leafOrder, const InstanceRec* __restrict__ inst, const uint32_t* __restrict__ instNodeBase,
-                              const float* __restrict__ instPad, TlasLeaf* __restrict__ out)
+                              const float* __restrict__ instPad, TlasLeaf* __restrict__ out, uint32_t mergedNodeBase)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
   const uint32_t id = __float_as_uint(leafOrder[i].p0w.w) & TRI_INDEX_MASK;
   TlasLeaf       l;
+  if(id == TRI_INDEX_MASK)
+  {  // the proxy of the merged world-space structure (pt_tlas_build): no transform, no padding
+    l.inst     = PT_INST_MERGED;
+    l.nodeBase = mergedNodeBase;
+    l.wflags   = 0;
+    l._pad0    = 0;
+    l.padC0 = l.padC1 = 0.f;
+    l._pad1[0] = l._pad1[1] = 0;
+    out[i]     = l;
+    return;
+  }
   l.inst     = id;
   l.nodeBase = instNodeBase[id];
   l.wflags   = inst[id].triBase | (inst[id].flags << 29);
@@ -1426,13 +1437,88 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
   return failed.load() ? -1 : 0;
 }
 
+// The merged world-space structure of the two-level mode: the flat build over the instances listed in hInst (copies of the scene's records
+// with triBase renumbered 0, n0, n0 + n1, ... so that k_world_tris finds them), then every record gets the identity it has in the scene --
+// instance id ids[j] and world index worldBase[j] + primitive -- and the child references become global (k_blas_rebase).
+__global__ void k_merged_identity(uint32_t n, TriRec* __restrict__ tris, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ worldBase)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const uint32_t j = __float_as_uint(tris[i].e1n.w), prim = __float_as_uint(tris[i].e2p.w);
+  const uint32_t w = __float_as_uint(tris[i].p0w.w);
+  tris[i].p0w.w    = __uint_as_float((w & ~TRI_INDEX_MASK) | (worldBase[j] + prim));
+  tris[i].e1n.w    = __uint_as_float(ids[j]);
+}
+int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
+                    const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide, uint32_t slotBase, uint32_t nodeBase, uint32_t* numWideOut, float* boxOut6, char* err,
+                    size_t errLen)
+{
+  InstanceRec* dInst = nullptr;
+  uint32_t*    dIds  = nullptr;
+  BvhNode*     dNodes = nullptr;
+  PtScratch    arena;
+  int          rc = -1;
+  BvhNode      root{};
+  const size_t arenaBytes = size_t(numTris) * 640 + (size_t(1) << 20);
+  if(hipMalloc(&dInst, sizeof(InstanceRec) * size_t(numInst)) != hipSuccess || hipMalloc(&dIds, 8 * size_t(numInst)) != hipSuccess ||
+     hipMalloc(&dNodes, sizeof(BvhNode) * size_t(std::max(1u, numTris))) != hipSuccess)
+  {
+    snprintf(err, errLen, "merged BLAS build: out of device memory");
+    goto done;
+  }
+  if(hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
+    arena.cap = arenaBytes;
+  else
+  {
+    arena.base = nullptr;
+    (void)hipGetLastError();
+  }
+  if(hipMemcpyAsync(dInst, hInst, sizeof(InstanceRec) * size_t(numInst), hipMemcpyHostToDevice, stream) != hipSuccess ||
+     hipMemcpyAsync(dIds, hIds, 4 * size_t(numInst), hipMemcpyHostToDevice, stream) != hipSuccess ||
+     hipMemcpyAsync(dIds + numInst, hWorldBase, 4 * size_t(numInst), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+  {
+    snprintf(err, errLen, "merged BLAS build: upload failed");
+    goto done;
+  }
+  if(pt_accel_build(stream, dInst, numInst, dVertices, dIndices, numTris, dTris + slotBase, dAlpha + slotBase, dNodes, dWide + nodeBase, numWideOut, err, errLen, nullptr, &arena) != 0)
+    goto done;
+  k_merged_identity<<<(numTris + 255) / 256, 256, 0, stream>>>(numTris, dTris + slotBase, dIds, dIds + numInst);
+  k_blas_rebase<<<(*numWideOut + 255) / 256, 256, 0, stream>>>(*numWideOut, dWide + nodeBase, nodeBase, slotBase);
+  if(hipMemcpyAsync(&root, dNodes, sizeof(BvhNode), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+  {
+    snprintf(err, errLen, "merged BLAS build: a kernel failed");
+    goto done;
+  }
+  {  // world box = union of the binary root's child boxes (one child when the structure is a single triangle)
+    const bool  two   = numTris > 1 && root.d.y != BVH_NONE;
+    const float l[6]  = {root.a.x, root.a.y, root.a.z, root.a.w, root.b.x, root.b.y}, r[6] = {root.b.z, root.b.w, root.c.x, root.c.y, root.c.z, root.c.w};
+    for(int k = 0; k < 3; ++k)
+    {
+      boxOut6[k]     = two ? std::min(l[k], r[k]) : l[k];
+      boxOut6[3 + k] = two ? std::max(l[3 + k], r[3 + k]) : l[3 + k];
+    }
+  }
+  rc = 0;
+done:
+  (void)hipStreamSynchronize(stream);
+  arena.release();
+  if(arena.base)
+    (void)hipFree(arena.base);
+  if(dInst) (void)hipFree(dInst);
+  if(dIds) (void)hipFree(dIds);
+  if(dNodes) (void)hipFree(dNodes);
+  return rc;
+}
+
 int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
-                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen)
+                  const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen,
+                  const float* mergedBox, uint32_t mergedNodeBase)
 {
   *numWideOut = 0;
-  if(numActive == 0)
+  const uint32_t n = numActive + (mergedBox ? 1u : 0u);  // the merged structure is one more primitive of the TLAS
+  if(n == 0)
     return 0;
-  const uint32_t n = numActive;
   TriRec *       dProx = nullptr, *dLeafOrder = nullptr;
   AlphaRec*      dAlpha = nullptr;
   BvhNode*       dNodes = nullptr;
@@ -1443,10 +1529,26 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
     snprintf(err, errLen, "TLAS build: out of device memory");
     goto done;
   }
-  k_instance_proxies<<<n, 256, 0, stream>>>(dActive, dInst, dVertices, dIndices, dProx);
+  if(numActive)
+    k_instance_proxies<<<numActive, 256, 0, stream>>>(dActive, dInst, dVertices, dIndices, dProx);
+  if(mergedBox)
+  {
+    TriRec r;
+    const uint32_t tag = TRI_INDEX_MASK;  // k_tlas_leaves recognises the proxy by this index
+    float          tagF;
+    std::memcpy(&tagF, &tag, 4);
+    r.p0w = make_float4(mergedBox[0], mergedBox[1], mergedBox[2], tagF);
+    r.e1n = make_float4(mergedBox[3] - mergedBox[0], mergedBox[4] - mergedBox[1], mergedBox[5] - mergedBox[2], 0.f);
+    r.e2p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(hipMemcpyAsync(dProx + numActive, &r, sizeof(r), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+    {
+      snprintf(err, errLen, "TLAS build: upload failed");
+      goto done;
+    }
+  }
   if(pt_accel_build(stream, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, numWideOut, err, errLen, dProx, nullptr) != 0)
     goto done;
-  k_tlas_leaves<<<(n + 255) / 256, 256, 0, stream>>>(n, dLeafOrder, dInst, dInstNodeBase, dInstPad, dLeavesOut);
+  k_tlas_leaves<<<(n + 255) / 256, 256, 0, stream>>>(n, dLeafOrder, dInst, dInstNodeBase, dInstPad, dLeavesOut, mergedNodeBase);
   if(hipMemcpyAsync(rootOut, dNodes, sizeof(BvhNode), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
   {
     snprintf(err, errLen, "TLAS build: a kernel failed");

@@ -38,6 +38,12 @@ struct pt_context {
   int      accelMode = PT_ACCEL_FLAT;
   DevBuf   dTlas, dTlasLeaves, dInstTriBase, dActive, dInstNodeBase, dInstPad;
   uint32_t numBlas = 0, numTlasNodes = 0, numActive = 0;
+  // two-level mode: the instances whose prim-mesh is instantiated exactly once live in one world-space structure (PT_INST_MERGED) at slot 0 /
+  // node 0 of the BLAS arrays; mergedOnly: nothing else exists, the structure IS the flat one and the flat kernels run on it
+  std::vector<uint32_t> hMerged;
+  uint32_t mergedTris = 0, mergedWide = 0;
+  float    mergedBox[6] = {0, 0, 0, 0, 0, 0};
+  bool     mergedOnly = false;
   std::vector<uint32_t> hInstNodeBase;  // per instance: root node of its BLAS (two-level mode, after the BLAS build)
   std::vector<float>    hPrimBound;     // per prim-mesh: max |coordinate| of its vertices (object space); bounds the rounding of the ray transform
   double   msBuildTlas = 0;
@@ -263,7 +269,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.envAccel     = (const pt_EnvAccel*)c->dEnvAccel.p;
   s.numTris      = c->numTris;
   s.numInstances = c->numInstances;
-  const bool two = c->accelMode == PT_ACCEL_TWO_LEVEL && c->haveAccel;
+  const bool two = c->accelMode == PT_ACCEL_TWO_LEVEL && c->haveAccel && !c->mergedOnly;
   s.tlas         = two ? (const WideNode*)c->dTlas.p : nullptr;
   s.tlasLeaves   = two ? (const TlasLeaf*)c->dTlasLeaves.p : nullptr;
   s.instTriBase  = two ? (const uint32_t*)c->dInstTriBase.p : nullptr;
@@ -363,10 +369,13 @@ int build_tlas(pt_context* c)
   const std::vector<InstanceRec> inst = effective_instances(c);
   std::vector<uint32_t>          active, triBase(inst.empty() ? 1 : inst.size(), 0u);
   std::vector<float>             pad(inst.empty() ? 2 : 2 * inst.size(), 0.f);
+  std::vector<char> isMerged(inst.size(), 0);
+  for(uint32_t i : c->hMerged)
+    isMerged[i] = 1;
   for(uint32_t i = 0; i < inst.size(); ++i)
   {
     triBase[i] = inst[i].triBase;
-    if(inst[i].triCount == 0)
+    if(inst[i].triCount == 0 || isMerged[i])
       continue;
     active.push_back(i);
     two_level_pad(inst[i], c->hPrimBound[inst[i].primMesh], pad[2 * i], pad[2 * i + 1]);
@@ -378,19 +387,47 @@ int build_tlas(pt_context* c)
   if((rc = upload(c, c->dInstTriBase, triBase.data(), 4 * triBase.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dInstPad, pad.data(), 4 * pad.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dInstNodeBase, c->hInstNodeBase.empty() ? &none : c->hInstNodeBase.data(), 4 * std::max<size_t>(1, c->hInstNodeBase.size()))) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dTlas, sizeof(WideNode) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
-  if((rc = dev_alloc(c, c->dTlasLeaves, sizeof(TlasLeaf) * size_t(std::max(1u, c->numActive)))) != PT_OK) return rc;
+  const uint32_t numPrims = c->numActive + (c->mergedTris ? 1u : 0u);
+  if((rc = dev_alloc(c, c->dTlas, sizeof(WideNode) * size_t(std::max(1u, numPrims)))) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dTlasLeaves, sizeof(TlasLeaf) * size_t(std::max(1u, numPrims)))) != PT_OK) return rc;
   auto    t0 = std::chrono::steady_clock::now();
   char    msg[256];
   BvhNode root{};
   if(pt_tlas_build(c->stream, (const InstanceRec*)c->dInstances.p, (const uint32_t*)c->dActive.p, c->numActive, (const uint32_t*)c->dInstNodeBase.p, (const float*)c->dInstPad.p,
-                   (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (WideNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, msg, sizeof(msg)) != 0)
+                   (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (WideNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, msg, sizeof(msg),
+                   c->mergedTris ? c->mergedBox : nullptr, 0u) != 0)
     return c->fail(PT_ERR_HIP, "TLAS build: %s", msg);
   c->msBuildTlas = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for(int k = 0; k < 3; ++k)
     c->scene.boundsMin[k] = c->scene.boundsInvExt[k] = 0.f;
-  if(c->numActive > 0)
-    bounds_from_root(c, root, c->numActive > 1 && root.d.y != BVH_NONE);
+  if(numPrims > 0)
+    bounds_from_root(c, root, numPrims > 1 && root.d.y != BVH_NONE);
+  c->mergedOnly = c->mergedTris > 0 && c->numActive == 0;
+  return PT_OK;
+}
+
+// (re)builds the merged world-space structure over c->hMerged with the current transforms, in place at slot 0 / node 0 of the BLAS arrays
+int build_merged(pt_context* c)
+{
+  c->mergedWide = 0;
+  if(c->hMerged.empty())
+    return PT_OK;
+  const std::vector<InstanceRec> inst = effective_instances(c);
+  std::vector<InstanceRec>       sub;
+  std::vector<uint32_t>          worldBase;
+  uint32_t                       n = 0;
+  for(uint32_t i : c->hMerged)
+  {
+    InstanceRec I = inst[i];
+    worldBase.push_back(I.triBase);
+    I.triBase = n;
+    n += I.triCount;
+    sub.push_back(I);
+  }
+  char msg[256];
+  if(pt_merged_build(c->stream, sub.data(), c->hMerged.data(), worldBase.data(), uint32_t(sub.size()), n, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p,
+                     (AlphaRec*)c->dAlphaRecs.p, (WideNode*)c->dWide.p, 0u, 0u, &c->mergedWide, c->mergedBox, msg, sizeof(msg)) != 0)
+    return c->fail(PT_ERR_HIP, "pt_build_accel (two-level, merged structure): %s", msg);
   return PT_OK;
 }
 
@@ -403,10 +440,31 @@ int build_two_level(pt_context* c)
   std::vector<PtBlasDesc>        blas;
   uint64_t                       slots = 0, nodes = 0;
   c->hInstNodeBase.assign(inst.size(), 0u);
+  // prim-meshes instantiated once: their instances share one world-space structure, first in the arrays
+  c->hMerged.clear();
+  c->mergedTris = 0;
+  c->mergedOnly = false;
+  std::vector<char> isMerged(inst.size(), 0);
+  if(g_tuning.mergeSingles)
+  {
+    std::map<int32_t, uint32_t> uses;
+    for(const InstanceRec& I : inst)
+      if(I.triCount)
+        uses[I.primMesh]++;
+    for(uint32_t i = 0; i < inst.size(); ++i)
+      if(inst[i].triCount && uses[inst[i].primMesh] == 1)
+      {
+        c->hMerged.push_back(i);
+        isMerged[i] = 1;
+        c->mergedTris += inst[i].triCount;
+      }
+    slots = c->mergedTris;
+    nodes = c->mergedTris ? std::max(1u, c->mergedTris - 1) : 0;
+  }
   for(uint32_t i = 0; i < inst.size(); ++i)
   {
     const InstanceRec& I = inst[i];
-    if(I.triCount == 0)
+    if(I.triCount == 0 || isMerged[i])
       continue;
     auto it = blasOf.find(I.primMesh);
     if(it == blasOf.end())
@@ -434,9 +492,11 @@ int build_two_level(pt_context* c)
   if(pt_blas_build(c->stream, blas.data(), uint32_t(blas.size()), (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p,
                    (WideNode*)c->dWide.p, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel (two-level): %s", msg);
-  c->numBlas      = uint32_t(blas.size());
+  if((rc = build_merged(c)) != PT_OK)
+    return rc;
+  c->numBlas      = uint32_t(blas.size()) + (c->mergedTris ? 1u : 0u);
   c->numBvhNodes  = uint32_t(nodes);
-  c->numWideNodes = 0;
+  c->numWideNodes = c->mergedWide;
   for(const PtBlasDesc& d : blas)
     c->numWideNodes += d.numWide;
   if((rc = build_tlas(c)) != PT_OK)
@@ -554,6 +614,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
     if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
     if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
+    if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) g_tuning.mergeSingles = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
@@ -924,6 +985,9 @@ int pt_build_accel(pt_context* c)
     return build_two_level(c);
   int rc;
   c->numBlas = c->numTlasNodes = c->numActive = 0;
+  c->hMerged.clear();
+  c->mergedTris = c->mergedWide = 0;
+  c->mergedOnly = false;
   c->numBvhNodes = c->numTris > 1 ? c->numTris - 1 : 1;
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
@@ -1089,6 +1153,7 @@ int pt_update_instances(pt_context* c, const pt_Node* nodes, uint32_t numNodes)
     if(!set_instance_transform(inst[n], nodes[n].worldMatrix, inst[n].flags))
       return c->fail(PT_ERR_INVALID, "node %u: singular world matrix", n);
   }
+  const std::vector<InstanceRec> before = c->hInstances;
   c->hInstances = inst;
   int rc = upload_instances(c);
   if(rc != PT_OK)
@@ -1097,8 +1162,17 @@ int pt_update_instances(pt_context* c, const pt_Node* nodes, uint32_t numNodes)
   if(!c->haveAccel)
     return PT_OK;
   if(c->accelMode == PT_ACCEL_TWO_LEVEL)
-  {  // refit: the object-space BLASes are untouched, only the instance boxes and the hierarchy over them are redone
+  {  // refit: the object-space BLASes are untouched, only the instance boxes and the hierarchy over them are redone; the merged world-space
+     // structure is rebuilt when one of its instances moved
     auto t0 = std::chrono::steady_clock::now();
+    bool mergedMoved = false;
+    for(uint32_t i : c->hMerged)
+      mergedMoved = mergedMoved || std::memcmp(&before[i].objectToWorld, &c->hInstances[i].objectToWorld, sizeof(Affine)) != 0;
+    if(mergedMoved && (rc = build_merged(c)) != PT_OK)
+    {
+      c->haveAccel = false;
+      return rc;
+    }
     if((rc = build_tlas(c)) != PT_OK)
     {
       c->haveAccel = false;
@@ -1875,6 +1949,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.msTail       = c->timers.ms[5];
   s.launchesTraceClosest = c->timers.launchesClosest;
   s.launchesTail         = c->timers.launchesTail;
+  s.numMergedTriangles   = c->mergedTris;
   s.tailClosestRays = k.tailClosestRays; s.tailShadowRays = k.tailShadowRays; s.tailShadedHits = k.tailShadedHits; s.tailMisses = k.tailMisses;
   s.tailAlphaTests = k.tailAlphaTests;
   s.numTriangles = c->numTris;

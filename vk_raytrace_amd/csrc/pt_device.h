@@ -79,6 +79,10 @@ struct WideNode {
 // are global indices into them), DeviceScene::tlas the instance hierarchy.  A BLAS leaf record keeps the three OBJECT-space vertex
 // positions (p0w.xyz, e1n.xyz, e2p.xyz; p0w.w = primitive index): the triangle test transforms them with the instance matrix exactly as
 // trace contract T1 does and runs in world space, so hits are bit-identical to the flat structure; only the box tests happen in object space.
+// The prim-meshes a scene instantiates exactly once share ONE bottom-level structure in world space (pt_capi.hip build_two_level): its leaf
+// records are the flat structure's (world-space edge form, instance and primitive in the w lanes), its TLAS leaf carries this instance id, and
+// a lane inside it keeps its world-space ray constants -- no ray transform on entry, no vertex transform per triangle.
+#define PT_INST_MERGED 0xfffffffeu
 struct TlasLeaf {  // 32 B, one per TLAS leaf (= non-empty instance), TLAS leaf order
   uint32_t inst;      // instance (glTF node) index
   uint32_t nodeBase;  // root WideNode of the instance's BLAS

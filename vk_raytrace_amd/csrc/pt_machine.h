@@ -165,7 +165,8 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
   {  // TLAS leaf: enter the instance (pt_trace.h: enter_instance)
     const TlasLeaf tl = S.tlasLeaves[slot];
     L.ic   = InstCtx{tl.inst, L.sp, tl.wflags};
-    L.rbox = enter_instance(S, tl, L.o, L.d);
+    if(tl.inst != PT_INST_MERGED)
+      L.rbox = enter_instance(S, tl, L.o, L.d);
     L.cur  = tl.nodeBase;
     return;
   }
@@ -175,7 +176,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
   if(L.cur & BVH_ALPHA)
     ar = S.alphaRecs[slot];
 #if PT_BVH_WIDTH != 2
-  if(TWO)
+  if(TWO && L.ic.inst != PT_INST_MERGED)
     tr = world_tri(S, L.ic, tr);
 #endif
   const uint32_t wbits = __float_as_uint(tr.p0w.w);

@@ -462,7 +462,8 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
     {  // TLAS leaf: enter the instance (its BLAS root is an inner node)
       const TlasLeaf tl = S.tlasLeaves[cur & BVH_SLOT_MASK];
       ic    = InstCtx{tl.inst, sp, tl.wflags};
-      rbox  = enter_instance(S, tl, o, d);
+      if(tl.inst != PT_INST_MERGED)
+        rbox = enter_instance(S, tl, o, d);
       nodes = S.wide;
       cur   = tl.nodeBase;
       continue;
@@ -476,7 +477,7 @@ PT_DEV void traverse(const DeviceScene& S, f3 o, f3 d, float tmax, float tPrev, 
       if(cur & BVH_ALPHA)  // non-opaque triangle: its any-hit inputs travel with the triangle (one round trip)
         ar = S.alphaRecs[slot];
 #if PT_BVH_WIDTH != 2
-      if(TWO)
+      if(TWO && ic.inst != PT_INST_MERGED)
         tr = world_tri(S, ic, tr);
 #endif
       const uint32_t wbits = __float_as_uint(tr.p0w.w);
