@@ -474,7 +474,6 @@ def main():
         bc, bs = trace_bytes(st_c, st_s, st_a * fa, st_a * (1 - fa))
         tc, ts = trace_bytes(tl["closestRays"], tl["shadowRays"], tl_a * ft, tl_a * (1 - ft))
         st_hits, st_miss = sr["shadedHits"] - tl["shadedHits"], sr["misses"] - tl["misses"]
-        nb = max(1, serial["launches_per_stage"] // max(1, wl.depth)) if serial["launches_per_stage"] >= wl.depth else 1  # launch sequences of the measured batch
         stage_bytes = {
             "closest": bc, "shadow": bs, "shade": shade_bytes(st_hits, st_miss, st_hits),
             "tail": tc + ts + shade_bytes(tl["shadedHits"], tl["misses"], tl["shadedHits"]),
