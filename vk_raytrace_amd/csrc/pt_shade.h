@@ -375,25 +375,32 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
   f3 nextO = offset_ray(hitPos, dot3(L, sf.ffnormal) > 0 ? sf.ffnormal : -sf.ffnormal);
 
-  rb.ps.rayO[slot]   = make_float4(nextO.x, nextO.y, nextO.z, 0.f);
-  rb.ps.rayD[slot]   = make_float4(L.x, L.y, L.z, __uint_as_float(seed));
-  rb.ps.thr[slot]    = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
-  rb.ps.rad[slot]    = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
-  rb.ps.absorb[slot] = make_float4(absorption.x, absorption.y, absorption.z, lightDist);
+  rb.ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
   if(visible)
-  {
+  {  // the shadow kernel adds the contribution and draws the roulette (finish_bounce_core)
+    rb.ps.rayO[slot]   = make_float4(nextO.x, nextO.y, nextO.z, 0.f);
+    rb.ps.rayD[slot]   = make_float4(L.x, L.y, L.z, __uint_as_float(seed));
+    rb.ps.thr[slot]    = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
+    rb.ps.absorb[slot] = make_float4(absorption.x, absorption.y, absorption.z, lightDist);
     rb.ps.neeDir[slot] = make_float4(lightDir.x, lightDir.y, lightDir.z, 1.f);
     rb.ps.neeRad[slot] = make_float4(neeRadiance.x, neeRadiance.y, neeRadiance.z, 0.f);
     return SHADE_TO_SHADOW;
   }
-  // no shadow ray for this bounce: the Russian-roulette draw follows the BSDF draws directly (pathtrace.glsl:333-338)
-  const bool die     = rng_next(seed) >= rrPcont;
-  rb.ps.rayD[slot].w = __uint_as_float(seed);
-  if(die)
+  // no shadow ray for this bounce: the Russian-roulette draw follows the BSDF draws directly (pathtrace.glsl:333-338).  A path that ends here
+  // leaves only its radiance and the RNG state behind (the stream continues across the samples of a frame); the ray, throughput and
+  // absorption of a bounce that is never traced are not written
+  const bool die = rng_next(seed) >= rrPcont;
+  if(die || depth == st.maxDepth - 1)
+  {
+    rb.ps.rayD[slot].w = __uint_as_float(seed);
     return SHADE_DONE;
+  }
   throughput /= rrPcont;
-  rb.ps.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
-  return depth != st.maxDepth - 1 ? SHADE_TO_NEXT : SHADE_DONE;
+  rb.ps.rayO[slot]   = make_float4(nextO.x, nextO.y, nextO.z, 0.f);
+  rb.ps.rayD[slot]   = make_float4(L.x, L.y, L.z, __uint_as_float(seed));
+  rb.ps.thr[slot]    = make_float4(throughput.x, throughput.y, throughput.z, rrPcont);
+  rb.ps.absorb[slot] = make_float4(absorption.x, absorption.y, absorption.z, lightDist);
+  return SHADE_TO_NEXT;
 }
 
 // ---- shadow + Russian roulette ---------------------------------------------------------------------------------
