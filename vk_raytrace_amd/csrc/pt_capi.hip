@@ -274,6 +274,10 @@ void refresh_scene_ptrs(pt_context* c)
   s.tlasLeaves   = two ? (const TlasLeaf*)c->dTlasLeaves.p : nullptr;
   s.instTriBase  = two ? (const uint32_t*)c->dInstTriBase.p : nullptr;
   s.twoLevel     = two ? 1u : 0u;
+  s.allOpaque    = 1u;
+  for(const InstanceRec& I : c->hInstances)
+    if(I.triCount && c->anyHit && !(I.flags & TRI_OPAQUE))
+      s.allOpaque = 0u;
 }
 
 

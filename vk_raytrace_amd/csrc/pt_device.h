@@ -145,6 +145,9 @@ struct DeviceScene {
   const TlasLeaf*             tlasLeaves;
   const uint32_t*             instTriBase;  // InstanceRec::triBase of every instance, compact (world triangle index -> instance)
   uint32_t                    twoLevel;
+  uint32_t                    allOpaque;    // 1: no instance with triangles lacks TRI_OPAQUE (scene without MASK / BLEND materials, or pt_use_any_hit(0)):
+                                            // no candidate ever draws, so a shadow ray may stop at the first hit it finds (TerminateOnFirstHit,
+                                            // shaders/traceray_rq.glsl:157) -- which hit commits first cannot change its result
 };
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------

@@ -519,7 +519,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
+      {
         lane_leaf<false, TWO>(S, L, lds, spill);
+        if(S.allOpaque && L.bslot != BVH_NONE)
+          L.done = true;  // all-opaque scene: any hit inside (0, tmax) occludes and nothing draws -- the nearest one need not be found
+      }
     }
   }
 #ifdef PT_HIST
