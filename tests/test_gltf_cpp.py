@@ -96,6 +96,36 @@ def test_cpp_importer_synthesis_and_trs(tmp_path):
     cpp.close()
 
 
+def test_scene_selection_and_nodes_outside_the_scene(tmp_path):
+    """Import rules the reference leaves to nvh::GltfScene (src/scene.cpp:56-76), pinned here on both importers: only the nodes reachable from the
+    roots of the file's default scene (`scene`, 0 when absent) are instantiated -- a second scene and orphan nodes contribute nothing; a file
+    without `scenes` instantiates every node that is nobody's child; a mesh used by two nodes of the scene is ONE prim-mesh with two
+    instances, a mesh that no instantiated node uses is not imported at all."""
+    doc = _tri_doc()
+    doc["meshes"].append({"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]})      # same accessors: de-duplicated with mesh 0
+    doc["nodes"] = [{"mesh": 0, "translation": [1, 0, 0]}, {"mesh": 1, "translation": [0, 2, 0]}, {"mesh": 0, "translation": [0, 0, 3]}, {"mesh": 0, "translation": [9, 9, 9]}]
+    doc["scenes"] = [{"nodes": [3]}, {"nodes": [0, 1]}]
+    doc["scene"] = 1
+    path = _write(tmp_path, doc)
+    py, cpp = gltf.load_gltf(path), CppScene(path)
+    compare(py, cpp, exact=False)
+    assert len(py.nodes) == 2 and len(py.prim_meshes) == 1                                     # nodes 0 and 1; node 2 (orphan) and scene 0 are ignored
+    assert sorted(float(m[0][3] + m[1][3] + m[2][3]) for m, _ in py.nodes) == [1.0, 2.0]
+    cpp.close()
+    del doc["scene"]                                                                            # default scene = 0
+    path = _write(tmp_path, doc, "t0.gltf")
+    py, cpp = gltf.load_gltf(path), CppScene(path)
+    compare(py, cpp, exact=False)
+    assert len(py.nodes) == 1 and float(py.nodes[0][0][0][3]) == 9.0
+    cpp.close()
+    del doc["scenes"]                                                                           # no scenes: every root node
+    path = _write(tmp_path, doc, "t1.gltf")
+    py, cpp = gltf.load_gltf(path), CppScene(path)
+    compare(py, cpp, exact=False)
+    assert len(py.nodes) == 4 and len(py.prim_meshes) == 1
+    cpp.close()
+
+
 def test_cpp_importer_errors(tmp_path):
     with pytest.raises(ValueError):
         CppScene(str(tmp_path / "missing.gltf"))

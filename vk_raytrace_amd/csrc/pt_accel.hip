@@ -1365,7 +1365,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
   // A build is a chain of small level-synchronous launches with a host round trip per level: one mesh alone leaves the GPU and the host idle
   // most of the time.  A few host threads, each with its own stream, arena and binary-node scratch, take the meshes from a shared counter
   // (largest first would balance better; the meshes of a scene are usually of similar size).
-  const unsigned       numWorkers = std::max(1u, std::min(std::min(numBlas, 4u), uint32_t(g_tuning.blasWorkers > 0 ? g_tuning.blasWorkers : 1)));
+  const unsigned       numWorkers = std::max(1u, std::min(std::min(numBlas, 16u), uint32_t(g_tuning.blasWorkers > 0 ? g_tuning.blasWorkers : 1)));
   std::atomic<uint32_t> next{0};
   std::atomic<int>      failed{0};
   std::mutex            errLock;

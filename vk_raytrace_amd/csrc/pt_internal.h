@@ -128,7 +128,7 @@ struct PtTuning {
   int tailBelow            = 65536;  // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
                                    // queue is expected to hold at most this many paths (0: never)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
-  int blasWorkers          = 4;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
+  int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
   int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
