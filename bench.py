@@ -155,6 +155,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world  # under a launcher the launcher's world size is the truth
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver: dmabuf IPC only (RCCL reads it at init)
 
     from vk_raytrace_amd import capi, workloads
     from vk_raytrace_amd.renderer import HipRenderer

@@ -35,7 +35,7 @@ class InstIn(C.Structure):
 
 def harness():
     capi.lib()  # libptmi.so must exist: the harness links its test hooks (device-builder emulation, two_level_pad)
-    deps = [SRC] + [os.path.join(ROOT, "vk_raytrace_amd", "csrc", f) for f in ("pt_trace.h", "pt_surface.h", "pt_device.h", "pt_math.h")] + [capi.LIB_PATH]
+    deps = [SRC] + [os.path.join(ROOT, "vk_raytrace_amd", "csrc", f) for f in ("pt_trace.h", "pt_machine.h", "pt_settle.h", "pt_shade.h", "pt_surface.h", "pt_device.h", "pt_math.h")] + [capi.LIB_PATH]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         lib_dir = os.path.dirname(capi.LIB_PATH)
