@@ -120,6 +120,7 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 #endif
 #include "pt_shade.h"  // pt_settle.h (pt_trace.h + the per-ray settle functions k_tail runs) + the shading steps of a path (generate_ray, shade_path, ...)
 #include "pt_machine.h"  // the resumable per-lane traversal of the persistent kernels (k_closest_p / k_shadow_p)
+#include "pt_cnode.h"    // WideNode -> CompactNode (what pt_accel.hip k_compact_nodes runs per node)
 #include "../../include/pt_types.h"
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
@@ -311,6 +312,7 @@ struct Scene {
   Bvh                      tlas;
   std::vector<TlasLeaf>    tlasLeaves;
   std::vector<AlphaRec>    flatAlpha;
+  std::vector<CompactNode> flatCNodes;  // PT_TUNE cnodes=1: the flat structure's nodes in the compact form (read by lane_inner only)
   AlphaMat                 alphaMat;
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
@@ -355,6 +357,9 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
   return ar;
 }
 
+static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
+extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
+extern "C" int  th_compact_ok() { return g_compactOk; }
 static int g_mergeSingles = 1;  // PT_TUNE mergeSingles (pt_internal.h): the product's default
 extern "C" void th_set_merge_singles(int on) { g_mergeSingles = on; }
 
@@ -530,6 +535,15 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   s->dsFlat.wide      = s->flat.wide.data();
   s->dsFlat.tris      = s->flat.tris.data();
   s->dsFlat.alphaRecs = s->flatAlpha.data();
+  if(g_compactNodes)
+  {
+    s->flatCNodes.resize(s->flat.wide.size());
+    bool ok = true;
+    for(size_t i = 0; i < s->flat.wide.size(); ++i)
+      ok = cn_encode(s->flat.wide[i], s->flatCNodes[i]) && ok;
+    s->dsFlat.cnodes = ok ? s->flatCNodes.data() : nullptr;
+    g_compactOk      = ok ? 1 : 0;
+  }
   s->dsTwo            = d;
   s->dsTwo.wide        = s->blasWide.data();
   s->dsTwo.tris        = s->blasTris.data();

@@ -35,7 +35,7 @@ class InstIn(C.Structure):
 
 def harness():
     capi.lib()  # libptmi.so must exist: the harness links its test hooks (device-builder emulation, two_level_pad)
-    deps = [SRC] + [os.path.join(ROOT, "vk_raytrace_amd", "csrc", f) for f in ("pt_trace.h", "pt_machine.h", "pt_settle.h", "pt_shade.h", "pt_surface.h", "pt_device.h", "pt_math.h")] + [capi.LIB_PATH]
+    deps = [SRC] + [os.path.join(ROOT, "vk_raytrace_amd", "csrc", f) for f in ("pt_trace.h", "pt_machine.h", "pt_settle.h", "pt_shade.h", "pt_surface.h", "pt_device.h", "pt_math.h", "pt_cnode.h")] + [capi.LIB_PATH]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         lib_dir = os.path.dirname(capi.LIB_PATH)
@@ -343,6 +343,17 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
         assert same.all(), f"{name}: closest-hit, two={two} exact={exact}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
         if exact != 1:
             assert np.array_equal(got[3], ref[3])                   # the alpha-test counter (pt_Stats.alphaTests) counts the same draws
+    # the persistent kernels on the compact form of the flat structure's nodes (PT_TUNE cnodes=1: 80-byte nodes, fp16 grid planes): the boxes are
+    # looser, never tighter -- same hits, barycentrics, RNG states and draw counts
+    tr.L.th_set_compact_nodes(1)
+    trc = TracedScene(scene)
+    tr.L.th_set_compact_nodes(0)
+    assert trc.L.th_compact_ok() == 1
+    got = trc.settle(0, 0, 2, org, dirs, seeds)
+    same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
+    assert same.all(), f"{name}: closest-hit on compact nodes: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
+    assert np.array_equal(got[3], ref[3])
+    trc.close()
     tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
     for variant in (0, 1):
         ref = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
@@ -353,6 +364,28 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
         if variant == 1:
             assert np.array_equal(ref[2], seeds)                    # RT pipeline: the any-hit shader draws from a copy of the seed
     tr.close()
+
+
+@pytest.mark.parametrize("far", [False, True])
+def test_compact_nodes_never_lose_a_hit(far):
+    """The 80-byte form of the nodes (pt_cnode.h cn_encode, pt_trace.h wide_node_step_c) on the adversarial instanced scene -- scales 0.2 .. 5, mirrored
+    and coincident instances, rays that start thousands of units away (far=True: every coordinate carries an offset of thousands, the worst case
+    for the per-node grid's p * idir + n): the persistent kernels' walk on compact nodes returns the hits of the walk on the fp32 nodes."""
+    sc, flags, off = instanced_scene(11, far=far)
+    tr = TracedScene(sc)
+    tr.L.th_set_compact_nodes(1)
+    trc = TracedScene(sc)
+    tr.L.th_set_compact_nodes(0)
+    assert trc.L.th_compact_ok() == 1
+    rng = np.random.default_rng(5)
+    org, dirs = rays_for(tr, rng, off, 8000)
+    seeds = np.zeros(len(org), np.uint32)
+    want = tr.settle(0, 0, 2, org, dirs, seeds)
+    got = trc.settle(0, 0, 2, org, dirs, seeds)
+    assert (want[0] != NONE).mean() > 0.3
+    same = (got[0] == want[0]) & (got[1].view(np.uint32) == want[1].view(np.uint32)).all(1)
+    assert same.all(), f"{np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
+    tr.close(); trc.close()
 
 
 # ---- whole frames: the product's shading source on the host against the oracle ---------------------------------------------------------------

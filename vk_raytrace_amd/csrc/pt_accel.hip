@@ -24,6 +24,7 @@
 #include "pt_device.h"
 #include "pt_internal.h"
 #include "pt_sahdev.h"
+#include "pt_cnode.h"
 
 namespace {
 
@@ -1435,6 +1436,40 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
     t.join();
   (void)hipFree(dPseudo);
   return failed.load() ? -1 : 0;
+}
+
+// WideNode -> CompactNode (pt_cnode.h cn_encode), one thread per node.  bad[0] counts nodes that cannot be represented (non-finite boxes): the
+// caller then keeps the WideNode walk.
+__global__ void k_compact_nodes(uint32_t n, const WideNode* __restrict__ in, CompactNode* __restrict__ out, uint32_t* __restrict__ bad)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  CompactNode c;
+  const bool  ok = cn_encode(in[i], c);
+  out[i]         = c;
+  if(!ok)
+    atomicAdd(bad, 1u);
+}
+int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out)
+{
+  if(n == 0)
+    return 0;
+  uint32_t* dBad = nullptr;
+  uint32_t  bad  = 1;
+  if(hipMalloc(&dBad, 4) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if(hipMemsetAsync(dBad, 0, 4, stream) == hipSuccess)
+  {
+    k_compact_nodes<<<(n + 127) / 128, 128, 0, stream>>>(n, in, out, dBad);
+    if(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      bad = 1;
+  }
+  (void)hipFree(dBad);
+  return bad ? -1 : 0;
 }
 
 // The merged world-space structure of the two-level mode: the flat build over the instances listed in hInst (copies of the scene's records

@@ -33,6 +33,8 @@ struct pt_context {
 
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
+  DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
+  bool     haveCNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
   // two-level acceleration structure (pt_set_accel_mode): dWide / dTris / dAlphaRecs hold the concatenated BLASes, dTlas the instance hierarchy
   int      accelMode = PT_ACCEL_FLAT;
@@ -263,6 +265,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.wide         = (const WideNode*)c->dWide.p;
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
+  s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
   s.env          = (const float4*)c->dEnv.p;
@@ -367,6 +370,7 @@ std::vector<InstanceRec> effective_instances(const pt_context* c)
   return inst;
 }
 
+void build_cnodes(pt_context* c, uint32_t n);
 // TLAS of the two-level structure over the current instance transforms (also the refit after pt_update_instances: the BLASes stay)
 int build_tlas(pt_context* c)
 {
@@ -407,7 +411,25 @@ int build_tlas(pt_context* c)
   if(numPrims > 0)
     bounds_from_root(c, root, numPrims > 1 && root.d.y != BVH_NONE);
   c->mergedOnly = c->mergedTris > 0 && c->numActive == 0;
+  build_cnodes(c, c->mergedOnly ? c->mergedWide : 0u);
   return PT_OK;
+}
+
+// DeviceScene::cnodes over the first n wide nodes of a flat-format structure (best effort: without it the kernels walk the WideNodes)
+void build_cnodes(pt_context* c, uint32_t n)
+{
+  c->haveCNodes = false;
+  if(!g_tuning.cnodes || n == 0)
+  {
+    dev_free(c->dCNodes);
+    return;
+  }
+  if(dev_alloc(c, c->dCNodes, sizeof(CompactNode) * size_t(n)) != PT_OK)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
 }
 
 // (re)builds the merged world-space structure over c->hMerged with the current transforms, in place at slot 0 / node 0 of the BLAS arrays
@@ -619,6 +641,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
     if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
     if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) g_tuning.mergeSingles = v;
+    if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) g_tuning.cnodes = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
@@ -672,7 +695,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1019,6 +1042,7 @@ int pt_build_accel(pt_context* c)
     (void)hipFree(arena.base);
   if(brc != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
+  build_cnodes(c, c->numWideNodes);
   HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // world bounds of the triangles = union of the root's two child boxes (origin cells of the ray-sort keys)

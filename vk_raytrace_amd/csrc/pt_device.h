@@ -73,6 +73,19 @@ struct WideNode {
   uint4  pad[PT_WIDE_Q];     // pads the node to 128 B (W=4) / 256 B (W=8)
 };
 
+// The same node in 80 bytes = five 16-byte requests instead of seven (PT_TUNE cnodes=1; read by the persistent trace kernels of the flat
+// structure only, converted from the WideNode array after the build -- same node numbering).  The child boxes sit on a per-node grid: origin
+// p (the lower corner of the union of the children's boxes), one power-of-two step per axis (exponent byte e: step 2^(e-127), 2047 steps cover
+// the extent), the planes as fp16 INTEGERS 0 .. 2047 -- lower planes rounded down, upper planes rounded up, so the decoded box encloses the
+// fp32 box.  A plane's ray parameter is q * (step * idir) + (p * idir + n): one v_fma_mix_f32 (the fp16 operand is read out of a register half).
+struct CompactNode {
+  float    px, py, pz;
+  uint32_t exps;    // ex | ey << 8 | ez << 16
+  uint4    ax[3];   // per axis: x = lo0 | lo1 << 16, y = lo2 | lo3 << 16, z = hi0 | hi1 << 16, w = hi2 | hi3 << 16
+  uint4    child;   // as WideNode::child
+};
+#define CN_GRID_MAX 2047
+
 // ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
 // One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
 // the instances' world boxes.  DeviceScene::wide / tris / alphaRecs then hold the concatenated BLASes (child references and leaf slots
@@ -127,6 +140,7 @@ struct DeviceScene {
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
+  const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
   const TriRec*               tris;
   const AlphaRec*             alphaRecs;  // leaf order, parallel to tris
   const AlphaMat*             alphaMats;  // one per material

@@ -61,6 +61,8 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
                   const float* mergedBox = nullptr, uint32_t mergedNodeBase = 0);
 // ... with mergedBox (lo xyz, hi xyz) one more TLAS primitive: the merged world-space structure of the prim-meshes instantiated once
 // (pt_trace.h PT_INST_MERGED), built by pt_merged_build into dTris / dAlpha / dWide at slotBase / nodeBase like a BLAS.
+// WideNode -> CompactNode for the first n nodes; -1 when a node cannot be represented (the caller keeps the WideNode walk)
+int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out);
 int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
                     const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide, uint32_t slotBase, uint32_t nodeBase, uint32_t* numWideOut, float* boxOut6, char* err,
                     size_t errLen);
@@ -129,6 +131,7 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
+  int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (measurement; see pt_device.h CompactNode)
   int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
   int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)

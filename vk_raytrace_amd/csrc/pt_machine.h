@@ -102,14 +102,17 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
     return;
   }
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
-  const uint32_t nxt = wide_node_step((TWO && L.ic.inst == BVH_NONE) ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, [&](uint32_t c) {
+  auto pushChild = [&](uint32_t c) {
     if(L.sp < STACK_LDS)
       lds[L.sp++ * TRACE_BLOCK] = c;
     else if(L.sp < STACK_LDS + STACK_SPILL)
       spill[L.sp++ - STACK_LDS] = c;
     else
       atomicAdd(&counters->stackOverflow, 1u);
-  });
+  };
+  // flat structure with compact nodes (wave-uniform choice): five requests per node instead of seven
+  const uint32_t nxt = (!TWO && S.cnodes) ? wide_node_step_c(S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
+                                          : wide_node_step((TWO && L.ic.inst == BVH_NONE) ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else
@@ -173,7 +176,7 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
 #endif
   TriRec         tr    = S.tris[slot];
   AlphaRec       ar;
-  if(L.cur & BVH_ALPHA)
+  if(L.cur & BVH_ALPHA)  // with the triangle, not after its test: fetching it only for candidates measured 4 % slower (one more round trip per candidate)
     ar = S.alphaRecs[slot];
 #if PT_BVH_WIDTH != 2
   if(TWO && L.ic.inst != PT_INST_MERGED)

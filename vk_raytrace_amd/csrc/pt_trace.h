@@ -220,6 +220,10 @@ PT_DEV RayBox make_raybox(f3 o, f3 d)
   return rb;
 }
 
+template <class Push>
+PT_DEV uint32_t wide_node_decide(const float* nx, const float* fx, const float* ny, const float* fy, const float* nz, const float* fz, const uint32_t* cc, float lim, bool alphaOnly,
+                                 Push&& push);
+
 // One wide-node visit: slab-tests the 4 child boxes against [0, lim], pushes the hit children far-to-near through
 // `push` and returns the nearest one (BVH_NONE when nothing is hit).  Empty slots carry inverted infinite boxes.
 // alphaOnly: visit only children tagged BVH_ALPHA (pass B and the non-opaque fallback never need an opaque subtree).
@@ -240,6 +244,14 @@ PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node
   const float    nz[4] = {__builtin_fmaf(pz.x, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.y, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.z, rb.idir.z, rb.nlo.z), __builtin_fmaf(pz.w, rb.idir.z, rb.nlo.z)};
   const float    fz[4] = {__builtin_fmaf(qz.x, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.y, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.z, rb.idir.z, rb.nhi.z), __builtin_fmaf(qz.w, rb.idir.z, rb.nhi.z)};
   const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
+  return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
+}
+
+// second half of a node visit: from the six ray parameters per child to "push the hit children far-to-near, return the nearest"
+template <class Push>
+PT_DEV uint32_t wide_node_decide(const float* nx, const float* fx, const float* ny, const float* fy, const float* nz, const float* fz, const uint32_t* cc, float lim, bool alphaOnly,
+                                 Push&& push)
+{
   float          tn[4];
   uint32_t       cid[4];
   int            nh = 0;
@@ -279,6 +291,56 @@ PT_DEV uint32_t wide_node_step(const WideNode* __restrict__ nodes, uint32_t node
   for(int i = 0; i < PT_BVH_WIDTH; ++i)
     nearest = tn[i] < 3.0e38f ? cid[i] : nearest;
   return nearest;
+}
+
+// fp16 grid coordinate out of a register half (device: folds into v_fma_mix_f32's op_sel)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 pt_h2v __attribute__((ext_vector_type(2)));
+PT_DEV float cn_plane(uint32_t word, int hi)
+{
+  const pt_h2v h = __builtin_bit_cast(pt_h2v, word);
+  return float(hi ? h.y : h.x);
+}
+#else
+PT_DEV float cn_plane(uint32_t word, int hi)
+{
+  const uint32_t h = (hi ? (word >> 16) : word) & 0xffffu;  // non-negative normal halves and zero only: what the nodes hold
+  return h == 0 ? 0.0f : __uint_as_float((((h >> 10) + 112u) << 23) | ((h & 0x3ffu) << 13));
+}
+#endif
+// The same visit on the compact form of the node (pt_device.h CompactNode): five 16-byte requests.  t = q * s + b with s = step * idir (exact: the
+// step is a power of two) and b = p * idir + n in one FMA; b is biased by (|b| + 2047 |s|) * 8e-7 towards "hit" (its own rounding is 2^-24 |b|, the
+// plane FMA's 2^-24 |t| with |t| <= |b| + 2047 |s|; the (1 -+ 4e-7) factors of the decision stay on top).  The planes of a slab share one request, so
+// near / far are picked by the direction sign with selects.
+template <class Push>
+PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
+{
+  const char*    nb = reinterpret_cast<const char*>(nodes);
+  const uint32_t at = (node & BVH_SLOT_MASK) * uint32_t(sizeof(CompactNode));
+  const float4   h  = *reinterpret_cast<const float4*>(nb + at);
+  const uint4    X = *reinterpret_cast<const uint4*>(nb + (at + 16u)), Y = *reinterpret_cast<const uint4*>(nb + (at + 32u)), Z = *reinterpret_cast<const uint4*>(nb + (at + 48u));
+  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 64u));
+  const uint32_t ex = __float_as_uint(h.w);
+  const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
+  const float    blx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
+  const float    bly0 = __builtin_fmaf(h.y, rb.idir.y, rb.nlo.y), bhy0 = __builtin_fmaf(h.y, rb.idir.y, rb.nhi.y);
+  const float    blz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nlo.z), bhz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nhi.z);
+  const float    gm = float(CN_GRID_MAX);
+  const float    blx = blx0 - (fabsf(blx0) + gm * fabsf(sx)) * 8.0e-7f, bhx = bhx0 + (fabsf(bhx0) + gm * fabsf(sx)) * 8.0e-7f;
+  const float    bly = bly0 - (fabsf(bly0) + gm * fabsf(sy)) * 8.0e-7f, bhy = bhy0 + (fabsf(bhy0) + gm * fabsf(sy)) * 8.0e-7f;
+  const float    blz = blz0 - (fabsf(blz0) + gm * fabsf(sz)) * 8.0e-7f, bhz = bhz0 + (fabsf(bhz0) + gm * fabsf(sz)) * 8.0e-7f;
+  const bool     ngx = rb.nearOff[0] != 0, ngy = rb.nearOff[1] != 0, ngz = rb.nearOff[2] != 0;  // negative direction: the upper plane is the near one
+  const uint32_t nX0 = ngx ? X.z : X.x, nX1 = ngx ? X.w : X.y, fX0 = ngx ? X.x : X.z, fX1 = ngx ? X.y : X.w;
+  const uint32_t nY0 = ngy ? Y.z : Y.x, nY1 = ngy ? Y.w : Y.y, fY0 = ngy ? Y.x : Y.z, fY1 = ngy ? Y.y : Y.w;
+  const uint32_t nZ0 = ngz ? Z.z : Z.x, nZ1 = ngz ? Z.w : Z.y, fZ0 = ngz ? Z.x : Z.z, fZ1 = ngz ? Z.y : Z.w;
+  const float    nx[4] = {__builtin_fmaf(cn_plane(nX0, 0), sx, blx), __builtin_fmaf(cn_plane(nX0, 1), sx, blx), __builtin_fmaf(cn_plane(nX1, 0), sx, blx), __builtin_fmaf(cn_plane(nX1, 1), sx, blx)};
+  const float    fx[4] = {__builtin_fmaf(cn_plane(fX0, 0), sx, bhx), __builtin_fmaf(cn_plane(fX0, 1), sx, bhx), __builtin_fmaf(cn_plane(fX1, 0), sx, bhx), __builtin_fmaf(cn_plane(fX1, 1), sx, bhx)};
+  const float    ny[4] = {__builtin_fmaf(cn_plane(nY0, 0), sy, bly), __builtin_fmaf(cn_plane(nY0, 1), sy, bly), __builtin_fmaf(cn_plane(nY1, 0), sy, bly), __builtin_fmaf(cn_plane(nY1, 1), sy, bly)};
+  const float    fy[4] = {__builtin_fmaf(cn_plane(fY0, 0), sy, bhy), __builtin_fmaf(cn_plane(fY0, 1), sy, bhy), __builtin_fmaf(cn_plane(fY1, 0), sy, bhy), __builtin_fmaf(cn_plane(fY1, 1), sy, bhy)};
+  const float    nz[4] = {__builtin_fmaf(cn_plane(nZ0, 0), sz, blz), __builtin_fmaf(cn_plane(nZ0, 1), sz, blz), __builtin_fmaf(cn_plane(nZ1, 0), sz, blz), __builtin_fmaf(cn_plane(nZ1, 1), sz, blz)};
+  const float    fz[4] = {__builtin_fmaf(cn_plane(fZ0, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ0, 1), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 1), sz, bhz)};
+  const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
+  return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
 }
 #endif
 
