@@ -1472,6 +1472,29 @@ int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, Compact
   return bad ? -1 : 0;
 }
 
+// DeviceScene::shadeTris of a flat-format structure: per leaf slot the three vertices' attribute pairs, copied from where the record's instance and
+// primitive point
+__global__ void k_shade_tris(uint32_t n, const TriRec* __restrict__ tris, const InstanceRec* __restrict__ inst, const float4* __restrict__ vertices,
+                             const uint32_t* __restrict__ indices, float4* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const InstanceRec& I = inst[__float_as_uint(tris[i].e1n.w)];
+  const uint32_t*    t = indices + I.firstIndex + 3 * size_t(__float_as_uint(tris[i].e2p.w));
+  for(int k = 0; k < 3; ++k)
+  {
+    const size_t v = size_t(I.vertexOffset + t[k]) * 2;
+    out[size_t(i) * 6 + 2 * k]     = vertices[v];
+    out[size_t(i) * 6 + 2 * k + 1] = vertices[v + 1];
+  }
+}
+void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out)
+{
+  if(n)
+    k_shade_tris<<<(n + 255) / 256, 256, 0, stream>>>(n, tris, inst, vertices, indices, out);
+}
+
 // The merged world-space structure of the two-level mode: the flat build over the instances listed in hInst (copies of the scene's records
 // with triBase renumbered 0, n0, n0 + n1, ... so that k_world_tris finds them), then every record gets the identity it has in the scene --
 // instance id ids[j] and world index worldBase[j] + primitive -- and the child references become global (k_blas_rebase).

@@ -33,6 +33,8 @@ struct pt_context {
 
   // scene (host copies kept only for what build_accel needs)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
+  DevBuf   dShadeTris;
+  bool     haveShadeTris = false;
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
@@ -266,6 +268,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
+  s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
   s.env          = (const float4*)c->dEnv.p;
@@ -371,6 +374,7 @@ std::vector<InstanceRec> effective_instances(const pt_context* c)
 }
 
 void build_cnodes(pt_context* c, uint32_t n);
+void build_shade_tris(pt_context* c, uint32_t n);
 // TLAS of the two-level structure over the current instance transforms (also the refit after pt_update_instances: the BLASes stay)
 int build_tlas(pt_context* c)
 {
@@ -412,6 +416,7 @@ int build_tlas(pt_context* c)
     bounds_from_root(c, root, numPrims > 1 && root.d.y != BVH_NONE);
   c->mergedOnly = c->mergedTris > 0 && c->numActive == 0;
   build_cnodes(c, c->mergedOnly ? c->mergedWide : 0u);
+  build_shade_tris(c, c->mergedOnly ? c->mergedTris : 0u);
   return PT_OK;
 }
 
@@ -430,6 +435,24 @@ void build_cnodes(pt_context* c, uint32_t n)
     return;
   }
   c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
+}
+// DeviceScene::shadeTris over the first n leaf records of a flat-format structure (best effort: without the memory k_shade takes the indexed route)
+void build_shade_tris(pt_context* c, uint32_t n)
+{
+  c->haveShadeTris = false;
+  if(!g_tuning.shadeTris || n == 0)
+  {
+    dev_free(c->dShadeTris);
+    return;
+  }
+  if(dev_alloc(c, c->dShadeTris, sizeof(float4) * 6 * size_t(n)) != PT_OK)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  pt_launch_shade_tris(c->stream, n, (const TriRec*)c->dTris.p, (const InstanceRec*)c->dInstances.p, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p,
+                       (float4*)c->dShadeTris.p);
+  c->haveShadeTris = hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
 }
 
 // (re)builds the merged world-space structure over c->hMerged with the current transforms, in place at slot 0 / node 0 of the BLAS arrays
@@ -642,6 +665,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
     if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) g_tuning.mergeSingles = v;
     if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) g_tuning.cnodes = v;
+    if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) g_tuning.shadeTris = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
@@ -1043,6 +1067,7 @@ int pt_build_accel(pt_context* c)
   if(brc != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel: %s", msg);
   build_cnodes(c, c->numWideNodes);
+  build_shade_tris(c, c->numTris);
   HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // world bounds of the triangles = union of the root's two child boxes (origin cells of the ray-sort keys)
@@ -1987,7 +2012,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.numTlasNodes = c->numTlasNodes;
   s.batchFrames    = uint32_t(c->batchMax);
   s.framesInFlight = uint32_t(c->inflight);
-  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes;
+  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes + c->dCNodes.bytes + c->dShadeTris.bytes;
   uint64_t bytes = 0;
   const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel,
                         &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase};

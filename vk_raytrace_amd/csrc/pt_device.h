@@ -141,6 +141,9 @@ struct DeviceScene {
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
+  const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot the six float4 of the triangle's three pt_VertexAttributes next to
+                                          // each other (96 B): k_shade reads them with the hit's slot, together with the triangle record, instead of
+                                          // after instance -> index triple -> three vertices (two dependent round trips fewer per shading)
   const TriRec*               tris;
   const AlphaRec*             alphaRecs;  // leaf order, parallel to tris
   const AlphaMat*             alphaMats;  // one per material

@@ -62,6 +62,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 // ... with mergedBox (lo xyz, hi xyz) one more TLAS primitive: the merged world-space structure of the prim-meshes instantiated once
 // (pt_trace.h PT_INST_MERGED), built by pt_merged_build into dTris / dAlpha / dWide at slotBase / nodeBase like a BLAS.
 // WideNode -> CompactNode for the first n nodes; -1 when a node cannot be represented (the caller keeps the WideNode walk)
+void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out);
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out);
 int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
                     const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide, uint32_t slotBase, uint32_t nodeBase, uint32_t* numWideOut, float* boxOut6, char* err,
@@ -131,6 +132,7 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
+  int shadeTris            = 1;    // flat-format structures: per-slot copy of the triangles' vertex attributes for k_shade (96 B per triangle; 0: none)
   int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (measurement; see pt_device.h CompactNode)
   int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)

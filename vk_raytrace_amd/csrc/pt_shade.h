@@ -218,7 +218,9 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
   // ---- hit ----
   events |= EV_HIT;
-  uint32_t hitInst, hitPrim;
+  uint32_t     hitInst, hitPrim;
+  VertexTriple vt;
+  bool         haveVt = false;
   if(S.twoLevel)
   {  // the hit names the world triangle (store_hit): a BLAS leaf is shared by every instance of its mesh
     const uint32_t w = __float_as_uint(hit.y);
@@ -227,14 +229,22 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   }
   else
   {
-    const TriRec tr = S.tris[__float_as_uint(hit.y)];
-    hitInst         = __float_as_uint(tr.e1n.w);
-    hitPrim         = __float_as_uint(tr.e2p.w);
+    const uint32_t hslot = __float_as_uint(hit.y);
+    const TriRec   tr    = S.tris[hslot];
+    if(S.shadeTris)
+    {
+      vt     = fetch_triangle_slot(S, hslot);
+      haveVt = true;
+    }
+    hitInst = __float_as_uint(tr.e1n.w);
+    hitPrim = __float_as_uint(tr.e2p.w);
   }
   const InstanceRec& I = S.instances[hitInst];
   Surface            sf;
   f3                 vcolor;
-  surface_at_hit(S, I, hitPrim, hit.z, hit.w, sf, vcolor);
+  if(!haveVt)
+    vt = fetch_triangle(S, I, hitPrim);
+  surface_at_hit(S, I, vt, hit.z, hit.w, sf, vcolor);
   const f3 hitPos = sf.position;
   sf.ffnormal     = dot3(sf.normal, rdir) <= 0.0f ? sf.normal : -sf.normal;
   resolve_material(S, S.materials[I.materialIndex < 0 ? 0 : I.materialIndex], rdir, sf);

@@ -223,9 +223,16 @@ PT_DEV bool alpha_test(const DeviceScene& S, uint32_t slot, float bu, float bv, 
 }
 
 // Interpolated attributes -> world-space shading frame.  Returns vertex colour in `vcolor`.
-PT_DEV void surface_at_hit(const DeviceScene& S, const InstanceRec& I, uint32_t prim, float bu, float bv, Surface& sf, f3& vcolor)
+// the same six float4 from the per-slot copy (DeviceScene::shadeTris, written by pt_accel.hip k_shade_tris)
+PT_DEV VertexTriple fetch_triangle_slot(const DeviceScene& S, uint32_t slot)
 {
-  const VertexTriple v  = fetch_triangle(S, I, prim);
+  const float4* p = S.shadeTris + size_t(slot) * 6;
+  VertexTriple  v;
+  v.a0 = p[0]; v.b0 = p[1]; v.a1 = p[2]; v.b1 = p[3]; v.a2 = p[4]; v.b2 = p[5];
+  return v;
+}
+PT_DEV void surface_at_hit(const DeviceScene& S, const InstanceRec& I, const VertexTriple& v, float bu, float bv, Surface& sf, f3& vcolor)
+{
   const float        b0 = 1.0f - bu - bv;
   const f3           p0 = xyz(v.a0), p1 = xyz(v.a1), p2 = xyz(v.a2);
   const f3           pos = p0 * b0 + p1 * bu + p2 * bv;
