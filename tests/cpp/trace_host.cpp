@@ -312,6 +312,8 @@ struct Scene {
   Bvh                      tlas;
   std::vector<TlasLeaf>    tlasLeaves;
   std::vector<AlphaRec>    flatAlpha;
+  std::vector<uint32_t>    instBlock;  // DeviceScene::instBlock (pt_capi.hip build_tlas)
+  std::vector<CompactNode> blasCNodes, tlasCNodes;  // ... and the two-level structure's
   std::vector<CompactNode> flatCNodes;  // PT_TUNE cnodes=1: the flat structure's nodes in the compact form (read by lane_inner only)
   AlphaMat                 alphaMat;
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
@@ -360,6 +362,7 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
 extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
 extern "C" int  th_compact_ok() { return g_compactOk; }
+
 static int g_mergeSingles = 1;  // PT_TUNE mergeSingles (pt_internal.h): the product's default
 extern "C" void th_set_merge_singles(int on) { g_mergeSingles = on; }
 
@@ -552,6 +555,41 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   s->dsTwo.tlasLeaves  = s->tlasLeaves.data();
   s->dsTwo.instTriBase = s->instTriBase.data();
   s->dsTwo.twoLevel    = 1;
+  {
+    const size_t entries = (size_t(triTotal) >> PT_INST_BLOCK_SHIFT) + 2;
+    s->instBlock.assign(entries, 0u);
+    uint32_t at = 0;
+    for(size_t e = 0; e < entries; ++e)
+    {
+      const uint64_t first = uint64_t(e) << PT_INST_BLOCK_SHIFT;
+      while(at + 1 < s->instTriBase.size() && uint64_t(s->instTriBase[at + 1]) <= first)
+        ++at;
+      s->instBlock[e] = at;
+    }
+    s->dsTwo.instBlock = s->instBlock.data();
+  }
+  if(g_compactNodes && g_compactOk)
+  {
+    bool ok = true;
+    s->blasCNodes.resize(s->blasWide.size());
+    for(size_t i = 0; i < s->blasWide.size(); ++i)
+      ok = cn_encode(s->blasWide[i], s->blasCNodes[i]) && ok;
+    s->tlasCNodes.resize(s->tlas.wide.size());
+    for(size_t i = 0; i < s->tlas.wide.size(); ++i)
+      ok = cn_encode(s->tlas.wide[i], s->tlasCNodes[i]) && ok;
+    if(ok && !s->blasCNodes.empty() && !s->tlasCNodes.empty())
+    {
+      s->dsTwo.cnodes = s->blasCNodes.data();
+      s->dsTwo.ctlas  = s->tlasCNodes.data();
+    }
+    g_compactOk = ok ? 1 : 0;
+  }
+}
+
+extern "C" int th_compact_in_use(void* p, int two)  // 1: the walk of that structure reads compact nodes
+{
+  const Scene* s = static_cast<const Scene*>(p);
+  return two ? (s->dsTwo.cnodes != nullptr && s->dsTwo.ctlas != nullptr) : (s->dsFlat.cnodes != nullptr);
 }
 
 // plain geometry + per-instance flags (every instance's material is the default: no any-hit evaluation is reachable with TRI_OPAQUE)

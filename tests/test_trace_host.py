@@ -46,6 +46,7 @@ def harness():
     L.th_create.restype = C.c_void_p
     L.th_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.th_destroy.argtypes = [C.c_void_p]
+    L.th_compact_in_use.argtypes = [C.c_void_p, C.c_int]
     L.th_num_tris.restype = C.c_uint32
     L.th_num_tris.argtypes = [C.c_void_p]
     L.th_sizes.argtypes = [C.c_void_p, C.c_void_p]
@@ -349,10 +350,11 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
     trc = TracedScene(scene)
     tr.L.th_set_compact_nodes(0)
     assert trc.L.th_compact_ok() == 1
-    got = trc.settle(0, 0, 2, org, dirs, seeds)
-    same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
-    assert same.all(), f"{name}: closest-hit on compact nodes: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
-    assert np.array_equal(got[3], ref[3])
+    for two in (0, 1):
+        got = trc.settle(0, two, 2, org, dirs, seeds)
+        same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
+        assert same.all(), f"{name}: closest-hit on compact nodes, two={two}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
+        assert np.array_equal(got[3], ref[3])
     trc.close()
     tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
     for variant in (0, 1):
@@ -380,11 +382,13 @@ def test_compact_nodes_never_lose_a_hit(far):
     rng = np.random.default_rng(5)
     org, dirs = rays_for(tr, rng, off, 8000)
     seeds = np.zeros(len(org), np.uint32)
-    want = tr.settle(0, 0, 2, org, dirs, seeds)
-    got = trc.settle(0, 0, 2, org, dirs, seeds)
-    assert (want[0] != NONE).mean() > 0.3
-    same = (got[0] == want[0]) & (got[1].view(np.uint32) == want[1].view(np.uint32)).all(1)
-    assert same.all(), f"{np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
+    for two in (0, 1):   # flat structure; two-level structure (TLAS + object-space BLASes with their per-instance padding + the merged structure)
+        assert trc.L.th_compact_in_use(trc.h, two) == 1 and tr.L.th_compact_in_use(tr.h, two) == 0
+        want = tr.settle(0, two, 2, org, dirs, seeds)
+        got = trc.settle(0, two, 2, org, dirs, seeds)
+        assert (want[0] != NONE).mean() > 0.3
+        same = (got[0] == want[0]) & (got[1].view(np.uint32) == want[1].view(np.uint32)).all(1)
+        assert same.all(), f"two={two}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
     tr.close(); trc.close()
 
 

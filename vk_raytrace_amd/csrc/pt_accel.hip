@@ -1451,6 +1451,40 @@ __global__ void k_compact_nodes(uint32_t n, const WideNode* __restrict__ in, Com
   if(!ok)
     atomicAdd(bad, 1u);
 }
+// the same over a list of node ranges (the bottom-level structures of the two-level mode sit at their node bases with unused nodes between them):
+// one block per range
+__global__ void k_compact_ranges(const uint2* __restrict__ ranges, const WideNode* __restrict__ in, CompactNode* __restrict__ out, uint32_t* __restrict__ bad)
+{
+  const uint2 r = ranges[blockIdx.x];
+  for(uint32_t i = threadIdx.x; i < r.y; i += blockDim.x)
+  {
+    CompactNode c;
+    const bool  ok = cn_encode(in[r.x + i], c);
+    out[r.x + i]   = c;
+    if(!ok)
+      atomicAdd(bad, 1u);
+  }
+}
+int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint32_t numRanges, const WideNode* in, CompactNode* out)
+{
+  if(numRanges == 0)
+    return 0;
+  uint32_t* dBuf = nullptr;  // [0]: bad counter, then the ranges
+  uint32_t  bad  = 1;
+  if(hipMalloc(&dBuf, 8 + 8 * size_t(numRanges)) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if(hipMemsetAsync(dBuf, 0, 8, stream) == hipSuccess && hipMemcpyAsync(dBuf + 2, hBaseCount, 8 * size_t(numRanges), hipMemcpyHostToDevice, stream) == hipSuccess)
+  {
+    k_compact_ranges<<<numRanges, 128, 0, stream>>>((const uint2*)(dBuf + 2), in, out, dBuf);
+    if(hipMemcpyAsync(&bad, dBuf, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      bad = 1;
+  }
+  (void)hipFree(dBuf);
+  return bad ? -1 : 0;
+}
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out)
 {
   if(n == 0)

@@ -35,6 +35,10 @@ struct pt_context {
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   DevBuf   dShadeTris;
   bool     haveShadeTris = false;
+  DevBuf   dInstBlock;  // DeviceScene::instBlock
+  DevBuf   dCTlas;   // DeviceScene::ctlas
+  std::vector<uint32_t> hBlasRanges;  // two-level mode: (node base, wide nodes) of every object-space BLAS
+  uint32_t nodeCapacity = 0;          // nodes dWide was sized for (two-level mode: the BLASes sit at their node bases)
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
@@ -268,6 +272,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
+  s.ctlas        = c->haveCNodes ? (const CompactNode*)c->dCTlas.p : nullptr;
   s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
@@ -279,6 +284,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.tlas         = two ? (const WideNode*)c->dTlas.p : nullptr;
   s.tlasLeaves   = two ? (const TlasLeaf*)c->dTlasLeaves.p : nullptr;
   s.instTriBase  = two ? (const uint32_t*)c->dInstTriBase.p : nullptr;
+  s.instBlock    = two ? (const uint32_t*)c->dInstBlock.p : nullptr;
   s.twoLevel     = two ? 1u : 0u;
   s.allOpaque    = 1u;
   for(const InstanceRec& I : c->hInstances)
@@ -374,6 +380,7 @@ std::vector<InstanceRec> effective_instances(const pt_context* c)
 }
 
 void build_cnodes(pt_context* c, uint32_t n);
+void build_cnodes_two_level(pt_context* c);
 void build_shade_tris(pt_context* c, uint32_t n);
 // TLAS of the two-level structure over the current instance transforms (also the refit after pt_update_instances: the BLASes stay)
 int build_tlas(pt_context* c)
@@ -397,6 +404,19 @@ int build_tlas(pt_context* c)
   const uint32_t none = 0;
   if((rc = upload(c, c->dActive, active.empty() ? &none : active.data(), 4 * std::max<size_t>(1, active.size()))) != PT_OK) return rc;
   if((rc = upload(c, c->dInstTriBase, triBase.data(), 4 * triBase.size())) != PT_OK) return rc;
+  {  // block table of instance_of_world_tri (pt_trace.h): entry e = the last instance whose triBase <= e << PT_INST_BLOCK_SHIFT
+    const size_t          entries = (size_t(c->numTris) >> PT_INST_BLOCK_SHIFT) + 2;
+    std::vector<uint32_t> block(entries, 0u);
+    uint32_t              at = 0;
+    for(size_t e = 0; e < entries; ++e)
+    {
+      const uint64_t first = uint64_t(e) << PT_INST_BLOCK_SHIFT;
+      while(at + 1 < triBase.size() && uint64_t(triBase[at + 1]) <= first)
+        ++at;
+      block[e] = at;
+    }
+    if((rc = upload(c, c->dInstBlock, block.data(), 4 * block.size())) != PT_OK) return rc;
+  }
   if((rc = upload(c, c->dInstPad, pad.data(), 4 * pad.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dInstNodeBase, c->hInstNodeBase.empty() ? &none : c->hInstNodeBase.data(), 4 * std::max<size_t>(1, c->hInstNodeBase.size()))) != PT_OK) return rc;
   const uint32_t numPrims = c->numActive + (c->mergedTris ? 1u : 0u);
@@ -415,9 +435,37 @@ int build_tlas(pt_context* c)
   if(numPrims > 0)
     bounds_from_root(c, root, numPrims > 1 && root.d.y != BVH_NONE);
   c->mergedOnly = c->mergedTris > 0 && c->numActive == 0;
-  build_cnodes(c, c->mergedOnly ? c->mergedWide : 0u);
+  if(c->mergedOnly)
+    build_cnodes(c, c->mergedWide);  // the flat kernels run on the merged structure
+  else
+    build_cnodes_two_level(c);
   build_shade_tris(c, c->mergedOnly ? c->mergedTris : 0u);
   return PT_OK;
+}
+
+// compact nodes of a real two-level structure: every bottom-level structure at its node base, and the TLAS
+void build_cnodes_two_level(pt_context* c)
+{
+  c->haveCNodes = false;
+  if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
+  {
+    dev_free(c->dCNodes);
+    dev_free(c->dCTlas);
+    return;
+  }
+  if(dev_alloc(c, c->dCNodes, sizeof(CompactNode) * size_t(c->nodeCapacity)) != PT_OK || dev_alloc(c, c->dCTlas, sizeof(CompactNode) * size_t(c->numTlasNodes)) != PT_OK)
+  {
+    (void)hipGetLastError();
+    return;
+  }
+  std::vector<uint32_t> ranges = c->hBlasRanges;
+  if(c->mergedWide)
+  {
+    ranges.push_back(0u);
+    ranges.push_back(c->mergedWide);
+  }
+  c->haveCNodes = pt_compact_node_ranges(c->stream, ranges.data(), uint32_t(ranges.size() / 2), (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0 &&
+                  pt_compact_nodes(c->stream, c->numTlasNodes, (const WideNode*)c->dTlas.p, (CompactNode*)c->dCTlas.p) == 0;
 }
 
 // DeviceScene::cnodes over the first n wide nodes of a flat-format structure (best effort: without it the kernels walk the WideNodes)
@@ -543,6 +591,13 @@ int build_two_level(pt_context* c)
     return c->fail(PT_ERR_HIP, "pt_build_accel (two-level): %s", msg);
   if((rc = build_merged(c)) != PT_OK)
     return rc;
+  c->hBlasRanges.clear();
+  for(const PtBlasDesc& d : blas)
+  {
+    c->hBlasRanges.push_back(d.nodeBase);
+    c->hBlasRanges.push_back(d.numWide);
+  }
+  c->nodeCapacity = uint32_t(std::max<uint64_t>(1, nodes));
   c->numBlas      = uint32_t(blas.size()) + (c->mergedTris ? 1u : 0u);
   c->numBvhNodes  = uint32_t(nodes);
   c->numWideNodes = c->mergedWide;
@@ -719,7 +774,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1039,6 +1094,9 @@ int pt_build_accel(pt_context* c)
   c->hMerged.clear();
   c->mergedTris = c->mergedWide = 0;
   c->mergedOnly = false;
+  c->hBlasRanges.clear();
+  c->nodeCapacity = 0;
+  dev_free(c->dCTlas);
   c->numBvhNodes = c->numTris > 1 ? c->numTris - 1 : 1;
   if((rc = dev_alloc(c, c->dTris, sizeof(TriRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
   if((rc = dev_alloc(c, c->dAlphaRecs, sizeof(AlphaRec) * size_t(c->numTris ? c->numTris : 1))) != PT_OK) return rc;
@@ -2012,7 +2070,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.numTlasNodes = c->numTlasNodes;
   s.batchFrames    = uint32_t(c->batchMax);
   s.framesInFlight = uint32_t(c->inflight);
-  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes + c->dCNodes.bytes + c->dShadeTris.bytes;
+  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes + c->dCNodes.bytes + c->dCTlas.bytes + c->dShadeTris.bytes;
   uint64_t bytes = 0;
   const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel,
                         &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase};

@@ -96,6 +96,7 @@ struct CompactNode {
 // records are the flat structure's (world-space edge form, instance and primitive in the w lanes), its TLAS leaf carries this instance id, and
 // a lane inside it keeps its world-space ray constants -- no ray transform on entry, no vertex transform per triangle.
 #define PT_INST_MERGED 0xfffffffeu
+#define PT_INST_BLOCK_SHIFT 8
 struct TlasLeaf {  // 32 B, one per TLAS leaf (= non-empty instance), TLAS leaf order
   uint32_t inst;      // instance (glTF node) index
   uint32_t nodeBase;  // root WideNode of the instance's BLAS
@@ -159,8 +160,11 @@ struct DeviceScene {
   float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
   // two-level mode (null / 0 otherwise)
   const WideNode*             tlas;         // instance hierarchy; its leaf references index tlasLeaves
+  const CompactNode*          ctlas;        // its nodes in the compact form (nullptr: none); DeviceScene::cnodes then covers the bottom-level structures
   const TlasLeaf*             tlasLeaves;
   const uint32_t*             instTriBase;  // InstanceRec::triBase of every instance, compact (world triangle index -> instance)
+  const uint32_t*             instBlock;    // [(numTris >> PT_INST_BLOCK_SHIFT) + 2]: entry e = the last instance whose triBase <= e << PT_INST_BLOCK_SHIFT, so that
+                                            // the search for a world triangle's instance starts inside a handful of candidates (nullptr: search all)
   uint32_t                    twoLevel;
   uint32_t                    allOpaque;    // 1: no instance with triangles lacks TRI_OPAQUE (scene without MASK / BLEND materials, or pt_use_any_hit(0)):
                                             // no candidate ever draws, so a shadow ray may stop at the first hit it finds (TerminateOnFirstHit,

@@ -110,9 +110,10 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
     else
       atomicAdd(&counters->stackOverflow, 1u);
   };
-  // flat structure with compact nodes (wave-uniform choice): five requests per node instead of seven
-  const uint32_t nxt = (!TWO && S.cnodes) ? wide_node_step_c(S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
-                                          : wide_node_step((TWO && L.ic.inst == BVH_NONE) ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
+  // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
+  const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
+  const uint32_t nxt    = S.cnodes ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
+                                   : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else

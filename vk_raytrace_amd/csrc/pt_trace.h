@@ -389,6 +389,13 @@ PT_DEV TriRec world_tri(const DeviceScene& S, const InstCtx& ic, const TriRec& o
 PT_DEV uint32_t instance_of_world_tri(const DeviceScene& S, uint32_t w)
 {
   uint32_t lo = 0, hi = S.numInstances - 1;
+  if(S.instBlock)
+  {  // both ends from the block table (two independent loads): the answer lies between the last instance that starts at or before the block's first
+     // triangle and the last one that starts at or before the next block's
+    const uint32_t b = w >> PT_INST_BLOCK_SHIFT;
+    lo               = S.instBlock[b];
+    hi               = S.instBlock[b + 1];
+  }
   while(lo < hi)
   {
     const uint32_t mid = (lo + hi + 1) >> 1;
