@@ -586,6 +586,53 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   }
 }
 
+// Number of (node, child, axis, side) planes of the compact nodes that lie INSIDE the fp32 box they stand for, evaluated in double (must be 0: the
+// decoded box has to enclose the original), plus the nodes whose child references differ; also reports how loose the boxes are.
+extern "C" unsigned long long th_cnode_violations(void* p, double* meanExtraExtent)
+{
+  const Scene*       s     = static_cast<const Scene*>(p);
+  unsigned long long bad   = 0;
+  double             extra = 0.0;
+  unsigned long long n     = 0;
+  auto check = [&](const std::vector<WideNode>& wide, const std::vector<CompactNode>& cn) {
+    for(size_t i = 0; i < wide.size() && i < cn.size(); ++i)
+    {
+      const WideNode&    w = wide[i];
+      const CompactNode& c = cn[i];
+      const float*    lo[3] = {&w.minx[0].x, &w.miny[0].x, &w.minz[0].x};
+      const float*    hi[3] = {&w.maxx[0].x, &w.maxy[0].x, &w.maxz[0].x};
+      const uint32_t* cc    = &w.child[0].x;
+      const uint32_t* cd    = &c.child.x;
+      const double    org[3] = {c.px, c.py, c.pz};
+      for(int k = 0; k < 4; ++k)
+      {
+        if(cc[k] != cd[k])
+          ++bad;
+        if(cc[k] == BVH_NONE)
+          continue;
+        for(int a = 0; a < 3; ++a)
+        {
+          const double   step = std::ldexp(1.0, int((c.exps >> (8 * a)) & 0xffu) - 127);
+          const uint32_t wl = (&c.ax[a].x)[k >> 1], wh = (&c.ax[a].x)[2 + (k >> 1)];
+          const double   ql = cn_plane(wl, k & 1), qh = cn_plane(wh, k & 1);
+          const double   dl = org[a] + ql * step, dh = org[a] + qh * step;
+          if(dl > double(lo[a][k]) || dh < double(hi[a][k]))
+            ++bad;
+          const double ext = double(hi[a][k]) - double(lo[a][k]);
+          extra += ((dh - dl) - ext) / (step * double(CN_GRID_MAX));  // growth of the child's extent in units of the node's grid extent
+          ++n;
+        }
+      }
+    }
+  };
+  check(s->flat.wide, s->flatCNodes);
+  check(s->blasWide, s->blasCNodes);
+  check(s->tlas.wide, s->tlasCNodes);
+  if(meanExtraExtent)
+    *meanExtraExtent = n ? extra / double(n) : 0.0;
+  return bad;
+}
+
 extern "C" int th_compact_in_use(void* p, int two)  // 1: the walk of that structure reads compact nodes
 {
   const Scene* s = static_cast<const Scene*>(p);

@@ -382,6 +382,12 @@ def test_compact_nodes_never_lose_a_hit(far):
     rng = np.random.default_rng(5)
     org, dirs = rays_for(tr, rng, off, 8000)
     seeds = np.zeros(len(org), np.uint32)
+    # the property itself, plane by plane in double: every decoded box encloses the fp32 box it stands for, the child references are the same
+    trc.L.th_cnode_violations.restype = C.c_ulonglong
+    trc.L.th_cnode_violations.argtypes = [C.c_void_p, C.c_void_p]
+    loose = C.c_double()
+    assert trc.L.th_cnode_violations(trc.h, C.byref(loose)) == 0
+    assert 0.0 <= loose.value <= 2.0 / 2047, loose.value  # and by at most one grid step per plane (mean growth of a child's extent, in units of the node's grid extent)
     for two in (0, 1):   # flat structure; two-level structure (TLAS + object-space BLASes with their per-instance padding + the merged structure)
         assert trc.L.th_compact_in_use(trc.h, two) == 1 and tr.L.th_compact_in_use(tr.h, two) == 0
         want = tr.settle(0, two, 2, org, dirs, seeds)
