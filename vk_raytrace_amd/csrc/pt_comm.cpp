@@ -234,7 +234,10 @@ int pt_gather_shards(pt_context* ctx, pt_comm* comm, int root)
     return PT_ERR_INVALID;
   }
   if(hipSetDevice(device) != hipSuccess)
+  {  // every error return after pt_comm_internal_shard goes through pt_comm_internal_fail: a later pt_gather_finish must see "nothing enqueued"
+    pt_comm_internal_fail(ctx, PT_ERR_HIP, "pt_gather_shards: hipSetDevice failed");
     return PT_ERR_HIP;
+  }
   const size_t count = bytes / sizeof(float);
   rcclResult_t r;
   (void)hipGetLastError();  // (see pt_comm_init_rank)

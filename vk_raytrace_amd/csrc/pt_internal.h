@@ -132,6 +132,8 @@ struct PtTuning {
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
   int tailBelow            = 65536;  // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
                                    // queue is expected to hold at most this many paths (0: never)
+  int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
+                                   // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
   int shadeTris            = 1;    // flat-format structures: per-slot copy of the triangles' vertex attributes for k_shade (96 B per triangle; 0: none)

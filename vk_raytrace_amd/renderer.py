@@ -62,6 +62,7 @@ class HipRenderer(Renderer):
         """Renderer::setup: bind to one GPU (`device` is the HIP ordinal)."""
         if self._ctx is not None:
             return
+        self._display_sizes = []  # a new context has no display image pending
         ctx = C.c_void_p()
         rc = self._lib.pt_create(int(device), C.byref(ctx))
         if rc != capi.PT_OK:
@@ -72,6 +73,7 @@ class HipRenderer(Renderer):
         if self._ctx is not None:
             self._lib.pt_destroy(self._ctx)
             self._ctx = None
+        self._display_sizes = []  # the C side's display ring went with the context
 
     def __del__(self):
         try:
@@ -178,7 +180,7 @@ class HipRenderer(Renderer):
         """pt_tonemap_begin: the display pass enqueued behind the frames rendered so far; later frames overlap it.  tonemap_end() returns the
         oldest image begun (at most 4 may be pending)."""
         w, h = display_size or self.size
-        self._check(self._lib.pt_tonemap_begin(self._ctx, C.byref(tm), w, h))
+        self._check(self._lib.pt_tonemap_begin(self._ctx, C.byref(tm), w, h))  # raises before the shadow list grows: the two stay in step
         self._display_sizes.append((w, h))
 
     def tonemap_pending(self):
@@ -187,6 +189,9 @@ class HipRenderer(Renderer):
     def tonemap_end(self):
         if not self._display_sizes:
             self._check(self._lib.pt_tonemap_end(self._ctx, np.empty(4, np.uint8).ctypes.data))  # reports the error
+        if self.tonemap_pending() != len(self._display_sizes):  # the C side is the truth; never size a buffer from a stale shadow entry
+            self._display_sizes = []
+            raise capi.PtError(capi.PT_ERR_STATE, "tonemap_end: the display ring and its Python shadow disagree (context re-created?)")
         w, h = self._display_sizes[0]
         out = np.empty((h, w, 4), np.uint8)
         self._check(self._lib.pt_tonemap_end(self._ctx, out.ctypes.data))

@@ -23,7 +23,7 @@ class LocalGroup:
         self.rank, self.world = int(rank), int(world)
         if key is None:
             key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        self.path = os.path.join(tempfile.gettempdir(), f"ptmi_rdzv_{key}.sock")
+        self.path = os.path.join(self._private_dir(), f"{key}.sock")
         self.peers = {}
         self.sock = None
         if self.world == 1:
@@ -31,20 +31,31 @@ class LocalGroup:
         deadline = time.monotonic() + timeout
         if self.rank == 0:
             try:
-                os.unlink(self.path)
+                os.unlink(self.path)  # inside a directory only this user can write: a leftover of an earlier job of ours, nothing else
             except FileNotFoundError:
                 pass
             srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-            srv.bind(self.path)
-            srv.listen(self.world)
-            srv.settimeout(timeout)
-            while len(self.peers) < self.world - 1:
-                c, _ = srv.accept()
-                c.settimeout(timeout)
-                r = struct.unpack("<i", self._recv(c, 4))[0]
-                self.peers[r] = c
-            srv.close()
-            os.unlink(self.path)
+            try:
+                srv.bind(self.path)
+                srv.listen(self.world)
+                srv.settimeout(timeout)
+                while len(self.peers) < self.world - 1:
+                    c, _ = srv.accept()
+                    c.settimeout(timeout)
+                    if not self._same_user(c):
+                        c.close()
+                        continue
+                    r = struct.unpack("<i", self._recv(c, 4))[0]
+                    if not (0 < r < self.world) or r in self.peers:
+                        c.close()
+                        raise ConnectionError(f"rendezvous: a peer announced rank {r} (world {self.world}, already seen: {sorted(self.peers)})")
+                    self.peers[r] = c
+            finally:
+                srv.close()
+                try:
+                    os.unlink(self.path)
+                except FileNotFoundError:
+                    pass
         else:
             while True:
                 s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
@@ -59,6 +70,33 @@ class LocalGroup:
             s.settimeout(timeout)
             s.sendall(struct.pack("<i", self.rank))
             self.sock = s
+
+    @staticmethod
+    def _private_dir():
+        """$XDG_RUNTIME_DIR (per user, 0700 by specification) or a 0700 directory of this user under the temp dir: nobody else can pre-bind or
+        replace the socket path"""
+        base = os.environ.get("XDG_RUNTIME_DIR")
+        if base and os.path.isdir(base) and os.access(base, os.W_OK):
+            return base
+        d = os.path.join(tempfile.gettempdir(), f"ptmi_rdzv_{os.getuid()}")
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(d)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError(f"{d} exists and is not a private directory of uid {os.getuid()}")
+        return d
+
+    @staticmethod
+    def _same_user(conn):
+        """SO_PEERCRED: the connecting process runs under this user's uid (Linux)"""
+        try:
+            pid, uid, gid = struct.unpack("3i", conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+            return uid == os.getuid()
+        except (OSError, AttributeError):
+            return True  # no peer credentials on this platform: the private directory is the protection
 
     @staticmethod
     def _recv(s, n):
