@@ -87,6 +87,25 @@ int main(int argc, char** argv)
     }
     r.setAccelMode(PT_ACCEL_FLAT);
   }
+  {  // the display pass with frames in flight (tonemapBegin / tonemapEnd) hands out the images of the synchronous pass
+    pt_Tonemapper        tm{1.f, 1.f, 1.f, 0.f, 1.f, 1.f, {1.f, 1.f}, 0, 0.5f, 0.5f, 1};
+    std::vector<uint8_t> a(64 * 64 * 4), b(64 * 64 * 4), sync(64 * 64 * 4);
+    r.setPushContants(st);
+    r.run({64, 64});
+    r.tonemapBegin(tm, 64, 64);
+    r.setPushContants(st);
+    r.run({64, 64});  // frame 0 again: the same image
+    r.tonemapBegin(tm, 64, 64);
+    const int pending = r.tonemapPending();
+    r.tonemapEnd(a.data());
+    r.tonemapEnd(b.data());
+    r.tonemap(tm, sync.data());
+    if(!r.ok() || pending != 2 || r.tonemapPending() != 0 || a != b || b != sync)
+    {
+      std::printf("ERROR pipelined display pass (pending %d, %s)\n", pending, r.lastError().c_str());
+      return 11;
+    }
+  }
   if(argc > 1)
   {  // Scene::load path: the same quad as a .glb written by vk_raytrace_amd.gltf.save_gltf must render the same image
     std::vector<float> ref = img;
