@@ -149,6 +149,110 @@ def latest_profile(kind):
     return None, None
 
 
+def cpu_leg(wl, cam, integral, W, H, frames_first, img_first, cpu_seconds):
+    """The CPU side of the line, N = 1 only: oracle/_ref (the reference's own pathtrace.comp compiled for the host, kind "reference") and the CPU oracle
+    (the restatement, kind "port") render frames 0 .. frames_first-1 of a bounded pixel sample of the SAME workload.  Those renders are both the timing
+    sample of `cpu_baseline` and -- when img_first (the GPU accumulation image of the same frames) is given -- the parity reference.
+    Returns (cpu_baseline, parity | None, alg): alg = per-ray node / triangle counts of the oracle's BVH2 for the SURVEY 8(d) algorithmic bytes."""
+    from vk_raytrace_amd import host_device as hd
+    out = {}
+    from tests import orc
+    o = orc.Oracle()
+    o.set_scene(wl.scene)
+    o.set_env(wl.env)
+    o.set_camera(cam)
+    o.set_sunsky(hd.default_sun_and_sky())
+    # bounded sample of the same workload: every s-th 8x8 pixel block, frames 0 .. F-1 with F = warmup + steps -- exactly the frames the GPU image
+    # read after the first timed window holds, so the SAME CPU renders are the baseline's timing sample AND the parity reference
+    # (BASELINE.json metric, second half: per-pixel L2 on the linear accumulation image, shaders/pathtrace.comp:122-133).  The block stride s
+    # is chosen so that one leg stays near --cpu-seconds / 2 at ~4 Msamples/s.
+    F = frames_first
+    bx, by = (W + 7) // 8, (H + 7) // 8
+    budget_samples = 4.0e6 * max(1.0, cpu_seconds / 2)
+    stride = max(1, int(np.ceil(bx * by * 64.0 * F / budget_samples)))
+    blocks = np.arange(bx * by)[::stride]
+    xs = (blocks % bx)[:, None, None] * 8 + np.arange(8)[None, None, :]
+    ys = (blocks // bx)[:, None, None] * 8 + np.arange(8)[None, :, None]
+    ok = (xs < W) & (ys < H)
+    ids = (ys * W + xs)[np.broadcast_to(ok, (len(blocks), 8, 8))].astype(np.uint32)
+    ost = hd.default_rtx_state()
+    ost.size[0], ost.size[1] = W, H
+    ost.maxDepth, ost.pbrMode, ost.maxSamples = wl.depth, wl.pbr_mode, 1
+    ost.fireflyClampThreshold = 4.0 * integral
+    # threads: what the scheduler / cgroup quota say, then a short probe (a box may show 256 cores and deliver a fraction: spinning
+    # OpenMP threads on throttled cores are slower than fewer threads) -- the fastest of {all, 64, 32, 16, 8} on two frames of the sample
+    cores, best_rate = usable_cores(), 0.0
+    probe_acc = np.zeros((H, W, 4), np.float32)
+    o.L.orc_set_threads(o.ctx, cores)
+    o.render_frames(ost, 0, 1, probe_acc, ids)  # (lazy BVH build of the oracle: not part of any timing)
+    for cand in sorted({c for c in (cores, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True):
+        o.L.orc_set_threads(o.ctx, cand)
+        t0 = time.perf_counter()
+        o.render_frames(ost, 1, 2, probe_acc, ids)
+        rate = 2 * len(ids) / (time.perf_counter() - t0)
+        if rate > best_rate * 1.05:
+            best_rate, threads = rate, cand
+    cores = threads
+    o.L.orc_set_threads(o.ctx, cores)
+    del probe_acc
+
+    def timed(render_frames):
+        """frames 0 .. F-1 of the sample in ONE call = one thread team (no fork / join per frame); BVH build and page faults happened in the probe"""
+        acc = np.zeros((H, W, 4), np.float32)
+        t0 = time.perf_counter()
+        render_frames(ost, 0, F, acc, ids)
+        dt = time.perf_counter() - t0
+        return len(ids) * F / dt / 1e6, dt, acc
+
+    def parity_against(acc, name):
+        """per-pixel L2 (sqrt(mean over pixels and RGB of (a - b)^2)) of the GPU accumulation image against a CPU render of the same frames"""
+        py_, px_ = np.divmod(ids.astype(np.int64), W)
+        a = img_first[py_, px_, :3].astype(np.float64)
+        b = acc[py_, px_, :3].astype(np.float64)
+        both_nan = np.isnan(a) & np.isnan(b)  # the reference's own NaN pixels (DESIGN.md section 2) are equal when they are NaN on both sides
+        d = np.where(both_nan, 0.0, np.nan_to_num(a - b, nan=np.inf))  # a NaN on one side only is a mismatch
+        bits_equal = int(np.count_nonzero(np.all((img_first[py_, px_, :3].view(np.uint32) == acc[py_, px_, :3].view(np.uint32)) | both_nan, axis=-1)))
+        return {"against": name, "l2": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.max(np.abs(d))), "pixels": int(len(ids)), "pixels_bit_identical": bits_equal,
+                "frames": int(F), "nan_pixels": int(np.count_nonzero(np.any(both_nan, axis=-1)))}
+
+    port_v, port_t, port_acc = timed(o.render_frames)
+    os_ = o.stats()
+    sample_txt = f"one 8x8 pixel block in {stride} of the same {W}x{H} workload ({len(ids)} pixels), frames 0..{F - 1}"
+    base = {"value": port_v, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (restatement of pathtrace.comp, OpenMP, one thread team), {sample_txt}, {port_t:.1f} s"}
+    parity = [parity_against(port_acc, "oracle (oracle/liborc.so)")] if img_first is not None else []
+    del port_acc
+    try:
+        from tests import ref
+        if os.path.exists(ref.LIB_PATH):
+            rr = ref.Reference(wl.scene, wl.env, oracle=o)
+            rr.set_camera(cam)
+            rr.set_sunsky(hd.default_sun_and_sky())
+            ref_v, ref_t, ref_acc = timed(lambda st_, f0, nf, acc, ids_: rr.render_frames(st_, f0, nf, acc, ids_, threads=cores))
+            base = {"value": ref_v, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                    "sample": f"oracle/_ref = the reference's shaders/pathtrace.comp compiled for the host (OpenMP, one invocation per pixel like vkCmdDispatch; ray queries and "
+                              f"texture filtering bound to the oracle's trace contract), {sample_txt}, {ref_t:.1f} s",
+                    "port_value": port_v, "port_sample": base["sample"]}
+            if img_first is not None:
+                parity.insert(0, parity_against(ref_acc, "oracle/_ref (the reference's pathtrace.comp compiled for the host)"))
+            del ref_acc
+    except Exception as e:  # the compiled reference is optional evidence; the port above stands
+        base["reference_error"] = repr(e)
+    if parity:
+        out["parity"] = dict(parity[0], tolerance=1e-3, also=parity[1:],
+                             note="GPU accumulation image after the first timed window (frames 0 .. warmup+steps-1) vs CPU renders of the same frames on the sampled pixels")
+    out["cpu_baseline"] = base
+    cr, sr = max(1, os_["closestRays"]), max(1, os_["shadowRays"])
+    alg = {
+        "nodes_per_closest_ray": (os_["nodesVisited"] - os_["nodesShadow"]) / cr,
+        "tris_per_closest_ray": (os_["trisTested"] - os_["trisShadow"]) / cr,
+        "nodes_per_shadow_ray": os_["nodesShadow"] / sr,
+        "tris_per_shadow_ray": os_["trisShadow"] / sr,
+        "tex_taps_per_hit": os_["texTaps"] / max(1, os_["shadedHits"]),
+    }
+    return out["cpu_baseline"], out.get("parity"), alg
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -323,100 +427,9 @@ def main():
     # texture filtering) is bound to the oracle's trace contract.  `port_value`: the oracle's own restatement on the same sample.
     alg = None
     if world == 1 and not args.no_cpu_baseline:
-        from tests import orc
-        o = orc.Oracle()
-        o.set_scene(wl.scene)
-        o.set_env(wl.env)
-        o.set_camera(cam)
-        o.set_sunsky(hd.default_sun_and_sky())
-        # bounded sample of the same workload: every s-th 8x8 pixel block, frames 0 .. F-1 with F = warmup + steps -- exactly the frames the GPU image
-        # read after the first timed window holds, so the SAME CPU renders are the baseline's timing sample AND the parity reference
-        # (BASELINE.json metric, second half: per-pixel L2 on the linear accumulation image, shaders/pathtrace.comp:122-133).  The block stride s
-        # is chosen so that one leg stays near --cpu-seconds / 2 at ~4 Msamples/s.
-        F = frames_first
-        bx, by = (W + 7) // 8, (H + 7) // 8
-        budget_samples = 4.0e6 * max(1.0, args.cpu_seconds / 2)
-        stride = max(1, int(np.ceil(bx * by * 64.0 * F / budget_samples)))
-        blocks = np.arange(bx * by)[::stride]
-        xs = (blocks % bx)[:, None, None] * 8 + np.arange(8)[None, None, :]
-        ys = (blocks // bx)[:, None, None] * 8 + np.arange(8)[None, :, None]
-        ok = (xs < W) & (ys < H)
-        ids = (ys * W + xs)[np.broadcast_to(ok, (len(blocks), 8, 8))].astype(np.uint32)
-        ost = hd.default_rtx_state()
-        ost.size[0], ost.size[1] = W, H
-        ost.maxDepth, ost.pbrMode, ost.maxSamples = wl.depth, wl.pbr_mode, 1
-        ost.fireflyClampThreshold = 4.0 * integral
-        # threads: what the scheduler / cgroup quota say, then a short probe (a box may show 256 cores and deliver a fraction: spinning
-        # OpenMP threads on throttled cores are slower than fewer threads) -- the fastest of {all, 64, 32, 16, 8} on two frames of the sample
-        cores, best_rate = usable_cores(), 0.0
-        probe_acc = np.zeros((H, W, 4), np.float32)
-        o.L.orc_set_threads(o.ctx, cores)
-        o.render_frames(ost, 0, 1, probe_acc, ids)  # (lazy BVH build of the oracle: not part of any timing)
-        for cand in sorted({c for c in (cores, 64, 32, 16, 8) if 1 <= c <= cores}, reverse=True):
-            o.L.orc_set_threads(o.ctx, cand)
-            t0 = time.perf_counter()
-            o.render_frames(ost, 1, 2, probe_acc, ids)
-            rate = 2 * len(ids) / (time.perf_counter() - t0)
-            if rate > best_rate * 1.05:
-                best_rate, threads = rate, cand
-        cores = threads
-        o.L.orc_set_threads(o.ctx, cores)
-        del probe_acc
-
-        def timed(render_frames):
-            """frames 0 .. F-1 of the sample in ONE call = one thread team (no fork / join per frame); BVH build and page faults happened in the probe"""
-            acc = np.zeros((H, W, 4), np.float32)
-            t0 = time.perf_counter()
-            render_frames(ost, 0, F, acc, ids)
-            dt = time.perf_counter() - t0
-            return len(ids) * F / dt / 1e6, dt, acc
-
-        def parity_against(acc, name):
-            """per-pixel L2 (sqrt(mean over pixels and RGB of (a - b)^2)) of the GPU accumulation image against a CPU render of the same frames"""
-            py_, px_ = np.divmod(ids.astype(np.int64), W)
-            a = img_first[py_, px_, :3].astype(np.float64)
-            b = acc[py_, px_, :3].astype(np.float64)
-            both_nan = np.isnan(a) & np.isnan(b)  # the reference's own NaN pixels (DESIGN.md section 2) are equal when they are NaN on both sides
-            d = np.where(both_nan, 0.0, np.nan_to_num(a - b, nan=np.inf))  # a NaN on one side only is a mismatch
-            bits_equal = int(np.count_nonzero(np.all((img_first[py_, px_, :3].view(np.uint32) == acc[py_, px_, :3].view(np.uint32)) | both_nan, axis=-1)))
-            return {"against": name, "l2": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.max(np.abs(d))), "pixels": int(len(ids)), "pixels_bit_identical": bits_equal,
-                    "frames": int(F), "nan_pixels": int(np.count_nonzero(np.any(both_nan, axis=-1)))}
-
-        port_v, port_t, port_acc = timed(o.render_frames)
-        os_ = o.stats()
-        sample_txt = f"one 8x8 pixel block in {stride} of the same {W}x{H} workload ({len(ids)} pixels), frames 0..{F - 1}"
-        base = {"value": port_v, "unit": "Msamples/s", "cores": cores, "kind": "port",
-                "sample": f"CPU oracle (restatement of pathtrace.comp, OpenMP, one thread team), {sample_txt}, {port_t:.1f} s"}
-        parity = [parity_against(port_acc, "oracle (oracle/liborc.so)")] if img_first is not None else []
-        del port_acc
-        try:
-            from tests import ref
-            if os.path.exists(ref.LIB_PATH):
-                rr = ref.Reference(wl.scene, wl.env, oracle=o)
-                rr.set_camera(cam)
-                rr.set_sunsky(hd.default_sun_and_sky())
-                ref_v, ref_t, ref_acc = timed(lambda st_, f0, nf, acc, ids_: rr.render_frames(st_, f0, nf, acc, ids_, threads=cores))
-                base = {"value": ref_v, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                        "sample": f"oracle/_ref = the reference's shaders/pathtrace.comp compiled for the host (OpenMP, one invocation per pixel like vkCmdDispatch; ray queries and "
-                                  f"texture filtering bound to the oracle's trace contract), {sample_txt}, {ref_t:.1f} s",
-                        "port_value": port_v, "port_sample": base["sample"]}
-                if img_first is not None:
-                    parity.insert(0, parity_against(ref_acc, "oracle/_ref (the reference's pathtrace.comp compiled for the host)"))
-                del ref_acc
-        except Exception as e:  # the compiled reference is optional evidence; the port above stands
-            base["reference_error"] = repr(e)
-        if parity:
-            out["parity"] = dict(parity[0], tolerance=1e-3, also=parity[1:],
-                                 note="GPU accumulation image after the first timed window (frames 0 .. warmup+steps-1) vs CPU renders of the same frames on the sampled pixels")
-        out["cpu_baseline"] = base
-        cr, sr = max(1, os_["closestRays"]), max(1, os_["shadowRays"])
-        alg = {
-            "nodes_per_closest_ray": (os_["nodesVisited"] - os_["nodesShadow"]) / cr,
-            "tris_per_closest_ray": (os_["trisTested"] - os_["trisShadow"]) / cr,
-            "nodes_per_shadow_ray": os_["nodesShadow"] / sr,
-            "tris_per_shadow_ray": os_["trisShadow"] / sr,
-            "tex_taps_per_hit": os_["texTaps"] / max(1, os_["shadedHits"]),
-        }
+        out["cpu_baseline"], par, alg = cpu_leg(wl, cam, integral, W, H, frames_first, img_first, args.cpu_seconds)
+        if par is not None:
+            out["parity"] = par
     elif os.path.exists(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")):
         alg = json.load(open(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")))
 

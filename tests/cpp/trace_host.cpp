@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <atomic>
 
 // the device intrinsics pt_trace.h and the headers it includes use
 static inline unsigned int __float_as_uint(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }
@@ -314,6 +315,7 @@ struct Scene {
   std::vector<AlphaRec>    flatAlpha;
   std::vector<uint32_t>    instBlock;  // DeviceScene::instBlock (pt_capi.hip build_tlas)
   std::vector<CompactNode> blasCNodes, tlasCNodes;  // ... and the two-level structure's
+  std::vector<CompactNode8> flatCNodes8;  // experiment: the 64-byte form (th_set_compact_nodes(2))
   std::vector<CompactNode> flatCNodes;  // PT_TUNE cnodes=1: the flat structure's nodes in the compact form (read by lane_inner only)
   AlphaMat                 alphaMat;
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
@@ -359,6 +361,8 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
   return ar;
 }
 
+static std::atomic<unsigned long long> g_innerSteps{0};  // node steps of the machine walks since the last th_take_inner_steps()
+extern "C" unsigned long long th_take_inner_steps() { return g_innerSteps.exchange(0); }
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
 extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
 extern "C" int  th_compact_ok() { return g_compactOk; }
@@ -545,6 +549,13 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     for(size_t i = 0; i < s->flat.wide.size(); ++i)
       ok = cn_encode(s->flat.wide[i], s->flatCNodes[i]) && ok;
     s->dsFlat.cnodes = ok ? s->flatCNodes.data() : nullptr;
+    if(g_compactNodes == 2)
+    {
+      s->flatCNodes8.resize(s->flat.wide.size());
+      for(size_t i = 0; i < s->flat.wide.size(); ++i)
+        ok = cn_encode8(s->flat.wide[i], s->flatCNodes8[i]) && ok;
+      s->dsFlat.cnodes8 = ok ? s->flatCNodes8.data() : nullptr;
+    }
     g_compactOk      = ok ? 1 : 0;
   }
   s->dsTwo            = d;
@@ -633,10 +644,42 @@ extern "C" unsigned long long th_cnode_violations(void* p, double* meanExtraExte
   return bad;
 }
 
+// the same for the 64-byte form of the flat structure's nodes
+extern "C" unsigned long long th_cnode8_violations(void* p)
+{
+  const Scene*       s   = static_cast<const Scene*>(p);
+  unsigned long long bad = 0;
+  for(size_t i = 0; i < s->flat.wide.size() && i < s->flatCNodes8.size(); ++i)
+  {
+    const WideNode&     w = s->flat.wide[i];
+    const CompactNode8& c = s->flatCNodes8[i];
+    const float*    lo[3] = {&w.minx[0].x, &w.miny[0].x, &w.minz[0].x};
+    const float*    hi[3] = {&w.maxx[0].x, &w.maxy[0].x, &w.maxz[0].x};
+    const uint32_t* cc    = &w.child[0].x;
+    const uint32_t* cd    = &c.child.x;
+    const double    org[3] = {c.px, c.py, c.pz};
+    for(int k = 0; k < 4; ++k)
+    {
+      if(cc[k] != cd[k])
+        ++bad;
+      if(cc[k] == BVH_NONE)
+        continue;
+      for(int a = 0; a < 3; ++a)
+      {
+        const double step = std::ldexp(1.0, int((c.exps >> (8 * a)) & 0xffu) - 127);
+        const double dl = org[a] + double((c.lo[a] >> (8 * k)) & 0xffu) * step, dh = org[a] + double((c.hi[a] >> (8 * k)) & 0xffu) * step;
+        if(dl > double(lo[a][k]) || dh < double(hi[a][k]))
+          ++bad;
+      }
+    }
+  }
+  return bad;
+}
+
 extern "C" int th_compact_in_use(void* p, int two)  // 1: the walk of that structure reads compact nodes
 {
   const Scene* s = static_cast<const Scene*>(p);
-  return two ? (s->dsTwo.cnodes != nullptr && s->dsTwo.ctlas != nullptr) : (s->dsFlat.cnodes != nullptr);
+  return two ? (s->dsTwo.cnodes != nullptr && s->dsTwo.ctlas != nullptr) : (s->dsFlat.cnodes8 != nullptr ? 2 : (s->dsFlat.cnodes != nullptr ? 1 : 0));
 }
 
 // plain geometry + per-instance flags (every instance's material is the default: no any-hit evaluation is reachable with TRI_OPAQUE)
@@ -845,6 +888,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       const f3    o = xyz(rayO[r]), d = xyz(rayD[r]);
       uint32_t    seed = seeds[r], draws = 0;
       bool machineFallback = false;
+      unsigned long long innerSteps = 0;
       if(exact == 2)
       {
         TraceLane             L;
@@ -856,6 +900,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
           {
             if(!(L.cur & BVH_LEAF))
             {
+              ++innerSteps;
               if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt); else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
             }
             if(!L.done && (L.cur & BVH_LEAF))
@@ -896,6 +941,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
               fallback = true;
           }
           machineFallback = fallback;  // queueX / queueX2: the exact kernels take over (below)
+          g_innerSteps += innerSteps;
           break;
         }
       }

@@ -1485,6 +1485,38 @@ int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint3
   (void)hipFree(dBuf);
   return bad ? -1 : 0;
 }
+// EXPERIMENT: the 64-byte form
+__global__ void k_compact_nodes8(uint32_t n, const WideNode* __restrict__ in, CompactNode8* __restrict__ out, uint32_t* __restrict__ bad)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  CompactNode8 c;
+  const bool   ok = cn_encode8(in[i], c);
+  out[i]          = c;
+  if(!ok)
+    atomicAdd(bad, 1u);
+}
+int pt_compact_nodes8(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode8* out)
+{
+  if(n == 0)
+    return 0;
+  uint32_t* dBad = nullptr;
+  uint32_t  bad  = 1;
+  if(hipMalloc(&dBad, 4) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if(hipMemsetAsync(dBad, 0, 4, stream) == hipSuccess)
+  {
+    k_compact_nodes8<<<(n + 127) / 128, 128, 0, stream>>>(n, in, out, dBad);
+    if(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      bad = 1;
+  }
+  (void)hipFree(dBad);
+  return bad ? -1 : 0;
+}
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out)
 {
   if(n == 0)

@@ -39,6 +39,8 @@ struct pt_context {
   DevBuf   dCTlas;   // DeviceScene::ctlas
   std::vector<uint32_t> hBlasRanges;  // two-level mode: (node base, wide nodes) of every object-space BLAS
   uint32_t nodeCapacity = 0;          // nodes dWide was sized for (two-level mode: the BLASes sit at their node bases)
+  DevBuf   dCNodes8;  // experiment (PT_TUNE cnodes=2)
+  bool     haveCNodes8 = false;
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
@@ -273,6 +275,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
   s.ctlas        = c->haveCNodes ? (const CompactNode*)c->dCTlas.p : nullptr;
+  s.cnodes8      = c->haveCNodes8 ? (const CompactNode8*)c->dCNodes8.p : nullptr;
   s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
@@ -483,6 +486,9 @@ void build_cnodes(pt_context* c, uint32_t n)
     return;
   }
   c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
+  c->haveCNodes8 = false;
+  if(g_tuning.cnodes == 2 && dev_alloc(c, c->dCNodes8, sizeof(CompactNode8) * size_t(n)) == PT_OK)  // experiment: the 64-byte form on top
+    c->haveCNodes8 = pt_compact_nodes8(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode8*)c->dCNodes8.p) == 0;
 }
 // DeviceScene::shadeTris over the first n leaf records of a flat-format structure (best effort: without the memory k_shade takes the indexed route)
 void build_shade_tris(pt_context* c, uint32_t n)
@@ -786,7 +792,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCNodes8, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)

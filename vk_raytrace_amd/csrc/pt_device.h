@@ -85,6 +85,18 @@ struct CompactNode {
   uint4    child;   // as WideNode::child
 };
 #define CN_GRID_MAX 2047
+// EXPERIMENT (branch cnodes64-experiment; validated on the CPU harness only, never run on the GPU): the node in 64 bytes = FOUR requests.  Same grid,
+// 255 steps per axis, the planes as bytes (child k in byte k of a word): a conversion (v_cvt_f32_ubyteK) and an FMA per plane, one select per
+// axis and side for near / far.  PT_TUNE cnodes=2.
+struct CompactNode8 {
+  float    px, py, pz;
+  uint32_t exps;      // ex | ey << 8 | ez << 16: step 2^(e-127), 255 steps cover the extent
+  uint4    child;
+  uint32_t lo[3];     // lower planes per axis, child k in byte k
+  uint32_t hi[3];     // upper planes
+  uint32_t pad[2];
+};
+#define CN8_GRID_MAX 255
 
 // ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
 // One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
@@ -142,6 +154,7 @@ struct DeviceScene {
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
+  const CompactNode8*         cnodes8; // experiment: the 64-byte form (flat structure only; takes precedence)
   const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot the six float4 of the triangle's three pt_VertexAttributes next to
                                           // each other (96 B): k_shade reads them with the hit's slot, together with the triangle record, instead of
                                           // after instance -> index triple -> three vertices (two dependent round trips fewer per shading)

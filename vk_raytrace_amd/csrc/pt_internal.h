@@ -64,6 +64,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 // WideNode -> CompactNode for the first n nodes; -1 when a node cannot be represented (the caller keeps the WideNode walk)
 void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out);
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out);
+int pt_compact_nodes8(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode8* out);  // experiment: the 64-byte form (PT_TUNE cnodes=2)
 // ... over numRanges node ranges given as (base, count) pairs
 int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint32_t numRanges, const WideNode* in, CompactNode* out);
 int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,

@@ -112,8 +112,9 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   };
   // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
   const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
-  const uint32_t nxt    = S.cnodes ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
-                                   : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
+  const uint32_t nxt    = (!TWO && S.cnodes8) ? wide_node_step_c8(S.cnodes8, L.cur, L.rbox, lim, L.pass == 1, pushChild)  // experiment, flat structure only
+                          : S.cnodes          ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
+                                              : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else

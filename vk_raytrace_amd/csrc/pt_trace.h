@@ -342,6 +342,39 @@ PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t
   const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
   return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
 }
+// EXPERIMENT (branch cnodes64-experiment): the visit on the 64-byte form -- four requests; a conversion and an FMA per plane
+template <class Push>
+PT_DEV uint32_t wide_node_step_c8(const CompactNode8* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
+{
+  const char*    nb = reinterpret_cast<const char*>(nodes);
+  const uint32_t at = (node & BVH_SLOT_MASK) * uint32_t(sizeof(CompactNode8));
+  const float4   h  = *reinterpret_cast<const float4*>(nb + at);
+  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 16u));
+  const uint4    P0 = *reinterpret_cast<const uint4*>(nb + (at + 32u)), P1 = *reinterpret_cast<const uint4*>(nb + (at + 48u));  // lo.xyz hi.x | hi.yz pad
+  const uint32_t ex = __float_as_uint(h.w);
+  const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
+  const float    blx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
+  const float    bly0 = __builtin_fmaf(h.y, rb.idir.y, rb.nlo.y), bhy0 = __builtin_fmaf(h.y, rb.idir.y, rb.nhi.y);
+  const float    blz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nlo.z), bhz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nhi.z);
+  const float    gm = float(CN8_GRID_MAX);
+  const float    blx = blx0 - (fabsf(blx0) + gm * fabsf(sx)) * 8.0e-7f, bhx = bhx0 + (fabsf(bhx0) + gm * fabsf(sx)) * 8.0e-7f;
+  const float    bly = bly0 - (fabsf(bly0) + gm * fabsf(sy)) * 8.0e-7f, bhy = bhy0 + (fabsf(bhy0) + gm * fabsf(sy)) * 8.0e-7f;
+  const float    blz = blz0 - (fabsf(blz0) + gm * fabsf(sz)) * 8.0e-7f, bhz = bhz0 + (fabsf(bhz0) + gm * fabsf(sz)) * 8.0e-7f;
+  const bool     ngx = rb.nearOff[0] != 0, ngy = rb.nearOff[1] != 0, ngz = rb.nearOff[2] != 0;
+  const uint32_t nX = ngx ? P0.w : P0.x, fX = ngx ? P0.x : P0.w;
+  const uint32_t nY = ngy ? P1.x : P0.y, fY = ngy ? P0.y : P1.x;
+  const uint32_t nZ = ngz ? P1.y : P0.z, fZ = ngz ? P0.z : P1.y;
+  float          nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
+#pragma unroll
+  for(int k = 0; k < 4; ++k)
+  {
+    nx[k] = __builtin_fmaf(float((nX >> (8 * k)) & 0xffu), sx, blx); fx[k] = __builtin_fmaf(float((fX >> (8 * k)) & 0xffu), sx, bhx);
+    ny[k] = __builtin_fmaf(float((nY >> (8 * k)) & 0xffu), sy, bly); fy[k] = __builtin_fmaf(float((fY >> (8 * k)) & 0xffu), sy, bhy);
+    nz[k] = __builtin_fmaf(float((nZ >> (8 * k)) & 0xffu), sz, blz); fz[k] = __builtin_fmaf(float((fZ >> (8 * k)) & 0xffu), sz, bhz);
+  }
+  const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
+  return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
+}
 #endif
 
 #if PT_BVH_WIDTH != 2
