@@ -363,6 +363,11 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
 
 static std::atomic<unsigned long long> g_innerSteps{0};  // node steps of the machine walks since the last th_take_inner_steps()
 extern "C" unsigned long long th_take_inner_steps() { return g_innerSteps.exchange(0); }
+static std::atomic<unsigned long long> g_leafSteps{0}, g_restarts{0};  // triangle steps / EARLY walks that started over, same bracket
+extern "C" unsigned long long th_take_leaf_steps() { return g_leafSteps.exchange(0); }
+extern "C" unsigned long long th_take_restarts() { return g_restarts.exchange(0); }
+static int g_shadowEarly = 1;  // shadow rays of the flat structure walk with the exact early-out (pt_machine.h EARLY), like k_shadow_p
+extern "C" void th_set_shadow_early(int on) { g_shadowEarly = on; }
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
 extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
 extern "C" int  th_compact_ok() { return g_compactOk; }
@@ -888,9 +893,10 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       const f3    o = xyz(rayO[r]), d = xyz(rayD[r]);
       uint32_t    seed = seeds[r], draws = 0;
       bool machineFallback = false;
-      unsigned long long innerSteps = 0;
+      unsigned long long innerSteps = 0, leafSteps = 0;
       if(exact == 2)
       {
+        const bool early = kind == 1 && !two && g_shadowEarly;
         TraceLane             L;
         std::vector<uint32_t> spill(STACK_SPILL);
         lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
@@ -901,11 +907,19 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
             if(!(L.cur & BVH_LEAF))
             {
               ++innerSteps;
-              if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt); else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
+              if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt);
+              else if(early) lane_inner<false, false, true>(S, L, stack.data(), spill.data(), &cnt);
+              else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
             }
             if(!L.done && (L.cur & BVH_LEAF))
             {
-              if(two) lane_leaf<false, true>(S, L, stack.data(), spill.data()); else lane_leaf<false, false>(S, L, stack.data(), spill.data());
+              ++leafSteps;
+              const uint32_t e0 = L.early;
+              if(two) lane_leaf<false, true>(S, L, stack.data(), spill.data());
+              else if(early) lane_leaf<false, false, true>(S, L, stack.data(), spill.data());
+              else lane_leaf<false, false>(S, L, stack.data(), spill.data());
+              if(e0 == 1 && L.early == 2)
+                ++g_restarts;
             }
           }
           // service round of k_closest_p / k_shadow_p for this lane
@@ -942,6 +956,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
           }
           machineFallback = fallback;  // queueX / queueX2: the exact kernels take over (below)
           g_innerSteps += innerSteps;
+          g_leafSteps += leafSteps;
           break;
         }
       }

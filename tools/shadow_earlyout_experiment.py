@@ -3,6 +3,9 @@
 certain hit (trace contract T6) need the full front-to-back walk.  Counts, for shadow rays from primary hit points towards the sun and towards uniformly
 random sky directions: occluded rays, and occluded rays with no draw at all (the ones an early-out helps).  Uses the product's settle logic on the host
 (tests/cpp/trace_host.cpp th_settle).
+Round 4: the early-out itself (pt_machine.h EARLY: after an opaque hit with nothing non-opaque seen, only BVH_ALPHA-tagged references are entered; a
+non-opaque candidate in front of the hit starts the plain walk over) run ray by ray on the trace machine of the persistent kernels, with and without
+it: node steps, triangle steps, walks that started over; results (verdict + RNG state) must be identical.
    python tools/shadow_earlyout_experiment.py [rays]"""
 import os
 import sys
@@ -43,4 +46,18 @@ for name, d in (("towards the sun", np.repeat(sun[None], len(p1), 0)), ("towards
     nodraw = occ & (dr == 0)
     print(f"  {name:32s} occluded {occ.mean():.3f}   occluded with no draw in front (early-out applies) {nodraw.mean():.3f}   "
           f"occluded but draws in front (needs the full walk) {(occ & (dr > 0)).mean():.3f}   unoccluded {1 - occ.mean():.3f} (full walk by definition)")
+    import ctypes as C
+    for f in ("th_take_inner_steps", "th_take_leaf_steps", "th_take_restarts"):
+        getattr(tr.L, f).restype = C.c_uint64
+    res = {}
+    for early in (0, 1):
+        tr.L.th_set_shadow_early(early)
+        tr.L.th_take_inner_steps(); tr.L.th_take_leaf_steps(); tr.L.th_take_restarts()
+        wm, _, sdm, drm = tr.settle(1, 0, 2, o, d, seeds, tmax=np.full(len(o), 1e32, np.float32))
+        res[early] = (tr.L.th_take_inner_steps(), tr.L.th_take_leaf_steps(), tr.L.th_take_restarts(), wm, sdm)
+        assert np.array_equal(wm, w) and np.array_equal(sdm, sd), "the machine walk differs from the definition"
+    (n0, l0, _, _, _), (n1, l1, r1, _, _) = res[0], res[1]
+    print(f"      trace machine, per ray: node steps {n0 / len(o):.2f} -> {n1 / len(o):.2f} ({n1 / n0:.3f}x), triangle steps {l0 / len(o):.2f} -> {l1 / len(o):.2f} ({l1 / l0:.3f}x), "
+          f"walks started over {r1 / len(o):.3f} of the rays; verdicts and RNG states identical")
+tr.L.th_set_shadow_early(1)
 tr.close()

@@ -1546,14 +1546,18 @@ __global__ void k_shade_tris(uint32_t n, const TriRec* __restrict__ tris, const 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  const InstanceRec& I = inst[__float_as_uint(tris[i].e1n.w)];
-  const uint32_t*    t = indices + I.firstIndex + 3 * size_t(__float_as_uint(tris[i].e2p.w));
+  const uint32_t     ii = __float_as_uint(tris[i].e1n.w), prim = __float_as_uint(tris[i].e2p.w);
+  const InstanceRec& I = inst[ii];
+  const uint32_t*    t = indices + I.firstIndex + 3 * size_t(prim);
+  float4*            o = out + size_t(i) * PT_SHADE_REC_QUADS;  // one 128-byte line per slot
   for(int k = 0; k < 3; ++k)
   {
     const size_t v = size_t(I.vertexOffset + t[k]) * 2;
-    out[size_t(i) * 6 + 2 * k]     = vertices[v];
-    out[size_t(i) * 6 + 2 * k + 1] = vertices[v + 1];
+    o[2 * k]     = vertices[v];
+    o[2 * k + 1] = vertices[v + 1];
   }
+  o[6] = make_float4(__uint_as_float(ii), __uint_as_float(prim), 0.f, 0.f);  // what k_shade read the 48-byte TriRec for
+  o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out)
 {

@@ -499,7 +499,7 @@ void build_shade_tris(pt_context* c, uint32_t n)
     dev_free(c->dShadeTris);
     return;
   }
-  if(dev_alloc(c, c->dShadeTris, sizeof(float4) * 6 * size_t(n)) != PT_OK)
+  if(dev_alloc(c, c->dShadeTris, sizeof(float4) * PT_SHADE_REC_QUADS * size_t(n)) != PT_OK)
   {
     (void)hipGetLastError();
     return;
@@ -738,6 +738,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) g_tuning.shadeTris = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) g_tuning.warm = v;
+    if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) g_tuning.texTile = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
@@ -936,6 +937,20 @@ __attribute__((format(printf, 2, 3))) static int records_fail(std::string& err, 
   err = buf;
   return PT_ERR_INVALID;
 }
+// the texels of image `td` in the storage order its record says (row-major source -> row-major or block-linear, pt_device.h tex_index)
+static void store_texture(uint32_t* dst, const TexRec& tr, const void* rgba8RowMajor)
+{
+  const uint32_t* src = static_cast<const uint32_t*>(rgba8RowMajor);
+  if(!tr.tiled)
+  {
+    std::memcpy(dst, src, size_t(tr.w) * tr.h * 4);
+    return;
+  }
+  for(int y = 0; y < tr.h; ++y)
+    for(int x = 0; x < tr.w; x += PT_TEX_TILE_W)
+      std::memcpy(dst + tex_index(tr.w, x, y, true), src + size_t(y) * tr.w + x, PT_TEX_TILE_W * 4);
+}
+
 static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::string& err)
 {
   if(!d || !d->vertices || !d->indices || !d->primMeshes || !d->nodes || !d->materials || d->numMaterials == 0)
@@ -1009,6 +1024,9 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
     const pt_TextureDesc& td = d->textures[t];
     if(!td.rgba8 || td.width <= 0 || td.height <= 0)
       return records_fail(err, "texture %u: empty image", t);
+    R.texRecs[t].tiled  = (g_tuning.texTile && td.width % PT_TEX_TILE_W == 0 && td.height % PT_TEX_TILE_H == 0) ? 1 : 0;
+    if(R.texRecs[t].tiled)
+      R.texels = (R.texels + 31u) & ~size_t(31);  // a tile = one 128-byte line (the pool itself is 256-byte aligned)
     R.texRecs[t].offset = uint32_t(R.texels);
     R.texRecs[t].w      = td.width;
     R.texRecs[t].h      = td.height;
@@ -1045,6 +1063,8 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
       a.texOffset = tr.offset; a.texW = tr.w; a.texH = tr.h; a.texMag = tr.mag; a.texWrap = tr.wrapS | (tr.wrapT << 8) | (tr.pot << 16);
       if(tr.wrapS == PT_WRAP_REPEAT && tr.wrapT == PT_WRAP_REPEAT && tr.pot == 3)
         a.texWrap |= ALPHA_FAST_TAP;
+      if(tr.tiled)
+        a.texWrap |= ALPHA_TILED;
     }
   }
   build_opacity_maps(d, R.alphaMats, R.alphaMaps);
@@ -1083,8 +1103,21 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     uint32_t white = 0xffffffffu;
     HIP_TRY(c, hipMemcpy(c->dTexels.p, &white, 4, hipMemcpyHostToDevice));
   }
-  for(uint32_t t = 0; t < d->numTextures; ++t)
-    HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + R.texRecs[t].offset, d->textures[t].rgba8, size_t(R.texRecs[t].w) * R.texRecs[t].h * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> staged;  // one image at a time in its storage order
+    for(uint32_t t = 0; t < d->numTextures; ++t)
+    {
+      const TexRec& tr = R.texRecs[t];
+      const void*   src = d->textures[t].rgba8;
+      if(tr.tiled)
+      {
+        staged.resize(size_t(tr.w) * tr.h);
+        store_texture(staged.data(), tr, src);
+        src = staged.data();
+      }
+      HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + tr.offset, src, size_t(tr.w) * tr.h * 4, hipMemcpyHostToDevice));
+    }
+  }
   if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;
@@ -2205,7 +2238,7 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(con
     if(d->numTextures == 0)
       texelsOut[0] = 0xffffffffu;
     for(uint32_t t = 0; t < d->numTextures; ++t)
-      std::memcpy(texelsOut + R.texRecs[t].offset, d->textures[t].rgba8, size_t(R.texRecs[t].w) * R.texRecs[t].h * 4);
+      store_texture(texelsOut + R.texRecs[t].offset, R.texRecs[t], d->textures[t].rgba8);
   }
   return PT_OK;
 }

@@ -47,6 +47,7 @@ struct AlphaMat {
   uint32_t mapOffset;             // first word of this material's opacity map in DeviceScene::alphaMaps, ALPHA_NO_MAP: none
 };
 #define ALPHA_FAST_TAP (1 << 24)
+#define ALPHA_TILED (1 << 25)  // the texture is stored block-linear (TexRec::tiled)
 #define ALPHA_NO_MAP 0xffffffffu
 // Opacity map: a conservative 2-bit classification of every ALPHA_MAP_BLOCK^2 block of base texels (+ a one-texel
 // apron, so that it bounds every bilinear tap whose base texel lies in the block) under the material's factor /
@@ -140,9 +141,22 @@ struct TexRec {
   int32_t  w, h;
   int32_t  mag, wrapS, wrapT;
   int32_t  pot;  // bit0: w is a power of two, bit1: h is
-  int32_t  _pad;
+  int32_t  tiled;  // 1: block-linear storage (see tex_index), 0: row-major
 };
+// Texel (ix, iy) of a w-texel-wide image -> index into its storage.  Block-linear images (w % 8 == 0, h % 4 == 0) keep every 8 x 4-texel tile in one
+// 128-byte line, so the 2 x 2 footprint of a bilinear tap is ONE line two times out of three instead of always two (rows w texels apart).
+// A storage order only: the texel VALUES and the filter arithmetic are untouched (k_shade is bound by the lines it pulls through L2).
+#define PT_TEX_TILE_W 8
+#define PT_TEX_TILE_H 4
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
+{
+  return tiled ? ((uint32_t(iy) >> 2) * (uint32_t(w) >> 3) + (uint32_t(ix) >> 3)) * 32u + ((uint32_t(iy) & 3u) << 3) + (uint32_t(ix) & 7u) : uint32_t(iy) * uint32_t(w) + uint32_t(ix);
+}
 
+#define PT_SHADE_REC_QUADS 8
 struct DeviceScene {
   const float4*               vertices;  // pt_VertexAttributes as 2 x float4
   const uint32_t*             indices;
@@ -155,7 +169,9 @@ struct DeviceScene {
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
   const CompactNode8*         cnodes8; // experiment: the 64-byte form (flat structure only; takes precedence)
-  const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot the six float4 of the triangle's three pt_VertexAttributes next to
+  const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot ONE 128-byte line (PT_SHADE_REC_QUADS float4): the six float4 of the
+                                          // triangle's three pt_VertexAttributes, then (instance, primitive) -- everything k_shade needs of the hit
+                                          // triangle in one aligned line instead of a 48-byte TriRec (1.4 lines) + 96 bytes at a 96-byte stride (1.7 lines).  Was: next to
                                           // each other (96 B): k_shade reads them with the hit's slot, together with the triangle record, instead of
                                           // after instance -> index triple -> three vertices (two dependent round trips fewer per shading)
   const TriRec*               tris;

@@ -135,9 +135,10 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
                                    // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
+  int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
-  int shadeTris            = 1;    // flat-format structures: per-slot copy of the triangles' vertex attributes for k_shade (96 B per triangle; 0: none)
+  int shadeTris            = 1;    // flat-format structures: per-slot shading line for k_shade: the triangle's vertex attributes + (instance, primitive), 128 B per triangle (0: none)
   int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (measurement; see pt_device.h CompactNode)
   int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)

@@ -32,6 +32,8 @@ struct TraceLane {
   int      pass;           // 0: pass A (nearest certain hit), 1: pass B (count zero-opacity candidates in front of it)
   bool     opaqueHit;      // shadow rays: an opaque occluder was found
   bool     done;
+  uint32_t early;          // EARLY walks (shadow rays): 0 normal, 1 an opaque hit is the best hit and no non-opaque candidate has been seen: only subtrees
+                           // that hold non-opaque triangles are still looked at, 2 such a candidate turned up in front of the hit: full walk again, for good
 #if PT_BVH_WIDTH != 2
   InstCtx  ic;             // two-level instantiations only (the flat ones never touch it): the instance the lane is inside of
   uint32_t steps;          //   and the loop-iteration guard
@@ -48,6 +50,7 @@ PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
 #endif
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
   L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f; L.zeroMaxT2 = -1.0f; L.zeroMaxT3 = -1.0f;
+  L.early = 0;
 #if PT_BVH_WIDTH != 2
   L.ic = InstCtx{BVH_NONE, 0, 0u}; L.steps = 0;
 #endif
@@ -69,7 +72,14 @@ PT_DEV void lane_begin_count(TraceLane& L)
 #endif
 }
 
-template <bool TWO = false>
+// EARLY (shadow rays of the flat structure; trace contract T6): what a shadow ray reports is (occluded or not, the RNG state after the draws of the
+// zero-opacity candidates in front of the nearest certain hit).  Once an OPAQUE hit at t0 is the best hit and no non-opaque candidate has been
+// seen, the answer can only change through a non-opaque candidate inside (0, t0) -- a nearer OPAQUE hit changes neither the verdict nor the (zero)
+// draws.  From then on the walk enters only references tagged BVH_ALPHA (subtrees / leaves that hold non-opaque triangles); opaque-only subtrees
+// in front of t0 are skipped.  If such a candidate does turn up in front of the hit (any opacity), the draws depend on which certain hit is the
+// nearest after all: the walk starts over as the plain front-to-back walk bounded by t0 (L.early = 2).  The reference's own shadow ray is
+// gl_RayFlagsTerminateOnFirstHitEXT (shaders/traceray_rq.glsl:157, traceray_rtx.glsl:56).
+template <bool TWO = false, bool EARLY = false>
 PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
 {
 #if PT_BVH_WIDTH != 2
@@ -80,18 +90,23 @@ PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
     L.rbox    = make_raybox(L.o, L.d);
   }
 #endif
-  if(L.sp == 0)
+  for(;;)
   {
-    L.done = true;
-    return;
+    if(L.sp == 0)
+    {
+      L.done = true;
+      return;
+    }
+    --L.sp;
+    L.cur = L.sp < STACK_LDS ? lds[L.sp * TRACE_BLOCK] : spill[L.sp - STACK_LDS];
+    if(!(EARLY && L.early == 1) || (L.cur & BVH_ALPHA))
+      return;  // (EARLY, after the opaque hit: references without non-opaque triangles below them are dropped unvisited)
   }
-  --L.sp;
-  L.cur = L.sp < STACK_LDS ? lds[L.sp * TRACE_BLOCK] : spill[L.sp - STACK_LDS];
 }
 
 // One inner-node visit.  SHADOW: true for shadow rays (they must keep looking for opaque triangles behind the best
 // alpha candidate, so only tmax prunes).
-template <bool SHADOW, bool TWO = false>
+template <bool SHADOW, bool TWO = false, bool EARLY = false>
 PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters)
 {
 #if PT_BVH_WIDTH != 2
@@ -112,13 +127,14 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   };
   // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
   const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
-  const uint32_t nxt    = (!TWO && S.cnodes8) ? wide_node_step_c8(S.cnodes8, L.cur, L.rbox, lim, L.pass == 1, pushChild)  // experiment, flat structure only
-                          : S.cnodes          ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, L.pass == 1, pushChild)
-                                              : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, L.pass == 1, pushChild);
+  const bool     alphaOnly = L.pass == 1 || (EARLY && L.early == 1);
+  const uint32_t nxt    = (!TWO && S.cnodes8) ? wide_node_step_c8(S.cnodes8, L.cur, L.rbox, lim, alphaOnly, pushChild)  // experiment, flat structure only
+                          : S.cnodes          ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
+                                              : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else
-    lane_pop<TWO>(L, lds, spill);
+    lane_pop<TWO, EARLY>(L, lds, spill);
 }
 #else
   const BvhNode* np = S.bvh + (L.cur & BVH_SLOT_MASK);
@@ -161,7 +177,7 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 #endif
 
 // One leaf (triangle) visit; same candidate rules as traverse<TM_CLOSEST / TM_SHADOW / TM_COUNT>.
-template <bool SHADOW, bool TWO = false>
+template <bool SHADOW, bool TWO = false, bool EARLY = false>
 PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill)
 {
   const uint32_t slot  = L.cur & BVH_SLOT_MASK;
@@ -210,6 +226,14 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
         L.done      = true;
         return;
       }
+      else if(EARLY && L.early == 1)
+      {  // only non-opaque leaves are visited in this state
+        if(key_less(t, w, L.bt, L.bw & TRI_INDEX_MASK))
+        {  // a non-opaque candidate in front of the opaque hit: which certain hit is the nearest matters after all -- the plain walk, bounded by the hit
+          L.early = 2; L.cur = 0; L.sp = 0;
+          return;
+        }
+      }
       else if(L.bslot == BVH_NONE || key_less(t, w, L.bt, L.bw & TRI_INDEX_MASK))
       {
         bool certain = opq;
@@ -230,11 +254,13 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
         if(certain)
         {
           L.bt = t; L.bu = u; L.bv = v; L.bslot = slot; L.bw = wbits;
+          if(EARLY && opq && L.early == 0 && L.cnt == 0 && L.flags == 0)
+            L.early = 1;
         }
       }
     }
   }
-  lane_pop<TWO>(L, lds, spill);
+  lane_pop<TWO, EARLY>(L, lds, spill);
 }
 
 // Wave-uniform ray supply: a wave reserves PT_CHUNK consecutive queue entries with one atomic and hands them to

@@ -55,6 +55,11 @@ namespace {
                           // loads in flight (+5 % on the 96-step bench against 3 waves / 137 VGPRs, profiles/r03h_*)
 #endif
 constexpr int SHADE_BLOCK = 256;
+#ifndef PT_SHADOW_EARLY
+#define PT_SHADOW_EARLY 0  // 1: k_shadow_p walks with the exact early-out of pt_machine.h (EARLY).  Measured before it was built: 0.965x node steps,
+                           // 0.96x triangle steps per shadow ray on the C3 stand-in (profiles/r04_shadow_earlyout_experiment.txt) -- the front-to-back walk
+                           // finds the nearest hit first almost always, so little is left to skip
+#endif
 
 // ---- wave-aggregated helpers ---------------------------------------------------------------------------
 PT_DEV void count_event(unsigned long long* ctr)
@@ -512,15 +517,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 #ifdef PT_HIST
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
+      constexpr bool EARLY = !TWO && PT_SHADOW_EARLY != 0;
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
+        lane_inner<false, TWO, EARLY>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
       {
-        lane_leaf<false, TWO>(S, L, lds, spill);
+        lane_leaf<false, TWO, EARLY>(S, L, lds, spill);
         if(S.allOpaque && L.bslot != BVH_NONE)
           L.done = true;  // all-opaque scene: any hit inside (0, tmax) occludes and nothing draws -- the nearest one need not be found
       }

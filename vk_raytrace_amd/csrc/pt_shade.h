@@ -230,14 +230,20 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   else
   {
     const uint32_t hslot = __float_as_uint(hit.y);
-    const TriRec   tr    = S.tris[hslot];
     if(S.shadeTris)
-    {
-      vt     = fetch_triangle_slot(S, hslot);
-      haveVt = true;
+    {  // the slot's shading line: vertex attributes + (instance, primitive)
+      vt              = fetch_triangle_slot(S, hslot);
+      haveVt          = true;
+      const float4 id = S.shadeTris[size_t(hslot) * PT_SHADE_REC_QUADS + 6];
+      hitInst         = __float_as_uint(id.x);
+      hitPrim         = __float_as_uint(id.y);
     }
-    hitInst = __float_as_uint(tr.e1n.w);
-    hitPrim = __float_as_uint(tr.e2p.w);
+    else
+    {
+      const TriRec tr = S.tris[hslot];
+      hitInst         = __float_as_uint(tr.e1n.w);
+      hitPrim         = __float_as_uint(tr.e2p.w);
+    }
   }
   const InstanceRec& I = S.instances[hitInst];
   Surface            sf;

@@ -35,7 +35,7 @@ PT_DEV int wrap_index(int i, int n, int mode, bool pot)
 
 PT_DEV f4 texel_bytes(const uint32_t* pool, const TexRec& tr, int ix, int iy)
 {
-  uint32_t p = pool[tr.offset + uint32_t(wrap_index(iy, tr.h, tr.wrapT, (tr.pot & 2) != 0)) * uint32_t(tr.w) + uint32_t(wrap_index(ix, tr.w, tr.wrapS, (tr.pot & 1) != 0))];
+  uint32_t p = pool[tr.offset + tex_index(tr.w, wrap_index(ix, tr.w, tr.wrapS, (tr.pot & 1) != 0), wrap_index(iy, tr.h, tr.wrapT, (tr.pot & 2) != 0), tr.tiled != 0)];
   return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)};
 }
 
@@ -180,14 +180,15 @@ PT_DEV float opacity_eval(const DeviceScene& S, const AlphaRec& ar, float bu, fl
           return st == ALPHA_ST_ONE ? 1.0f : 0.0f;
       }
       const uint32_t* tp = S.texels + am.texOffset;
+      const bool      til = (am.texWrap & ALPHA_TILED) != 0;
       float           ta;
       if(!linear)
-        ta = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xa)] >> 24);
+        ta = float(tp[tex_index(am.texW, xa, ya, til)] >> 24);
       else
       {
         const int   xb = (x0 + 1) & mx, yb = (y0 + 1) & my;
-        const float t00 = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xa)] >> 24), t10 = float(tp[uint32_t(ya) * uint32_t(am.texW) + uint32_t(xb)] >> 24);
-        const float t01 = float(tp[uint32_t(yb) * uint32_t(am.texW) + uint32_t(xa)] >> 24), t11 = float(tp[uint32_t(yb) * uint32_t(am.texW) + uint32_t(xb)] >> 24);
+        const float t00 = float(tp[tex_index(am.texW, xa, ya, til)] >> 24), t10 = float(tp[tex_index(am.texW, xb, ya, til)] >> 24);
+        const float t01 = float(tp[tex_index(am.texW, xa, yb, til)] >> 24), t11 = float(tp[tex_index(am.texW, xb, yb, til)] >> 24);
         const float fa = x - fx, fb = y - fy;
         const float top = t00 * (1.0f - fa) + t10 * fa;
         const float bot = t01 * (1.0f - fa) + t11 * fa;
@@ -198,7 +199,7 @@ PT_DEV float opacity_eval(const DeviceScene& S, const AlphaRec& ar, float bu, fl
     else
     {
       TexRec tr;
-      tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = (am.texWrap >> 8) & 0xff; tr.pot = (am.texWrap >> 16) & 3;
+      tr.offset = am.texOffset; tr.w = am.texW; tr.h = am.texH; tr.mag = am.texMag; tr.wrapS = am.texWrap & 0xff; tr.wrapT = (am.texWrap >> 8) & 0xff; tr.pot = (am.texWrap >> 16) & 3; tr.tiled = (am.texWrap & ALPHA_TILED) ? 1 : 0;
       a *= sample_rgba8_rec(S.texels, tr, tuv).w;
     }
   }
@@ -226,7 +227,7 @@ PT_DEV bool alpha_test(const DeviceScene& S, uint32_t slot, float bu, float bv, 
 // the same six float4 from the per-slot copy (DeviceScene::shadeTris, written by pt_accel.hip k_shade_tris)
 PT_DEV VertexTriple fetch_triangle_slot(const DeviceScene& S, uint32_t slot)
 {
-  const float4* p = S.shadeTris + size_t(slot) * 6;
+  const float4* p = S.shadeTris + size_t(slot) * PT_SHADE_REC_QUADS;
   VertexTriple  v;
   v.a0 = p[0]; v.b0 = p[1]; v.a1 = p[2]; v.b1 = p[3]; v.a2 = p[4]; v.b2 = p[5];
   return v;
