@@ -315,7 +315,6 @@ struct Scene {
   std::vector<AlphaRec>    flatAlpha;
   std::vector<uint32_t>    instBlock;  // DeviceScene::instBlock (pt_capi.hip build_tlas)
   std::vector<CompactNode> blasCNodes, tlasCNodes;  // ... and the two-level structure's
-  std::vector<CompactNode8> flatCNodes8;  // experiment: the 64-byte form (th_set_compact_nodes(2))
   std::vector<CompactNode> flatCNodes;  // PT_TUNE cnodes=1: the flat structure's nodes in the compact form (read by lane_inner only)
   AlphaMat                 alphaMat;
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
@@ -554,12 +553,16 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     for(size_t i = 0; i < s->flat.wide.size(); ++i)
       ok = cn_encode(s->flat.wide[i], s->flatCNodes[i]) && ok;
     s->dsFlat.cnodes = ok ? s->flatCNodes.data() : nullptr;
-    if(g_compactNodes == 2)
-    {
-      s->flatCNodes8.resize(s->flat.wide.size());
-      for(size_t i = 0; i < s->flat.wide.size(); ++i)
-        ok = cn_encode8(s->flat.wide[i], s->flatCNodes8[i]) && ok;
-      s->dsFlat.cnodes8 = ok ? s->flatCNodes8.data() : nullptr;
+    if(ok)
+    {  // DeviceScene::cnodeBound like pt_accel.hip k_compact_nodes + pt_capi.hip build_cnodes: the reach of the nodes' grids
+      float reach = 0.0f;
+      for(const CompactNode& c : s->flatCNodes)
+      {
+        const float gm = float(CN_GRID_MAX);
+        reach = fmaxf(reach, fmaxf(fmaxf(fabsf(c.px) + gm * __uint_as_float((c.exps & 0xffu) << 23), fabsf(c.py) + gm * __uint_as_float(((c.exps >> 8) & 0xffu) << 23)),
+                                   fabsf(c.pz) + gm * __uint_as_float(((c.exps >> 16) & 0xffu) << 23)));
+      }
+      s->dsFlat.cnodeBound = (std::isfinite(reach) && reach > 0.0f) ? reach * 1.0001f : 0.0f;
     }
     g_compactOk      = ok ? 1 : 0;
   }
@@ -650,41 +653,10 @@ extern "C" unsigned long long th_cnode_violations(void* p, double* meanExtraExte
 }
 
 // the same for the 64-byte form of the flat structure's nodes
-extern "C" unsigned long long th_cnode8_violations(void* p)
-{
-  const Scene*       s   = static_cast<const Scene*>(p);
-  unsigned long long bad = 0;
-  for(size_t i = 0; i < s->flat.wide.size() && i < s->flatCNodes8.size(); ++i)
-  {
-    const WideNode&     w = s->flat.wide[i];
-    const CompactNode8& c = s->flatCNodes8[i];
-    const float*    lo[3] = {&w.minx[0].x, &w.miny[0].x, &w.minz[0].x};
-    const float*    hi[3] = {&w.maxx[0].x, &w.maxy[0].x, &w.maxz[0].x};
-    const uint32_t* cc    = &w.child[0].x;
-    const uint32_t* cd    = &c.child.x;
-    const double    org[3] = {c.px, c.py, c.pz};
-    for(int k = 0; k < 4; ++k)
-    {
-      if(cc[k] != cd[k])
-        ++bad;
-      if(cc[k] == BVH_NONE)
-        continue;
-      for(int a = 0; a < 3; ++a)
-      {
-        const double step = std::ldexp(1.0, int((c.exps >> (8 * a)) & 0xffu) - 127);
-        const double dl = org[a] + double((c.lo[a] >> (8 * k)) & 0xffu) * step, dh = org[a] + double((c.hi[a] >> (8 * k)) & 0xffu) * step;
-        if(dl > double(lo[a][k]) || dh < double(hi[a][k]))
-          ++bad;
-      }
-    }
-  }
-  return bad;
-}
-
 extern "C" int th_compact_in_use(void* p, int two)  // 1: the walk of that structure reads compact nodes
 {
   const Scene* s = static_cast<const Scene*>(p);
-  return two ? (s->dsTwo.cnodes != nullptr && s->dsTwo.ctlas != nullptr) : (s->dsFlat.cnodes8 != nullptr ? 2 : (s->dsFlat.cnodes != nullptr ? 1 : 0));
+  return two ? (s->dsTwo.cnodes != nullptr && s->dsTwo.ctlas != nullptr) : (s->dsFlat.cnodes != nullptr ? 1 : 0);
 }
 
 // plain geometry + per-instance flags (every instance's material is the default: no any-hit evaluation is reachable with TRI_OPAQUE)
@@ -899,7 +871,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
         const bool early = kind == 1 && !two && g_shadowEarly;
         TraceLane             L;
         std::vector<uint32_t> spill(STACK_SPILL);
-        lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
+        lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0, two ? 0.0f : S.cnodeBound);
         for(;;)
         {
           while(!L.done)

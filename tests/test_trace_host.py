@@ -398,28 +398,6 @@ def test_compact_nodes_never_lose_a_hit(far):
     tr.close(); trc.close()
 
 
-@pytest.mark.parametrize("far", [False, True])
-def test_experimental_64_byte_nodes_never_lose_a_hit(far):
-    """EXPERIMENT (PT_TUNE cnodes=2; never run on the GPU): the node in 64 bytes with 8-bit planes.  Same property, same adversarial scene."""
-    sc, flags, off = instanced_scene(12, far=far)
-    tr = TracedScene(sc)
-    tr.L.th_set_compact_nodes(2)
-    trc = TracedScene(sc)
-    tr.L.th_set_compact_nodes(0)
-    assert trc.L.th_compact_ok() == 1 and trc.L.th_compact_in_use(trc.h, 0) == 2
-    trc.L.th_cnode8_violations.restype = C.c_ulonglong
-    trc.L.th_cnode8_violations.argtypes = [C.c_void_p]
-    assert trc.L.th_cnode8_violations(trc.h) == 0
-    rng = np.random.default_rng(6)
-    org, dirs = rays_for(tr, rng, off, 8000)
-    seeds = np.zeros(len(org), np.uint32)
-    want = tr.settle(0, 0, 2, org, dirs, seeds)
-    got = trc.settle(0, 0, 2, org, dirs, seeds)
-    same = (got[0] == want[0]) & (got[1].view(np.uint32) == want[1].view(np.uint32)).all(1)
-    assert same.all(), f"{np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
-    tr.close(); trc.close()
-
-
 # ---- whole frames: the product's shading source on the host against the oracle ---------------------------------------------------------------
 def host_render(cfg, frames, two=0, shard=None):
     """cfg: tests.common.Config.  The frames k_generate / k_tail / k_accumulate would produce, computed by the same functions (pt_shade.h,

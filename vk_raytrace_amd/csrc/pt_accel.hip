@@ -1440,6 +1440,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
 
 // WideNode -> CompactNode (pt_cnode.h cn_encode), one thread per node.  bad[0] counts nodes that cannot be represented (non-finite boxes): the
 // caller then keeps the WideNode walk.
+// bad[1]: the float bits of max over nodes and axes of |p| + 2047 step, the reach of the nodes' grids (DeviceScene::cnodeBound)
 __global__ void k_compact_nodes(uint32_t n, const WideNode* __restrict__ in, CompactNode* __restrict__ out, uint32_t* __restrict__ bad)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1450,6 +1451,13 @@ __global__ void k_compact_nodes(uint32_t n, const WideNode* __restrict__ in, Com
   out[i]         = c;
   if(!ok)
     atomicAdd(bad, 1u);
+  else
+  {
+    const float gm = float(CN_GRID_MAX);
+    const float m  = fmaxf(fmaxf(fabsf(c.px) + gm * __uint_as_float((c.exps & 0xffu) << 23), fabsf(c.py) + gm * __uint_as_float(((c.exps >> 8) & 0xffu) << 23)),
+                           fabsf(c.pz) + gm * __uint_as_float(((c.exps >> 16) & 0xffu) << 23));
+    atomicMax(bad + 1, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  }
 }
 // the same over a list of node ranges (the bottom-level structures of the two-level mode sit at their node bases with unused nodes between them):
 // one block per range
@@ -1485,57 +1493,29 @@ int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint3
   (void)hipFree(dBuf);
   return bad ? -1 : 0;
 }
-// EXPERIMENT: the 64-byte form
-__global__ void k_compact_nodes8(uint32_t n, const WideNode* __restrict__ in, CompactNode8* __restrict__ out, uint32_t* __restrict__ bad)
+int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out, float* reachOut)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  CompactNode8 c;
-  const bool   ok = cn_encode8(in[i], c);
-  out[i]          = c;
-  if(!ok)
-    atomicAdd(bad, 1u);
-}
-int pt_compact_nodes8(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode8* out)
-{
+  if(reachOut)
+    *reachOut = 0.0f;
   if(n == 0)
     return 0;
   uint32_t* dBad = nullptr;
-  uint32_t  bad  = 1;
-  if(hipMalloc(&dBad, 4) != hipSuccess)
+  uint32_t  bad[2] = {1u, 0u};
+  if(hipMalloc(&dBad, 8) != hipSuccess)
   {
     (void)hipGetLastError();
     return -1;
   }
-  if(hipMemsetAsync(dBad, 0, 4, stream) == hipSuccess)
-  {
-    k_compact_nodes8<<<(n + 127) / 128, 128, 0, stream>>>(n, in, out, dBad);
-    if(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
-      bad = 1;
-  }
-  (void)hipFree(dBad);
-  return bad ? -1 : 0;
-}
-int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out)
-{
-  if(n == 0)
-    return 0;
-  uint32_t* dBad = nullptr;
-  uint32_t  bad  = 1;
-  if(hipMalloc(&dBad, 4) != hipSuccess)
-  {
-    (void)hipGetLastError();
-    return -1;
-  }
-  if(hipMemsetAsync(dBad, 0, 4, stream) == hipSuccess)
+  if(hipMemsetAsync(dBad, 0, 8, stream) == hipSuccess)
   {
     k_compact_nodes<<<(n + 127) / 128, 128, 0, stream>>>(n, in, out, dBad);
-    if(hipMemcpyAsync(&bad, dBad, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
-      bad = 1;
+    if(hipMemcpyAsync(bad, dBad, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      bad[0] = 1;
   }
   (void)hipFree(dBad);
-  return bad ? -1 : 0;
+  if(reachOut && !bad[0])
+    std::memcpy(reachOut, &bad[1], 4);
+  return bad[0] ? -1 : 0;
 }
 
 // DeviceScene::shadeTris of a flat-format structure: per leaf slot the three vertices' attribute pairs, copied from where the record's instance and

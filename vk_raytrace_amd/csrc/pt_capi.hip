@@ -39,8 +39,6 @@ struct pt_context {
   DevBuf   dCTlas;   // DeviceScene::ctlas
   std::vector<uint32_t> hBlasRanges;  // two-level mode: (node base, wide nodes) of every object-space BLAS
   uint32_t nodeCapacity = 0;          // nodes dWide was sized for (two-level mode: the BLASes sit at their node bases)
-  DevBuf   dCNodes8;  // experiment (PT_TUNE cnodes=2)
-  bool     haveCNodes8 = false;
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
@@ -275,7 +273,6 @@ void refresh_scene_ptrs(pt_context* c)
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
   s.ctlas        = c->haveCNodes ? (const CompactNode*)c->dCTlas.p : nullptr;
-  s.cnodes8      = c->haveCNodes8 ? (const CompactNode8*)c->dCNodes8.p : nullptr;
   s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
   s.alphaMaps    = (const uint32_t*)c->dAlphaMaps.p;
@@ -450,6 +447,7 @@ int build_tlas(pt_context* c)
 void build_cnodes_two_level(pt_context* c)
 {
   c->haveCNodes = false;
+  c->scene.cnodeBound = 0.0f;  // (object-space structures have a reach of their own each: their visits keep the per-node slack)
   if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
   {
     dev_free(c->dCNodes);
@@ -475,6 +473,7 @@ void build_cnodes_two_level(pt_context* c)
 void build_cnodes(pt_context* c, uint32_t n)
 {
   c->haveCNodes = false;
+  c->scene.cnodeBound = 0.0f;
   if(!g_tuning.cnodes || n == 0)
   {
     dev_free(c->dCNodes);
@@ -485,10 +484,10 @@ void build_cnodes(pt_context* c, uint32_t n)
     (void)hipGetLastError();
     return;
   }
-  c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
-  c->haveCNodes8 = false;
-  if(g_tuning.cnodes == 2 && dev_alloc(c, c->dCNodes8, sizeof(CompactNode8) * size_t(n)) == PT_OK)  // experiment: the 64-byte form on top
-    c->haveCNodes8 = pt_compact_nodes8(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode8*)c->dCNodes8.p) == 0;
+  float reach   = 0.0f;
+  c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p, &reach) == 0;
+  // the per-ray slack of the prebiased visit (pt_trace.h prebias_raybox) is sized from the reach of the nodes' grids, with a margin for its own rounding
+  c->scene.cnodeBound = (c->haveCNodes && g_tuning.prebias && std::isfinite(reach) && reach > 0.0f) ? reach * 1.0001f : 0.0f;
 }
 // DeviceScene::shadeTris over the first n leaf records of a flat-format structure (best effort: without the memory k_shade takes the indexed route)
 void build_shade_tris(pt_context* c, uint32_t n)
@@ -739,6 +738,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) g_tuning.warm = v;
     if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) g_tuning.texTile = v;
+    if(const char* p = strstr(tune, "prebias=")) if(sscanf(p, "prebias=%d", &v) == 1) g_tuning.prebias = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
@@ -793,7 +793,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCNodes8, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)

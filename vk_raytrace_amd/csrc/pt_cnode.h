@@ -84,59 +84,3 @@ CN_FN bool cn_encode(const WideNode& w, CompactNode& c)
   return ok;
 }
 
-// EXPERIMENT: the 64-byte form (pt_device.h CompactNode8), 255 grid steps per axis.
-CN_FN bool cn_encode8(const WideNode& w, CompactNode8& c)
-{
-  const float    lo[3][4] = {{w.minx[0].x, w.minx[0].y, w.minx[0].z, w.minx[0].w}, {w.miny[0].x, w.miny[0].y, w.miny[0].z, w.miny[0].w}, {w.minz[0].x, w.minz[0].y, w.minz[0].z, w.minz[0].w}};
-  const float    hi[3][4] = {{w.maxx[0].x, w.maxx[0].y, w.maxx[0].z, w.maxx[0].w}, {w.maxy[0].x, w.maxy[0].y, w.maxy[0].z, w.maxy[0].w}, {w.maxz[0].x, w.maxz[0].y, w.maxz[0].z, w.maxz[0].w}};
-  const uint32_t cc[4]    = {w.child[0].x, w.child[0].y, w.child[0].z, w.child[0].w};
-  bool           ok = true;
-  uint32_t       e[3];
-  float          p[3];
-  c.pad[0] = c.pad[1] = 0;
-  for(int a = 0; a < 3; ++a)
-  {
-    float mn = FLT_MAX, mx = -FLT_MAX;
-    for(int k = 0; k < 4; ++k)
-      if(cc[k] != BVH_NONE)
-      {
-        const bool fin = fabsf(lo[a][k]) <= FLT_MAX && fabsf(hi[a][k]) <= FLT_MAX;
-        ok = ok && fin && lo[a][k] <= hi[a][k];
-        mn = fminf(mn, lo[a][k]);
-        mx = fmaxf(mx, hi[a][k]);
-      }
-    if(!(mn <= mx))
-      mn = mx = 0.f;
-    p[a]             = mn;
-    const double ext = double(mx) - double(mn);
-    int          ee  = 27;
-    while(ee < 254 && double(CN8_GRID_MAX) * ldexp(1.0, ee - 127) < ext)
-      ++ee;
-    ok   = ok && double(CN8_GRID_MAX) * ldexp(1.0, ee - 127) >= ext;
-    e[a] = uint32_t(ee);
-    const double step = ldexp(1.0, ee - 127);
-    uint32_t     wl = 0, wh = 0;
-    for(int k = 0; k < 4; ++k)
-    {
-      double ql = 0.0, qh = 0.0;
-      if(cc[k] != BVH_NONE && ok)
-      {
-        ql = fmin(fmax(floor((double(lo[a][k]) - double(mn)) / step), 0.0), double(CN8_GRID_MAX));
-        qh = fmin(fmax(ceil((double(hi[a][k]) - double(mn)) / step), 0.0), double(CN8_GRID_MAX));
-        while(ql > 0.0 && double(mn) + ql * step > double(lo[a][k]))
-          ql -= 1.0;
-        while(qh < double(CN8_GRID_MAX) && double(mn) + qh * step < double(hi[a][k]))
-          qh += 1.0;
-        ok = ok && double(mn) + qh * step >= double(hi[a][k]);
-      }
-      wl |= uint32_t(ql) << (8 * k);
-      wh |= uint32_t(qh) << (8 * k);
-    }
-    c.lo[a] = wl;
-    c.hi[a] = wh;
-  }
-  c.px = p[0]; c.py = p[1]; c.pz = p[2];
-  c.exps  = e[0] | (e[1] << 8) | (e[2] << 16);
-  c.child = w.child[0];
-  return ok;
-}

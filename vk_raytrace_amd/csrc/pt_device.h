@@ -86,18 +86,6 @@ struct CompactNode {
   uint4    child;   // as WideNode::child
 };
 #define CN_GRID_MAX 2047
-// EXPERIMENT (branch cnodes64-experiment; validated on the CPU harness only, never run on the GPU): the node in 64 bytes = FOUR requests.  Same grid,
-// 255 steps per axis, the planes as bytes (child k in byte k of a word): a conversion (v_cvt_f32_ubyteK) and an FMA per plane, one select per
-// axis and side for near / far.  PT_TUNE cnodes=2.
-struct CompactNode8 {
-  float    px, py, pz;
-  uint32_t exps;      // ex | ey << 8 | ez << 16: step 2^(e-127), 255 steps cover the extent
-  uint4    child;
-  uint32_t lo[3];     // lower planes per axis, child k in byte k
-  uint32_t hi[3];     // upper planes
-  uint32_t pad[2];
-};
-#define CN8_GRID_MAX 255
 
 // ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
 // One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
@@ -168,7 +156,6 @@ struct DeviceScene {
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
-  const CompactNode8*         cnodes8; // experiment: the 64-byte form (flat structure only; takes precedence)
   const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot ONE 128-byte line (PT_SHADE_REC_QUADS float4): the six float4 of the
                                           // triangle's three pt_VertexAttributes, then (instance, primitive) -- everything k_shade needs of the hit
                                           // triangle in one aligned line instead of a 48-byte TriRec (1.4 lines) + 96 bytes at a 96-byte stride (1.7 lines).  Was: next to
@@ -185,6 +172,7 @@ struct DeviceScene {
   uint32_t                    numInstances;
   pt_SceneCamera              camera;
   pt_SunAndSky                sunsky;
+  float                       cnodeBound;       // flat-format compact nodes: M >= |p| + 2047 step over every node and axis (pt_trace.h prebias_raybox); 0: unknown
   float                       boundsMin[3];     // world bounds of the triangles (ray-sort keys: origin cell)
   float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
   // two-level mode (null / 0 otherwise)

@@ -63,8 +63,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 // (pt_trace.h PT_INST_MERGED), built by pt_merged_build into dTris / dAlpha / dWide at slotBase / nodeBase like a BLAS.
 // WideNode -> CompactNode for the first n nodes; -1 when a node cannot be represented (the caller keeps the WideNode walk)
 void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out);
-int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out);
-int pt_compact_nodes8(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode8* out);  // experiment: the 64-byte form (PT_TUNE cnodes=2)
+int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out, float* reachOut = nullptr);  // reachOut: max |p| + 2047 step over the nodes
 // ... over numRanges node ranges given as (base, count) pairs
 int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint32_t numRanges, const WideNode* in, CompactNode* out);
 int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
@@ -135,6 +134,7 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
                                    // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
+  int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently

@@ -12,6 +12,9 @@
 // same candidate rules); rays that need the exact key-ordered fallback are handed to the simple kernels.
 #pragma once
 #include "pt_trace.h"
+#ifndef PT_SORTED_VISIT
+#define PT_SORTED_VISIT 1  // the persistent kernels' node visit in its round-4 form (pt_trace.h wide_node_step_cs); 0: the round-3 form, for A/B builds
+#endif
 
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)
 
@@ -40,11 +43,14 @@ struct TraceLane {
 #endif
 };
 
-PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
+// cbound: DeviceScene::cnodeBound when the lane will walk prebiased compact nodes (pt_trace.h wide_node_step_cs<true>: flat-format structure), else 0
+PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene, float cbound = 0.0f)
 {
   L.o = o; L.d = d;
 #if PT_BVH_WIDTH != 2
   L.rbox = make_raybox(o, d);
+  if(cbound > 0.0f)
+    prebias_raybox(L.rbox, o, cbound);
 #else
   L.idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 #endif
@@ -128,9 +134,34 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
   const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
   const bool     alphaOnly = L.pass == 1 || (EARLY && L.early == 1);
-  const uint32_t nxt    = (!TWO && S.cnodes8) ? wide_node_step_c8(S.cnodes8, L.cur, L.rbox, lim, alphaOnly, pushChild)  // experiment, flat structure only
-                          : S.cnodes          ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
-                                              : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
+  if(PT_SORTED_VISIT && S.cnodes)
+  {  // (wave-uniform) the round-4 form of the visit: sorted far-to-near list, straight-line pushes
+    uint32_t       far3[3];
+    const uint32_t amask = alphaOnly ? BVH_ALPHA : 0u;
+    const uint32_t nxt2  = TWO ? wide_node_step_cs<false>(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, amask, far3)
+                               : (S.cnodeBound > 0.0f ? wide_node_step_cs<true>(S.cnodes, L.cur, L.rbox, lim, amask, far3) : wide_node_step_cs<false>(S.cnodes, L.cur, L.rbox, lim, amask, far3));
+    if(!__ballot(L.sp > STACK_LDS - 3))
+    {  // every lane of the visit has room for three entries in the LDS part of its stack
+#pragma unroll
+      for(int i = 0; i < 3; ++i)
+        if(far3[i] != BVH_NONE)
+          lds[L.sp++ * TRACE_BLOCK] = far3[i];
+    }
+    else
+    {
+#pragma unroll
+      for(int i = 0; i < 3; ++i)
+        if(far3[i] != BVH_NONE)
+          pushChild(far3[i]);
+    }
+    if(nxt2 != BVH_NONE)
+      L.cur = nxt2;
+    else
+      lane_pop<TWO, EARLY>(L, lds, spill);
+    return;
+  }
+  const uint32_t nxt    = (!PT_SORTED_VISIT && S.cnodes) ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
+                                                         : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else

@@ -342,38 +342,86 @@ PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t
   const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
   return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
 }
-// EXPERIMENT (branch cnodes64-experiment): the visit on the 64-byte form -- four requests; a conversion and an FMA per plane
-template <class Push>
-PT_DEV uint32_t wide_node_step_c8(const CompactNode8* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
+// ---- the node visit of the persistent kernels (round 4) -----------------------------------------------------------------------------------------
+// The trace machine is bound by VALU issue, not by memory (profiles/r03_valu.json: a VALU instruction in flight during 19 % of a wavefront's
+// cycles x 5 wavefronts per SIMD; fewer requests at more arithmetic per plane -- the 64-byte nodes -- measured 3 % slower, profiles/r04a_*), so
+// this form of the visit spends fewer instructions on the same decisions:
+//  * PREBIASED: the conservative slack of the compact planes, (|b| + 2047 |s|) x 8e-7 per node, axis and side, is replaced by ONE per-ray bound
+//    folded into RayBox::nlo / nhi by prebias_raybox -- E = (M + |o|) |idir| x 1e-6 with M >= |p| + 2047 step of every node of the structure
+//    (DeviceScene::cnodeBound, from the conversion kernel) -- 18 instructions per visit less; the boxes grow by ~1e-6 of the scene's size;
+//  * the hit children are ordered by a five-exchange sorting network on (entry distance, reference) pairs instead of the select-the-farthest
+//    loop (three divergent rounds of ~45 instructions per wave visit), and handed back as a far-to-near list that the caller pushes with
+//    straight-line stores.  Entry distances are compared with their two lowest mantissa bits cleared (the key carries nothing else): the
+//    order among children 4 ulp apart is immaterial, results never depend on the visiting order (trace contract).
+PT_DEV void prebias_raybox(RayBox& rb, f3 o, float bound)
 {
-  const char*    nb = reinterpret_cast<const char*>(nodes);
-  const uint32_t at = (node & BVH_SLOT_MASK) * uint32_t(sizeof(CompactNode8));
-  const float4   h  = *reinterpret_cast<const float4*>(nb + at);
-  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 16u));
-  const uint4    P0 = *reinterpret_cast<const uint4*>(nb + (at + 32u)), P1 = *reinterpret_cast<const uint4*>(nb + (at + 48u));  // lo.xyz hi.x | hi.yz pad
-  const uint32_t ex = __float_as_uint(h.w);
-  const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
-  const float    blx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
-  const float    bly0 = __builtin_fmaf(h.y, rb.idir.y, rb.nlo.y), bhy0 = __builtin_fmaf(h.y, rb.idir.y, rb.nhi.y);
-  const float    blz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nlo.z), bhz0 = __builtin_fmaf(h.z, rb.idir.z, rb.nhi.z);
-  const float    gm = float(CN8_GRID_MAX);
-  const float    blx = blx0 - (fabsf(blx0) + gm * fabsf(sx)) * 8.0e-7f, bhx = bhx0 + (fabsf(bhx0) + gm * fabsf(sx)) * 8.0e-7f;
-  const float    bly = bly0 - (fabsf(bly0) + gm * fabsf(sy)) * 8.0e-7f, bhy = bhy0 + (fabsf(bhy0) + gm * fabsf(sy)) * 8.0e-7f;
-  const float    blz = blz0 - (fabsf(blz0) + gm * fabsf(sz)) * 8.0e-7f, bhz = bhz0 + (fabsf(bhz0) + gm * fabsf(sz)) * 8.0e-7f;
-  const bool     ngx = rb.nearOff[0] != 0, ngy = rb.nearOff[1] != 0, ngz = rb.nearOff[2] != 0;
-  const uint32_t nX = ngx ? P0.w : P0.x, fX = ngx ? P0.x : P0.w;
-  const uint32_t nY = ngy ? P1.x : P0.y, fY = ngy ? P0.y : P1.x;
-  const uint32_t nZ = ngz ? P1.y : P0.z, fZ = ngz ? P0.z : P1.y;
-  float          nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
+  const f3 e = f3{(bound + fabsf(o.x)) * fabsf(rb.idir.x) * 1.0e-6f, (bound + fabsf(o.y)) * fabsf(rb.idir.y) * 1.0e-6f, (bound + fabsf(o.z)) * fabsf(rb.idir.z) * 1.0e-6f};
+  rb.nlo = rb.nlo - e;
+  rb.nhi = rb.nhi + e;
+}
+#define PT_CE(ka, ia, kb, ib)                \
+  {                                          \
+    const bool     sw_ = kb < ka;            \
+    const uint32_t lo_ = sw_ ? kb : ka, hi_ = sw_ ? ka : kb, li_ = sw_ ? ib : ia, hj_ = sw_ ? ia : ib; \
+    ka = lo_; kb = hi_; ia = li_; ib = hj_;  \
+  }
+// amask: BVH_ALPHA when only references tagged with it may be entered (pass B, EARLY state 1), else 0.  far3: the hit children other than the
+// nearest, farthest first (BVH_NONE where there is none).  Returns the nearest hit child (BVH_NONE: nothing hit).
+PT_DEV uint32_t wide_node_decide_sorted(const float* nx, const float* fx, const float* ny, const float* fy, const float* nz, const float* fz, const uint32_t* cc, float lim, uint32_t amask,
+                                        uint32_t (&far3)[3])
+{
+  uint32_t key[4], id[4];
 #pragma unroll
   for(int k = 0; k < 4; ++k)
   {
-    nx[k] = __builtin_fmaf(float((nX >> (8 * k)) & 0xffu), sx, blx); fx[k] = __builtin_fmaf(float((fX >> (8 * k)) & 0xffu), sx, bhx);
-    ny[k] = __builtin_fmaf(float((nY >> (8 * k)) & 0xffu), sy, bly); fy[k] = __builtin_fmaf(float((fY >> (8 * k)) & 0xffu), sy, bhy);
-    nz[k] = __builtin_fmaf(float((nZ >> (8 * k)) & 0xffu), sz, blz); fz[k] = __builtin_fmaf(float((fZ >> (8 * k)) & 0xffu), sz, bhz);
+    const float nr = fmaxf(fmaxf(nx[k], ny[k]), fmaxf(nz[k], 0.0f)) * 0.9999996f;
+    const float fr = fminf(fminf(fx[k], fy[k]), fminf(fz[k], lim)) * 1.0000004f;
+    const bool  h  = (nr <= fr) && (cc[k] != BVH_NONE) && ((cc[k] & amask) == amask);
+    key[k]         = h ? (__float_as_uint(nr) & ~3u) : 0xffffffffu;  // nr >= 0: unsigned order == float order
+    id[k]          = h ? cc[k] : BVH_NONE;
   }
+  PT_CE(key[0], id[0], key[1], id[1]);
+  PT_CE(key[2], id[2], key[3], id[3]);
+  PT_CE(key[0], id[0], key[2], id[2]);
+  PT_CE(key[1], id[1], key[3], id[3]);
+  PT_CE(key[1], id[1], key[2], id[2]);
+  far3[0] = id[3];
+  far3[1] = id[2];
+  far3[2] = id[1];
+  return id[0];
+}
+template <bool PREBIASED>
+PT_DEV uint32_t wide_node_step_cs(const CompactNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, uint32_t amask, uint32_t (&far3)[3])
+{
+  const char*    nb = reinterpret_cast<const char*>(nodes);
+  const uint32_t at = (node & BVH_SLOT_MASK) * uint32_t(sizeof(CompactNode));
+  const float4   h  = *reinterpret_cast<const float4*>(nb + at);
+  const uint4    X = *reinterpret_cast<const uint4*>(nb + (at + 16u)), Y = *reinterpret_cast<const uint4*>(nb + (at + 32u)), Z = *reinterpret_cast<const uint4*>(nb + (at + 48u));
+  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 64u));
+  const uint32_t ex = __float_as_uint(h.w);
+  const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
+  float          blx = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
+  float          bly = __builtin_fmaf(h.y, rb.idir.y, rb.nlo.y), bhy = __builtin_fmaf(h.y, rb.idir.y, rb.nhi.y);
+  float          blz = __builtin_fmaf(h.z, rb.idir.z, rb.nlo.z), bhz = __builtin_fmaf(h.z, rb.idir.z, rb.nhi.z);
+  if(!PREBIASED)
+  {
+    const float gm = float(CN_GRID_MAX);
+    blx -= (fabsf(blx) + gm * fabsf(sx)) * 8.0e-7f; bhx += (fabsf(bhx) + gm * fabsf(sx)) * 8.0e-7f;
+    bly -= (fabsf(bly) + gm * fabsf(sy)) * 8.0e-7f; bhy += (fabsf(bhy) + gm * fabsf(sy)) * 8.0e-7f;
+    blz -= (fabsf(blz) + gm * fabsf(sz)) * 8.0e-7f; bhz += (fabsf(bhz) + gm * fabsf(sz)) * 8.0e-7f;
+  }
+  const bool     ngx = rb.nearOff[0] != 0, ngy = rb.nearOff[1] != 0, ngz = rb.nearOff[2] != 0;  // negative direction: the upper plane is the near one
+  const uint32_t nX0 = ngx ? X.z : X.x, nX1 = ngx ? X.w : X.y, fX0 = ngx ? X.x : X.z, fX1 = ngx ? X.y : X.w;
+  const uint32_t nY0 = ngy ? Y.z : Y.x, nY1 = ngy ? Y.w : Y.y, fY0 = ngy ? Y.x : Y.z, fY1 = ngy ? Y.y : Y.w;
+  const uint32_t nZ0 = ngz ? Z.z : Z.x, nZ1 = ngz ? Z.w : Z.y, fZ0 = ngz ? Z.x : Z.z, fZ1 = ngz ? Z.y : Z.w;
+  const float    nx[4] = {__builtin_fmaf(cn_plane(nX0, 0), sx, blx), __builtin_fmaf(cn_plane(nX0, 1), sx, blx), __builtin_fmaf(cn_plane(nX1, 0), sx, blx), __builtin_fmaf(cn_plane(nX1, 1), sx, blx)};
+  const float    fx[4] = {__builtin_fmaf(cn_plane(fX0, 0), sx, bhx), __builtin_fmaf(cn_plane(fX0, 1), sx, bhx), __builtin_fmaf(cn_plane(fX1, 0), sx, bhx), __builtin_fmaf(cn_plane(fX1, 1), sx, bhx)};
+  const float    ny[4] = {__builtin_fmaf(cn_plane(nY0, 0), sy, bly), __builtin_fmaf(cn_plane(nY0, 1), sy, bly), __builtin_fmaf(cn_plane(nY1, 0), sy, bly), __builtin_fmaf(cn_plane(nY1, 1), sy, bly)};
+  const float    fy[4] = {__builtin_fmaf(cn_plane(fY0, 0), sy, bhy), __builtin_fmaf(cn_plane(fY0, 1), sy, bhy), __builtin_fmaf(cn_plane(fY1, 0), sy, bhy), __builtin_fmaf(cn_plane(fY1, 1), sy, bhy)};
+  const float    nz[4] = {__builtin_fmaf(cn_plane(nZ0, 0), sz, blz), __builtin_fmaf(cn_plane(nZ0, 1), sz, blz), __builtin_fmaf(cn_plane(nZ1, 0), sz, blz), __builtin_fmaf(cn_plane(nZ1, 1), sz, blz)};
+  const float    fz[4] = {__builtin_fmaf(cn_plane(fZ0, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ0, 1), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 1), sz, bhz)};
   const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
-  return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
+  return wide_node_decide_sorted(nx, fx, ny, fy, nz, fz, cc, lim, amask, far3);
 }
 #endif
 
