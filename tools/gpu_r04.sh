@@ -12,6 +12,7 @@
 #   smoke               __graft_entry__.smoke()
 #   pmc[:<frames>]      tools/pmc_r03.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
 #   shards:<wl>:<steps> every rank's shard of N = 1, 2, 4, 8 on this one GPU (bench.py --emulate-shard R/N); max over ranks per N
+#   shardtune:<wl>:<steps>:<R/N>:<A>;<B>;...   one rank's shard under each PT_TUNE string, two alternating rounds
 #   sh:<command>        anything else
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
@@ -46,6 +47,10 @@ for step in "$@"; do
                ms=$(python -c "import json; print(json.loads(open('$O/shard_${a}_${r}of${n}_$b.json').readline())['ms_per_step'])" 2>/dev/null || echo 0)
                worst=$(python -c "print(max($worst, $ms))"); done
                echo "$a steps $b N=$n: slowest rank $worst ms/frame" | tee -a $O/log.txt; done ;;
+    shardtune) IFS=: read -r st_steps st_rn st_tunes <<< "$b"
+             for round in 1 2; do IFS=';' read -ra TS <<< "$st_tunes"; for t in "${TS[@]}"; do tt=$t; [ "$t" = "-" ] && tt=""
+               echo -n "$a shard $st_rn steps $st_steps PT_TUNE=$tt : " | tee -a $O/log.txt
+               PT_TUNE=$tt timeout 300 python bench.py --workload $a --emulate-shard $st_rn --steps $st_steps --warmup 5 --no-cpu-baseline --no-profile --no-interactive 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(round(d["ms_per_step"],4), "ms/frame  windows:", [round(x) for x in d["repeats"]])' | tee -a $O/log.txt; done; done ;;
     sh)      timeout 900 bash -c "${step#sh:}" 2>&1 | tail -20 | tee -a $O/log.txt ;;
     *)       echo "unknown step $step" | tee -a $O/log.txt ;;
   esac
