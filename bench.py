@@ -139,7 +139,7 @@ def usable_cores():
 
 def latest_profile(kind):
     """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{kind}.json")
         if os.path.exists(p):
             try:
@@ -251,6 +251,120 @@ def cpu_leg(wl, cam, integral, W, H, frames_first, img_first, cpu_seconds):
         "tex_taps_per_hit": os_["texTaps"] / max(1, os_["shadedHits"]),
     }
     return out["cpu_baseline"], out.get("parity"), alg
+
+
+# SURVEY.md 8(d) algorithmic bytes: reference-layout BVH2 visits x 32 B, triangle tests x 36 B, hit shading 348 B + 16 B per texture tap,
+# any-hit evaluation 340 B, NEE lookup 80 B, miss 64 B, framebuffer 32 B per sample
+def trace_bytes(alg, closest, shadow, alpha_c, alpha_s):
+    return (closest * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + alpha_c * 340,
+            shadow * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36) + alpha_s * 340)
+
+
+def shade_bytes(alg, hits, misses, nee):
+    return hits * (348 + 16 * alg["tex_taps_per_hit"]) + nee * 80 + misses * 64
+
+
+def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
+    """Roofline / binding / HBM / VALU fields of the line from the serialised pass of this run and the committed PMC summaries (profiles/).  Pure
+    post-processing: a CPU test feeds it a recorded run (tests/test_bench_cpu.py)."""
+    # ---- roofline of the dominant stage: chosen by its standalone time, priced on algorithmic bytes (SURVEY.md 8(d)) ---------------------
+    if alg is not None and serial is not None:
+        sr, tl = serial["rays"], serial["rays_in_tail"]
+        st_c, st_s = sr["closestRays"] - tl["closestRays"], sr["shadowRays"] - tl["shadowRays"]           # rays of the staged kernels
+        st_a, tl_a = sr["alphaTests"] - tl["alphaTests"], tl["alphaTests"]
+        fa = st_c / max(1, st_c + st_s)
+        ft = tl["closestRays"] / max(1, tl["closestRays"] + tl["shadowRays"])
+        bc, bs = trace_bytes(alg, st_c, st_s, st_a * fa, st_a * (1 - fa))
+        tc, ts = trace_bytes(alg, tl["closestRays"], tl["shadowRays"], tl_a * ft, tl_a * (1 - ft))
+        st_hits, st_miss = sr["shadedHits"] - tl["shadedHits"], sr["misses"] - tl["misses"]
+        stage_bytes = {
+            "closest": bc, "shadow": bs, "shade": shade_bytes(alg, st_hits, st_miss, st_hits),
+            "tail": tc + ts + shade_bytes(alg, tl["shadedHits"], tl["misses"], tl["shadedHits"]),
+            "generate": 0.0,
+            # per sample the radiance handed over (16 B); per launch the running mean of the local framebuffer read and written ONCE (32 B per pixel)
+            "accumulate": serial["samples"] * 16.0 + serial["samples"] / max(1, serial["frames"]) * 32.0,
+        }
+        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate",
+                   "accumulate": "k_accumulate"}
+        launches = max(1, serial["launches_per_stage"])
+        cache, cache_src = latest_profile("cache")
+        traffic_j, traffic_src = latest_profile("traffic")
+        table = {}
+        for k, ms in serial["stage_ms"].items():
+            n_l = launches if k in ("closest", "shade", "shadow") else max(1, serial["launches_tail"]) if k == "tail" else 1
+            row = {"kernel": kernels[k], "ms": ms, "launches": n_l, "avg_launch_ms": ms / n_l, "alg_bytes": stage_bytes[k],
+                   "alg_GBps": (stage_bytes[k] / (ms * 1e-3) / 1e9) if ms > 0 else None}
+            if traffic_j and traffic_j["hbm_bytes_per_sample"].get(k) is not None and ms > 0:
+                row["hbm_bytes"] = traffic_j["hbm_bytes_per_sample"][k] * serial["samples"]
+                row["hbm_GBps"] = row["hbm_bytes"] / (ms * 1e-3) / 1e9
+            if cache and cache.get("l2_requests_per_sample", {}).get(k) is not None and ms > 0:
+                row["l2_bytes"] = cache["l2_requests_per_sample"][k] * L2_LINE * serial["samples"]
+                row["l2_GBps"] = row["l2_bytes"] / (ms * 1e-3) / 1e9
+                row["l2_hit_rate"] = cache.get("l2_hit_rate", {}).get(k)
+            table[k] = row
+        # The ceiling that actually binds each stage, as a measured fraction (SURVEY 8(d)'s HBM model above does not bind: its `frac` exceeds 1):
+        #   shade            HBM-side bytes (PMC) / standalone time against the streaming-read ceiling CALIBRATED IN THIS RUN (pt_measure_peaks)
+        #   closest, shadow  L1 (TCP) accesses (PMC, 64-byte accesses after the texture addresser's coalescing) / standalone time against one access per
+        #                    clock and CU -- the per-lane request path of divergent rays -- next to the share of a wavefront's cycles spent waiting
+        #                    (SQ_WAIT_ANY / SQ_WAVE_CYCLES of the stage's kernels): these stages are latency-chained, neither ceiling is reached
+        valu_b, valu_b_src = latest_profile("valu")
+        cu, clk = out["calibration"]["compute_units"], out["calibration"]["clock_MHz"] * 1e6
+        stage_kernels = {"closest": ("k_closest_k", "k_closest_p"), "shadow": ("k_shadow_p",), "shade": ("k_shade",), "tail": ("k_tail",)}
+        for k, row in table.items():
+            if not row.get("ms"):
+                continue
+            if k == "shade" and row.get("hbm_GBps"):
+                row["binding"] = {"ceiling": "HBM streaming read measured in this run (pt_measure_peaks)", "achieved_GBps": row["hbm_GBps"], "peak_GBps": out["calibration"]["hbm_read_GBps"],
+                                  "frac": row["hbm_GBps"] / out["calibration"]["hbm_read_GBps"], "frac_of_spec_peak": row["hbm_GBps"] / HBM_PEAK_GBS}
+            elif k in ("closest", "shadow") and cache and cache.get("l1_accesses_per_sample", {}).get(k) is not None:
+                acc = cache["l1_accesses_per_sample"][k] * serial["samples"] / (row["ms"] * 1e-3)
+                b = {"ceiling": "L1 (TCP) request rate: one 64-byte access per clock and CU", "achieved_G_per_s": acc / 1e9, "peak_G_per_s": cu * clk / 1e9, "frac": acc / (cu * clk),
+                     "l1_accesses_per_sample": cache["l1_accesses_per_sample"][k], "source": cache_src}
+                try:
+                    cyc = valu_b["sq_cycles_per_sample"]
+                    w = sum(cyc[kn]["SQ_WAIT_ANY"] for kn in stage_kernels[k] if kn in cyc)
+                    t = sum(cyc[kn]["SQ_WAVE_CYCLES"] for kn in stage_kernels[k] if kn in cyc)
+                    va = sum(cyc[kn]["SQ_ACTIVE_INST_VALU"] for kn in stage_kernels[k] if kn in cyc)
+                    b.update({"wave_cycles_waiting_frac": w / t, "wave_cycles_valu_active_frac": va / t, "sq_source": valu_b_src})
+                except Exception:
+                    pass
+                row["binding"] = b
+        out["stages_serialised"] = table
+        dom = max(("closest", "shade", "shadow", "tail"), key=lambda k: serial["stage_ms"][k])
+        d = table[dom]
+        traffic = d.get("hbm_bytes") / d["launches"] if d.get("hbm_bytes") else None
+        if traffic_j:
+            tot = traffic_j["hbm_bytes_per_sample"]["total"]
+            out["hbm_measured"] = {"bytes_per_sample": tot, "GBps": tot * samples / max(1, world) / elapsed / 1e9, "frac": tot * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
+                                   "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r03.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
+                                   "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
+        # `achieved` / `frac`: SURVEY.md 8(d) -- algorithmic bytes per launch over the stage's average standalone launch duration, against the HBM peak.
+        # The algorithmic bytes are reference-layout node / triangle / material records; most of them are served by L2 / Infinity Cache (scene + BVH
+        # ~115 MB), so this fraction can exceed 1 while the HBM interface (`traffic`, `traffic_frac`: PMC-measured bytes) is far from saturated;
+        # `l2_frac` prices the same stage's L2 requests against the L2 ceiling.
+        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
+                           "achieved_basis": "SURVEY 8(d) algorithmic bytes per launch / average standalone launch duration (HIP events on the launching stream, serialised pass of this run)",
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                           "traffic": traffic, "traffic_GBps": d.get("hbm_GBps"), "traffic_frac": d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None, "traffic_source": traffic_src,
+                           "l2_GBps": d.get("l2_GBps"), "l2_frac": d["l2_GBps"] / L2_PEAK_GBS if d.get("l2_GBps") else None, "l2_hit_rate": d.get("l2_hit_rate"), "l2_source": cache_src,
+                           "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
+                           "binding": d.get("binding"),
+                           "alg_model_note": "the numerator prices BVH2-EQUIVALENT node visits of the oracle's binary tree (about 110 per ray, SURVEY 8(d)) at 32 B each; the kernels "
+                                             "make about 22 four-wide visits per ray on nodes that live in L2 / Infinity Cache, so frac is an accounting figure, not a speed -- `binding` is the ceiling",
+                           "note": "dominant stage = largest STANDALONE time; frac > 1 means the algorithmic bytes are cache-served, traffic_frac is the HBM interface, l2_frac the L2"}
+    # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round); the rate is
+    # this run's; the ceiling is the one measured above on this box.
+    valu_j, valu_src = latest_profile("valu")
+    if workload == "c3" and valu_j:
+        try:
+            per_sample = valu_j["valu_wave_instr_per_sample"]
+            peak = out["calibration"]["valu_G_wave_instr_per_s"] * 1e9
+            ach = per_sample * samples / elapsed / max(1, world)
+            out["issue_roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU", "frac": ach / peak,
+                                     "valu_wave_instr_per_sample": per_sample, "source": f"{valu_src} x this run's rate / this run's calibration"}
+        except Exception:
+            pass
 
 
 def main():
@@ -433,20 +547,11 @@ def main():
     elif os.path.exists(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")):
         alg = json.load(open(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")))
 
-    # SURVEY.md 8(d) algorithmic bytes: reference-layout BVH2 visits x 32 B, triangle tests x 36 B, hit shading 348 B + 16 B per texture tap,
-    # any-hit evaluation 340 B, NEE lookup 80 B, miss 64 B, framebuffer 32 B per sample
-    def trace_bytes(closest, shadow, alpha_c, alpha_s):
-        return (closest * (alg["nodes_per_closest_ray"] * 32 + alg["tris_per_closest_ray"] * 36) + alpha_c * 340,
-                shadow * (alg["nodes_per_shadow_ray"] * 32 + alg["tris_per_shadow_ray"] * 36) + alpha_s * 340)
-
-    def shade_bytes(hits, misses, nee):
-        return hits * (348 + 16 * alg["tex_taps_per_hit"]) + nee * 80 + misses * 64
-
     if alg is not None:
         rays = out["rays"]
         fc = rays["closestRays"] / max(1, rays["closestRays"] + rays["shadowRays"])
-        bc, bs = trace_bytes(rays["closestRays"], rays["shadowRays"], rays["alphaTests"] * fc, rays["alphaTests"] * (1 - fc))
-        b_total = bc + bs + shade_bytes(rays["shadedHits"], rays["misses"], rays["neeLookups"]) + samples * 32
+        bc, bs = trace_bytes(alg, rays["closestRays"], rays["shadowRays"], rays["alphaTests"] * fc, rays["alphaTests"] * (1 - fc))
+        b_total = bc + bs + shade_bytes(alg, rays["shadedHits"], rays["misses"], rays["neeLookups"]) + samples * 32
         out["alg_bytes_per_sample"] = b_total / samples
         out["alg_model"] = alg
 
@@ -519,74 +624,10 @@ def main():
                   "samples": nsamp}
         out["serialised"] = serial
 
-    # ---- roofline of the dominant stage: chosen by its standalone time, priced on algorithmic bytes ---------------------
-    if alg is not None and serial is not None:
-        sr, tl = serial["rays"], serial["rays_in_tail"]
-        st_c, st_s = sr["closestRays"] - tl["closestRays"], sr["shadowRays"] - tl["shadowRays"]           # rays of the staged kernels
-        st_a, tl_a = sr["alphaTests"] - tl["alphaTests"], tl["alphaTests"]
-        fa = st_c / max(1, st_c + st_s)
-        ft = tl["closestRays"] / max(1, tl["closestRays"] + tl["shadowRays"])
-        bc, bs = trace_bytes(st_c, st_s, st_a * fa, st_a * (1 - fa))
-        tc, ts = trace_bytes(tl["closestRays"], tl["shadowRays"], tl_a * ft, tl_a * (1 - ft))
-        st_hits, st_miss = sr["shadedHits"] - tl["shadedHits"], sr["misses"] - tl["misses"]
-        stage_bytes = {
-            "closest": bc, "shadow": bs, "shade": shade_bytes(st_hits, st_miss, st_hits),
-            "tail": tc + ts + shade_bytes(tl["shadedHits"], tl["misses"], tl["shadedHits"]),
-            "generate": 0.0,
-            # per sample the radiance handed over (16 B); per launch the running mean of the local framebuffer read and written ONCE (32 B per pixel)
-            "accumulate": serial["samples"] * 16.0 + serial["samples"] / max(1, serial["frames"]) * 32.0,
-        }
-        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate",
-                   "accumulate": "k_accumulate"}
-        launches = max(1, serial["launches_per_stage"])
-        cache, cache_src = latest_profile("cache")
-        traffic_j, traffic_src = latest_profile("traffic")
-        table = {}
-        for k, ms in serial["stage_ms"].items():
-            n_l = launches if k in ("closest", "shade", "shadow") else max(1, serial["launches_tail"]) if k == "tail" else 1
-            row = {"kernel": kernels[k], "ms": ms, "launches": n_l, "avg_launch_ms": ms / n_l, "alg_bytes": stage_bytes[k],
-                   "alg_GBps": (stage_bytes[k] / (ms * 1e-3) / 1e9) if ms > 0 else None}
-            if traffic_j and traffic_j["hbm_bytes_per_sample"].get(k) is not None and ms > 0:
-                row["hbm_bytes"] = traffic_j["hbm_bytes_per_sample"][k] * serial["samples"]
-                row["hbm_GBps"] = row["hbm_bytes"] / (ms * 1e-3) / 1e9
-            if cache and cache.get("l2_requests_per_sample", {}).get(k) is not None and ms > 0:
-                row["l2_bytes"] = cache["l2_requests_per_sample"][k] * L2_LINE * serial["samples"]
-                row["l2_GBps"] = row["l2_bytes"] / (ms * 1e-3) / 1e9
-                row["l2_hit_rate"] = cache.get("l2_hit_rate", {}).get(k)
-            table[k] = row
-        out["stages_serialised"] = table
-        dom = max(("closest", "shade", "shadow", "tail"), key=lambda k: serial["stage_ms"][k])
-        d = table[dom]
-        traffic = d.get("hbm_bytes") / d["launches"] if d.get("hbm_bytes") else None
-        if traffic_j:
-            tot = traffic_j["hbm_bytes_per_sample"]["total"]
-            out["hbm_measured"] = {"bytes_per_sample": tot, "GBps": tot * samples / max(1, world) / elapsed / 1e9, "frac": tot * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
-                                   "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r03.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
-                                   "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
-        # `achieved` / `frac`: SURVEY.md 8(d) -- algorithmic bytes per launch over the stage's average standalone launch duration, against the HBM peak.
-        # The algorithmic bytes are reference-layout node / triangle / material records; most of them are served by L2 / Infinity Cache (scene + BVH
-        # ~115 MB), so this fraction can exceed 1 while the HBM interface (`traffic`, `traffic_frac`: PMC-measured bytes) is far from saturated;
-        # `l2_frac` prices the same stage's L2 requests against the L2 ceiling.
-        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
-                           "achieved_basis": "SURVEY 8(d) algorithmic bytes per launch / average standalone launch duration (HIP events on the launching stream, serialised pass of this run)",
-                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
-                           "traffic": traffic, "traffic_GBps": d.get("hbm_GBps"), "traffic_frac": d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None, "traffic_source": traffic_src,
-                           "l2_GBps": d.get("l2_GBps"), "l2_frac": d["l2_GBps"] / L2_PEAK_GBS if d.get("l2_GBps") else None, "l2_hit_rate": d.get("l2_hit_rate"), "l2_source": cache_src,
-                           "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
-                           "note": "dominant stage = largest STANDALONE time; frac > 1 means the algorithmic bytes are cache-served, traffic_frac is the HBM interface, l2_frac the L2"}
-    # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round); the rate is
-    # this run's; the ceiling is the one measured above on this box.
-    valu_j, valu_src = latest_profile("valu")
-    if args.workload == "c3" and valu_j:
-        try:
-            per_sample = valu_j["valu_wave_instr_per_sample"]
-            peak = out["calibration"]["valu_G_wave_instr_per_s"] * 1e9
-            ach = per_sample * samples / elapsed / max(1, world)
-            out["issue_roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s per GPU", "frac": ach / peak,
-                                     "valu_wave_instr_per_sample": per_sample, "source": f"{valu_src} x this run's rate / this run's calibration"}
-        except Exception:
-            pass
+    try:
+        evidence_fields(out, serial, alg, samples, elapsed, world, args.workload)
+    except Exception as e:  # the evidence fields are additions: a failure in their post-processing must never cost the line itself
+        out["evidence_error"] = repr(e)
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:
