@@ -524,7 +524,7 @@ def test_launch_policy_never_changes_results():
 def test_launch_policy_sponza_like_and_samples_per_frame():
     """Same on the alpha-heavy scene, with maxSamples > 1 (the per-frame sample loop inside a batch)."""
     ref = _render_in_subprocess("tail=0,batch=1,inflight=1,packetClosest=0,build=lbvh", frames=3, max_samples=2, scene="sponza")
-    for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0", "accel=two,mergeSingles=0", "cnodes=0,shadeTris=0", "shadeTris=0,tail=0,batch=2", "texTile=0,prebias=0", "spread=0,tail=0,batch=2"):
+    for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0", "accel=two,mergeSingles=0", "cnodes=0,shadeTris=0", "shadeTris=0,tail=0,batch=2", "texTile=0,prebias=0"):
         got = _render_in_subprocess(tune, frames=3, max_samples=2, scene="sponza")
         assert np.array_equal(got, ref), tune
 

@@ -1536,7 +1536,7 @@ __global__ void k_shade_tris(uint32_t n, const TriRec* __restrict__ tris, const 
     o[2 * k]     = vertices[v];
     o[2 * k + 1] = vertices[v + 1];
   }
-  o[6] = make_float4(__uint_as_float(ii), __uint_as_float(prim), 0.f, 0.f);  // what k_shade read the 48-byte TriRec for
+  o[6] = make_float4(__uint_as_float(ii), __uint_as_float(prim), __uint_as_float(uint32_t(I.materialIndex)), 0.f);  // what k_shade read the 48-byte TriRec for + the material index
   o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out)

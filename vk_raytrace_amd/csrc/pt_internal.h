@@ -134,8 +134,6 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
                                    // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
-  int unequal              = 0;    // the pieces of a cut batch fall in size 4 : 3 : 2 : 1 instead of being equal (measurement knob)
-  int spread               = 1;    // persistent kernels: a queue smaller than the launch is spread over the wavefronts (8 .. 56 rays per wave; pt_render.hip rays_per_wave)
   int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other

@@ -157,18 +157,6 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
     atomicAdd(ctr, (unsigned long long)v);
 }
 
-// A queue smaller than the launch (fewer rays than gridDim.x x 64 lanes) is SPREAD over the wavefronts -- 8 .. 56 rays per wave instead of 64 on
-// as many waves as it takes: the small stages of a launch sequence (late bounces, a multi-GPU rank's shard) last as long as their slowest
-// wavefront, a wavefront lasts as long as the longest ray among its lanes, and the SIMDs have room for more resident waves than such a queue
-// fills.  `chunk` bit 16 switches it off (PT_TUNE spread=0).
-PT_DEV uint32_t rays_per_wave(uint32_t count, uint32_t waves, int chunk)
-{
-  if((chunk & 0x10000) || (unsigned long long)waves * TRACE_BLOCK <= count)
-    return TRACE_BLOCK;
-  const uint32_t per = ((count + waves - 1u) / waves + 7u) & ~7u;
-  return per < 8u ? 8u : (per > TRACE_BLOCK ? TRACE_BLOCK : per);
-}
-
 // Persistent wavefronts on the trace machine (pt_machine.h).  The loop alternates between
 //   service: lanes whose ray has finished settle it (pass A -> pass B transition, RNG draws, hit record) and every
 //            idle lane pulls the next ray from the queue;
@@ -186,14 +174,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[cntIn];
-  const uint32_t      per   = rays_per_wave(count, gridDim.x, chunk);
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * per >= count)
-    return;  // waves beyond the queue
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
+    return;  // small queue: fewer waves with full lanes.  Spreading such a queue over MORE waves (8 .. 56 rays each, so that the SIMDs hold more
+             // resident waves and a wave waits for fewer rays) measured 4-7 % slower on the 20-step run and on an 8-GPU rank's shard
+             // (profiles/r04d_*): a wave-instruction costs the same with 16 lanes as with 64
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
-  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`; a queue that does not fill the launch is spread (rays_per_wave)
-  rs.chunk = per < TRACE_BLOCK ? per : max(uint32_t(chunk & 0xffff), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
+  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -456,14 +445,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[cntIn];
-  const uint32_t      per   = rays_per_wave(count, gridDim.x, chunk);
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * per >= count)
-    return;  // waves beyond the queue
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
+    return;  // small queue: fewer waves with full lanes.  Spreading such a queue over MORE waves (8 .. 56 rays each, so that the SIMDs hold more
+             // resident waves and a wave waits for fewer rays) measured 4-7 % slower on the 20-step run and on an 8-GPU rank's shard
+             // (profiles/r04d_*): a wave-instruction costs the same with 16 lanes as with 64
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
-  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`; a queue that does not fill the launch is spread (rays_per_wave)
-  rs.chunk = per < TRACE_BLOCK ? per : max(uint32_t(chunk & 0xffff), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
+  // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -610,17 +600,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 // (traverse<>, shade_path, finish_bounce_core) on the same per-path state in the same order: results are bit-identical by construction
 // (paths never interact), which the launch-policy tests assert.
 template <bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int depth0, int spreadOff)
+__global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int depth0)
 {
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t*           C     = rb.counts + depth0 * CNT_STRIDE;
   const uint32_t      count = C[CNT_IN];
-  const uint32_t      per   = rays_per_wave(count, gridDim.x, spreadOff ? 0x10000 : 0);  // 65 536 paths on 2048 waves: 32 per wave, two waves per SIMD
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * per >= count)
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * TRACE_BLOCK >= count)
     return;
   uint32_t* lds = stack + threadIdx.x;
   RaySupply rs;
-  rs.chunk       = per;
+  rs.chunk       = 64;
   uint32_t slot  = 0, nClosest = 0, nShadow = 0, nAlpha = 0, nMiss = 0, nHit = 0, nNee = 0;
   int      depth = depth0;
   bool     alive = false;
@@ -1050,7 +1039,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost three latency floors
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 5);
-          k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth, g_tuning.spread ? 0 : 1);
+          k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
           pt_timers_end(tm, stream, 5);
         }, false});
         break;
@@ -1062,15 +1051,15 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         if(sortC)
           sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
         if(heat)
-          k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, (g_tuning.chunk & 0xffff) | (g_tuning.spread ? 0 : 0x10000), CNT_IN, CNT_CHUNK_CLOSEST);
+          k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         else if(!TWO && depth < g_tuning.packetClosestBounces)
         {
           const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
           k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
-          k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, (g_tuning.chunk & 0xffff) | (g_tuning.spread ? 0 : 0x10000), CNT_REDO, CNT_CHUNK_REDO);
+          k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
         }
         else
-          k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, (g_tuning.chunk & 0xffff) | (g_tuning.spread ? 0 : 0x10000), CNT_IN, CNT_CHUNK_CLOSEST);
+          k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
         pt_timers_end(tm, stream, 1);
       }, false});
@@ -1095,9 +1084,9 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
           shadowIn = rb.queueT;
         }
         if(heat)
-          k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, (g_tuning.chunk & 0xffff) | (g_tuning.spread ? 0 : 0x10000), fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
         else
-          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, (g_tuning.chunk & 0xffff) | (g_tuning.spread ? 0 : 0x10000), fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
         k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
         pt_timers_end(tm, stream, 3);
       }, false});

@@ -9,6 +9,9 @@
 #include "pt_sky.h"
 #include "pt_settle.h"
 
+#ifndef PT_ENV_EARLY
+#define PT_ENV_EARLY 1  // shade_path starts DirectLight's environment sample at the top of the hit branch (0: where pathtrace.glsl:122-128 has it; A/B builds)
+#endif
 enum { SHADE_DONE = 0, SHADE_TO_SHADOW = 1, SHADE_TO_NEXT = 2 };
 enum { EV_MISS = 1u, EV_HIT = 2u, EV_NEE = 4u };
 
@@ -218,7 +221,21 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
   // ---- hit ----
   events |= EV_HIT;
+  // The dependent chain of a shading is what this kernel waits for (hit -> shading line -> instance -> material -> texels -> alias table -> environment
+  // texels: six to seven round trips).  The environment sample of DirectLight depends on nothing but the path's RNG state when there are no punctual
+  // lights and no sun & sky (its three draws are then the first draws of the bounce, pathtrace.glsl:122-128), so its two round trips -- alias-table
+  // entry, then the four environment texels -- are started HERE and overlap the geometry / material chain.  Same draws, same arithmetic, issued earlier.
+  const bool envEarly = PT_ENV_EARLY != 0 && nbLights == 0 && !useSky;
+  f3         earlyContrib = splat3(0.0f), earlyDir = splat3(0.0f);
+  float      earlyPdf = 0.0f;
+  uint32_t   seedAfterEnv = seed;
+  if(envEarly)
+  {
+    const float a = rng_next(seedAfterEnv), b = rng_next(seedAfterEnv), c = rng_next(seedAfterEnv);
+    earlyContrib  = env_importance_sample(S, f3{a, b, c}, earlyDir, earlyPdf);
+  }
   uint32_t     hitInst, hitPrim;
+  int          hitMat = -2;  // material index when the shading line carries it (-2: take it from the instance record)
   VertexTriple vt;
   bool         haveVt = false;
   if(S.twoLevel)
@@ -237,6 +254,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
       const float4 id = S.shadeTris[size_t(hslot) * PT_SHADE_REC_QUADS + 6];
       hitInst         = __float_as_uint(id.x);
       hitPrim         = __float_as_uint(id.y);
+      hitMat          = int(__float_as_uint(id.z));  // the instance's material index: the material fetch need not wait for the instance record
     }
     else
     {
@@ -253,7 +271,8 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
   surface_at_hit(S, I, vt, hit.z, hit.w, sf, vcolor);
   const f3 hitPos = sf.position;
   sf.ffnormal     = dot3(sf.normal, rdir) <= 0.0f ? sf.normal : -sf.normal;
-  resolve_material(S, S.materials[I.materialIndex < 0 ? 0 : I.materialIndex], rdir, sf);
+  const int matIndex = hitMat != -2 ? hitMat : I.materialIndex;
+  resolve_material(S, S.materials[matIndex < 0 ? 0 : matIndex], rdir, sf);
   sf.albedo *= vcolor;
 
   if(dbg != PT_DEBUG_NONE && dbg < PT_DEBUG_RADIANCE)  // pathtrace.glsl:61-83,255-256
@@ -328,6 +347,15 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
       lightDir     = unit(T * dd.x + B * dd.y + sd * dd.z);
       lightContrib = sun_and_sky(S.sunsky, lightDir);
       lightPdf     = 0.5f;
+      lightContrib *= st.hdrMultiplier;
+    }
+    else if(envEarly)
+    {  // sampled at the top of the hit branch (same three draws)
+      seed = seedAfterEnv;
+      events |= EV_NEE;
+      lightContrib = earlyContrib;
+      lightDir     = earlyDir;
+      lightPdf     = earlyPdf;
       lightContrib *= st.hdrMultiplier;
     }
     else
