@@ -13,7 +13,9 @@
 #pragma once
 #include "pt_trace.h"
 #ifndef PT_SORTED_VISIT
-#define PT_SORTED_VISIT 1  // the persistent kernels' node visit in its round-4 form (pt_trace.h wide_node_step_cs); 0: the round-3 form, for A/B builds
+#define PT_SORTED_VISIT 0  // 1: the persistent kernels' node visit in the round-4 form (pt_trace.h wide_node_step_cs: sorting network, straight-line pushes,
+                           // per-ray plane slack).  Measured equal to the round-3 form within the run-to-run noise of 1 % (profiles/r04c_*, r04e_*) at more
+                           // scratch (192-208 B against 176 B per lane): kept as an A/B build, not the default
 #endif
 
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       pslot           = queueIn[qi];
       const float4 dw = rb.ps.rayD[pslot];
       seed            = __float_as_uint(dw.w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0, TWO ? 0.0f : S.cnodeBound);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
       alive = true;
       ++nRays;
       if(HEAT)
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     {
       pslot = queueIn[qi];
       seed  = __float_as_uint(rb.ps.rayD[pslot].w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0, TWO ? 0.0f : S.cnodeBound);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
       alive = true;
       ++nRays;
       if(HEAT)

@@ -9,9 +9,6 @@
 #include "pt_sky.h"
 #include "pt_settle.h"
 
-#ifndef PT_ENV_EARLY
-#define PT_ENV_EARLY 1  // shade_path starts DirectLight's environment sample at the top of the hit branch (0: where pathtrace.glsl:122-128 has it; A/B builds)
-#endif
 enum { SHADE_DONE = 0, SHADE_TO_SHADOW = 1, SHADE_TO_NEXT = 2 };
 enum { EV_MISS = 1u, EV_HIT = 2u, EV_NEE = 4u };
 
@@ -221,19 +218,9 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
   // ---- hit ----
   events |= EV_HIT;
-  // The dependent chain of a shading is what this kernel waits for (hit -> shading line -> instance -> material -> texels -> alias table -> environment
-  // texels: six to seven round trips).  The environment sample of DirectLight depends on nothing but the path's RNG state when there are no punctual
-  // lights and no sun & sky (its three draws are then the first draws of the bounce, pathtrace.glsl:122-128), so its two round trips -- alias-table
-  // entry, then the four environment texels -- are started HERE and overlap the geometry / material chain.  Same draws, same arithmetic, issued earlier.
-  const bool envEarly = PT_ENV_EARLY != 0 && nbLights == 0 && !useSky;
-  f3         earlyContrib = splat3(0.0f), earlyDir = splat3(0.0f);
-  float      earlyPdf = 0.0f;
-  uint32_t   seedAfterEnv = seed;
-  if(envEarly)
-  {
-    const float a = rng_next(seedAfterEnv), b = rng_next(seedAfterEnv), c = rng_next(seedAfterEnv);
-    earlyContrib  = env_importance_sample(S, f3{a, b, c}, earlyDir, earlyPdf);
-  }
+  // (Starting DirectLight's environment sample here -- its three draws are the first of the bounce when there are no punctual lights and no sun & sky,
+  // so its two round trips could overlap the geometry / material chain -- measured 1 % SLOWER: the seven values it keeps alive across the material
+  // code spill (96 -> 168 B of scratch at 128 VGPRs), profiles/r04e_*.)
   uint32_t     hitInst, hitPrim;
   int          hitMat = -2;  // material index when the shading line carries it (-2: take it from the instance record)
   VertexTriple vt;
@@ -347,15 +334,6 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
       lightDir     = unit(T * dd.x + B * dd.y + sd * dd.z);
       lightContrib = sun_and_sky(S.sunsky, lightDir);
       lightPdf     = 0.5f;
-      lightContrib *= st.hdrMultiplier;
-    }
-    else if(envEarly)
-    {  // sampled at the top of the hit branch (same three draws)
-      seed = seedAfterEnv;
-      events |= EV_NEE;
-      lightContrib = earlyContrib;
-      lightDir     = earlyDir;
-      lightPdf     = earlyPdf;
       lightContrib *= st.hdrMultiplier;
     }
     else
