@@ -27,7 +27,7 @@ After the timed region (never part of `value`), rank 0 measures what the JSON li
                      standalone stage durations (HIP events on the launching stream, nothing overlapped)
   roofline           the stage with the largest standalone time: `achieved` / `frac` = SURVEY.md 8(d) ALGORITHMIC bytes per launch / its average
                      launch duration vs 8 TB/s (may exceed 1: most algorithmic bytes are served by L2 / Infinity Cache); `traffic` /
-                     `traffic_frac` = HBM bytes per launch from this round's PMC passes (profiles/r03_traffic.json, tools/pmc_r03.sh);
+                     `traffic_frac` = HBM bytes per launch from this round's PMC passes (profiles/r03_traffic.json, tools/pmc_passes.sh);
                      `l2_*` = L2 requests of the same stage (profiles/r03_cache.json) against the 34.5 TB/s L2 ceiling
   hbm_measured       measured HBM bytes per sample x this run's rate
   issue_roofline     VALU wave-instructions per sample (profiles/r03_valu.json, same PMC run) x this run's rate / the calibrated ceiling
@@ -336,7 +336,7 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
         if traffic_j:
             tot = traffic_j["hbm_bytes_per_sample"]["total"]
             out["hbm_measured"] = {"bytes_per_sample": tot, "GBps": tot * samples / max(1, world) / elapsed / 1e9, "frac": tot * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
-                                   "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_r03.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
+                                   "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
                                    "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
         # `achieved` / `frac`: SURVEY.md 8(d) -- algorithmic bytes per launch over the stage's average standalone launch duration, against the HBM peak.
         # The algorithmic bytes are reference-layout node / triangle / material records; most of them are served by L2 / Infinity Cache (scene + BVH

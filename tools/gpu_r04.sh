@@ -10,7 +10,7 @@
 #   libs:<steps>:<a>,<b>,...    bench with each libptmi variant of vk_raytrace_amd/variants/ ("default" = the product), two alternating rounds
 #   tests[:<-k expression>]     pytest -m gpu
 #   smoke               __graft_entry__.smoke()
-#   pmc[:<frames>]      tools/pmc_r03.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
+#   pmc[:<frames>]      tools/pmc_passes.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
 #   shards:<wl>:<steps> every rank's shard of N = 1, 2, 4, 8 on this one GPU (bench.py --emulate-shard R/N); max over ranks per N
 #   shardtune:<wl>:<steps>:<R/N>:<A>;<B>;...   one rank's shard under each PT_TUNE string, two alternating rounds
 #   sh:<command>        anything else
@@ -41,7 +41,7 @@ for step in "$@"; do
                PT_LIB=$L timeout 300 python bench.py --steps $a --warmup 8 --no-cpu-baseline --no-profile --no-interactive 2>/dev/null | val | tee -a $O/log.txt; done; done ;;
     tests)   if [ -n "$a" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$a" > $O/gputest.txt 2>&1; else timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; fi; tail -5 $O/gputest.txt | tee -a $O/log.txt ;;
     smoke)   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a $O/log.txt ;;
-    pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_r03.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;
+    pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_passes.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;
     shards)  for n in 1 2 4 8; do worst=0; for ((r = 0; r < n; r++)); do
                timeout 300 python bench.py --workload $a --emulate-shard $r/$n --steps $b --warmup 5 --no-cpu-baseline --no-profile --no-interactive > $O/shard_${a}_${r}of${n}_$b.json 2>/dev/null
                ms=$(python -c "import json; print(json.loads(open('$O/shard_${a}_${r}of${n}_$b.json').readline())['ms_per_step'])" 2>/dev/null || echo 0)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU box: the PMC passes behind profiles/r03_traffic.json, r03_valu.json and r03_cache.json (read by bench.py).
+# GPU box: the PMC passes behind profiles/rNN_traffic.json, rNN_valu.json and rNN_cache.json (read by bench.py).
 # One rocprofv3 run per counter group (counters + kernel trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass; never together with
 # --stats / --sys-trace), each under `timeout`: a pass that wedges costs minutes, not the box.  The bench runs the TIMED pipeline (default
 # launch policy: k_tail takes the late bounces) as batches of 32 frames on one frame slot (inflight=1): rocprofv3 serialises kernels for
 # counter collection anyway, and the per-kernel attribution is then exact.  96 frames = three batches, so that the queue-size feedback
 # has settled for two of them.
-# usage: tools/pmc_r03.sh [tag]      -> gpurun_out/pmc_<tag>/{traffic.json,valu.json,cache.json}
+# usage: tools/pmc_passes.sh [tag]      -> gpurun_out/pmc_<tag>/{traffic.json,valu.json,cache.json}
 TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
@@ -16,10 +16,10 @@ rocprofv3 -L > $OUT/counters_available.txt 2>&1
 i=0
 for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
-  PT_TUNE=inflight=1 timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw$i -o p -- \
-    python $REPO/bench.py --steps $FRAMES --warmup 0 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
+  PT_TUNE=inflight=1,warm=0 timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw$i -o p -- \
+    python $REPO/bench.py --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
   echo "pass $i ($CTRS): rc $?"
   find $OUT/raw$i -name '*counter_collection.csv' -exec cp {} $OUT/counters$i.csv \;
   rm -rf $OUT/raw$i
 done
-python3 $REPO/tools/pmc_r03_json.py $OUT $FRAMES
+python3 $REPO/tools/pmc_passes_json.py $OUT $FRAMES

@@ -1,4 +1,4 @@
-"""Turns the rocprofv3 PMC passes of tools/pmc_r03.sh into
+"""Turns the rocprofv3 PMC passes of tools/pmc_passes.sh into
   traffic.json  HBM bytes per sample, per kernel / stage / total
   valu.json     VALU (and SALU / VMEM / LDS / SMEM) wave-instructions per sample, per kernel and total; SQ cycle counters where collected
   cache.json    L2 (TCC) requests, hits and misses per sample and the hit rate, per kernel / stage; L1 (TCP) accesses where collected
