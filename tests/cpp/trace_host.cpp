@@ -365,6 +365,8 @@ extern "C" unsigned long long th_take_inner_steps() { return g_innerSteps.exchan
 static std::atomic<unsigned long long> g_leafSteps{0}, g_restarts{0};  // triangle steps / EARLY walks that started over, same bracket
 extern "C" unsigned long long th_take_leaf_steps() { return g_leafSteps.exchange(0); }
 extern "C" unsigned long long th_take_restarts() { return g_restarts.exchange(0); }
+static int g_pipe = 1;  // the machine walks of the flat structure run the pipelined form (pt_machine.h lane_issue / lane_step) when it has compact nodes, like the kernels
+extern "C" void th_set_pipe(int on) { g_pipe = on; }
 static int g_shadowEarly = 1;  // shadow rays of the flat structure walk with the exact early-out (pt_machine.h EARLY), like k_shadow_p
 extern "C" void th_set_shadow_early(int on) { g_shadowEarly = on; }
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
@@ -872,8 +874,22 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
         TraceLane             L;
         std::vector<uint32_t> spill(STACK_SPILL);
         lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0, two ? 0.0f : S.cnodeBound);
+        const bool pipe = g_pipe && !two && S.cnodes != nullptr;
+        LaneFetch  F;
+        if(pipe && !L.done)
+          lane_issue(S, L, F);
         for(;;)
         {
+          while(pipe && !L.done)
+          {
+            if(L.cur & BVH_LEAF) ++leafSteps; else ++innerSteps;
+            const uint32_t e0 = L.early;
+            if(early) lane_step<true>(S, L, F, stack.data(), spill.data(), &cnt); else lane_step<false>(S, L, F, stack.data(), spill.data(), &cnt);
+            if(e0 == 1 && L.early == 2)
+              ++g_restarts;
+            if(!L.done)
+              lane_issue(S, L, F);
+          }
           while(!L.done)
           {
             if(!(L.cur & BVH_LEAF))
@@ -899,6 +915,8 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
           if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
           {
             if(two) lane_begin_count<true>(L); else lane_begin_count<false>(L);
+            if(pipe)
+              lane_issue(S, L, F);
             continue;
           }
           if(!fallback)

@@ -355,8 +355,19 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
         same = (got[0] == ref[0]) & (got[1].view(np.uint32) == ref[1].view(np.uint32)).all(1) & (got[2] == ref[2])
         assert same.all(), f"{name}: closest-hit on compact nodes, two={two}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
         assert np.array_equal(got[3], ref[3])
-    trc.close()
     tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
+    # ... and in both forms of the machine's loop on them: pipelined (lane_issue / lane_step: the next record requested one iteration ahead, what
+    # k_closest_p / k_shadow_p run on a flat-format structure) and two-phase (lane_inner / lane_leaf), closest-hit and bounded shadow rays
+    for pipe in (1, 0):
+        trc.L.th_set_pipe(pipe)
+        got = trc.settle(0, 0, 2, org, dirs, seeds)
+        assert (got[0] == ref[0]).all() and (got[1].view(np.uint32) == ref[1].view(np.uint32)).all() and (got[2] == ref[2]).all() and np.array_equal(got[3], ref[3]), f"{name}: pipe={pipe}"
+        for variant in (0, 1):
+            want = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
+            got = trc.settle(1, 0, 2, org, dirs, seeds, tmax, variant)
+            assert (got[0] == want[0]).all() and (got[2] == want[2]).all(), f"{name}: shadow rays on compact nodes, pipe={pipe} variant={variant}"
+    trc.L.th_set_pipe(1)
+    trc.close()
     for variant in (0, 1):
         ref = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
         for two, exact in ((0, 0), (1, 0), (1, 1), (0, 2), (1, 2)):

@@ -209,6 +209,8 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 }
 #endif
 
+template <bool SHADOW, bool TWO, bool EARLY>
+PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, uint32_t* lds, uint32_t* spill);
 // One leaf (triangle) visit; same candidate rules as traverse<TM_CLOSEST / TM_SHADOW / TM_COUNT>.
 template <bool SHADOW, bool TWO = false, bool EARLY = false>
 PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill)
@@ -233,6 +235,12 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
   if(TWO && L.ic.inst != PT_INST_MERGED)
     tr = world_tri(S, L.ic, tr);
 #endif
+  lane_leaf_with<SHADOW, TWO, EARLY>(S, L, slot, tr, ar, lds, spill);
+}
+// the triangle step on records already in registers
+template <bool SHADOW, bool TWO, bool EARLY>
+PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, uint32_t* lds, uint32_t* spill)
+{
   const uint32_t wbits = __float_as_uint(tr.p0w.w);
   const uint32_t flags = wbits >> 29;
   const bool     opq   = (flags & TRI_OPAQUE) != 0;
@@ -295,6 +303,66 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
   }
   lane_pop<TWO, EARLY>(L, lds, spill);
 }
+
+#if PT_BVH_WIDTH != 2
+// ---- the same machine with ONE memory wait per iteration (round 4; flat-format structure with compact nodes) -----------------------------------------
+// lane_inner / lane_leaf each fetch what they need and wait for it: a loop iteration (node step for the lanes at an inner node, then triangle step
+// for the lanes at a leaf) has two dependent round trips, and the wavefront sits out both.  Here a lane's NEXT record -- the 80-byte node, or the
+// 48-byte triangle (+ the 32-byte any-hit record of a non-opaque one) -- is requested at the END of its step (lane_issue) into five quads that stay
+// in registers across the loop's back edge, and consumed at the start of the next iteration (lane_step): one wait per iteration, covering node
+// lanes and triangle lanes alike, and five request instructions per iteration instead of five plus three to five.  Arithmetic, candidate rules and
+// stack discipline are those of lane_inner / lane_leaf (the visit bodies are shared: cnode_visit, lane_leaf_with).
+struct LaneFetch {
+  uint4 q[5];  // node: header, X, Y, Z planes, children.  leaf: p0w, e1n, e2p, AlphaRec (two quads, non-opaque triangles only)
+};
+PT_DEV void lane_issue(const DeviceScene& S, const TraceLane& L, LaneFetch& F)
+{
+  const bool     leaf = (L.cur & BVH_LEAF) != 0;
+  const uint32_t slot = L.cur & BVH_SLOT_MASK;
+  const char*    a    = leaf ? reinterpret_cast<const char*>(S.tris) + size_t(slot) * sizeof(TriRec) : reinterpret_cast<const char*>(S.cnodes) + size_t(slot) * sizeof(CompactNode);
+  F.q[0]              = *reinterpret_cast<const uint4*>(a);
+  F.q[1]              = *reinterpret_cast<const uint4*>(a + 16);
+  F.q[2]              = *reinterpret_cast<const uint4*>(a + 32);
+  if(!leaf || (L.cur & BVH_ALPHA))
+  {
+    const char* b = leaf ? reinterpret_cast<const char*>(S.alphaRecs) + size_t(slot) * sizeof(AlphaRec) : a + 48;
+    F.q[3]        = *reinterpret_cast<const uint4*>(b);
+    F.q[4]        = *reinterpret_cast<const uint4*>(b + 16);
+  }
+}
+PT_DEV float4 quad_as_float4(uint4 q) { return make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); }
+template <bool EARLY = false>
+PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const LaneFetch& F, uint32_t* lds, uint32_t* spill, Counters* counters)
+{
+  if(!(L.cur & BVH_LEAF))
+  {
+    const float lim = L.pass == 1 ? L.tmax : L.bt;
+    auto pushChild = [&](uint32_t c) {
+      if(L.sp < STACK_LDS)
+        lds[L.sp++ * TRACE_BLOCK] = c;
+      else if(L.sp < STACK_LDS + STACK_SPILL)
+        spill[L.sp++ - STACK_LDS] = c;
+      else
+        atomicAdd(&counters->stackOverflow, 1u);
+    };
+    const bool     alphaOnly = L.pass == 1 || (EARLY && L.early == 1);
+    const uint32_t nxt       = cnode_visit(quad_as_float4(F.q[0]), F.q[1], F.q[2], F.q[3], F.q[4], L.rbox, lim, alphaOnly, pushChild);
+    if(nxt != BVH_NONE)
+      L.cur = nxt;
+    else
+      lane_pop<false, EARLY>(L, lds, spill);
+  }
+  else
+  {
+    TriRec tr;
+    tr.p0w = quad_as_float4(F.q[0]); tr.e1n = quad_as_float4(F.q[1]); tr.e2p = quad_as_float4(F.q[2]);
+    AlphaRec ar;
+    ar.uv0[0] = __uint_as_float(F.q[3].x); ar.uv0[1] = __uint_as_float(F.q[3].y); ar.uv1[0] = __uint_as_float(F.q[3].z); ar.uv1[1] = __uint_as_float(F.q[3].w);
+    ar.uv2[0] = __uint_as_float(F.q[4].x); ar.uv2[1] = __uint_as_float(F.q[4].y); ar.material = F.q[4].z; ar._pad = F.q[4].w;
+    lane_leaf_with<false, false, EARLY>(S, L, L.cur & BVH_SLOT_MASK, tr, ar, lds, spill);
+  }
+}
+#endif
 
 // Wave-uniform ray supply: a wave reserves PT_CHUNK consecutive queue entries with one atomic and hands them to
 // its idle lanes.  Returns the queue index for this lane or 0xffffffff.

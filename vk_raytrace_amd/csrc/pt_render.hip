@@ -50,6 +50,9 @@ namespace {
 #ifndef PT_TRACE_WAVES_TWO
 #define PT_TRACE_WAVES_TWO 4  // two-level instantiations: object-space ray constants + instance context are live on top of the flat state (128 VGPRs)
 #endif
+#ifndef PT_TRACE_WAVES_PIPE
+#define PT_TRACE_WAVES_PIPE 4  // the pipelined machine keeps a lane's next record (five quads) in registers across the loop's back edge
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4  // 128 VGPRs.  The first bounce's shade launch streams ~700 B per path and is HBM-bound: a fourth wave per SIMD keeps more
                           // loads in flight (+5 % on the 96-step bench against 3 waves / 137 VGPRs, profiles/r03h_*)
@@ -166,9 +169,11 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
 // HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
 // instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
-template <bool HEAT, bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
+template <bool HEAT, bool TWO, bool PIPE = false>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE ? PT_TRACE_WAVES_PIPE : PT_TRACE_WAVES)) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
+  static_assert(!(PIPE && TWO), "the pipelined machine walks the flat-format structure");
+  LaneFetch F;  // (PIPE) the lane's next record, requested one iteration ahead
   uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
@@ -197,7 +202,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     {
       bool fallback = (L.flags & TF_SAW_FRAC) != 0;
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
+      {
         lane_begin_count<TWO>(L);  // stay alive: pass B runs in the same loop
+        if(PIPE)
+          lane_issue(S, L, F);
+      }
       else
       {
         if(!fallback)
@@ -230,6 +239,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       const float4 dw = rb.ps.rayD[pslot];
       seed            = __float_as_uint(dw.w);
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
+      if(PIPE && !L.done)
+        lane_issue(S, L, F);
       alive = true;
       ++nRays;
       if(HEAT)
@@ -247,6 +258,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 #ifdef PT_HIST
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
+      if(PIPE)
+      {  // one wait per iteration: the records were requested at the end of the previous step (pt_machine.h lane_issue / lane_step)
+        if(!L.done)
+        {
+          lane_step<false>(S, L, F, lds, spill, rb.counters);
+          if(!L.done)
+            lane_issue(S, L, F);
+        }
+        continue;
+      }
       if(!L.done && !(L.cur & BVH_LEAF))
         lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
@@ -434,10 +455,12 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
 
 // Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
 // zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
-template <bool HEAT, bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
+template <bool HEAT, bool TWO, bool PIPE = false>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE ? PT_TRACE_WAVES_PIPE : PT_TRACE_WAVES)) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
+  static_assert(!(PIPE && TWO), "the pipelined machine walks the flat-format structure");
+  LaneFetch F;
   uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -469,7 +492,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     {
       bool fallback = (L.flags & TF_SAW_FRAC) != 0;
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
+      {
         lane_begin_count<TWO>(L);
+        if(PIPE)
+          lane_issue(S, L, F);
+      }
       else
       {
         bool inShadow = false;
@@ -504,6 +531,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       pslot = queueIn[qi];
       seed  = __float_as_uint(rb.ps.rayD[pslot].w);
       lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
+      if(PIPE && !L.done)
+        lane_issue(S, L, F);
       alive = true;
       ++nRays;
       if(HEAT)
@@ -522,6 +551,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       constexpr bool EARLY = !TWO && PT_SHADOW_EARLY != 0;
+      if(PIPE)
+      {
+        if(!L.done)
+        {
+          const bool wasLeaf = (L.cur & BVH_LEAF) != 0;
+          lane_step<EARLY>(S, L, F, lds, spill, rb.counters);
+          if(wasLeaf && S.allOpaque && L.bslot != BVH_NONE)
+            L.done = true;  // (see below)
+          if(!L.done)
+            lane_issue(S, L, F);
+        }
+        continue;
+      }
       if(!L.done && !(L.cur & BVH_LEAF))
         lane_inner<false, TWO, EARLY>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
@@ -1021,6 +1063,10 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage, no k_tail
+  // the pipelined trace machine (pt_machine.h lane_issue / lane_step): flat-format structure with compact nodes
+  const bool     pipe      = !TWO && g_tuning.pipe && scene.cnodes != nullptr && !heat;
+  const uint32_t pwPipe    = uint32_t(g_tuning.pipeWaves > 0 ? g_tuning.pipeWaves : 1);
+  const uint32_t gridPipe  = wavesAll < pwPipe ? wavesAll : pwPipe;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
@@ -1056,8 +1102,13 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         {
           const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
           k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
-          k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+          if(pipe)
+            k_closest_p<false, false, true><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+          else
+            k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
         }
+        else if(pipe)
+          k_closest_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         else
           k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
         k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
@@ -1085,6 +1136,8 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         }
         if(heat)
           k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+        else if(pipe)
+          k_shadow_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
         else
           k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
         k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);

@@ -313,6 +313,8 @@ PT_DEV float cn_plane(uint32_t word, int hi)
 // plane FMA's 2^-24 |t| with |t| <= |b| + 2047 |s|; the (1 -+ 4e-7) factors of the decision stay on top).  The planes of a slab share one request, so
 // near / far are picked by the direction sign with selects.
 template <class Push>
+PT_DEV uint32_t cnode_visit(float4 h, uint4 X, uint4 Y, uint4 Z, uint4 ch, const RayBox& rb, float lim, bool alphaOnly, Push&& push);
+template <class Push>
 PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
 {
   const char*    nb = reinterpret_cast<const char*>(nodes);
@@ -320,6 +322,12 @@ PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t
   const float4   h  = *reinterpret_cast<const float4*>(nb + at);
   const uint4    X = *reinterpret_cast<const uint4*>(nb + (at + 16u)), Y = *reinterpret_cast<const uint4*>(nb + (at + 32u)), Z = *reinterpret_cast<const uint4*>(nb + (at + 48u));
   const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 64u));
+  return cnode_visit(h, X, Y, Z, ch, rb, lim, alphaOnly, push);
+}
+// the visit proper, on the five quads of the node already in registers (the pipelined machine of pt_machine.h fetches them one iteration ahead)
+template <class Push>
+PT_DEV uint32_t cnode_visit(float4 h, uint4 X, uint4 Y, uint4 Z, uint4 ch, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
+{
   const uint32_t ex = __float_as_uint(h.w);
   const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
   const float    blx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx0 = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
