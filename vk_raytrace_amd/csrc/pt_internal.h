@@ -134,7 +134,9 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
                                    // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
-  int pipe                 = 1;    // persistent trace kernels of the flat-format structure: the pipelined machine (one memory wait per iteration; pt_machine.h lane_issue / lane_step)
+  int pipe                 = 0;    // 1: persistent trace kernels of the flat-format structure run the pipelined machine (one memory wait per iteration; pt_machine.h
+                                   // lane_issue / lane_step).  Bit-identical, measured 8 % SLOWER (profiles/r04h_*): a lane then advances one step per iteration instead of
+                                   // node step + triangle step, so a ray needs ~28 iterations instead of ~22 and every iteration still issues both code paths
   int pipeWaves            = 4096; // its waves per launch (4 per SIMD: the next record lives in registers across the loop)
   int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)

@@ -208,7 +208,17 @@ PT_DEV float opacity_eval(const DeviceScene& S, const AlphaRec& ar, float bu, fl
 // exact value (the stochastic test of the key-ordered fallback compares a draw with it)
 PT_DEV float opacity_from(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<false>(S, ar, bu, bv); }
 // <= 0, >= 1 or the exact value in between (all the two-pass traversal needs)
-#ifdef PT_NO_ALPHA_MAP  // (measurement only)
+#if defined(PT_ALPHA_ALWAYS_ONE)  // (measurement only, changes the image: every non-opaque candidate counts as fully opaque WITHOUT being evaluated -- what the
+                                  // evaluation itself costs, as opposed to the rays that continue through transparent texels)
+PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return 1.0f; }
+#elif defined(PT_ALPHA_EVAL_THEN_ONE)  // (measurement only, changes the image: the evaluation runs in full, its result is overruled -- against
+                                      // PT_ALPHA_ALWAYS_ONE this isolates what the evaluation costs where it stands, inside the triangle step)
+PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv)
+{
+  const float v = opacity_eval<true>(S, ar, bu, bv);
+  return v > -1.0f ? 1.0f : v;
+}
+#elif defined(PT_NO_ALPHA_MAP)  // (measurement only)
 PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<false>(S, ar, bu, bv); }
 #else
 PT_DEV float opacity_class(const DeviceScene& S, const AlphaRec& ar, float bu, float bv) { return opacity_eval<true>(S, ar, bu, bv); }
