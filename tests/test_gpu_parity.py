@@ -180,8 +180,10 @@ def test_sponza_like_reduced(env_small, tail_policy):
 
 def test_c3_full_size_256spp():
     """BASELINE C3 as stated: 1920x1080, 256 spp, depth 8, Disney + HDR env (synthetic Sponza stand-in): determinism, tile-shard invariance,
-    and the converged 256-spp image against the oracle on every 256th 8x8 block (8 k pixels x 256 spp) -- bit-exact, i.e. L2 == 0 <= 1e-3."""
-    wl = workloads.c3_sponza(1920, 1080, 256, tex_size=256, env_w=1024)
+    and the converged 256-spp image against the oracle on every 256th 8x8 block (8 k pixels x 256 spp) -- bit-exact, i.e. L2 == 0 <= 1e-3.
+    The scene is the one bench.py times (workloads.c3_sponza's defaults: 1024^2 textures, 2048 x 1024 environment), not a reduced variant; the bench
+    line itself carries the same comparison for the frames of its first window (`parity`)."""
+    wl = workloads.c3_sponza(1920, 1080, 256)
     cfg = Config(wl.scene, wl.env, 1920, 1080, depth=8, pbr=0)
     a = render_hip(cfg, 2)
     assert np.array_equal(a, render_hip(cfg, 2))                          # run-to-run determinism (queue order is irrelevant)
