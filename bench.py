@@ -383,6 +383,9 @@ def main():
     from vk_raytrace_amd import host_device as hd
 
     # bind the GPU first: "device ordinal R out of range: K HIP device(s) visible" comes from pt_create, before any rendezvous can hang
+    same_device = os.environ.get("PT_BENCH_SAME_DEVICE") == "1"  # TEST HOOK (tests/test_comm.py): every rank on device 0, so that the multi-process flow --
+    if same_device:                                              # rendezvous, barriers around the windows, MAX of the ranks' times, counters summed -- runs
+        local_rank = 0                                           # on a one-GPU box; RCCL refuses two ranks on one device, so the gather is skipped
     r = HipRenderer()
     r.setup(local_rank)
 
@@ -465,7 +468,10 @@ def main():
 
     # the one collective of the path (untimed, reported): libptmi's own RCCL gather behind the C ABI (pt_gather_shards / pt_gather_finish)
     ranks_seen = 1
-    if world > 1 or force_dist:
+    if same_device and world > 1:
+        ranks_seen, img, gather_ms = world, None, None  # (test hook: no collective between two ranks on one device)
+        r.synchronize()
+    elif world > 1 or force_dist:
         gatherer = shard.NativeGather(rank, world, local_rank, dist)
         ranks_seen = gatherer.ranks_seen()
         r.synchronize()

@@ -80,6 +80,28 @@ def test_bench_gpus_2_on_a_one_gpu_box():
 
 
 @pytest.mark.gpu
+def test_bench_two_processes_share_one_gpu():
+    """The multi-process flow of bench.py for real -- two self-launched ranks, the torch-free rendezvous, barriers around every timed window, the MAX
+    of the ranks' times, counters summed over the ranks -- with both ranks on device 0 (PT_BENCH_SAME_DEVICE=1: RCCL refuses two ranks on one device,
+    so only the gather is left to the one-rank tests below and to the driver's 8-GPU run)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PT_BENCH_SAME_DEVICE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "256", "--height", "160", "--tex-size", "32",
+           "--tris", "2000", "--no-profile", "--no-interactive"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and len(line["repeats"]) == 2 and line["value"] > 0
+    assert line["scaling"] == "strong" and "parity" not in line and "cpu_baseline" not in line   # the CPU leg is rank 0 at N = 1 only
+    one = subprocess.run(cmd[:3] + ["1"] + cmd[4:] + ["--no-cpu-baseline"], env={k: v for k, v in env.items() if k != "PT_BENCH_SAME_DEVICE"}, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests"):
+        assert line["rays"][k] == ref["rays"][k], k   # the two shards together trace exactly the rays of the whole image
+
+
+@pytest.mark.gpu
 def test_single_process_gather_with_one_device():
     """pt_comm_init_all + pt_comm_group_begin / pt_gather_shards / pt_comm_group_end + pt_gather_finish: the flavour one process driving N GPUs
     uses, here with N = 1 (everything but the peer-to-peer transfers runs).  The gathered image equals the plain read-back."""
