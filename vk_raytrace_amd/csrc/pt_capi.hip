@@ -59,6 +59,7 @@ struct pt_context {
   bool     anyHit = true;               // RtxPipeline::useAnyHit (src/rtx_pipeline.cpp:269-276); false: every triangle is opaque
   std::vector<InstanceRec> hInstances;  // as built by pt_set_scene (flags without the useAnyHit override)  // frames were launched since the traversal-stack overflow counter was last looked at
   bool     haveScene = false, haveAccel = false, haveEnv = false, haveCamera = false;
+  bool     warmPending = true;  // the next pt_resize warms the frame slots (once per acceleration structure: not on the resizes of an interactive session)
   DeviceScene scene{};
 
   // output / path state
@@ -618,6 +619,7 @@ int build_two_level(pt_context* c)
   HIP_TRY(c, sync_all(c));
   c->msBuild   = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   c->haveAccel = true;
+  c->warmPending = true;
   refresh_scene_ptrs(c);
   return PT_OK;
 }
@@ -1194,6 +1196,7 @@ int pt_build_accel(pt_context* c)
     bounds_from_root(c, root, c->numTris > 1 && root.d.y != BVH_NONE);
   }
   c->haveAccel = true;
+  c->warmPending = true;
   refresh_scene_ptrs(c);
   return PT_OK;
 }
@@ -1366,12 +1369,13 @@ int pt_set_shard(pt_context* c, int rank, int nranks)
 // here, untimed by definition.  Every frame slot's path state and queues are written once (first use of ~45 GB of fresh allocations), and one
 // throw-away launch sequence runs on every slot's stream -- code objects of all stage kernels loaded, clocks up, scene / structure / textures
 // pulled through the caches once, and the queue-size feedback (where k_tail takes over) seeded with the alive fractions of THIS scene
-// instead of the 0.3-per-bounce guess.  Nothing the caller can observe changes: the accumulation image is cleared afterwards (pt_resize
+// instead of the 0.3-per-bounce guess.  Once per acceleration structure (pt_build_accel re-arms it).  Nothing the caller can observe changes: the accumulation image is cleared afterwards (pt_resize
 // clears it anyway), the device counters are put back, statistics and frame numbering are untouched.  PT_TUNE warm=0 skips it.
 static int warm_slots(pt_context* c)
 {
-  if(!g_tuning.warm || !c->haveScene || !c->haveAccel || !c->haveCamera || !(c->haveEnv || c->scene.sunsky.in_use == 1) || c->numSlots == 0)
+  if(!g_tuning.warm || !c->warmPending || !c->haveScene || !c->haveAccel || !c->haveCamera || !(c->haveEnv || c->scene.sunsky.in_use == 1) || c->numSlots == 0)
     return PT_OK;
+  c->warmPending = false;  // once per scene: the de-scaling resizes of an interactive session (sample_example.cpp:410-413) must not stall on it
   if(c->scene.camera.nbLights < 0 || uint32_t(c->scene.camera.nbLights) > c->numLights)
     return PT_OK;  // pt_render_frame reports it
   Counters saved;
