@@ -119,6 +119,67 @@ static inline bool th_tri_test_robust(const TriRec& tr, uint32_t flags, f3 o, f3
 }
 #define PT_TRI_TEST_OVERRIDE th_tri_test_robust
 #endif
+#ifdef TH_CERTIFIED_T2
+// EXPERIMENT (tools/t2_robust_experiment.py; not the contract): "certified" T2 -- the contract's fp32 Moeller-Trumbore, whose ACCEPTED candidates are kept
+// only when the forward error bound of round 2's experiment certifies their barycentrics to TH_TAU (and their distance to TH_TAU relative): no fp64, no
+// second code path for a wavefront to diverge into, ~35 more fp32 operations per test.  A candidate that fp32 cannot certify counts as a miss ON EVERY SIDE
+// (brute force, every walk), so what is left of "BVH-dependent" is a hit that lies up to TH_TAU of its triangle's extent outside the triangle's box.
+#include <atomic>
+#include "pt_device.h"
+#ifndef TH_TAU
+#define TH_TAU 0.0078125f  // 2^-7
+#endif
+static std::atomic<unsigned long long> g_t2Calls{0}, g_t2Double{0};  // [tests, fp32 accepts that certification turned into misses]
+static thread_local unsigned long long tl_t2Calls = 0, tl_t2Double = 0;
+extern "C" void th_t2_stats(unsigned long long* out2) { out2[0] = g_t2Calls.exchange(0); out2[1] = g_t2Double.exchange(0); }
+static std::atomic<unsigned long long> g_t2Accepts{0};
+static thread_local unsigned long long tl_t2Accepts = 0;
+extern "C" unsigned long long th_t2_accepts() { return g_t2Accepts.exchange(0); }
+static inline bool th_tri_test_certified(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
+{
+  const f3    e1 = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
+  const f3    pv = cross3(d, e2);
+  const float det = dot3(e1, pv);
+  ++tl_t2Calls;
+  if(det == 0.0f)
+    return false;
+  if(!(flags & TRI_NOCULL))
+  {
+    const bool front = (flags & TRI_FLIP) ? (det < 0.0f) : (det > 0.0f);
+    if(!front)
+      return false;
+  }
+  const float inv = 1.0f / det;
+  const f3    tv  = o - p0;
+  const float nu  = dot3(tv, pv);
+  u               = nu * inv;
+  if(u < 0.0f || u > 1.0f)
+    return false;
+  const f3    qv = cross3(tv, e1);
+  const float nv = dot3(d, qv);
+  v              = nv * inv;
+  if(v < 0.0f || u + v > 1.0f)
+    return false;
+  const float nt = dot3(e2, qv);
+  t              = nt * inv;
+  // certification of the accepted candidate
+  const f3    apv = f3{fabsf(d.y) * fabsf(e2.z) + fabsf(d.z) * fabsf(e2.y), fabsf(d.z) * fabsf(e2.x) + fabsf(d.x) * fabsf(e2.z), fabsf(d.x) * fabsf(e2.y) + fabsf(d.y) * fabsf(e2.x)};
+  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
+  const f3    aqv = f3{atv.y * fabsf(e1.z) + atv.z * fabsf(e1.y), atv.z * fabsf(e1.x) + atv.x * fabsf(e1.z), atv.x * fabsf(e1.y) + atv.y * fabsf(e1.x)};
+  const float k   = 8.0f * 5.9604645e-8f;
+  const float edet = k * (fabsf(e1.x) * apv.x + fabsf(e1.y) * apv.y + fabsf(e1.z) * apv.z);
+  const float eu   = k * (atv.x * apv.x + atv.y * apv.y + atv.z * apv.z);
+  const float ev   = k * (fabsf(d.x) * aqv.x + fabsf(d.y) * aqv.y + fabsf(d.z) * aqv.z);
+  const float et   = k * (fabsf(e2.x) * aqv.x + fabsf(e2.y) * aqv.y + fabsf(e2.z) * aqv.z);
+  const float adet = fabsf(det);
+  ++tl_t2Accepts;
+  const bool ok = (eu + ev + 2.0f * edet) <= TH_TAU * adet && (et * adet + fabsf(nt) * edet) <= TH_TAU * fabsf(nt) * adet;
+  if(!ok)
+    ++tl_t2Double;
+  return ok;
+}
+#define PT_TRI_TEST_OVERRIDE th_tri_test_certified
+#endif
 #include "pt_shade.h"  // pt_settle.h (pt_trace.h + the per-ray settle functions k_tail runs) + the shading steps of a path (generate_ray, shade_path, ...)
 #include "pt_machine.h"  // the resumable per-lane traversal of the persistent kernels (k_closest_p / k_shadow_p)
 #include "pt_cnode.h"    // WideNode -> CompactNode (what pt_accel.hip k_compact_nodes runs per node)
@@ -819,9 +880,13 @@ uint32_t th_candidates(void* p, int mode, uint32_t nrays, const float* org, cons
         wPrev = bw;
       }
     }
-#ifdef TH_ROBUST_T2
+#if defined(TH_ROBUST_T2) || defined(TH_CERTIFIED_T2)
     g_t2Calls += tl_t2Calls; g_t2Double += tl_t2Double;
     tl_t2Calls = tl_t2Double = 0;
+#endif
+#ifdef TH_CERTIFIED_T2
+    g_t2Accepts += tl_t2Accepts;
+    tl_t2Accepts = 0;
 #endif
 #pragma omp critical
     total.stackOverflow += cnt.stackOverflow;
@@ -1015,6 +1080,14 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       }
       outDraws[r] = draws;
     }
+#if defined(TH_ROBUST_T2) || defined(TH_CERTIFIED_T2)
+    g_t2Calls += tl_t2Calls; g_t2Double += tl_t2Double;
+    tl_t2Calls = tl_t2Double = 0;
+#endif
+#ifdef TH_CERTIFIED_T2
+    g_t2Accepts += tl_t2Accepts;
+    tl_t2Accepts = 0;
+#endif
 #pragma omp critical
     total.stackOverflow += cnt.stackOverflow;
   }

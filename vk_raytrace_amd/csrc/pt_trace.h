@@ -165,6 +165,23 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
   return true;
 }
 #else
+// T2: Moeller-Trumbore in the fixed operation order of the trace contract.
+// MEASUREMENT BUILD -DPT_CERTIFIED_T2 (round 4; not the contract -- oracle, _ref driver and goldens use plain T2): an ACCEPTED candidate is kept only when a
+// forward error bound of the same fp32 evaluation certifies its barycentrics and its distance to PT_T2_TAU -- otherwise it is a miss, on every side.
+// Why: plain fp32 Moeller-Trumbore accepts, by cancellation, triangles a ray passes at a macroscopic distance when they are seen edge-on or from far
+// away (det ~ 0: u = v = 0 "accidental" hits); whether a walk ever tests such a triangle depends on the shape of the boxes around it, which made the
+// flat and the two-level structure differ in one pixel-sample of 6.6e7.  A certified candidate lies within PT_T2_TAU of its
+// triangle's extent of the triangle, i.e. inside every conservative box around it.  No fp64, no second code path: the bound is ~35 more fp32
+// operations on the accept path (absolute values are operand modifiers).  Component-wise bound of round 2's experiment: a cross product's component
+// a_i b_j - a_j b_i is off by at most 2 ulp of |a_i b_j| + |a_j b_i|, a 3-term dot by 3 ulp of sum |x_i y_i| plus |x| . (error of y); 8 ulp covers
+// every chain.  On the CPU harness it closes the exception completely -- walks == brute force on all 120 000 adversarial rays (48 disagreements under plain
+// T2) with today's boxes -- and removes 0 of 122 k camera-ray and 5 of 142 k bounce-ray candidates of the bench scene, all grazing
+// (profiles/r04_t2_certified_experiment.txt).  On the GPU it costs 7 % of the bench line: the bound's live values do not fit 96 VGPRs (-19 % when they
+// spill at 5 waves per SIMD), and at 4 waves it is -4.5 % on top of the -2.6 % of the fourth wave (profiles/r04k_t2_certified_gpu.txt) -- the triangle
+// step runs every iteration at 14 of 64 lanes, so 30 instructions there weigh like 130.  Above the 2 % it was allowed: stays a measurement build.
+#ifndef PT_T2_TAU
+#define PT_T2_TAU 0.0078125f  // 2^-7
+#endif
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
 {
   f3    e1  = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
@@ -187,7 +204,25 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
   v     = dot3(d, qv) * inv;
   if(v < 0.0f || u + v > 1.0f)
     return false;
-  t = dot3(e2, qv) * inv;
+  const float nt = dot3(e2, qv);
+  t              = nt * inv;
+#ifdef PT_CERTIFIED_T2
+  // certification of the accepted candidate
+  const f3    ad = f3{fabsf(d.x), fabsf(d.y), fabsf(d.z)}, ae1 = f3{fabsf(e1.x), fabsf(e1.y), fabsf(e1.z)}, ae2 = f3{fabsf(e2.x), fabsf(e2.y), fabsf(e2.z)};
+  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
+  const f3    apv = f3{ad.y * ae2.z + ad.z * ae2.y, ad.z * ae2.x + ad.x * ae2.z, ad.x * ae2.y + ad.y * ae2.x};
+  const f3    aqv = f3{atv.y * ae1.z + atv.z * ae1.y, atv.z * ae1.x + atv.x * ae1.z, atv.x * ae1.y + atv.y * ae1.x};
+  const float k8   = 8.0f * 5.9604645e-8f;
+  const float edet = k8 * dot3(ae1, apv);
+  const float eu   = k8 * dot3(atv, apv);
+  const float ev   = k8 * dot3(ad, aqv);
+  const float et   = k8 * dot3(ae2, aqv);
+  const float adet = fabsf(det), ant = fabsf(nt);
+  if(!((eu + ev) + 2.0f * edet <= PT_T2_TAU * adet))
+    return false;
+  if(!(et * adet + ant * edet <= (PT_T2_TAU * ant) * adet))
+    return false;
+#endif
   return true;
 }
 #endif
