@@ -1028,6 +1028,8 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
     const pt_TextureDesc& td = d->textures[t];
     if(!td.rgba8 || td.width <= 0 || td.height <= 0)
       return records_fail(err, "texture %u: empty image", t);
+    if(td.width > 65536 || td.height > 65536)  // (pt_device.h tex_index multiplies row x stride in 24 bits)
+      return records_fail(err, "texture %u: %d x %d exceeds 65536 texels a side", t, td.width, td.height);
     R.texRecs[t].tiled  = (g_tuning.texTile && td.width % PT_TEX_TILE_W == 0 && td.height % PT_TEX_TILE_H == 0) ? 1 : 0;
     if(R.texRecs[t].tiled)
       R.texels = (R.texels + 31u) & ~size_t(31);  // a tile = one 128-byte line (the pool itself is 256-byte aligned)
@@ -2212,7 +2214,7 @@ int pt_reset_stats(pt_context* c)
 // Test hook (not part of the ABI; tests/cpp/trace_host.cpp): the host-side records pt_set_scene derives from a scene description, copied into
 // caller arrays (no GPU involved).  Call with null outputs to get the counts: counts[0] instances, [1] materials, [2] opacity-map words,
 // [3] texels of the RGBA8 pool, [4] world triangles.  instOut: InstanceRec[counts[0]] (128 B each); padOut: 2 floats per instance
-// (TlasLeaf::padC0 / padC1 of the two-level walk); alphaMatsOut: AlphaMat[counts[1]] (64 B each); texelsOut: the pool in upload order;
+// (TlasLeaf::padC0 / padC1 of the two-level walk); alphaMatsOut: AlphaMat[counts[1]] (80 B each); texelsOut: the pool in upload order;
 // texRecsOut: TexRec[max(1, numTextures)] (32 B each).
 extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut,
                                                                             uint32_t* alphaMapsOut, uint32_t* texelsOut, void* texRecsOut, char* err, size_t errLen)

@@ -36,7 +36,7 @@ struct AlphaRec {
   uint32_t material;
   uint32_t _pad;
 };
-// The alpha-relevant part of a material + its base-colour texture descriptor (64 B, one per material, cache resident).
+// The alpha-relevant part of a material + its base-colour texture descriptor (80 B, one per material, cache resident).
 struct AlphaMat {
   float    factorA, cutoff;
   int32_t  mode, tex;             // alphaMode, pbrBaseColorTexture (-1: none)
@@ -45,7 +45,9 @@ struct AlphaMat {
   int32_t  texW, texH, texMag;    // texWrap = wrapS | wrapT << 8 | pot << 16 | ALPHA_FAST_TAP (REPEAT x REPEAT, both sizes 2^k)
   int32_t  texWrap;
   uint32_t mapOffset;             // first word of this material's opacity map in DeviceScene::alphaMaps, ALPHA_NO_MAP: none
+  uint32_t _pad[2];               // 80 bytes: five aligned quads, fetched together (pt_surface.h opacity_eval)
 };
+static_assert(sizeof(AlphaMat) == 80, "AlphaMat is read as five 16-byte quads");
 #define ALPHA_FAST_TAP (1 << 24)
 #define ALPHA_TILED (1 << 25)  // the texture is stored block-linear (TexRec::tiled)
 #define ALPHA_NO_MAP 0xffffffffu
@@ -141,7 +143,16 @@ __host__ __device__
 #endif
 inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 {
-  return tiled ? ((uint32_t(iy) >> 2) * (uint32_t(w) >> 3) + (uint32_t(ix) >> 3)) * 32u + ((uint32_t(iy) & 3u) << 3) + (uint32_t(ix) & 7u) : uint32_t(iy) * uint32_t(w) + uint32_t(ix);
+  // one multiply for both orders, selects instead of a branch per texel: index = row x stride + rest, with (row, stride, rest) =
+  // (iy / 4, 4 w, tile column x 32 + offset in the tile) block-linear and (iy, w, ix) row-major.  Image sides are < 2^16: a 24-bit multiply does.
+  const uint32_t ux = uint32_t(ix), uy = uint32_t(iy), uw = uint32_t(w);
+  const uint32_t row = tiled ? (uy >> 2) : uy, stride = tiled ? (uw << 2) : uw;
+  const uint32_t rest = tiled ? (((ux >> 3) << 5) | ((uy & 3u) << 3) | (ux & 7u)) : ux;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(row, stride) + rest;
+#else
+  return row * stride + rest;
+#endif
 }
 
 #define PT_SHADE_REC_QUADS 8

@@ -151,7 +151,21 @@ PT_DEV void make_frame(f3 N, f3& T, f3& B)
 template <bool useMap>
 PT_DEV float opacity_eval(const DeviceScene& S, const AlphaRec& ar, float bu, float bv)
 {
-  const AlphaMat am = S.alphaMats[ar.material];
+  // the 80-byte record in ONE round trip: left to itself the compiler fetches the first quad, waits, looks at `tex`, and only then fetches the rest
+  // (a dependent round trip more on every evaluation, inside the triangle step of the trace kernels)
+  AlphaMat am;
+  {
+    const uint4* q  = reinterpret_cast<const uint4*>(S.alphaMats + ar.material);
+    const uint4  q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : : "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(q4.x));  // (keeps the compiler from sinking these loads behind the test of q0's `tex`)
+#endif
+    am.factorA = __uint_as_float(q0.x); am.cutoff = __uint_as_float(q0.y); am.mode = int32_t(q0.z); am.tex = int32_t(q0.w);
+    am.m[0] = __uint_as_float(q1.x); am.m[1] = __uint_as_float(q1.y); am.m[2] = __uint_as_float(q1.z); am.m[3] = __uint_as_float(q1.w);
+    am.m[4] = __uint_as_float(q2.x); am.m[5] = __uint_as_float(q2.y); am.m[6] = __uint_as_float(q2.z); am.m[7] = __uint_as_float(q2.w);
+    am.texOffset = q3.x; am.texW = int32_t(q3.y); am.texH = int32_t(q3.z); am.texMag = int32_t(q3.w);
+    am.texWrap = int32_t(q4.x); am.mapOffset = q4.y; am._pad[0] = am._pad[1] = 0u;
+  }
   float          a  = am.factorA;
   if(am.tex > -1)
   {
