@@ -228,4 +228,5 @@ struct FrameParams {
   uint32_t    batch;     // consecutive frames (st.frame, st.frame + 1, ...) traced together: path slot = f * numSlots + pixel slot
   int32_t     sample;    // index of the sample inside this frame
   int32_t     variant;   // PT_VARIANT_RAYQUERY / PT_VARIANT_RTX (include/pt_api.h)
+  int32_t     regen;     // 1: k_generate only builds the queue; the packet kernel of bounce 0 computes the camera rays itself (pt_render.hip plan_frame decides)
 };

@@ -148,6 +148,12 @@ __global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers 
   enqueue_block(rb.queueA, &rb.counts[CNT_IN], slot, valid);  // bounce 0 reads queueA
   if(!valid)
     return;
+  if(fp.regen)
+  {  // the packet kernel of bounce 0 computes the camera ray of its paths itself (k_closest_k): nothing but the queue is written here
+    if(fp.st.maxDepth == 0)
+      rb.ps.rad[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   generate_ray(S, rb, fp, slot, fb, px, py);
 }
 
@@ -297,7 +303,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
 #ifndef PT_PACKET_WAVES
 #define PT_PACKET_WAVES 8
 #endif
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce)
+// fp.regen (bounce 0 only): the camera rays are computed HERE from (path slot -> pixel, frame) instead of being written by k_generate and read back --
+// 32 B per sample less written, 32 B less read; what later stages need is written from here: the direction and RNG state (k_shade), and the whole
+// ray of a path that goes on to the refilling trace machine (queueR).
+__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int bounce)
 {
   __shared__ uint32_t wstack[PACKET_STACK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -311,17 +320,29 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
     const bool     valid = i < count;
     uint32_t       slot = 0, seed = 0;
     f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
+    const bool regen = fp.regen != 0;
     if(valid)
     {
-      slot            = queueIn[i];
-      o               = xyz(rb.ps.rayO[slot]);
-      const float4 dw = rb.ps.rayD[slot];
-      d               = xyz(dw);
-      seed            = __float_as_uint(dw.w);
+      slot = queueIn[i];
+      if(regen)
+      {
+        const uint32_t fb = slot / fp.numSlots;
+        int            px = 0, py = 0;
+        (void)slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py);  // (valid slots only are queued)
+        camera_ray(S, fp, fb, px, py, seed, o, d);
+      }
+      else
+      {
+        o               = xyz(rb.ps.rayO[slot]);
+        const float4 dw = rb.ps.rayD[slot];
+        d               = xyz(dw);
+        seed            = __float_as_uint(dw.w);
+      }
     }
     RayHit     h;
     const bool packet = traverse_packet_closest(S, valid, o, d, wstack, h, rb.counters);
     bool       redo   = valid && !packet;
+    uint32_t   seedOut = seed;
     if(valid && packet)
     {
       redo = (h.flags & TF_SAW_FRAC) != 0 || ((h.flags & TF_SAW_ZERO) && !pass_a_settles(h.slot, h.t, h.zeroMaxT, h.zeroMaxT2, h.zeroMaxT3, h.count));
@@ -334,14 +355,21 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
         if(consume_rejected_draws(s2, nDraw))
         {
           store_hit(rb, slot, h.slot, h.w, false, h.t, h.u, h.v);
-          if(nDraw)
+          if(nDraw && !regen)
             rb.ps.rayD[slot].w = __uint_as_float(s2);
+          seedOut = s2;
           nAlpha += nDraw;
           ++nRays;
         }
         else
           redo = true;
       }
+    }
+    if(regen && valid)
+    {  // what the next stages read of the ray: k_shade the direction + RNG state; the trace machine (redo) the whole ray with the untouched seed
+      rb.ps.rayD[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(redo ? seed : seedOut));
+      if(redo)
+        rb.ps.rayO[slot] = make_float4(o.x, o.y, o.z, 0.f);
     }
     stage_push(stage, nStage, redo, slot, rb.queueR, &C[CNT_REDO]);
   }
@@ -1067,6 +1095,9 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const bool     pipe      = !TWO && g_tuning.pipe && scene.cnodes != nullptr && !heat;
   const uint32_t pwPipe    = uint32_t(g_tuning.pipeWaves > 0 ? g_tuning.pipeWaves : 1);
   const uint32_t gridPipe  = wavesAll < pwPipe ? wavesAll : pwPipe;
+  // camera rays computed by the packet kernel instead of written by k_generate: one sample per frame (the RNG stream of a second sample continues
+  // from the stored state), a packet stage at bounce 0, no heat map (it keeps the path's cost in rayO.w), bounce 0 not already in k_tail
+  fp.regen = (g_tuning.regen && !TWO && !heat && fp.st.maxSamples == 1 && g_tuning.packetClosestBounces >= 1 && tailFrom > 0 && fp.st.maxDepth > 0) ? 1 : 0;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
@@ -1101,7 +1132,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         else if(!TWO && depth < g_tuning.packetClosestBounces)
         {
           const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-          k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth);
+          k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
           if(pipe)
             k_closest_p<false, false, true><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
           else

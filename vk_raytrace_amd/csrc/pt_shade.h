@@ -62,16 +62,14 @@ PT_DEV f3 heat_temperature(float intensity)
          + red * smooth(0.75f, 1.0f, intensity);
 }
 
-// the camera ray of path `slot` (pixel px, py; frame of the batch fb): seed, sub-pixel jitter, depth of field -> path state
-PT_DEV void generate_ray(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, uint32_t fb, int px, int py)
+// the camera ray of a path (pixel px, py; frame of the batch fb): seed, sub-pixel jitter, depth of field.  `seed`: in / out -- the caller passes the state
+// the stream continues from when fp.sample > 0 (pathtrace.comp:97-105), it is (re)seeded here for the first sample of a frame.
+PT_DEV void camera_ray(const DeviceScene& S, const FrameParams& fp, uint32_t fb, int px, int py, uint32_t& seed, f3& org, f3& dir)
 {
   pt_RtxState st = fp.st;
   st.frame += int(fb);
-  uint32_t seed;
   if(fp.sample == 0)
     seed = rng_tea(uint32_t(st.size[0]) * uint32_t(py) + uint32_t(px), uint32_t(fp.variant == PT_VARIANT_RTX ? st.frame : st.frame * st.maxSamples));
-  else
-    seed = __float_as_uint(rb.ps.rayD[slot].w);  // the stream continues across the samples of a frame (pathtrace.comp:97-105)
 
   f2 jitter = f2{0.5f, 0.5f};
   if(st.frame != 0)
@@ -95,14 +93,20 @@ PT_DEV void generate_ray(const DeviceScene& S, const RenderBuffers& rb, const Fr
   f4    cam_right  = mat4_mul(cam.viewInverse, f4{1, 0, 0, 0});
   f4    cam_up     = mat4_mul(cam.viewInverse, f4{0, 1, 0, 0});
   f3    lens       = (xyz(cam_right) * pt_cos(cam_r1) + xyz(cam_up) * pt_sin(cam_r1)) * sqrtf(cam_r2);
-  f3    dir        = unit(focalPoint - lens);
-  f3    org        = xyz(origin) + lens;
-
+  dir              = unit(focalPoint - lens);
+  org              = xyz(origin) + lens;
+}
+// ... and into the path state (k_generate; the packet kernel computes it itself when FrameParams::regen is set)
+PT_DEV void generate_ray(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, uint32_t fb, int px, int py)
+{
+  uint32_t seed = fp.sample == 0 ? 0u : __float_as_uint(rb.ps.rayD[slot].w);  // the stream continues across the samples of a frame (pathtrace.comp:97-105)
+  f3       org, dir;
+  camera_ray(S, fp, fb, px, py, seed, org, dir);
   rb.ps.rayO[slot]   = make_float4(org.x, org.y, org.z, 0.f);
   rb.ps.rayD[slot]   = make_float4(dir.x, dir.y, dir.z, __uint_as_float(seed));
   // throughput = 1, radiance = 0, absorption = 0 (pathtrace.glsl:201-203) are not written: shade_path knows them at depth 0 (48 B per sample
   // that would be written here and read back there).  Without a single bounce nobody else writes the radiance the accumulate step reads.
-  if(st.maxDepth == 0)
+  if(fp.st.maxDepth == 0)
     rb.ps.rad[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
