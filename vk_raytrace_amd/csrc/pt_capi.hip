@@ -742,6 +742,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) g_tuning.texTile = v;
     if(const char* p = strstr(tune, "prebias=")) if(sscanf(p, "prebias=%d", &v) == 1) g_tuning.prebias = v;
     if(const char* p = strstr(tune, "regen=")) if(sscanf(p, "regen=%d", &v) == 1) g_tuning.regen = v;
+    if(const char* p = strstr(tune, "packetTwo=")) if(sscanf(p, "packetTwo=%d", &v) == 1) g_tuning.packetTwo = v;
     if(const char* p = strstr(tune, "pipe=")) if(sscanf(p, "pipe=%d", &v) == 1) g_tuning.pipe = v;
     if(const char* p = strstr(tune, "pipeWaves=")) if(sscanf(p, "pipeWaves=%d", &v) == 1) g_tuning.pipeWaves = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;

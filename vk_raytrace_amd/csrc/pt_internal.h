@@ -138,6 +138,7 @@ struct PtTuning {
                                    // lane_issue / lane_step).  Bit-identical, measured 8 % SLOWER (profiles/r04h_*): a lane then advances one step per iteration instead of
                                    // node step + triangle step, so a ray needs ~28 iterations instead of ~22 and every iteration still issues both code paths
   int pipeWaves            = 4096; // its waves per launch (4 per SIMD: the next record lives in registers across the loop)
+  int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
   int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)

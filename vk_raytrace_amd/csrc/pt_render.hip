@@ -303,10 +303,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
 #ifndef PT_PACKET_WAVES
 #define PT_PACKET_WAVES 8
 #endif
+#ifndef PT_PACKET_WAVES_TWO
+#define PT_PACKET_WAVES_TWO 6  // two-level packets carry the object-space ray constants of the instance they are in on top of the world-space ones
+#endif
 // fp.regen (bounce 0 only): the camera rays are computed HERE from (path slot -> pixel, frame) instead of being written by k_generate and read back --
 // 32 B per sample less written, 32 B less read; what later stages need is written from here: the direction and RNG state (k_shade), and the whole
 // ray of a path that goes on to the refilling trace machine (queueR).
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int bounce)
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_PACKET_WAVES_TWO : PT_PACKET_WAVES) k_closest_k(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, int bounce)
 {
   __shared__ uint32_t wstack[PACKET_STACK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
       }
     }
     RayHit     h;
-    const bool packet = traverse_packet_closest(S, valid, o, d, wstack, h, rb.counters);
+    const bool packet = TWO ? traverse_packet_two(S, valid, o, d, wstack, h, rb.counters) : traverse_packet_closest(S, valid, o, d, wstack, h, rb.counters);
     bool       redo   = valid && !packet;
     uint32_t   seedOut = seed;
     if(valid && packet)
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, PT_PACKET_WAVES) k_closest_k(Devi
         uint32_t s2 = seed;
         if(consume_rejected_draws(s2, nDraw))
         {
-          store_hit(rb, slot, h.slot, h.w, false, h.t, h.u, h.v);
+          store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
           if(nDraw && !regen)
             rb.ps.rayD[slot].w = __uint_as_float(s2);
           seedOut = s2;
@@ -1097,7 +1101,8 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t gridPipe  = wavesAll < pwPipe ? wavesAll : pwPipe;
   // camera rays computed by the packet kernel instead of written by k_generate: one sample per frame (the RNG stream of a second sample continues
   // from the stored state), a packet stage at bounce 0, no heat map (it keeps the path's cost in rayO.w), bounce 0 not already in k_tail
-  fp.regen = (g_tuning.regen && !TWO && !heat && fp.st.maxSamples == 1 && g_tuning.packetClosestBounces >= 1 && tailFrom > 0 && fp.st.maxDepth > 0) ? 1 : 0;
+  const bool packetStage = !TWO || g_tuning.packetTwo;  // the two-level structure has a packet stage of its own since round 4 (pt_packet.h traverse_packet_two)
+  fp.regen = (g_tuning.regen && packetStage && !heat && fp.st.maxSamples == 1 && g_tuning.packetClosestBounces >= 1 && tailFrom > 0 && fp.st.maxDepth > 0) ? 1 : 0;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
@@ -1129,14 +1134,15 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
           sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
         if(heat)
           k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-        else if(!TWO && depth < g_tuning.packetClosestBounces)
+        else if(packetStage && depth < g_tuning.packetClosestBounces)
         {
-          const uint32_t kw = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-          k_closest_k<<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
+          const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+          const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
+          k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
           if(pipe)
-            k_closest_p<false, false, true><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+            k_closest_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
           else
-            k_closest_p<false, false><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
         }
         else if(pipe)
           k_closest_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
