@@ -6,14 +6,16 @@ import numpy as np
 from vk_raytrace_amd import capi, workloads, host_device as hd
 from vk_raytrace_amd.renderer import HipRenderer
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-wl = workloads.c3_sponza(1920, 1080, 8)
+which = sys.argv[2] if len(sys.argv) > 2 else "c3"   # c3 | c5 (PT_TUNE=accel=two for the two-level structure)
+W, H = (1920, 1080) if which == "c3" else (3840, 2160)
+wl = workloads.c3_sponza(W, H, 8) if which == "c3" else workloads.c5_bistro()
 if os.environ.get("PT_OPAQUE_FOLIAGE") == "1":
     for m in wl.scene.materials:
         m["alphaMode"] = 0
 wl.scene.finalize(capi.pack_vertices)
 r = HipRenderer(); r.setup(0); r.set_scene(wl.scene); integ, _ = r.set_env(wl.env)
-r.set_camera(capi.camera_lookat(wl.scene.camera, 1920 / 1080)); r.set_sunsky(hd.default_sun_and_sky()); r.create((1920, 1080))
-st = hd.default_rtx_state(); st.size[0], st.size[1] = 1920, 1080; st.maxDepth = 8; st.fireflyClampThreshold = 4 * integ
+r.set_camera(capi.camera_lookat(wl.scene.camera, W / H)); r.set_sunsky(hd.default_sun_and_sky()); r.create((W, H))
+st = hd.default_rtx_state(); st.size[0], st.size[1] = W, H; st.maxDepth = 8; st.fireflyClampThreshold = 4 * integ
 L = capi.lib()
 L.pt_debug_hist.restype = C.c_int
 L.pt_debug_hist.argtypes = [C.c_void_p, C.c_int]
@@ -46,3 +48,7 @@ if int(h[7, 2]):
     print(f"packet: waves/frame {int(h[7, 2]) / frames / 1e3:.1f}k  inner visits/wave {int(h[7, 0]) / int(h[7, 2]):.1f}  leaf visits/wave {int(h[7, 1]) / int(h[7, 2]):.1f}")
 if int(h[7, 6]):
     print(f"shadow packet: waves/frame {int(h[7, 6]) / frames / 1e3:.1f}k  lanes in packet {int(h[7, 7]) / int(h[7, 6]):.1f}  inner visits/wave {int(h[7, 4]) / int(h[7, 6]):.1f}  leaf visits/wave {int(h[7, 5]) / int(h[7, 6]):.1f}")
+if int(h[7, 12]):
+    n = int(h[7, 12])
+    print(f"two-level packet: waves/frame {n / frames / 1e3:.1f}k  TLAS nodes/wave {int(h[7, 8]) / n:.1f}  instances entered/wave {int(h[7, 9]) / n:.1f} (merged block {int(h[7, 14]) / n:.2f}, "
+          f"sign-incoherent inside {int(h[7, 13]) / n:.2f})  BLAS nodes/wave {int(h[7, 10]) / n:.1f}  leaves/wave {int(h[7, 11]) / n:.1f}")

@@ -8,6 +8,7 @@
 #   prof20              rocprofv3 --kernel-trace --stats over the driver's command line -> kernel_stats_bench20.csv
 #   tune:<steps>:<A>;<B>;...    bench under each PT_TUNE string, two alternating rounds ("-" = the defaults)
 #   libs:<steps>:<a>,<b>,...    bench with each libptmi variant of vk_raytrace_amd/variants/ ("default" = the product), two alternating rounds
+#   libs5:<steps>:<a>,<b>,...   the same on the C5 stand-in with the two-level structure
 #   tests[:<-k expression>]     pytest -m gpu
 #   smoke               __graft_entry__.smoke()
 #   pmc[:<frames>]      tools/pmc_passes.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
@@ -39,6 +40,9 @@ for step in "$@"; do
     libs)    for round in 1 2; do IFS=',' read -ra VS <<< "$b"; for v in "${VS[@]}"; do L=""; [ "$v" != default ] && L="$REPO/vk_raytrace_amd/variants/libptmi_$v.so"
                echo -n "steps $a lib $v : " | tee -a $O/log.txt
                PT_LIB=$L timeout 300 python bench.py --steps $a --warmup 8 --no-cpu-baseline --no-profile --no-interactive 2>/dev/null | val | tee -a $O/log.txt; done; done ;;
+    libs5)   for round in 1 2; do IFS=',' read -ra VS <<< "$b"; for v in "${VS[@]}"; do L=""; [ "$v" != default ] && L="$REPO/vk_raytrace_amd/variants/libptmi_$v.so"
+               echo -n "c5 two-level steps $a lib $v : " | tee -a $O/log.txt
+               PT_LIB=$L timeout 300 python bench.py --workload c5 --accel two --steps $a --warmup 8 --no-cpu-baseline --no-profile --no-interactive 2>/dev/null | val | tee -a $O/log.txt; done; done ;;
     tests)   if [ -n "$a" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$a" > $O/gputest.txt 2>&1; else timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; fi; tail -5 $O/gputest.txt | tee -a $O/log.txt ;;
     smoke)   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a $O/log.txt ;;
     pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_passes.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;

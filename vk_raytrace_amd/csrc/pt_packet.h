@@ -203,6 +203,9 @@ PT_DEV bool traverse_packet_two(const DeviceScene& S, bool valid, f3 o, f3 d, ui
   InstCtx     ic{BVH_NONE, 0, 0u};
   uint32_t    cur = 0, guard = 0;
   int         sp  = 0;
+#ifdef PT_HIST
+  uint32_t hTop = 0, hEnter = 0, hInner = 0, hLeaf = 0, hMixed = 0, hMerged = 0;
+#endif
   for(;;)
   {
     if(!(cur & BVH_LEAF))
@@ -213,6 +216,9 @@ PT_DEV bool traverse_packet_two(const DeviceScene& S, bool valid, f3 o, f3 d, ui
           atomicAdd(&counters->stackOverflow, 1u);
         break;
       }
+#ifdef PT_HIST
+      if(ic.inst == BVH_NONE) ++hTop; else ++hInner;
+#endif
       const uint32_t at = (cur & BVH_SLOT_MASK) << 7;
       // coherent: near planes at +off, far planes at +48-off per axis; else: lower planes (p*) and upper planes (q*)
       const float4   px = sload4(nodes, at + (coh ? offX : 0u)), qx = sload4(nodes, at + 48u - (coh ? offX : 0u));
@@ -288,6 +294,10 @@ PT_DEV bool traverse_packet_two(const DeviceScene& S, bool valid, f3 o, f3 d, ui
         coh  = !((sx != 0ull && sx != am) || (sy != 0ull && sy != am) || (sz != 0ull && sz != am));
         offX = sx ? 48u : 0u; offY = sy ? 48u : 0u; offZ = sz ? 48u : 0u;
       }
+#ifdef PT_HIST
+      ++hEnter;
+      if(tl.inst == PT_INST_MERGED) ++hMerged; else if(!coh) ++hMixed;
+#endif
       nodes = S.wide;
       cur   = tl.nodeBase;
       continue;
@@ -298,6 +308,9 @@ PT_DEV bool traverse_packet_two(const DeviceScene& S, bool valid, f3 o, f3 d, ui
       const float4   t0 = sload4(S.tris, slot * 48u), t1 = sload4(S.tris, slot * 48u + 16u), t2 = sload4(S.tris, slot * 48u + 32u);
       TriRec         tr;
       tr.p0w = t0; tr.e1n = t1; tr.e2p = t2;
+#ifdef PT_HIST
+      ++hLeaf;
+#endif
       if(ic.inst != PT_INST_MERGED)
         tr = world_tri(S, ic, tr);
       const uint32_t wbits = __float_as_uint(tr.p0w.w);
@@ -344,6 +357,14 @@ PT_DEV bool traverse_packet_two(const DeviceScene& S, bool valid, f3 o, f3 d, ui
       break;
     cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
   }
+#ifdef PT_HIST
+  if((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&g_hist[7][8], (unsigned long long)hTop); atomicAdd(&g_hist[7][9], (unsigned long long)hEnter); atomicAdd(&g_hist[7][10], (unsigned long long)hInner);
+    atomicAdd(&g_hist[7][11], (unsigned long long)hLeaf); atomicAdd(&g_hist[7][12], 1ull); atomicAdd(&g_hist[7][13], (unsigned long long)hMixed);
+    atomicAdd(&g_hist[7][14], (unsigned long long)hMerged);
+  }
+#endif
   return true;
 }
 #endif
