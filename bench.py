@@ -580,19 +580,22 @@ def main():
         out["interactive"] = {"value": job_pixels * n_i / ti / 1e6, "unit": "Msamples/s", "ms_per_frame": ti / n_i * 1e3, "frames": n_i,
                               "note": "render + pt_tonemap (RGBA8 read back to the host) per frame: batch = 1, the host waits for every image"}
         # the same loop with frames in flight (pt_tonemap_begin / pt_tonemap_end, the reference's prepareFrame / submitFrame loop): the host
-        # collects the image of the frame issued three calls earlier
-        n_p = 48
+        # collects the image of the frame issued five calls earlier -- six launch sequences of one frame each in flight, the four batch slots and
+        # the two one-frame display slots (profiles/r04y_display_slots.txt)
+        n_p = 96
+        behind = 5
         r.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_p):
             st.frame = frame; r.setPushContants(st); r.run(); r.tonemap_begin(tm); frame += 1
-            if r.tonemap_pending() > 3:
+            if r.tonemap_pending() > behind:
                 r.tonemap_end()
         while r.tonemap_pending():
             r.tonemap_end()
         tp = time.perf_counter() - t0
         out["interactive"].update({"pipelined_value": job_pixels * n_p / tp / 1e6, "pipelined_ms_per_frame": tp / n_p * 1e3, "pipelined_frames": n_p,
-                                   "pipelined_note": "render + pt_tonemap_begin per frame, pt_tonemap_end for the frame issued three calls earlier (every image still reaches the host)"})
+                                   "pipelined_frames_behind": behind,
+                                   "pipelined_note": "render + pt_tonemap_begin per frame, pt_tonemap_end for the frame issued five calls earlier (every image still reaches the host)"})
     # (3) standalone kernel durations: the timed loop overlaps four launch sequences on separate streams, so a HIP-event bracket there is not a
     # kernel's own duration.  One batch is rendered again on a second context with ONE frame slot (PT_TUNE inflight=1) and otherwise the launch
     # policy of the timed run (k_tail takes the late bounces): nothing overlaps, HIP events on the launching stream bracket each stage.

@@ -163,10 +163,11 @@ int pt_tonemap_zoom(pt_context* ctx, const pt_Tonemapper* tm, int disp_width, in
  * recorded).
  * pt_tonemap_begin enqueues pt_tonemap_zoom's work behind the frames rendered so far and returns; frames rendered afterwards overlap it (their
  * accumulate step waits until the pass has read the accumulation image).  pt_tonemap_end blocks until the OLDEST image begun is in host memory
- * and copies it to rgba8_out (the size given to its pt_tonemap_begin).  At most PT_DISPLAY_RING (4) images may be pending
+ * and copies it to rgba8_out (the size given to its pt_tonemap_begin).  At most PT_DISPLAY_RING (8) images may be pending
  * (PT_ERR_STATE beyond, and for pt_tonemap_end with none pending); pt_tonemap_pending returns how many are.  The images are bit-identical to
  * what pt_tonemap_zoom returns at the same point of the frame sequence.  A traversal-stack overflow is reported by the next synchronising
  * call (pt_synchronize, pt_tonemap, pt_read_accum), not by pt_tonemap_end. */
+#define PT_DISPLAY_RING 8
 int pt_tonemap_begin(pt_context* ctx, const pt_Tonemapper* tm, int disp_width, int disp_height);
 int pt_tonemap_end(pt_context* ctx, uint8_t* rgba8_out);
 int pt_tonemap_pending(pt_context* ctx);

@@ -13,6 +13,7 @@ from . import host_device as hd
 
 PT_VARIANT_RAYQUERY, PT_VARIANT_RTX = 0, 1
 PT_ACCEL_FLAT, PT_ACCEL_TWO_LEVEL = 0, 1
+PT_DISPLAY_RING = 8  # images pt_tonemap_begin may have pending (include/pt_api.h)
 PT_FN = {"sin": 0, "cos": 1, "tan": 2, "asin": 3, "acos": 4, "atan2": 5, "exp": 6, "log": 7, "pow": 8}
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_STATE, PT_ERR_OOM, PT_ERR_UNAVAILABLE = 0, -1, -2, -3, -4, -5, -6
 

@@ -86,6 +86,12 @@ struct pt_context {
   FrameSlot slots[PT_MAX_INFLIGHT];
   int       inflight     = 1;  // frame slots in use (<= inflightMax: pt_resize drops slots when the device memory is short)
   int       inflightMax  = 1;  // frame slots created (streams / events exist for these)
+  // Display slots: slots[inflightMax .. inflightMax + displaySlots) hold the path state of ONE frame each and join the ring only for launches of a
+  // single frame -- the display loop (render, tonemap, present per frame), where six short sequences in flight beat four by 12 %, while batches
+  // are fastest on four full slots (profiles/r04y_display_slots.txt)
+  int       displaySlots    = 0;  // in use after pt_resize
+  int       displaySlotsMax = 0;  // created
+  uint64_t  displayCounter  = 0;  // ring position of the single-frame launches
   // frames handed to pt_render_frame but not launched yet: consecutive frames with identical state are traced as one
   // batch (flushed when full and by every call that reads results or changes inputs)
   pt_RtxState pendState{};
@@ -215,6 +221,9 @@ bool affine_inverse(const float* m, double inv[12], double& det3)
   inv[11] = -(i20 * tx + i21 * ty + i22 * tz);
   return true;
 }
+
+static inline int slot_total(const pt_context* c) { return c->inflight + c->displaySlots; }
+static inline pt_context::FrameSlot& slot_at(pt_context* c, int k) { return c->slots[k < c->inflight ? k : c->inflightMax + (k - c->inflight)]; }
 
 hipError_t sync_all(pt_context* c)
 {
@@ -753,6 +762,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
+    if(const char* p = strstr(tune, "displaySlots=")) if(sscanf(p, "displaySlots=%d", &v) == 1) g_tuning.displaySlots = v;
     if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) g_tuning.stateGB = v;
     if(const char* p = strstr(tune, "shadeSpec=")) if(sscanf(p, "shadeSpec=%d", &v) == 1) g_tuning.shadeSpecialised = v;
     if(const char* p = strstr(tune, "sortClosest=")) if(sscanf(p, "sortClosest=%d", &v) == 1) g_tuning.sortClosest = v;
@@ -773,7 +783,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
   c->timers.stream = c->stream;
   c->inflight      = g_tuning.framesInFlight < 1 ? 1 : (g_tuning.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : g_tuning.framesInFlight);
   c->inflightMax = c->inflight;
-  for(int i = 0; i < c->inflight; ++i)
+  c->displaySlotsMax = std::max(0, std::min(g_tuning.displaySlots, PT_MAX_INFLIGHT - c->inflightMax));
+  for(int i = 0; i < c->inflightMax + c->displaySlotsMax; ++i)
     if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess ||
        hipEventCreateWithFlags(&c->slots[i].countsDone, hipEventDisableTiming) != hipSuccess ||
        hipHostMalloc((void**)&c->slots[i].hCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2)) != hipSuccess)
@@ -1392,23 +1403,32 @@ static int warm_slots(pt_context* c)
   fp.batch = uint32_t(std::min(c->batchMax, 8));
   StageTimers off;  // disabled: the warm-up never shows in the stage timings
   const int tailFrom = tail_from_depth(double(fp.batch) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, 0);
-  for(int i = 0; i < c->inflight; ++i)
+  for(int k = 0; k < slot_total(c); ++k)
   {
-    pt_context::FrameSlot& fs = c->slots[i];
+    pt_context::FrameSlot& fs = slot_at(c, k);
     for(DevBuf& bf : fs.dState)
       (void)hipMemsetAsync(bf.p, 0, bf.bytes, fs.stream);
     DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
     for(DevBuf* bf : q)
       (void)hipMemsetAsync(bf->p, 0, bf->bytes, fs.stream);
   }
-  for(int i = 0; i < c->inflight; ++i)
-    pt_launch_frame(c->slots[i].stream, c->scene, c->slots[i].rb, fp, &off, nullptr, nullptr, tailFrom);
+  for(int k = 0; k < slot_total(c); ++k)
+  {
+    FrameParams fk = fp;
+    int         tk = tailFrom;
+    if(k >= c->inflight)
+    {  // a display slot holds one frame
+      fk.batch = 1;
+      tk       = tail_from_depth(double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, 0);
+    }
+    pt_launch_frame(slot_at(c, k).stream, c->scene, slot_at(c, k).rb, fk, &off, nullptr, nullptr, tk);
+  }
   pt_context::FrameSlot& f0 = c->slots[0];
   const int nd = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);
   if(f0.hCounts)
     (void)hipMemcpyAsync(f0.hCounts, f0.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(nd), hipMemcpyDeviceToHost, f0.stream);
-  for(int i = 0; i < c->inflight; ++i)
-    HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
+  for(int k = 0; k < slot_total(c); ++k)
+    HIP_TRY(c, hipStreamSynchronize(slot_at(c, k).stream));
   if(f0.hCounts && c->qRatioDepths == 0)
   {
     const double paths = double(fp.batch) * double(c->numSlots);
@@ -1463,6 +1483,7 @@ int pt_resize(pt_context* c, int width, int height)
   // one slot, before PT_ERR_OOM is reported.  Smaller batches only cost throughput, never results.
   const size_t perPath = 9 * sizeof(float4) + 9 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
+  c->displaySlots      = c->displaySlotsMax;
   {
     // what is free now PLUS what the frame slots already hold (those buffers are re-used or released below): a repeated pt_resize at the same
     // size must arrive at the same batch, not at half of it.  A failed query means "no cap" -- the retry loop below still shrinks on a failed allocation.
@@ -1477,7 +1498,9 @@ int pt_resize(pt_context* c, int width, int height)
       for(const DevBuf* bf : q) held += bf->bytes;
     }
     const double budget = g_tuning.stateMB > 0 ? g_tuning.stateMB * 1e6 : g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
-    auto need = [&]() { return double(perPath) * double(c->numSlots ? c->numSlots : 1) * c->batchMax * c->inflight; };
+    auto need = [&]() { return double(perPath) * double(c->numSlots ? c->numSlots : 1) * (double(c->batchMax) * c->inflight + c->displaySlots); };
+    if(need() > budget)
+      c->displaySlots = 0;  // the one-frame display slots go first
     while(c->batchMax > 1 && need() > budget)
       c->batchMax = (c->batchMax + 1) / 2;
     while(c->inflight > 1 && need() > budget)
@@ -1487,11 +1510,11 @@ int pt_resize(pt_context* c, int width, int height)
   }
   for(;;)
   {
-    const size_t n  = size_t(c->numSlots ? c->numSlots : 1) * size_t(c->batchMax);
     bool         ok = true;
-    for(int i = 0; i < c->inflight && ok; ++i)
+    for(int k = 0; k < slot_total(c) && ok; ++k)
     {
-      pt_context::FrameSlot& fs = c->slots[i];
+      pt_context::FrameSlot& fs = slot_at(c, k);
+      const size_t           n  = size_t(c->numSlots ? c->numSlots : 1) * size_t(k < c->inflight ? c->batchMax : 1);
       for(DevBuf& bf : fs.dState)
         ok = ok && dev_alloc_quiet(bf, sizeof(float4) * n);
       DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
@@ -1502,7 +1525,19 @@ int pt_resize(pt_context* c, int width, int height)
         HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
     }
     if(ok)
+    {  // slots that dropped out (a smaller budget than at the last pt_resize) give their buffers back
+      for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+      {
+        const bool used = i < c->inflight || (i >= c->inflightMax && i < c->inflightMax + c->displaySlots);
+        if(used)
+          continue;
+        pt_context::FrameSlot& fs = c->slots[i];
+        for(DevBuf& bf : fs.dState) dev_free(bf);
+        DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+        for(DevBuf* bf : q) dev_free(*bf);
+      }
       break;
+    }
     (void)hipGetLastError();
     for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
     {  // release everything before retrying smaller
@@ -1511,7 +1546,9 @@ int pt_resize(pt_context* c, int width, int height)
       DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
       for(DevBuf* bf : q) dev_free(*bf);
     }
-    if(c->batchMax > 1)
+    if(c->displaySlots > 0)
+      c->displaySlots = 0;
+    else if(c->batchMax > 1)
       c->batchMax = (c->batchMax + 1) / 2;
     else if(c->inflight > 1)
       c->inflight = (c->inflight + 1) / 2;
@@ -1529,9 +1566,9 @@ int pt_resize(pt_context* c, int width, int height)
   c->width    = width;
   c->height   = height;
   c->haveFull = false;
-  for(int i = 0; i < c->inflight; ++i)
+  for(int k = 0; k < slot_total(c); ++k)
   {
-    pt_context::FrameSlot& fs = c->slots[i];
+    pt_context::FrameSlot& fs = slot_at(c, k);
     PathState&             ps = fs.rb.ps;
     ps.rayO = (float4*)fs.dState[0].p; ps.rayD = (float4*)fs.dState[1].p; ps.thr = (float4*)fs.dState[2].p; ps.rad = (float4*)fs.dState[3].p;
     ps.absorb = (float4*)fs.dState[4].p; ps.neeDir = (float4*)fs.dState[5].p; ps.neeRad = (float4*)fs.dState[6].p; ps.hit = (float4*)fs.dState[7].p;
@@ -1633,10 +1670,10 @@ int flush_pending(pt_context* c)
   c->pendCount          = 0;
   c->renderedSinceCheck = true;
   // queue-size feedback: take the counters of the newest launch sequence that has finished
-  for(int i = 0; i < c->inflightMax; ++i)
+  for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
   {
     pt_context::FrameSlot& fs = c->slots[i];
-    if(fs.countsSeq > c->qRatioSeq && fs.countsPaths > 0 && hipEventQuery(fs.countsDone) == hipSuccess)
+    if(fs.countsDone && fs.countsSeq > c->qRatioSeq && fs.countsPaths > 0 && hipEventQuery(fs.countsDone) == hipSuccess)
     {
       const int nd = std::min(fs.countsDepths, PT_MAX_DEPTH);
       for(int d = 0; d < nd; ++d)
@@ -1666,7 +1703,8 @@ int flush_pending(pt_context* c)
     // alive fraction observed at that bounce; bounces beyond the observed ones continue the last observed shrink factor; before anything was
     // observed a shrink of 0.3 per bounce is assumed.  A wrong guess costs time, never results.
     const int tailFrom = tail_from_depth(double(n) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, c->qRatioDepths);
-    pt_context::FrameSlot& fs = c->slots[c->frameCounter++ % uint64_t(c->inflight)];
+    // a launch of ONE frame (the display loop flushes per frame) rotates over the batch slots and the display slots, a batch over the batch slots
+    pt_context::FrameSlot& fs = (total == 1 && c->displaySlots > 0) ? slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c)))) : c->slots[c->frameCounter++ % uint64_t(c->inflight)];
     plans.emplace_back();
     planSlot.push_back(&fs);
     pt_plan_frame(plans.back(), fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);

@@ -86,7 +86,9 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
 #define CNT_CHUNK_TAIL 10         // path-supply chunk counter of k_tail (the bounce it starts at)
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
-#define PT_DISPLAY_RING 4  // images pt_tonemap_begin may have in flight before pt_tonemap_end collects the oldest
+#ifndef PT_DISPLAY_RING
+#define PT_DISPLAY_RING 8  // images pt_tonemap_begin may have in flight before pt_tonemap_end collects the oldest
+#endif
 #define PT_PERSISTENT_WAVES (256u * 20u)
 
 struct RenderBuffers {
@@ -139,6 +141,7 @@ struct PtTuning {
                                    // node step + triangle step, so a ray needs ~28 iterations instead of ~22 and every iteration still issues both code paths
   int pipeWaves            = 4096; // its waves per launch (4 per SIMD: the next record lives in registers across the loop)
   int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
+  int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
   int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)

@@ -338,7 +338,7 @@ class SampleExample:
         if self.m_framesInFlight <= 0:
             return self.m_pRender.tonemap(self.m_tonemapper, display_size=size)
         self.m_pRender.tonemap_begin(self.m_tonemapper, display_size=size)
-        if self.m_pRender.tonemap_pending() > min(self.m_framesInFlight, 3):
+        if self.m_pRender.tonemap_pending() > min(self.m_framesInFlight, capi.PT_DISPLAY_RING - 1):
             return self.m_pRender.tonemap_end()
         return None
 
