@@ -482,7 +482,19 @@ if %r == "feature":
 else:
     cfg = Config(synth.sponza_like(target_tris=30000, tex_size=64), synth.procedural_sky(128, 64), 192, 108, depth=6, max_samples=%d)
 frames = %d
-if %r != "camswitch":
+if %r == "perframe":
+    # a display loop that waits for every frame: each frame is a launch of its own on an idle GPU (the band split of flush_pending)
+    from vk_raytrace_amd.renderer import HipRenderer
+    r = HipRenderer(); r.setup(0); r.set_scene(cfg.scene); integral, _ = r.set_env(cfg.env)
+    r.set_camera(cfg.camera); r.set_sunsky(cfg.sunsky); r.create((cfg.width, cfg.height))
+    st = cfg.state(integral)
+    for f in range(frames):
+        st.frame = f
+        r.setPushContants(st)
+        r.run()
+        r.synchronize()
+    np.save(sys.argv[1], r.read_accum())
+elif %r != "camswitch":
     np.save(sys.argv[1], render_hip(cfg, frames))
 else:
     # the camera moves in the middle of an accumulation: frames handed over before the move keep the old camera
@@ -500,7 +512,7 @@ else:
         r.setPushContants(st)
         r.run()
     np.save(sys.argv[1], r.read_accum())
-""" % (ROOT, scene.replace("camswitch", "feature"), max_samples, max_samples, frames, scene)
+""" % (ROOT, scene.replace("camswitch", "feature").replace("perframe-", ""), max_samples, max_samples, frames, "perframe" if scene.startswith("perframe-") else scene, scene)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "acc.npy")
         env = dict(os.environ)
@@ -529,6 +541,18 @@ def test_launch_policy_sponza_like_and_samples_per_frame():
     for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0", "accel=two,mergeSingles=0", "cnodes=0,shadeTris=0", "shadeTris=0,tail=0,batch=2", "texTile=0,prebias=0", "pipe=0,tail=0,batch=2"):
         got = _render_in_subprocess(tune, frames=3, max_samples=2, scene="sponza")
         assert np.array_equal(got, ref), tune
+
+
+def test_single_frames_cut_into_bands():
+    """A frame launched alone on an idle GPU goes out as bands of its tiles on separate frame slots (PT_TUNE bands / bandTiles; the display
+    slots take part): the accumulation image must not change, on either structure, with samples per frame, and against the batched run."""
+    for scene, ms in (("perframe-feature", 1), ("perframe-sponza", 2)):
+        ref = _render_in_subprocess("bands=1", frames=4, max_samples=ms, scene=scene)
+        assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+        assert np.array_equal(_render_in_subprocess("batch=4", frames=4, max_samples=ms, scene=scene.replace("perframe-", "")), ref)
+        for tune in ("bands=4,bandTiles=2", "bands=6,bandTiles=1", "bands=6,bandTiles=1,displaySlots=0", "bands=3,bandTiles=3,inflight=2,displaySlots=3", "accel=two,bands=5,bandTiles=2", "bands=4,bandTiles=2,interleave=0,tail=0"):
+            got = _render_in_subprocess(tune, frames=4, max_samples=ms, scene=scene)
+            assert np.array_equal(got, ref), (scene, tune)
 
 
 def test_camera_change_flushes_pending_frames():

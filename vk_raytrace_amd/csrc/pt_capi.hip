@@ -763,6 +763,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
     if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
     if(const char* p = strstr(tune, "displaySlots=")) if(sscanf(p, "displaySlots=%d", &v) == 1) g_tuning.displaySlots = v;
+    if(const char* p = strstr(tune, "bands=")) if(sscanf(p, "bands=%d", &v) == 1) g_tuning.bands = v;
+    if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) g_tuning.bandTiles = v > 0 ? v : 1;
     if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) g_tuning.stateGB = v;
     if(const char* p = strstr(tune, "shadeSpec=")) if(sscanf(p, "shadeSpec=%d", &v) == 1) g_tuning.shadeSpecialised = v;
     if(const char* p = strstr(tune, "sortClosest=")) if(sscanf(p, "sortClosest=%d", &v) == 1) g_tuning.sortClosest = v;
@@ -1667,6 +1669,25 @@ int flush_pending(pt_context* c)
     const int minPart = total < c->batchMax ? 2 : ((g_tuning.splitFull > 0 && busy == 0) ? g_tuning.splitFull : total);
     parts = std::max(1, std::min(freeSlots, total / minPart));
   }
+  // A launch of ONE frame while nothing else runs (a display loop that waits for every image) is cut the other way: into bands of the frame's
+  // tiles, one launch sequence per idle slot.  A band addresses its part of the tile list, of the accumulation image and of nothing else, so it
+  // is an ordinary launch with shifted base pointers; the bands' late, thin bounces overlap each other's full ones (profiles/r04z_*).
+  int bands = 1;
+  if(total == 1 && g_tuning.bands > 1 && !c->timers.enabled)
+  {
+    int idle = 0;
+    for(int k = 0; k < slot_total(c); ++k)
+    {
+      pt_context::FrameSlot& fs = slot_at(c, k);
+      if(fs.launched && hipEventQuery(fs.accumDone) == hipErrorNotReady)
+        continue;
+      fs.launched = false;
+      ++idle;
+    }
+    (void)hipGetLastError();
+    if(idle == slot_total(c))  // with frames in flight the slots are the pipeline: one sequence per frame
+      bands = std::max(1, std::min(std::min(idle, g_tuning.bands), int(c->numLocalTiles / uint32_t(g_tuning.bandTiles))));
+  }
   c->pendCount          = 0;
   c->renderedSinceCheck = true;
   // queue-size feedback: take the counters of the newest launch sequence that has finished
@@ -1685,13 +1706,40 @@ int flush_pending(pt_context* c)
   (void)hipGetLastError();  // hipErrorNotReady is not an error
   int done              = 0;
   // interleaved submission needs every piece to have exactly one accumulate step, and the stage timers record their events in launch order
-  const bool                       interleave = g_tuning.interleave && parts > 1 && fp.st.maxSamples == 1 && !c->timers.enabled;
+  const bool                       interleave = g_tuning.interleave && (parts > 1 || bands > 1) && fp.st.maxSamples == 1 && !c->timers.enabled;
   std::vector<std::vector<PtStep>> plans;
   std::vector<pt_context::FrameSlot*> planSlot;
   std::vector<int>                 planTail;
   std::vector<uint32_t>            planPaths;
-  plans.reserve(size_t(parts));
-  for(int p = 0; p < parts; ++p)
+  plans.reserve(size_t(std::max(parts, bands)));
+  for(int b = 0; b < bands && bands > 1; ++b)
+  {
+    const uint32_t t0 = uint32_t(uint64_t(c->numLocalTiles) * uint64_t(b) / uint64_t(bands)), t1 = uint32_t(uint64_t(c->numLocalTiles) * uint64_t(b + 1) / uint64_t(bands));
+    FrameParams    fb = fp;
+    fb.st.frame       = c->pendState.frame;
+    fb.batch          = 1;
+    fb.numLocalTiles  = t1 - t0;
+    fb.numSlots       = (t1 - t0) * 1024u;
+    const int tailFrom = tail_from_depth(double(fb.numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, c->qRatioDepths);
+    pt_context::FrameSlot& fs = slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c))));
+    RenderBuffers  rbb = fs.rb;
+    rbb.slotTile += t0;
+    rbb.frame += size_t(t0) * 1024u;
+    plans.emplace_back();
+    planSlot.push_back(&fs);
+    pt_plan_frame(plans.back(), fs.stream, c->scene, rbb, fb, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
+    c->lastAccum = fs.accumDone;
+    fs.launched  = true;
+    if(!interleave)
+    {
+      for(PtStep& st : plans.back())
+        st.fn();
+      plans.back().clear();
+    }
+    planTail.push_back(tailFrom);
+    planPaths.push_back(fb.numSlots);
+  }
+  for(int p = 0; p < parts && bands == 1; ++p)
   {
     // (equal pieces: sizes falling 4 : 3 : 2 : 1, meant to let the streams drift apart so that trace and shade stages overlap, measured 5 % slower,
     // eight pieces on eight slots 20 % slower, profiles/r04d_*)

@@ -141,6 +141,8 @@ struct PtTuning {
                                    // node step + triangle step, so a ray needs ~28 iterations instead of ~22 and every iteration still issues both code paths
   int pipeWaves            = 4096; // its waves per launch (4 per SIMD: the next record lives in registers across the loop)
   int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
+  int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
+  int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
   int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
   int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
