@@ -13,7 +13,7 @@ for rnd in range(2):
     for combo in sys.argv[1:]:
         f = [int(x) for x in combo.split(":")]
         infl, pend, disp, bands = f[0], f[1], (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 1)
-        os.environ["PT_TUNE"] = f"inflight={infl},displaySlots={disp},bands={bands}"
+        os.environ["PT_TUNE"] = f"inflight={infl},displaySlots={disp},bands={bands}" + ("," + os.environ["PT_TUNE_EXTRA"] if os.environ.get("PT_TUNE_EXTRA") else "")
         r = HipRenderer(); r.setup(0); r.set_scene(wl.scene); integ, _ = r.set_env(wl.env)
         r.set_camera(capi.camera_lookat(wl.scene.camera, W / H)); r.set_sunsky(hd.default_sun_and_sky()); r.create((W, H))
         st = hd.default_rtx_state(); st.size[0], st.size[1] = W, H; st.maxDepth = 8; st.fireflyClampThreshold = 4 * integ
