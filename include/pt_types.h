@@ -258,7 +258,7 @@ typedef struct pt_Stats {
   uint32_t numTlasNodes;     /* PT_ACCEL_TWO_LEVEL: nodes of the instance hierarchy, else 0 */
   double   msTail;           /* kernel time of the fused late bounces (closest + shade + shadow of small queues in one launch) */
   uint32_t batchFrames;      /* frames traced as one wavefront after the path-state budget was applied (pt_resize) */
-  uint32_t framesInFlight;   /* launch sequences overlapped on separate streams after the budget was applied */
+  uint32_t framesInFlight;   /* frame slots (a full batch each) overlapped on separate streams after the budget was applied; the one-frame display slots are not counted */
   uint64_t tailClosestRays;  /* the part of closestRays / shadowRays / shadedHits / misses / alphaTests that the fused late-bounce kernel processed */
   uint64_t tailShadowRays;
   uint64_t tailShadedHits;
