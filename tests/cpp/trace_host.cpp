@@ -924,7 +924,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
     std::memset(&cnt, 0, sizeof(cnt));
     RenderBuffers rb;
     std::memset(&rb, 0, sizeof(rb));
-    rb.ps.rayO = rayO.data(); rb.ps.rayD = rayD.data(); rb.ps.absorb = absorb.data(); rb.ps.neeDir = neeDir.data(); rb.ps.hit = hit.data();
+    rb.ps.rayO.p = rayO.data(); rb.ps.rayD.p = rayD.data(); rb.ps.absorb.p = absorb.data(); rb.ps.neeDir.p = neeDir.data(); rb.ps.hit.p = hit.data();
     rb.counters = &cnt;
 #pragma omp for schedule(dynamic, 64)
     for(long long r = 0; r < (long long)nrays; ++r)
@@ -1301,8 +1301,8 @@ uint32_t th_render_shard(void* p, int two, const pt_RtxState* stIn, int variant,
   std::memset(&total, 0, sizeof(total));
   RenderBuffers rb;
   std::memset(&rb, 0, sizeof(rb));
-  rb.ps.rayO = st9[0].data(); rb.ps.rayD = st9[1].data(); rb.ps.thr = st9[2].data(); rb.ps.rad = st9[3].data(); rb.ps.absorb = st9[4].data();
-  rb.ps.neeDir = st9[5].data(); rb.ps.neeRad = st9[6].data(); rb.ps.hit = st9[7].data(); rb.ps.sum = st9[8].data();
+  rb.ps.rayO.p = st9[0].data(); rb.ps.rayD.p = st9[1].data(); rb.ps.thr.p = st9[2].data(); rb.ps.rad.p = st9[3].data(); rb.ps.absorb.p = st9[4].data();
+  rb.ps.neeDir.p = st9[5].data(); rb.ps.neeRad.p = st9[6].data(); rb.ps.hit.p = st9[7].data(); rb.ps.sum.p = st9[8].data();
   rb.frame = frame.data(); rb.slotTile = slotTile.data();
   for(int f = 0; f < frames; ++f)
   {

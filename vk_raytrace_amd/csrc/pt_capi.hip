@@ -1572,9 +1572,9 @@ int pt_resize(pt_context* c, int width, int height)
   {
     pt_context::FrameSlot& fs = slot_at(c, k);
     PathState&             ps = fs.rb.ps;
-    ps.rayO = (float4*)fs.dState[0].p; ps.rayD = (float4*)fs.dState[1].p; ps.thr = (float4*)fs.dState[2].p; ps.rad = (float4*)fs.dState[3].p;
-    ps.absorb = (float4*)fs.dState[4].p; ps.neeDir = (float4*)fs.dState[5].p; ps.neeRad = (float4*)fs.dState[6].p; ps.hit = (float4*)fs.dState[7].p;
-    ps.sum = (float4*)fs.dState[8].p;
+    ps.rayO.p = (float4*)fs.dState[0].p; ps.rayD.p = (float4*)fs.dState[1].p; ps.thr.p = (float4*)fs.dState[2].p; ps.rad.p = (float4*)fs.dState[3].p;
+    ps.absorb.p = (float4*)fs.dState[4].p; ps.neeDir.p = (float4*)fs.dState[5].p; ps.neeRad.p = (float4*)fs.dState[6].p; ps.hit.p = (float4*)fs.dState[7].p;
+    ps.sum.p = (float4*)fs.dState[8].p;
     fs.rb.queueA   = (uint32_t*)fs.dQueueA.p;
     fs.rb.queueB   = (uint32_t*)fs.dQueueB.p;
     fs.rb.queueS   = (uint32_t*)fs.dQueueS.p;

@@ -200,16 +200,59 @@ struct DeviceScene {
 };
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------
+// -DPT_NT_STATE=1 (measurement build): every access to the path state carries the non-temporal hint -- the state is streamed through once per
+// stage (11 GB per batch), the scene's working set (textures, structure, environment: a few hundred MB) is what the caches should keep.  The
+// arrays become thin proxies so that the access sites stay as they are.
+#ifndef PT_NT_STATE
+#define PT_NT_STATE 0
+#endif
+#if PT_NT_STATE && defined(__HIP_DEVICE_COMPILE__)
+typedef float pt_nt_f4 __attribute__((ext_vector_type(4)));
+struct StateF1Ref {
+  float* p;
+  PT_DEV operator float() const { return __builtin_nontemporal_load(p); }
+  PT_DEV StateF1Ref& operator=(float v) { __builtin_nontemporal_store(v, p); return *this; }
+  PT_DEV StateF1Ref& operator+=(float v) { __builtin_nontemporal_store(__builtin_nontemporal_load(p) + v, p); return *this; }
+};
+struct StateF4Ref {
+  float4*    p;
+  StateF1Ref x, y, z, w;
+  PT_DEV explicit StateF4Ref(float4* q) : p(q), x{&q->x}, y{&q->y}, z{&q->z}, w{&q->w} {}
+  PT_DEV operator float4() const
+  {
+    const pt_nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const pt_nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  PT_DEV StateF4Ref& operator=(const float4& v)
+  {
+    pt_nt_f4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<pt_nt_f4*>(p));
+    return *this;
+  }
+};
+struct StateArray {
+  float4* p;
+  PT_DEV StateF4Ref operator[](size_t i) const { return StateF4Ref(p + i); }
+  PT_DEV operator float4*() const { return p; }
+};
+#else
+struct StateArray {  // the plain form: a pointer
+  float4* p;
+  PT_DEV float4& operator[](size_t i) const { return p[i]; }
+  PT_DEV operator float4*() const { return p; }
+};
+#endif
 struct PathState {
-  float4* rayO;    // origin.xyz, -
-  float4* rayD;    // direction.xyz, bits(seed)
-  float4* thr;     // throughput.xyz, rrPcont
-  float4* rad;     // radiance.xyz, -
-  float4* absorb;  // absorption.xyz, lightDist
-  float4* neeDir;  // lightDir.xyz, visible (1/0)
-  float4* neeRad;  // vcontrib.radiance.xyz, -
-  float4* hit;     // t, bits(tri slot in leaf order | 0xffffffff miss), u, v
-  float4* sum;     // per-frame sample sum (maxSamples > 1)
+  StateArray rayO;    // origin.xyz, -
+  StateArray rayD;    // direction.xyz, bits(seed)
+  StateArray thr;     // throughput.xyz, rrPcont
+  StateArray rad;     // radiance.xyz, -
+  StateArray absorb;  // absorption.xyz, lightDist
+  StateArray neeDir;  // lightDir.xyz, visible (1/0)
+  StateArray neeRad;  // vcontrib.radiance.xyz, -
+  StateArray hit;     // t, bits(tri slot in leaf order | 0xffffffff miss), u, v
+  StateArray sum;     // per-frame sample sum (maxSamples > 1)
 };
 
 struct Counters {
