@@ -381,6 +381,7 @@ struct Scene {
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
   std::vector<TexRec>      texRecs;
+  std::vector<uint4>       texDesc;  // PT_TEX_BATCH flavour: tex_desc_pack of every TexRec
   std::vector<pt_GltfShadeMaterial> materials;
   std::vector<pt_Light>    lights;
   std::vector<float4>      env;
@@ -604,6 +605,9 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   d.alphaMats = s->alphaMats.data(); d.alphaMaps = s->alphaMaps.data(); d.texels = s->texels.data();
   d.materials = s->materials.empty() ? nullptr : s->materials.data(); d.lights = s->lights.empty() ? nullptr : s->lights.data();
   d.texRecs = s->texRecs.empty() ? nullptr : s->texRecs.data();
+#if PT_TEX_BATCH
+  d.texDesc = s->texDesc.empty() ? nullptr : s->texDesc.data();
+#endif
   d.numTris = triTotal; d.numInstances = numInst;
   s->dsFlat           = d;
   s->dsFlat.wide      = s->flat.wide.data();
@@ -785,6 +789,9 @@ void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
     delete s;
     return nullptr;
   }
+  s->texDesc.resize(s->texRecs.size());
+  for(size_t t = 0; t < s->texRecs.size(); ++t)
+    s->texDesc[t] = tex_desc_pack(s->texRecs[t]);
   std::vector<float> padC0(counts[0]), padC1(counts[0]);
   for(size_t i = 0; i < counts[0]; ++i)
   {

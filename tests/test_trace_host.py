@@ -33,13 +33,19 @@ class InstIn(C.Structure):
     _fields_ = [("vertexOffset", C.c_uint32), ("firstIndex", C.c_uint32), ("triCount", C.c_uint32), ("flags", C.c_uint32), ("primMesh", C.c_int32), ("worldMatrix", C.c_float * 16)]
 
 
+FLAVOUR = ""  # "" = the product's defaults; "texbatch" = -DPT_TEX_BATCH=1 (the material's four common textures fetched in two round trips)
+FLAVOURS = {"": [], "texbatch": ["-DPT_TEX_BATCH=1"]}
+
+
 def harness():
     capi.lib()  # libptmi.so must exist: the harness links its test hooks (device-builder emulation, two_level_pad)
+    global OUT
+    OUT = os.path.join(ROOT, "tests", "cpp", "_build", "libtracehost%s.so" % ("_" + FLAVOUR if FLAVOUR else ""))
     deps = [SRC] + [os.path.join(ROOT, "vk_raytrace_amd", "csrc", f) for f in ("pt_trace.h", "pt_machine.h", "pt_settle.h", "pt_shade.h", "pt_surface.h", "pt_device.h", "pt_math.h", "pt_cnode.h")] + [capi.LIB_PATH]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         lib_dir = os.path.dirname(capi.LIB_PATH)
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DSTACK_LDS=24", "-Wno-attributes",
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-DSTACK_LDS=24", "-Wno-attributes"] + FLAVOURS[FLAVOUR] + [
                                "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "vk_raytrace_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), SRC,
                                "-L" + lib_dir, "-l:libptmi.so", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", OUT])
     L = C.CDLL(OUT)
@@ -460,6 +466,31 @@ def test_host_build_of_the_shading_source_renders_the_oracles_frames(two):
     sc = synth.fuzz_scene(4); sc.camera.aperture = 0.05
     cfg = Config(sc, env, 50, 37, depth=4, hdr_multiplier=2.0)
     assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), "odd size, depth of field"
+
+
+def test_batched_texture_fetch_flavour_renders_the_oracles_frames():
+    """-DPT_TEX_BATCH=1 (a measurement build of the product: resolve_material fetches the normal / emissive / metallic-roughness / base-colour
+    textures through 16-byte descriptors in two round trips): the host build of that flavour still gives the oracle's frames bit for bit --
+    every material feature, both BSDFs, NEAREST and LINEAR taps, all wrap modes, odd-sized and block-linear textures."""
+    global FLAVOUR
+    from tests.common import Config, render_oracle
+    env = synth.procedural_sky(128, 64)
+    FLAVOUR = "texbatch"
+    try:
+        for pbr in (0, 1):
+            cfg = Config(synth.feature_box(tex_size=32, lights=True), env, 64, 48, depth=6, pbr=pbr, max_samples=2)
+            assert _bits_equal(host_render(cfg, 2, 0), render_oracle(cfg, 2)), ("feature box", pbr)
+        cfg = Config(synth.feature_box(tex_size=32), env, 64, 48, debug=hd.eBaseColor)
+        assert _bits_equal(host_render(cfg, 1, 1), render_oracle(cfg, 1))
+        cfg = Config(synth.fuzz_scene(2), env, 96, 64, depth=5)
+        assert _bits_equal(host_render(cfg, 3, 0), render_oracle(cfg, 3)), "fuzz scene"
+        from vk_raytrace_amd import workloads
+        wl = workloads.c3_sponza(160, 90, 4, tex_size=64, env_w=256)
+        cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
+        assert _bits_equal(host_render(cfg, 3, 0), render_oracle(cfg, 3)), "C3 stand-in"
+        assert os.path.basename(OUT) == "libtracehost_texbatch.so"  # (the flavoured library is what rendered)
+    finally:
+        FLAVOUR = ""
 
 
 def test_host_build_renders_the_c3_stand_in_like_the_oracle():

@@ -32,6 +32,7 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
+  DevBuf   dTexDesc;  // PT_TEX_BATCH builds only (16-byte texture descriptors); empty otherwise
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   DevBuf   dShadeTris;
   bool     haveShadeTris = false;
@@ -276,6 +277,9 @@ void refresh_scene_ptrs(pt_context* c)
   s.materials    = (const pt_GltfShadeMaterial*)c->dMaterials.p;
   s.lights       = (const pt_Light*)c->dLights.p;
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
+#if PT_TEX_BATCH
+  s.texDesc      = (const uint4*)c->dTexDesc.p;
+#endif
   s.texels       = (const uint32_t*)c->dTexels.p;
   s.bvh          = (const BvhNode*)c->dBvh.p;
   s.wide         = (const WideNode*)c->dWide.p;
@@ -812,7 +816,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dTexDesc, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1140,6 +1144,14 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     }
   }
   if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
+#if PT_TEX_BATCH
+  {
+    std::vector<uint4> desc(R.texRecs.size());
+    for(size_t t = 0; t < desc.size(); ++t)
+      desc[t] = tex_desc_pack(R.texRecs[t]);
+    if((rc = upload(c, c->dTexDesc, desc.data(), sizeof(uint4) * desc.size())) != PT_OK) return rc;
+  }
+#endif
   if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;
   c->numInstances = d->numNodes;

@@ -155,6 +155,40 @@ inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 #endif
 }
 
+// PT_TEX_BATCH (pt_surface.h): a texture's descriptor in 16 bytes, so that the four descriptors a material fetches together cost 16 registers, not 32:
+// x = texel offset, y = w | h << 16 (sides < 2^16, pt_set_scene checks), z = bit 0 NEAREST, bits 1-2 wrapS, bits 3-4 wrapT, bits 5-6 pot, bit 7 tiled.
+#ifndef PT_TEX_BATCH
+#define PT_TEX_BATCH 0
+#endif
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline uint4 tex_desc_pack(const TexRec& t)
+{
+  uint4 d;
+  d.x = t.offset;
+  d.y = uint32_t(t.w) | (uint32_t(t.h) << 16);
+  d.z = (t.mag == 0 ? 1u : 0u) | (uint32_t(t.wrapS) << 1) | (uint32_t(t.wrapT) << 3) | (uint32_t(t.pot & 3) << 5) | (t.tiled ? 128u : 0u);
+  d.w = 0;
+  return d;
+}
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline TexRec tex_desc_unpack(const uint4& d)
+{
+  TexRec t;
+  t.offset = d.x;
+  t.w      = int32_t(d.y & 0xffffu);
+  t.h      = int32_t(d.y >> 16);
+  t.mag    = (d.z & 1u) ? 0 : 1;  // PT_FILTER_NEAREST = 0, PT_FILTER_LINEAR = 1 (include/pt_types.h)
+  t.wrapS  = int32_t((d.z >> 1) & 3u);
+  t.wrapT  = int32_t((d.z >> 3) & 3u);
+  t.pot    = int32_t((d.z >> 5) & 3u);
+  t.tiled  = int32_t((d.z >> 7) & 1u);
+  return t;
+}
+
 #define PT_SHADE_REC_QUADS 8
 struct DeviceScene {
   const float4*               vertices;  // pt_VertexAttributes as 2 x float4
@@ -163,6 +197,9 @@ struct DeviceScene {
   const pt_GltfShadeMaterial* materials;
   const pt_Light*             lights;
   const TexRec*               texRecs;
+#if PT_TEX_BATCH
+  const uint4*                texDesc;  // tex_desc_pack of every TexRec
+#endif
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH

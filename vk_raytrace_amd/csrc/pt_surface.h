@@ -58,6 +58,51 @@ PT_DEV f4 sample_rgba8_rec(const uint32_t* texels, const TexRec& tr, f2 uv)
 }
 PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv) { return sample_rgba8_rec(S.texels, S.texRecs[id], uv); }
 
+// -DPT_TEX_BATCH=1 (measurement build): resolve_material fetches the four textures nearly every material has -- normal, emissive, metallic-roughness,
+// base colour -- as TWO round trips (all four descriptors, then all sixteen texels) instead of up to eight dependent ones (descriptor, texels, per
+// texture, each behind its own `if`).  An absent texture stands in as texture 0 (which always exists) and its value is never used.  The tap is
+// sample_rgba8_rec cut in two: where the texels are (tex_tap) and what is made of them (tex_filter) -- the same expressions in the same order.
+struct TexTap {
+  uint32_t i[4];  // texel indices into the pool: (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1); four times the nearest texel for a NEAREST tap
+  float    a, b;
+  bool     nearest;
+};
+PT_DEV TexTap tex_tap(const TexRec& tr, f2 uv)
+{
+  TexTap t;
+  float  x = uv.x * float(tr.w), y = uv.y * float(tr.h);
+  t.nearest = tr.mag == PT_FILTER_NEAREST;
+  const bool ps = (tr.pot & 1) != 0, pt = (tr.pot & 2) != 0, tiled = tr.tiled != 0;
+  if(t.nearest)
+  {
+    t.a = t.b = 0.0f;
+    t.i[0] = t.i[1] = t.i[2] = t.i[3] = tr.offset + tex_index(tr.w, wrap_index((int)floorf(x), tr.w, tr.wrapS, ps), wrap_index((int)floorf(y), tr.h, tr.wrapT, pt), tiled);
+    return t;
+  }
+  x -= 0.5f;
+  y -= 0.5f;
+  const float fx = floorf(x), fy = floorf(y);
+  t.a = x - fx;
+  t.b = y - fy;
+  const int x0 = (int)fx, y0 = (int)fy;
+  const int wx0 = wrap_index(x0, tr.w, tr.wrapS, ps), wx1 = wrap_index(x0 + 1, tr.w, tr.wrapS, ps), wy0 = wrap_index(y0, tr.h, tr.wrapT, pt), wy1 = wrap_index(y0 + 1, tr.h, tr.wrapT, pt);
+  t.i[0] = tr.offset + tex_index(tr.w, wx0, wy0, tiled);
+  t.i[1] = tr.offset + tex_index(tr.w, wx1, wy0, tiled);
+  t.i[2] = tr.offset + tex_index(tr.w, wx0, wy1, tiled);
+  t.i[3] = tr.offset + tex_index(tr.w, wx1, wy1, tiled);
+  return t;
+}
+PT_DEV f4 texel_unpack(uint32_t p) { return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)}; }
+PT_DEV f4 tex_filter(const TexTap& t, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3)
+{
+  const float s255 = 1.0f / 255.0f;
+  if(t.nearest)
+    return texel_unpack(p0) * s255;
+  const f4 top = texel_unpack(p0) * (1.0f - t.a) + texel_unpack(p1) * t.a;
+  const f4 bot = texel_unpack(p2) * (1.0f - t.a) + texel_unpack(p3) * t.a;
+  return (top * (1.0f - t.b) + bot * t.b) * s255;
+}
+
 // Environment: RGBA32F, LINEAR, U repeat / V clamp (reference: src/hdr_sampling.cpp:68-77)
 PT_DEV f3 sample_env(const DeviceScene& S, f2 uv)
 {
@@ -305,9 +350,28 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   sf.uv           = f2{((sf.uv.x * um[0] + sf.uv.y * um[1]) + 1.0f * um[2]) + 1.0f * um[3], ((sf.uv.x * um[4] + sf.uv.y * um[5]) + 1.0f * um[6]) + 1.0f * um[7]};
   const f3 T0 = sf.tangent, B0 = sf.bitangent, N0 = sf.normal;  // TBN before normal mapping
 
+#if PT_TEX_BATCH
+  const bool   hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
+  const uint4  dN = S.texDesc[hasN ? m.normalTexture : 0], dE = S.texDesc[hasE ? m.emissiveTexture : 0], dM = S.texDesc[hasM ? m.pbrMetallicRoughnessTexture : 0],
+               dB = S.texDesc[hasB ? m.pbrBaseColorTexture : 0];
+  const TexRec trN = tex_desc_unpack(dN), trE = tex_desc_unpack(dE), trM = tex_desc_unpack(dM), trB = tex_desc_unpack(dB);
+  const TexTap tN = tex_tap(trN, sf.uv), tE = tex_tap(trE, sf.uv), tM = tex_tap(trM, sf.uv), tB = tex_tap(trB, sf.uv);
+  const uint32_t* tx = S.texels;
+  const uint32_t  n0 = tx[tN.i[0]], n1 = tx[tN.i[1]], n2 = tx[tN.i[2]], n3 = tx[tN.i[3]], e0 = tx[tE.i[0]], e1 = tx[tE.i[1]], e2 = tx[tE.i[2]], e3 = tx[tE.i[3]];
+  const uint32_t  m0 = tx[tM.i[0]], m1 = tx[tM.i[1]], m2 = tx[tM.i[2]], m3 = tx[tM.i[3]], b0 = tx[tB.i[0]], b1 = tx[tB.i[1]], b2 = tx[tB.i[2]], b3 = tx[tB.i[3]];
+#define PT_TAP_N tex_filter(tN, n0, n1, n2, n3)
+#define PT_TAP_E tex_filter(tE, e0, e1, e2, e3)
+#define PT_TAP_M tex_filter(tM, m0, m1, m2, m3)
+#define PT_TAP_B tex_filter(tB, b0, b1, b2, b3)
+#else
+#define PT_TAP_N sample_rgba8(S, m.normalTexture, sf.uv)
+#define PT_TAP_E sample_rgba8(S, m.emissiveTexture, sf.uv)
+#define PT_TAP_M sample_rgba8(S, m.pbrMetallicRoughnessTexture, sf.uv)
+#define PT_TAP_B sample_rgba8(S, m.pbrBaseColorTexture, sf.uv)
+#endif
   if(m.normalTexture > -1)
   {
-    f3 nv       = xyz(sample_rgba8(S, m.normalTexture, sf.uv));
+    f3 nv       = xyz(PT_TAP_N);
     nv          = unit(nv * 2.0f - 1.0f);
     nv          = nv * f3{m.normalTextureScale, m.normalTextureScale, 1.0f};
     sf.normal   = unit(basis_mul(T0, B0, N0, nv));
@@ -317,7 +381,7 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
 
   sf.emission = f3{m.emissiveFactor[0], m.emissiveFactor[1], m.emissiveFactor[2]};
   if(m.emissiveTexture > -1)
-    sf.emission *= xyz(srgb_to_linear(sample_rgba8(S, m.emissiveTexture, sf.uv)));
+    sf.emission *= xyz(srgb_to_linear(PT_TAP_E));
 
   // metallic-roughness (gltf_material.glsl:52-93)
   float dielectricSpecular = (m.ior - 1) / (m.ior + 1);
@@ -325,13 +389,17 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   float rough = m.pbrRoughnessFactor, metal = m.pbrMetallicFactor;
   if(m.pbrMetallicRoughnessTexture > -1)
   {
-    f4 mr = sample_rgba8(S, m.pbrMetallicRoughnessTexture, sf.uv);
+    f4 mr = PT_TAP_M;
     rough = mr.y * rough;
     metal = mr.z * metal;
   }
   f4 base = f4{m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2], m.pbrBaseColorFactor[3]};
   if(m.pbrBaseColorTexture > -1)
-    base = base * srgb_to_linear(sample_rgba8(S, m.pbrBaseColorTexture, sf.uv));
+    base = base * srgb_to_linear(PT_TAP_B);
+#undef PT_TAP_N
+#undef PT_TAP_E
+#undef PT_TAP_M
+#undef PT_TAP_B
   sf.f0        = lerp(splat3(dielectricSpecular), f3{base.x, base.y, base.z}, metal);
   sf.albedo    = f3{base.x, base.y, base.z};
   sf.metallic  = metal;
