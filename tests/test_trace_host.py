@@ -34,7 +34,7 @@ class InstIn(C.Structure):
 
 
 FLAVOUR = ""  # "" = the product's defaults; "texbatch" = -DPT_TEX_BATCH=1 (the material's four common textures fetched in two round trips)
-FLAVOURS = {"": [], "texbatch": ["-DPT_TEX_BATCH=1"]}
+FLAVOURS = {"": [], "texbatch": ["-DPT_TEX_BATCH=1"], "texbatch2": ["-DPT_TEX_BATCH=2"]}
 
 
 def harness():
@@ -468,14 +468,16 @@ def test_host_build_of_the_shading_source_renders_the_oracles_frames(two):
     assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), "odd size, depth of field"
 
 
-def test_batched_texture_fetch_flavour_renders_the_oracles_frames():
+@pytest.mark.parametrize("flavour", ["texbatch", "texbatch2"])
+def test_batched_texture_fetch_flavour_renders_the_oracles_frames(flavour):
     """-DPT_TEX_BATCH=1 (a measurement build of the product: resolve_material fetches the normal / emissive / metallic-roughness / base-colour
-    textures through 16-byte descriptors in two round trips): the host build of that flavour still gives the oracle's frames bit for bit --
-    every material feature, both BSDFs, NEAREST and LINEAR taps, all wrap modes, odd-sized and block-linear textures."""
+    textures through 16-byte descriptors in two round trips) and =2 (the four descriptors stored per material, so that they arrive with the
+    material record): the host build of each flavour still gives the oracle's frames bit for bit -- every material feature, both BSDFs,
+    NEAREST and LINEAR taps, all wrap modes, odd-sized and block-linear textures."""
     global FLAVOUR
     from tests.common import Config, render_oracle
     env = synth.procedural_sky(128, 64)
-    FLAVOUR = "texbatch"
+    FLAVOUR = flavour
     try:
         for pbr in (0, 1):
             cfg = Config(synth.feature_box(tex_size=32, lights=True), env, 64, 48, depth=6, pbr=pbr, max_samples=2)
@@ -488,7 +490,7 @@ def test_batched_texture_fetch_flavour_renders_the_oracles_frames():
         wl = workloads.c3_sponza(160, 90, 4, tex_size=64, env_w=256)
         cfg = Config(wl.scene, wl.env, wl.width, wl.height, depth=wl.depth, pbr=wl.pbr_mode)
         assert _bits_equal(host_render(cfg, 3, 0), render_oracle(cfg, 3)), "C3 stand-in"
-        assert os.path.basename(OUT) == "libtracehost_texbatch.so"  # (the flavoured library is what rendered)
+        assert os.path.basename(OUT) == "libtracehost_%s.so" % flavour  # (the flavoured library is what rendered)
     finally:
         FLAVOUR = ""
 

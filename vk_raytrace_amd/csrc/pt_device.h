@@ -199,6 +199,8 @@ struct DeviceScene {
   const TexRec*               texRecs;
 #if PT_TEX_BATCH
   const uint4*                texDesc;  // tex_desc_pack of every TexRec
+  const uint4*                matDesc;  // PT_TEX_BATCH=2: per material the descriptors of its normal / emissive / metallic-roughness / base-colour textures (texture 0
+                                        // for an absent one), so that they arrive WITH the material record instead of one round trip after it
 #endif
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)

@@ -340,7 +340,7 @@ PT_DEV f4 srgb_to_linear(f4 c)
 }
 
 // glTF material + KHR extensions -> Surface (everything the BSDFs need).  `rayDir` is the incoming ray.
-PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m, f3 rayDir, Surface& sf)
+PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m, f3 rayDir, Surface& sf, int matIndex = 0)
 {
   sf.specular     = 0.5f;
   sf.subsurface   = 0.0f;
@@ -352,8 +352,12 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
 
 #if PT_TEX_BATCH
   const bool   hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
+#if PT_TEX_BATCH == 2
+  const uint4  dN = S.matDesc[4 * matIndex], dE = S.matDesc[4 * matIndex + 1], dM = S.matDesc[4 * matIndex + 2], dB = S.matDesc[4 * matIndex + 3];
+#else
   const uint4  dN = S.texDesc[hasN ? m.normalTexture : 0], dE = S.texDesc[hasE ? m.emissiveTexture : 0], dM = S.texDesc[hasM ? m.pbrMetallicRoughnessTexture : 0],
                dB = S.texDesc[hasB ? m.pbrBaseColorTexture : 0];
+#endif
   const TexRec trN = tex_desc_unpack(dN), trE = tex_desc_unpack(dE), trM = tex_desc_unpack(dM), trB = tex_desc_unpack(dB);
   const TexTap tN = tex_tap(trN, sf.uv), tE = tex_tap(trE, sf.uv), tM = tex_tap(trM, sf.uv), tB = tex_tap(trB, sf.uv);
   const uint32_t* tx = S.texels;
