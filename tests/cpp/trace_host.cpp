@@ -381,7 +381,7 @@ struct Scene {
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
   std::vector<TexRec>      texRecs;
-  std::vector<uint4>       texDesc, matDesc;  // PT_TEX_BATCH flavours: tex_desc_pack of every TexRec; per material its four common textures
+  std::vector<uint4>       matDesc;  // PT_TEX_BATCH flavour: per material the packed descriptors of its four common textures
   std::vector<pt_GltfShadeMaterial> materials;
   std::vector<pt_Light>    lights;
   std::vector<float4>      env;
@@ -606,7 +606,6 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   d.materials = s->materials.empty() ? nullptr : s->materials.data(); d.lights = s->lights.empty() ? nullptr : s->lights.data();
   d.texRecs = s->texRecs.empty() ? nullptr : s->texRecs.data();
 #if PT_TEX_BATCH
-  d.texDesc = s->texDesc.empty() ? nullptr : s->texDesc.data();
   d.matDesc = s->matDesc.empty() ? nullptr : s->matDesc.data();
 #endif
   d.numTris = triTotal; d.numInstances = numInst;
@@ -790,16 +789,13 @@ void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
     delete s;
     return nullptr;
   }
-  s->texDesc.resize(s->texRecs.size());
-  for(size_t t = 0; t < s->texRecs.size(); ++t)
-    s->texDesc[t] = tex_desc_pack(s->texRecs[t]);
-  s->matDesc.assign(size_t(4) * std::max<size_t>(1, s->materials.size()), s->texDesc[0]);
+  s->matDesc.assign(size_t(4) * std::max<size_t>(1, s->materials.size()), tex_desc_pack(s->texRecs[0]));
   for(size_t i = 0; i < s->materials.size(); ++i)
   {
     const pt_GltfShadeMaterial& mt = s->materials[i];
     const int ids[4] = {mt.normalTexture, mt.emissiveTexture, mt.pbrMetallicRoughnessTexture, mt.pbrBaseColorTexture};
     for(int k = 0; k < 4; ++k)
-      s->matDesc[4 * i + k] = s->texDesc[ids[k] > -1 ? size_t(ids[k]) : 0];
+      s->matDesc[4 * i + k] = tex_desc_pack(s->texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
   }
   std::vector<float> padC0(counts[0]), padC1(counts[0]);
   for(size_t i = 0; i < counts[0]; ++i)

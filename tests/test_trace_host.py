@@ -33,8 +33,8 @@ class InstIn(C.Structure):
     _fields_ = [("vertexOffset", C.c_uint32), ("firstIndex", C.c_uint32), ("triCount", C.c_uint32), ("flags", C.c_uint32), ("primMesh", C.c_int32), ("worldMatrix", C.c_float * 16)]
 
 
-FLAVOUR = ""  # "" = the product's defaults; "texbatch" = -DPT_TEX_BATCH=1 (the material's four common textures fetched in two round trips)
-FLAVOURS = {"": [], "texbatch": ["-DPT_TEX_BATCH=1"], "texbatch2": ["-DPT_TEX_BATCH=2"]}
+FLAVOUR = ""  # "" = the product's defaults; "texbatch" = -DPT_TEX_BATCH=1 (a material's texture descriptors arrive with it, its texel requests go out together)
+FLAVOURS = {"": [], "texbatch": ["-DPT_TEX_BATCH=1"]}
 
 
 def harness():
@@ -468,12 +468,12 @@ def test_host_build_of_the_shading_source_renders_the_oracles_frames(two):
     assert _bits_equal(host_render(cfg, 2, two), render_oracle(cfg, 2)), "odd size, depth of field"
 
 
-@pytest.mark.parametrize("flavour", ["texbatch", "texbatch2"])
+@pytest.mark.parametrize("flavour", ["texbatch"])
 def test_batched_texture_fetch_flavour_renders_the_oracles_frames(flavour):
-    """-DPT_TEX_BATCH=1 (a measurement build of the product: resolve_material fetches the normal / emissive / metallic-roughness / base-colour
-    textures through 16-byte descriptors in two round trips) and =2 (the four descriptors stored per material, so that they arrive with the
-    material record): the host build of each flavour still gives the oracle's frames bit for bit -- every material feature, both BSDFs,
-    NEAREST and LINEAR taps, all wrap modes, odd-sized and block-linear textures."""
+    """-DPT_TEX_BATCH=1 (a measurement build of the product: the 16-byte descriptors of a material's normal / emissive / metallic-roughness /
+    base-colour textures are stored per material and arrive with the material record; the texels of the textures it has are requested up
+    front): the host build of the flavour still gives the oracle's frames bit for bit -- every material feature, both BSDFs, NEAREST and
+    LINEAR taps, all wrap modes, odd-sized and block-linear textures."""
     global FLAVOUR
     from tests.common import Config, render_oracle
     env = synth.procedural_sky(128, 64)

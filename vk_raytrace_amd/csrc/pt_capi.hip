@@ -32,7 +32,7 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
-  DevBuf   dTexDesc, dMatDesc;  // PT_TEX_BATCH builds only (16-byte texture descriptors, per texture and per material); empty otherwise
+  DevBuf   dMatDesc;  // PT_TEX_BATCH builds only (16-byte texture descriptors, four per material); empty otherwise
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   DevBuf   dShadeTris;
   bool     haveShadeTris = false;
@@ -278,7 +278,6 @@ void refresh_scene_ptrs(pt_context* c)
   s.lights       = (const pt_Light*)c->dLights.p;
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
 #if PT_TEX_BATCH
-  s.texDesc      = (const uint4*)c->dTexDesc.p;
   s.matDesc      = (const uint4*)c->dMatDesc.p;
 #endif
   s.texels       = (const uint32_t*)c->dTexels.p;
@@ -817,7 +816,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dTexDesc, &c->dMatDesc, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dMatDesc, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1147,17 +1146,13 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
 #if PT_TEX_BATCH
   {
-    std::vector<uint4> desc(R.texRecs.size());
-    for(size_t t = 0; t < desc.size(); ++t)
-      desc[t] = tex_desc_pack(R.texRecs[t]);
-    if((rc = upload(c, c->dTexDesc, desc.data(), sizeof(uint4) * desc.size())) != PT_OK) return rc;
-    std::vector<uint4> md(size_t(4) * std::max<size_t>(1, d->numMaterials), desc[0]);
+    std::vector<uint4> md(size_t(4) * std::max<size_t>(1, d->numMaterials), tex_desc_pack(R.texRecs[0]));
     for(uint32_t i = 0; i < d->numMaterials; ++i)
     {
       const pt_GltfShadeMaterial& mt = d->materials[i];
       const int ids[4] = {mt.normalTexture, mt.emissiveTexture, mt.pbrMetallicRoughnessTexture, mt.pbrBaseColorTexture};
       for(int k = 0; k < 4; ++k)
-        md[size_t(4) * i + k] = desc[ids[k] > -1 ? size_t(ids[k]) : 0];
+        md[size_t(4) * i + k] = tex_desc_pack(R.texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
     }
     if((rc = upload(c, c->dMatDesc, md.data(), sizeof(uint4) * md.size())) != PT_OK) return rc;
   }

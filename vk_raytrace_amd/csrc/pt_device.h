@@ -155,7 +155,7 @@ inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 #endif
 }
 
-// PT_TEX_BATCH (pt_surface.h): a texture's descriptor in 16 bytes, so that the four descriptors a material fetches together cost 16 registers, not 32:
+// PT_TEX_BATCH (pt_surface.h, a measurement build): a texture's descriptor in 16 bytes, so that a material's four descriptors cost 16 registers, not 32:
 // x = texel offset, y = w | h << 16 (sides < 2^16, pt_set_scene checks), z = bit 0 NEAREST, bits 1-2 wrapS, bits 3-4 wrapT, bits 5-6 pot, bit 7 tiled.
 #ifndef PT_TEX_BATCH
 #define PT_TEX_BATCH 0
@@ -198,9 +198,8 @@ struct DeviceScene {
   const pt_Light*             lights;
   const TexRec*               texRecs;
 #if PT_TEX_BATCH
-  const uint4*                texDesc;  // tex_desc_pack of every TexRec
-  const uint4*                matDesc;  // PT_TEX_BATCH=2: per material the descriptors of its normal / emissive / metallic-roughness / base-colour textures (texture 0
-                                        // for an absent one), so that they arrive WITH the material record instead of one round trip after it
+  const uint4*                matDesc;  // per material the 16-byte descriptors (tex_desc_pack) of its normal / emissive / metallic-roughness / base-colour textures
+                                        // (texture 0 for an absent one): they arrive WITH the material record instead of one round trip after it
 #endif
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)

@@ -58,10 +58,12 @@ PT_DEV f4 sample_rgba8_rec(const uint32_t* texels, const TexRec& tr, f2 uv)
 }
 PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv) { return sample_rgba8_rec(S.texels, S.texRecs[id], uv); }
 
-// -DPT_TEX_BATCH=1 (measurement build): resolve_material fetches the four textures nearly every material has -- normal, emissive, metallic-roughness,
-// base colour -- as TWO round trips (all four descriptors, then all sixteen texels) instead of up to eight dependent ones (descriptor, texels, per
-// texture, each behind its own `if`).  An absent texture stands in as texture 0 (which always exists) and its value is never used.  The tap is
-// sample_rgba8_rec cut in two: where the texels are (tex_tap) and what is made of them (tex_filter) -- the same expressions in the same order.
+// -DPT_TEX_BATCH=1 (measurement build, never the product until measured): resolve_material reaches its four common textures -- normal, emissive,
+// metallic-roughness, base colour -- through up to eight DEPENDENT round trips (descriptor, then texels, per texture, each behind its own `if`).
+// The flavour stores the four 16-byte descriptors per material (DeviceScene::matDesc), so that they arrive with the material record, and requests
+// the texels of the textures a material HAS up front, so that those requests are in flight together.  First forms that also fetched the absent
+// textures (as texture 0) were 7 % SLOWER on the bench line (profiles/r04tb_batched_texture_fetch.txt): k_shade is short of requests, not of latency.
+// The tap is sample_rgba8_rec cut in two: where the texels are (tex_tap) and what is made of them (tex_filter) -- the same expressions in the same order.
 struct TexTap {
   uint32_t i[4];  // texel indices into the pool: (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1); four times the nearest texel for a NEAREST tap
   float    a, b;
@@ -351,18 +353,16 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   const f3 T0 = sf.tangent, B0 = sf.bitangent, N0 = sf.normal;  // TBN before normal mapping
 
 #if PT_TEX_BATCH
-  const bool   hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
-#if PT_TEX_BATCH == 2
-  const uint4  dN = S.matDesc[4 * matIndex], dE = S.matDesc[4 * matIndex + 1], dM = S.matDesc[4 * matIndex + 2], dB = S.matDesc[4 * matIndex + 3];
-#else
-  const uint4  dN = S.texDesc[hasN ? m.normalTexture : 0], dE = S.texDesc[hasE ? m.emissiveTexture : 0], dM = S.texDesc[hasM ? m.pbrMetallicRoughnessTexture : 0],
-               dB = S.texDesc[hasB ? m.pbrBaseColorTexture : 0];
-#endif
-  const TexRec trN = tex_desc_unpack(dN), trE = tex_desc_unpack(dE), trM = tex_desc_unpack(dM), trB = tex_desc_unpack(dB);
-  const TexTap tN = tex_tap(trN, sf.uv), tE = tex_tap(trE, sf.uv), tM = tex_tap(trM, sf.uv), tB = tex_tap(trB, sf.uv);
+  const bool      hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
+  const uint4     dN = S.matDesc[4 * matIndex], dE = S.matDesc[4 * matIndex + 1], dM = S.matDesc[4 * matIndex + 2], dB = S.matDesc[4 * matIndex + 3];
   const uint32_t* tx = S.texels;
-  const uint32_t  n0 = tx[tN.i[0]], n1 = tx[tN.i[1]], n2 = tx[tN.i[2]], n3 = tx[tN.i[3]], e0 = tx[tE.i[0]], e1 = tx[tE.i[1]], e2 = tx[tE.i[2]], e3 = tx[tE.i[3]];
-  const uint32_t  m0 = tx[tM.i[0]], m1 = tx[tM.i[1]], m2 = tx[tM.i[2]], m3 = tx[tM.i[3]], b0 = tx[tB.i[0]], b1 = tx[tB.i[1]], b2 = tx[tB.i[2]], b3 = tx[tB.i[3]];
+  // each texture behind its `if`, but nothing waits inside the blocks
+  TexTap   tN{}, tE{}, tM{}, tB{};
+  uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  if(hasN) { tN = tex_tap(tex_desc_unpack(dN), sf.uv); n0 = tx[tN.i[0]]; n1 = tx[tN.i[1]]; n2 = tx[tN.i[2]]; n3 = tx[tN.i[3]]; }
+  if(hasE) { tE = tex_tap(tex_desc_unpack(dE), sf.uv); e0 = tx[tE.i[0]]; e1 = tx[tE.i[1]]; e2 = tx[tE.i[2]]; e3 = tx[tE.i[3]]; }
+  if(hasM) { tM = tex_tap(tex_desc_unpack(dM), sf.uv); m0 = tx[tM.i[0]]; m1 = tx[tM.i[1]]; m2 = tx[tM.i[2]]; m3 = tx[tM.i[3]]; }
+  if(hasB) { tB = tex_tap(tex_desc_unpack(dB), sf.uv); b0 = tx[tB.i[0]]; b1 = tx[tB.i[1]]; b2 = tx[tB.i[2]]; b3 = tx[tB.i[3]]; }
 #define PT_TAP_N tex_filter(tN, n0, n1, n2, n3)
 #define PT_TAP_E tex_filter(tE, e0, e1, e2, e3)
 #define PT_TAP_M tex_filter(tM, m0, m1, m2, m3)
