@@ -39,7 +39,9 @@ static Box isect(const Box& a, const Box& b)
 
 struct Tri { V3 a, b, c; bool opaque; };
 struct Ref { uint32_t tri; Box box; };
-struct Node { Box box; int left = -1, right = -1; int tri = -1; };  // leaf: tri >= 0
+struct Node { Box box; int left = -1, right = -1; int tri = -1; int cnt = 0; };  // leaf: tri >= 0 = first entry of g_leafTris, cnt entries
+static std::vector<int> g_leafTris;
+static size_t           g_maxLeaf = 1;  // argv[4]: references per leaf (the product: 1)
 
 static std::vector<Tri> g_tris;
 static const int BINS = 32;
@@ -89,9 +91,11 @@ struct Builder {
     for(const Ref& r : refs) nd.box.grow(r.box);
     const int id = int(nodes.size());
     nodes.push_back(nd);
-    if(refs.size() == 1)
+    if(refs.size() <= g_maxLeaf)
     {
-      nodes[id].tri = int(refs[0].tri);
+      nodes[id].tri = int(g_leafTris.size());
+      nodes[id].cnt = int(refs.size());
+      for(const Ref& r : refs) g_leafTris.push_back(int(r.tri));
       return id;
     }
     // --- object split: binned SAH over centroids, three axes
@@ -222,7 +226,7 @@ struct Builder {
 };
 
 // 4-wide collapse: a wide node's children = repeatedly replace the inner child of largest area by its two children until four (the product's k_collapse)
-struct Wide { Box box[4]; int child[4]; int tri[4]; int n; };
+struct Wide { Box box[4]; int child[4]; int tri[4]; int cnt[4]; int n; };
 static int collapse(const std::vector<Node>& bn, int root, std::vector<Wide>& out)
 {
   const int id = int(out.size());
@@ -238,7 +242,7 @@ static int collapse(const std::vector<Node>& bn, int root, std::vector<Wide>& ou
     ch[best] = bn[c].left; ch[n++] = bn[c].right;
   }
   Wide w; w.n = n;
-  for(int i = 0; i < n; ++i) { w.box[i] = bn[ch[i]].box; w.tri[i] = bn[ch[i]].tri; w.child[i] = -1; }
+  for(int i = 0; i < n; ++i) { w.box[i] = bn[ch[i]].box; w.tri[i] = bn[ch[i]].tri; w.cnt[i] = bn[ch[i]].cnt; w.child[i] = -1; }
   out[id] = w;
   for(int i = 0; i < n; ++i)
     if(bn[ch[i]].tri < 0)
@@ -277,7 +281,7 @@ static bool hit_tri(const Tri& t, const Ray& r, double& tt)
   tt = dot(e2, q) * inv;
   return tt > 1e-9;
 }
-struct Stats { double nodes = 0, tris = 0, rays = 0; };
+struct Stats { double nodes = 0, tris = 0, rays = 0, leaves = 0; };
 static bool trace(const std::vector<Wide>& w, const Ray& r, double& tbest, int& tribest, Stats& st)
 {
   const V3 inv{1 / r.d.x, 1 / r.d.y, 1 / r.d.z};
@@ -301,9 +305,14 @@ static bool trace(const std::vector<Wide>& w, const Ray& r, double& tbest, int& 
       const int i = c[k].i;
       if(n.tri[i] >= 0)
       {
-        double tt;
-        st.tris += 1;
-        if(hit_tri(g_tris[n.tri[i]], r, tt) && tt < tbest) { tbest = tt; tribest = n.tri[i]; }
+        st.leaves += 1;
+        for(int k2 = 0; k2 < n.cnt[i]; ++k2)
+        {
+          double    tt;
+          const int ti = g_leafTris[n.tri[i] + k2];
+          st.tris += 1;
+          if(hit_tri(g_tris[ti], r, tt) && tt < tbest) { tbest = tt; tribest = ti; }
+        }
       }
       else
         stack[sp++] = n.child[i];
@@ -340,6 +349,7 @@ int main(int argc, char** argv)
   }
   std::fclose(f);
   const double budget = std::atof(argv[3]);
+  if(argc > 4) g_maxLeaf = size_t(std::max(1, std::atoi(argv[4])));
   size_t nOpaque = 0;
   for(const Tri& t : g_tris) nOpaque += t.opaque;
   std::printf("%u triangles (%zu opaque), %u camera rays, reference budget +%.0f %%\n", n, nOpaque, m, budget * 100);
@@ -353,6 +363,7 @@ int main(int argc, char** argv)
       refs[i].box.grow(g_tris[i].a); refs[i].box.grow(g_tris[i].b); refs[i].box.grow(g_tris[i].c);
       root.grow(refs[i].box);
     }
+    g_leafTris.clear();
     Builder b;
     b.spatial = mode == 1;
     b.rootArea = root.area();
@@ -396,8 +407,8 @@ int main(int argc, char** argv)
     bounce(r2, s2, r3);
     std::printf("%s: %zu leaves (%.3f x triangles), %zu binary nodes, %zu wide nodes, SAH (sum of relative areas) %.1f, spatial / object splits %zu / %zu\n", mode ? "SBVH" : "SAH ", leaves,
                 double(leaves) / n, b.nodes.size(), wide.size(), sah, b.splitsSpatial, b.splitsObject);
-    std::printf("      camera rays: %.2f wide-node visits, %.2f triangle tests per ray | bounce 1 (%0.f rays): %.2f / %.2f | bounce 2 (%.0f rays): %.2f / %.2f\n", s0.nodes / s0.rays, s0.tris / s0.rays,
-                s1.rays, s1.nodes / s1.rays, s1.tris / s1.rays, s2.rays, s2.nodes / s2.rays, s2.tris / s2.rays);
+    std::printf("      camera rays: %.2f wide-node visits, %.2f leaf visits, %.2f triangle tests per ray | bounce 1 (%0.f rays): %.2f / %.2f / %.2f | bounce 2 (%.0f rays): %.2f / %.2f / %.2f\n", s0.nodes / s0.rays,
+                s0.leaves / s0.rays, s0.tris / s0.rays, s1.rays, s1.nodes / s1.rays, s1.leaves / s1.rays, s1.tris / s1.rays, s2.rays, s2.nodes / s2.rays, s2.leaves / s2.rays, s2.tris / s2.rays);
   }
   return 0;
 }

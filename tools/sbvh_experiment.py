@@ -1,6 +1,6 @@
 """CPU experiment (no GPU): node visits / triangle tests per ray on a 4-wide collapse of a binned-SAH BVH against the same with spatial splits of
 opaque triangles (tools/sbvh_experiment.cpp), on the bench scene (C3 stand-in) or the instanced C5 stand-in, for camera rays and two diffuse bounces.
-   python tools/sbvh_experiment.py [c3|c5] [camera rays, default 40000] [reference budget, default 0.3]"""
+   python tools/sbvh_experiment.py [c3|c5] [camera rays, default 40000] [reference budget, default 0.3] [references per leaf, default 1]"""
 import os, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,7 @@ from vk_raytrace_amd import capi, workloads
 which = sys.argv[1] if len(sys.argv) > 1 else "c3"
 nrays = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
+max_leaf = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 wl = workloads.c3_sponza(1920, 1080, 8, tex_size=64) if which == "c3" else workloads.c5_bistro(tex_size=64)
 sc = wl.scene
 sc.finalize(capi.pack_vertices)
@@ -51,4 +52,4 @@ with tempfile.TemporaryDirectory() as tmp:
         fh.write(np.uint32(len(rays)).tobytes()); fh.write(rays.tobytes())
     print(wl.name)
     sys.stdout.flush()
-    subprocess.check_call([exe, os.path.join(tmp, "t.bin"), os.path.join(tmp, "r.bin"), str(budget)])
+    subprocess.check_call([exe, os.path.join(tmp, "t.bin"), os.path.join(tmp, "r.bin"), str(budget), str(max_leaf)])
