@@ -267,6 +267,9 @@ typedef struct pt_Stats {
   uint64_t launchesTail;     /* launches of the fused late-bounce kernel (with profiling enabled, like launchesTraceClosest) */
   uint64_t numMergedTriangles; /* two-level mode: triangles of the prim-meshes instantiated once, kept in ONE world-space bottom-level structure
                                   (counted as one of numBlas); equal to numTriangles when the scene has no repeated mesh -- the flat kernels then run on it */
+  double   msTraceFused;     /* kernel time of the fused trace stage: shadow rays of bounce b + closest-hit rays of bounce b + 1 in one launch
+                                (msTraceClosest / msTraceShadow then hold bounce 0's closest-hit stage and the last staged bounce's shadow stage) */
+  uint64_t launchesTraceFused;
 } pt_Stats;
 
 /* pt_measure_peaks: ceilings measured on the device */

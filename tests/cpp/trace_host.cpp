@@ -424,13 +424,8 @@ static AlphaRec alpha_record(const Scene& s, const InstanceRec& I, uint32_t k)
 
 static std::atomic<unsigned long long> g_innerSteps{0};  // node steps of the machine walks since the last th_take_inner_steps()
 extern "C" unsigned long long th_take_inner_steps() { return g_innerSteps.exchange(0); }
-static std::atomic<unsigned long long> g_leafSteps{0}, g_restarts{0};  // triangle steps / EARLY walks that started over, same bracket
+static std::atomic<unsigned long long> g_leafSteps{0};  // triangle steps, same bracket
 extern "C" unsigned long long th_take_leaf_steps() { return g_leafSteps.exchange(0); }
-extern "C" unsigned long long th_take_restarts() { return g_restarts.exchange(0); }
-static int g_pipe = 1;  // the machine walks of the flat structure run the pipelined form (pt_machine.h lane_issue / lane_step) when it has compact nodes, like the kernels
-extern "C" void th_set_pipe(int on) { g_pipe = on; }
-static int g_shadowEarly = 1;  // shadow rays of the flat structure walk with the exact early-out (pt_machine.h EARLY), like k_shadow_p
-extern "C" void th_set_shadow_early(int on) { g_shadowEarly = on; }
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
 extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
 extern "C" int  th_compact_ok() { return g_compactOk; }
@@ -620,17 +615,6 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
     for(size_t i = 0; i < s->flat.wide.size(); ++i)
       ok = cn_encode(s->flat.wide[i], s->flatCNodes[i]) && ok;
     s->dsFlat.cnodes = ok ? s->flatCNodes.data() : nullptr;
-    if(ok)
-    {  // DeviceScene::cnodeBound like pt_accel.hip k_compact_nodes + pt_capi.hip build_cnodes: the reach of the nodes' grids
-      float reach = 0.0f;
-      for(const CompactNode& c : s->flatCNodes)
-      {
-        const float gm = float(CN_GRID_MAX);
-        reach = fmaxf(reach, fmaxf(fmaxf(fabsf(c.px) + gm * __uint_as_float((c.exps & 0xffu) << 23), fabsf(c.py) + gm * __uint_as_float(((c.exps >> 8) & 0xffu) << 23)),
-                                   fabsf(c.pz) + gm * __uint_as_float(((c.exps >> 16) & 0xffu) << 23)));
-      }
-      s->dsFlat.cnodeBound = (std::isfinite(reach) && reach > 0.0f) ? reach * 1.0001f : 0.0f;
-    }
     g_compactOk      = ok ? 1 : 0;
   }
   s->dsTwo            = d;
@@ -947,44 +931,24 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       unsigned long long innerSteps = 0, leafSteps = 0;
       if(exact == 2)
       {
-        const bool early = kind == 1 && !two && g_shadowEarly;
         TraceLane             L;
         std::vector<uint32_t> spill(STACK_SPILL);
-        lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0, two ? 0.0f : S.cnodeBound);
-        const bool pipe = g_pipe && !two && S.cnodes != nullptr;
-        LaneFetch  F;
-        if(pipe && !L.done)
-          lane_issue(S, L, F);
+        lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
         for(;;)
         {
-          while(pipe && !L.done)
-          {
-            if(L.cur & BVH_LEAF) ++leafSteps; else ++innerSteps;
-            const uint32_t e0 = L.early;
-            if(early) lane_step<true>(S, L, F, stack.data(), spill.data(), &cnt); else lane_step<false>(S, L, F, stack.data(), spill.data(), &cnt);
-            if(e0 == 1 && L.early == 2)
-              ++g_restarts;
-            if(!L.done)
-              lane_issue(S, L, F);
-          }
           while(!L.done)
           {
             if(!(L.cur & BVH_LEAF))
             {
               ++innerSteps;
               if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt);
-              else if(early) lane_inner<false, false, true>(S, L, stack.data(), spill.data(), &cnt);
               else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
             }
             if(!L.done && (L.cur & BVH_LEAF))
             {
               ++leafSteps;
-              const uint32_t e0 = L.early;
               if(two) lane_leaf<false, true>(S, L, stack.data(), spill.data());
-              else if(early) lane_leaf<false, false, true>(S, L, stack.data(), spill.data());
               else lane_leaf<false, false>(S, L, stack.data(), spill.data());
-              if(e0 == 1 && L.early == 2)
-                ++g_restarts;
             }
           }
           // service round of k_closest_p / k_shadow_p for this lane
@@ -992,8 +956,6 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
           if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
           {
             if(two) lane_begin_count<true>(L); else lane_begin_count<false>(L);
-            if(pipe)
-              lane_issue(S, L, F);
             continue;
           }
           if(!fallback)

@@ -523,14 +523,15 @@ else:
 
 
 def test_launch_policy_never_changes_results():
-    """Frame batches, frames in flight, the packet / machine / fused-tail kernels and the BVH builder are performance policy:
+    """Frame batches, frames in flight, the packet / machine / fused trace (k_trace_p; fuse=0: the staged chain) / tail kernels and the BVH builder are performance policy:
     every combination must produce bit-identical accumulation buffers (5 frames: a full batch, a partial one and the
     single-frame path all occur)."""
     ref = _render_in_subprocess("tail=0,batch=1,inflight=1,packetClosest=0,build=lbvh")
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
     for tune in ["tail=0", "tail=1000000000", "tail=3000,batch=2,inflight=2", "tail=700,batch=5", "interleave=0,batch=4,inflight=3", "tail=0,batch=4,inflight=3,packetClosest=0", "accel=two,tail=2000", "accel=two,tail=0,batch=2",
-                 "batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7", "packetClosest=0", "batch=4,inflight=3,packetClosest=2", "batch=32,inflight=3,build=sah", "batch=4,inflight=4,splitFull=2", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64", "build=ploc", "batch=2,build=ploc,plocRadius=3", "build=sahdev", "build=sah", "sortClosest=1,sortShadow=1,sortCells=3", "shadeSpec=1,stateGB=1",
-                 "texTile=0", "pipe=0", "regen=0", "regen=0,batch=2,inflight=2", "accel=two,packetTwo=0", "accel=two,regen=0", "pipeWaves=1024,batch=2", "prebias=0,batch=2,inflight=2,tail=0", "warm=0,texTile=0,shadeTris=0", "cnodes=0", "cnodes=0,shadeTris=0,batch=2,inflight=2,tail=0", "accel=two,cnodes=0,shadeTris=0", "shadeTris=0", "accel=two", "accel=two,mergeSingles=0", "accel=two,mergeSingles=0,tail=0,batch=2", "accel=two,batch=4,inflight=2,tail=100", "accel=two,build=lbvh,batch=3,refill=8,waves=16", "accel=two,build=sah,refill=1"]:
+                 "fuse=0", "fuse=0,tail=0", "fuse=0,tail=3000,batch=2,inflight=2", "fuse=0,accel=two,tail=0,batch=2", "fuse=0,tail=0,packetClosest=2,batch=2", "tail=0,packetClosest=2,batch=2", "tail=0,packetClosest=3,batch=2,regen=0",
+                 "batch=2,inflight=2", "batch=4,packetClosest=3,packetWaves=7", "packetClosest=0", "batch=4,inflight=3,packetClosest=2", "batch=32,inflight=3,build=sah", "batch=4,inflight=4,splitFull=2", "batch=3,inflight=1,build=lbvh,refill=8,waves=16,chunk=64", "build=ploc", "batch=2,build=ploc,plocRadius=3", "build=sahdev", "build=sah", "stateGB=1",
+                 "texTile=0", "regen=0", "regen=0,batch=2,inflight=2", "accel=two,packetTwo=0", "accel=two,regen=0", "warm=0,texTile=0,shadeTris=0", "cnodes=0", "cnodes=0,shadeTris=0,batch=2,inflight=2,tail=0", "accel=two,cnodes=0,shadeTris=0", "shadeTris=0", "accel=two", "accel=two,mergeSingles=0", "accel=two,mergeSingles=0,tail=0,batch=2", "accel=two,batch=4,inflight=2,tail=100", "accel=two,build=lbvh,batch=3,refill=8,waves=16", "accel=two,build=sah,refill=1"]:
         got = _render_in_subprocess(tune)
         assert np.array_equal(got, ref), tune
 
@@ -538,7 +539,7 @@ def test_launch_policy_never_changes_results():
 def test_launch_policy_sponza_like_and_samples_per_frame():
     """Same on the alpha-heavy scene, with maxSamples > 1 (the per-frame sample loop inside a batch)."""
     ref = _render_in_subprocess("tail=0,batch=1,inflight=1,packetClosest=0,build=lbvh", frames=3, max_samples=2, scene="sponza")
-    for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0", "accel=two,mergeSingles=0", "cnodes=0,shadeTris=0", "shadeTris=0,tail=0,batch=2", "texTile=0,prebias=0", "pipe=0,tail=0,batch=2"):
+    for tune in ("batch=2,inflight=2,build=sah", "tail=0,batch=2,inflight=2,build=ploc", "accel=two,batch=2,inflight=2", "tail=4000,batch=3", "accel=two,tail=0", "accel=two,mergeSingles=0", "cnodes=0,shadeTris=0", "shadeTris=0,tail=0,batch=2", "texTile=0", "fuse=0,tail=0,batch=2", "fuse=0,accel=two", "tail=0,batch=2", "tail=2000,batch=3,inflight=2"):
         got = _render_in_subprocess(tune, frames=3, max_samples=2, scene="sponza")
         assert np.array_equal(got, ref), tune
 

@@ -362,17 +362,11 @@ def test_two_pass_alpha_equals_the_key_ordered_loop(name, scene, eye, spread):
         assert same.all(), f"{name}: closest-hit on compact nodes, two={two}: {np.count_nonzero(~same)} rays differ, first {np.nonzero(~same)[0][:5]}"
         assert np.array_equal(got[3], ref[3])
     tmax = np.where(rng.random(n) < 0.3, np.float32(1e32), rng.uniform(0.3, 12.0, n)).astype(np.float32)
-    # ... and in both forms of the machine's loop on them: pipelined (lane_issue / lane_step: the next record requested one iteration ahead, what
-    # k_closest_p / k_shadow_p run on a flat-format structure) and two-phase (lane_inner / lane_leaf), closest-hit and bounded shadow rays
-    for pipe in (1, 0):
-        trc.L.th_set_pipe(pipe)
-        got = trc.settle(0, 0, 2, org, dirs, seeds)
-        assert (got[0] == ref[0]).all() and (got[1].view(np.uint32) == ref[1].view(np.uint32)).all() and (got[2] == ref[2]).all() and np.array_equal(got[3], ref[3]), f"{name}: pipe={pipe}"
-        for variant in (0, 1):
-            want = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
-            got = trc.settle(1, 0, 2, org, dirs, seeds, tmax, variant)
-            assert (got[0] == want[0]).all() and (got[2] == want[2]).all(), f"{name}: shadow rays on compact nodes, pipe={pipe} variant={variant}"
-    trc.L.th_set_pipe(1)
+    # ... and bounded shadow rays on them (the machine's loop as k_trace_p / k_closest_p / k_shadow_p drive it: lane_inner, then lane_leaf)
+    for variant in (0, 1):
+        want = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)
+        got = trc.settle(1, 0, 2, org, dirs, seeds, tmax, variant)
+        assert (got[0] == want[0]).all() and (got[2] == want[2]).all(), f"{name}: shadow rays on compact nodes, variant={variant}"
     trc.close()
     for variant in (0, 1):
         ref = tr.settle(1, 0, 1, org, dirs, seeds, tmax, variant)

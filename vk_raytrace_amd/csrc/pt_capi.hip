@@ -72,7 +72,7 @@ struct pt_context {
   // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
   // running-mean accumulate is ordered across frames (events).
   struct FrameSlot {
-    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dQueueR2, dQueueT, dSortKeys, dSortHist, dCounts;
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dCounts, dCountsDone;
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
@@ -461,7 +461,6 @@ int build_tlas(pt_context* c)
 void build_cnodes_two_level(pt_context* c)
 {
   c->haveCNodes = false;
-  c->scene.cnodeBound = 0.0f;  // (object-space structures have a reach of their own each: their visits keep the per-node slack)
   if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
   {
     dev_free(c->dCNodes);
@@ -487,7 +486,6 @@ void build_cnodes_two_level(pt_context* c)
 void build_cnodes(pt_context* c, uint32_t n)
 {
   c->haveCNodes = false;
-  c->scene.cnodeBound = 0.0f;
   if(!g_tuning.cnodes || n == 0)
   {
     dev_free(c->dCNodes);
@@ -498,10 +496,7 @@ void build_cnodes(pt_context* c, uint32_t n)
     (void)hipGetLastError();
     return;
   }
-  float reach   = 0.0f;
-  c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p, &reach) == 0;
-  // the per-ray slack of the prebiased visit (pt_trace.h prebias_raybox) is sized from the reach of the nodes' grids, with a margin for its own rounding
-  c->scene.cnodeBound = (c->haveCNodes && g_tuning.prebias && std::isfinite(reach) && reach > 0.0f) ? reach * 1.0001f : 0.0f;
+  c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
 }
 // DeviceScene::shadeTris over the first n leaf records of a flat-format structure (best effort: without the memory k_shade takes the indexed route)
 void build_shade_tris(pt_context* c, uint32_t n)
@@ -669,6 +664,8 @@ void pt_timers_end(StageTimers* t, hipStream_t s, int stage)
     t->launchesClosest++;
   if(stage == 5)
     t->launchesTail++;
+  if(stage == 6)
+    t->launchesFused++;
   t->npend++;
   if(t->npend == t->cap && t->cap >= 8192)
     pt_timers_collect(t);  // bound the number of live events
@@ -753,11 +750,8 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
     if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) g_tuning.warm = v;
     if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) g_tuning.texTile = v;
-    if(const char* p = strstr(tune, "prebias=")) if(sscanf(p, "prebias=%d", &v) == 1) g_tuning.prebias = v;
     if(const char* p = strstr(tune, "regen=")) if(sscanf(p, "regen=%d", &v) == 1) g_tuning.regen = v;
     if(const char* p = strstr(tune, "packetTwo=")) if(sscanf(p, "packetTwo=%d", &v) == 1) g_tuning.packetTwo = v;
-    if(const char* p = strstr(tune, "pipe=")) if(sscanf(p, "pipe=%d", &v) == 1) g_tuning.pipe = v;
-    if(const char* p = strstr(tune, "pipeWaves=")) if(sscanf(p, "pipeWaves=%d", &v) == 1) g_tuning.pipeWaves = v;
     if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
     if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
     if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
@@ -770,10 +764,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "bands=")) if(sscanf(p, "bands=%d", &v) == 1) g_tuning.bands = v;
     if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) g_tuning.bandTiles = v > 0 ? v : 1;
     if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) g_tuning.stateGB = v;
-    if(const char* p = strstr(tune, "shadeSpec=")) if(sscanf(p, "shadeSpec=%d", &v) == 1) g_tuning.shadeSpecialised = v;
-    if(const char* p = strstr(tune, "sortClosest=")) if(sscanf(p, "sortClosest=%d", &v) == 1) g_tuning.sortClosest = v;
-    if(const char* p = strstr(tune, "sortShadow=")) if(sscanf(p, "sortShadow=%d", &v) == 1) g_tuning.sortShadow = v;
-    if(const char* p = strstr(tune, "sortCells=")) if(sscanf(p, "sortCells=%d", &v) == 1) g_tuning.sortCellBits = v;
+    if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) g_tuning.fuse = v;
   }
 #undef g_tuning
   g_tuning = parsed;
@@ -825,7 +816,7 @@ int pt_destroy(pt_context* c)
   {
     for(DevBuf& b : fs.dState)
       dev_free(b);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys, &fs.dSortHist, &fs.dCounts};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dCounts, &fs.dCountsDone};
     for(DevBuf* b : q)
       dev_free(*b);
     if(fs.accumDone)
@@ -1427,7 +1418,7 @@ static int warm_slots(pt_context* c)
     pt_context::FrameSlot& fs = slot_at(c, k);
     for(DevBuf& bf : fs.dState)
       (void)hipMemsetAsync(bf.p, 0, bf.bytes, fs.stream);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
     for(DevBuf* bf : q)
       (void)hipMemsetAsync(bf->p, 0, bf->bytes, fs.stream);
   }
@@ -1445,7 +1436,7 @@ static int warm_slots(pt_context* c)
   pt_context::FrameSlot& f0 = c->slots[0];
   const int nd = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);
   if(f0.hCounts)
-    (void)hipMemcpyAsync(f0.hCounts, f0.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(nd), hipMemcpyDeviceToHost, f0.stream);
+    (void)hipMemcpyAsync(f0.hCounts, f0.rb.countsDone, sizeof(uint32_t) * CNT_STRIDE * size_t(nd), hipMemcpyDeviceToHost, f0.stream);
   for(int k = 0; k < slot_total(c); ++k)
     HIP_TRY(c, hipStreamSynchronize(slot_at(c, k).stream));
   if(f0.hCounts && c->qRatioDepths == 0)
@@ -1500,7 +1491,7 @@ int pt_resize(pt_context* c, int width, int height)
   // the defaults, sized for 288 GB of HBM.  It is a budget, not a requirement: PT_TUNE stateGB=<n> (or what hipMemGetInfo reports as free,
   // minus a reserve) caps it, and an allocation that still fails halves the batch / drops frame slots and retries, down to one frame on
   // one slot, before PT_ERR_OOM is reported.  Smaller batches only cost throughput, never results.
-  const size_t perPath = 9 * sizeof(float4) + 9 * sizeof(uint32_t);
+  const size_t perPath = 9 * sizeof(float4) + 6 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
   c->displaySlots      = c->displaySlotsMax;
   {
@@ -1513,7 +1504,7 @@ int pt_resize(pt_context* c, int width, int height)
     {
       pt_context::FrameSlot& fs = c->slots[i];
       for(DevBuf& bf : fs.dState) held += bf.bytes;
-      const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(const DevBuf* bf : q) held += bf->bytes;
     }
     const double budget = g_tuning.stateMB > 0 ? g_tuning.stateMB * 1e6 : g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
@@ -1536,12 +1527,16 @@ int pt_resize(pt_context* c, int width, int height)
       const size_t           n  = size_t(c->numSlots ? c->numSlots : 1) * size_t(k < c->inflight ? c->batchMax : 1);
       for(DevBuf& bf : fs.dState)
         ok = ok && dev_alloc_quiet(bf, sizeof(float4) * n);
-      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(DevBuf* bf : q)
         ok = ok && dev_alloc_quiet(*bf, 4 * n);
-      ok = ok && dev_alloc_quiet(fs.dSortHist, sizeof(uint32_t) * SORT_BINS) && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
+      ok = ok && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
+      ok = ok && dev_alloc_quiet(fs.dCountsDone, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
       if(ok)
+      {  // a sample pass starts on a cleared counter block: cleared here once, then by every k_accumulate
         HIP_TRY(c, hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes));
+        HIP_TRY(c, hipMemset(fs.dCountsDone.p, 0, fs.dCountsDone.bytes));
+      }
     }
     if(ok)
     {  // slots that dropped out (a smaller budget than at the last pt_resize) give their buffers back
@@ -1552,7 +1547,7 @@ int pt_resize(pt_context* c, int width, int height)
           continue;
         pt_context::FrameSlot& fs = c->slots[i];
         for(DevBuf& bf : fs.dState) dev_free(bf);
-        DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+        DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
         for(DevBuf* bf : q) dev_free(*bf);
       }
       break;
@@ -1562,7 +1557,7 @@ int pt_resize(pt_context* c, int width, int height)
     {  // release everything before retrying smaller
       pt_context::FrameSlot& fs = c->slots[i];
       for(DevBuf& bf : fs.dState) dev_free(bf);
-      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dQueueR2, &fs.dQueueT, &fs.dSortKeys};
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(DevBuf* bf : q) dev_free(*bf);
     }
     if(c->displaySlots > 0)
@@ -1598,11 +1593,8 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.queueX   = (uint32_t*)fs.dQueueX.p;
     fs.rb.queueX2  = (uint32_t*)fs.dQueueX2.p;
     fs.rb.queueR   = (uint32_t*)fs.dQueueR.p;
-    fs.rb.queueR2  = (uint32_t*)fs.dQueueR2.p;
-    fs.rb.queueT   = (uint32_t*)fs.dQueueT.p;
-    fs.rb.sortKeys = (uint32_t*)fs.dSortKeys.p;
-    fs.rb.sortHist = (uint32_t*)fs.dSortHist.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
+    fs.rb.countsDone = (uint32_t*)fs.dCountsDone.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
@@ -1819,7 +1811,7 @@ int flush_pending(pt_context* c)
     {
       fs.countsDepths = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);  // the bounce k_tail starts at still has its input count
       fs.countsPaths  = n;
-      if(hipMemcpyAsync(fs.hCounts, fs.rb.counts, sizeof(uint32_t) * CNT_STRIDE * size_t(fs.countsDepths), hipMemcpyDeviceToHost, fs.stream) == hipSuccess &&
+      if(hipMemcpyAsync(fs.hCounts, fs.rb.countsDone, sizeof(uint32_t) * CNT_STRIDE * size_t(fs.countsDepths), hipMemcpyDeviceToHost, fs.stream) == hipSuccess &&
          hipEventRecord(fs.countsDone, fs.stream) == hipSuccess)
         fs.countsSeq = ++c->launchSeq;
       else
@@ -2278,6 +2270,8 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.msTail       = c->timers.ms[5];
   s.launchesTraceClosest = c->timers.launchesClosest;
   s.launchesTail         = c->timers.launchesTail;
+  s.msTraceFused         = c->timers.ms[6];
+  s.launchesTraceFused   = c->timers.launchesFused;
   s.numMergedTriangles   = c->mergedTris;
   s.tailClosestRays = k.tailClosestRays; s.tailShadowRays = k.tailShadowRays; s.tailShadedHits = k.tailShadedHits; s.tailMisses = k.tailMisses;
   s.tailAlphaTests = k.tailAlphaTests;
@@ -2309,6 +2303,7 @@ int pt_reset_stats(pt_context* c)
     m = 0;
   c->timers.launchesClosest = 0;
   c->timers.launchesTail    = 0;
+  c->timers.launchesFused   = 0;
   c->stats                  = pt_Stats{};
   HIP_TRY(c, hipMemset(c->dCounters.p, 0, sizeof(Counters)));
   return PT_OK;

@@ -138,7 +138,7 @@ struct TexRec {
 // A storage order only: the texel VALUES and the filter arithmetic are untouched (k_shade is bound by the lines it pulls through L2).
 #define PT_TEX_TILE_W 8
 #define PT_TEX_TILE_H 4
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
@@ -160,7 +160,7 @@ inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 #ifndef PT_TEX_BATCH
 #define PT_TEX_BATCH 0
 #endif
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint4 tex_desc_pack(const TexRec& t)
@@ -172,7 +172,7 @@ inline uint4 tex_desc_pack(const TexRec& t)
   d.w = 0;
   return d;
 }
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline TexRec tex_desc_unpack(const uint4& d)
@@ -221,7 +221,6 @@ struct DeviceScene {
   uint32_t                    numInstances;
   pt_SceneCamera              camera;
   pt_SunAndSky                sunsky;
-  float                       cnodeBound;       // flat-format compact nodes: M >= |p| + 2047 step over every node and axis (pt_trace.h prebias_raybox); 0: unknown
   float                       boundsMin[3];     // world bounds of the triangles (ray-sort keys: origin cell)
   float                       boundsInvExt[3];  // 1 / extent per axis (0 for a flat axis)
   // two-level mode (null / 0 otherwise)

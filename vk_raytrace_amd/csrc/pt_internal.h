@@ -71,7 +71,7 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
                     size_t errLen);
 
 // pt_render.hip -- one frame of the wavefront pipeline, enqueued on `stream`
-// Per-bounce counter block (CNT_STRIDE words per bounce, all zeroed once per frame by one memset):
+// Per-bounce counter block (CNT_STRIDE words per bounce; zero when a sample pass starts: pt_resize clears it, k_accumulate leaves it cleared):
 #define CNT_STRIDE 16
 #define CNT_IN 0             // size of the bounce's input queue (bounce b+1's lives at +CNT_STRIDE)
 #define CNT_SHADOW 1         // size of queueS (paths with a shadow ray)
@@ -81,8 +81,7 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
 #define CNT_CHUNK_SHADOW 5   // ray-supply chunk counter of k_shadow_p
 #define CNT_REDO 6           // size of queueR
 #define CNT_CHUNK_REDO 7     // ray-supply chunk counter of k_closest_p on queueR
-#define CNT_REDO_SHADOW 8         // size of queueR2 (shadow rays the packet kernel could not settle)
-#define CNT_CHUNK_REDO_SHADOW 9   // ray-supply chunk counter of k_shadow_p on queueR2
+#define CNT_NEXT 8                // fused stage (k_trace_p): size of the queue of paths k_shade sent on without a shadow ray
 #define CNT_CHUNK_TAIL 10         // path-supply chunk counter of k_tail (the bounce it starts at)
 #define PT_MAX_DEPTH 256
 #define PT_MAX_INFLIGHT 8
@@ -99,11 +98,8 @@ struct RenderBuffers {
   uint32_t* queueX;    // exact-fallback queues (normally empty)
   uint32_t* queueX2;
   uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
-  uint32_t* queueR2;   // same for shadow rays
-  uint32_t* queueT;    // a queue re-ordered by the ray sort (closest-hit rays of bounce >= 1, shadow rays)
-  uint32_t* sortKeys;  // sort key of every entry of the queue being sorted
-  uint32_t* sortHist;  // SORT_BINS bin counters -> bin offsets
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
+  uint32_t* countsDone;  // the counter block of the latest finished sample pass (k_accumulate copies it here and clears `counts`)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
   Counters* counters;
@@ -123,11 +119,6 @@ struct PtTuning {
                                    // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
   int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
   int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
-  int shadeSpecialised     = 0;    // k_shade<0 / 1>: the common case (no debug output, no sun & sky, no punctual lights) compiled per BSDF
-  int sortClosest          = 0;    // bounce >= 1: the closest-hit queue is binned by (direction octant, origin cell) before it is traced, so that the 64 rays a
-                                   // wave of the trace machine pulls together (and refills with) start in the same region with the same direction signs
-  int sortShadow           = 0;    // same for the shadow-ray queue of every bounce
-  int sortCellBits         = 4;    // origin cells per axis = 2^sortCellBits (<= 5)
   int rotatePasses         = 2;    // device builders: bottom-up tree-rotation passes after the topology is built
   int plocFull             = 0;    // PLOC: below this many clusters the search covers all of them (exact agglomerative clustering of the top levels)
   int plocRadius           = 16;   // PLOC: clusters examined on either side of a cluster per round
@@ -136,16 +127,12 @@ struct PtTuning {
                                    // queue is expected to hold at most this many paths (0: never)
   int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
                                    // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
-  int pipe                 = 0;    // 1: persistent trace kernels of the flat-format structure run the pipelined machine (one memory wait per iteration; pt_machine.h
-                                   // lane_issue / lane_step).  Bit-identical, measured 8 % SLOWER (profiles/r04h_*): a lane then advances one step per iteration instead of
-                                   // node step + triangle step, so a ray needs ~28 iterations instead of ~22 and every iteration still issues both code paths
-  int pipeWaves            = 4096; // its waves per launch (4 per SIMD: the next record lives in registers across the loop)
   int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
   int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
   int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
   int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
+  int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p); 0: the round-4 chain
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
-  int prebias              = 1;    // flat-format compact nodes: the conservative slack of the planes as one per-ray bound (pt_trace.h prebias_raybox) instead of per node
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
@@ -170,8 +157,6 @@ void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceS
 // tailFrom: first bounce handed to k_tail (>= maxDepth: none)
 void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
                      hipEvent_t recordAfterAccum, int tailFrom);
-#define SORT_MAX_CELL_BITS 5
-#define SORT_BINS (8u << (3 * SORT_MAX_CELL_BITS))
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters);
 void pt_launch_untile(hipStream_t stream, const float4* frameTiles, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* outRowMajor);
@@ -190,8 +175,8 @@ void pt_launch_mean(hipStream_t stream, const float4* rowMajor, size_t n, double
 struct StageTimers {
   bool       enabled = false;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  double     ms[6] = {0, 0, 0, 0, 0, 0};  // generate, closest, shade, shadow, accumulate, tail (k_tail: the late bounces of a launch sequence)
-  uint64_t   launchesClosest = 0, launchesTail = 0;
+  double     ms[7] = {0, 0, 0, 0, 0, 0, 0};  // generate, closest, shade, shadow, accumulate, tail (k_tail: the late bounces of a launch sequence), fused trace (k_trace_p)
+  uint64_t   launchesClosest = 0, launchesTail = 0, launchesFused = 0;
   hipStream_t stream = nullptr;
   // pending (start,stop) pairs are resolved lazily to keep the stream asynchronous
   struct Pending { hipEvent_t a, b; int stage; };

@@ -12,11 +12,6 @@
 // same candidate rules); rays that need the exact key-ordered fallback are handed to the simple kernels.
 #pragma once
 #include "pt_trace.h"
-#ifndef PT_SORTED_VISIT
-#define PT_SORTED_VISIT 0  // 1: the persistent kernels' node visit in the round-4 form (pt_trace.h wide_node_step_cs: sorting network, straight-line pushes,
-                           // per-ray plane slack).  Measured equal to the round-3 form within the run-to-run noise of 1 % (profiles/r04c_*, r04e_*) at more
-                           // scratch (192-208 B against 176 B per lane): kept as an A/B build, not the default
-#endif
 
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)
 
@@ -37,28 +32,22 @@ struct TraceLane {
   int      pass;           // 0: pass A (nearest certain hit), 1: pass B (count zero-opacity candidates in front of it)
   bool     opaqueHit;      // shadow rays: an opaque occluder was found
   bool     done;
-  uint32_t early;          // EARLY walks (shadow rays): 0 normal, 1 an opaque hit is the best hit and no non-opaque candidate has been seen: only subtrees
-                           // that hold non-opaque triangles are still looked at, 2 such a candidate turned up in front of the hit: full walk again, for good
 #if PT_BVH_WIDTH != 2
   InstCtx  ic;             // two-level instantiations only (the flat ones never touch it): the instance the lane is inside of
   uint32_t steps;          //   and the loop-iteration guard
 #endif
 };
 
-// cbound: DeviceScene::cnodeBound when the lane will walk prebiased compact nodes (pt_trace.h wide_node_step_cs<true>: flat-format structure), else 0
-PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene, float cbound = 0.0f)
+PT_DEV void lane_begin(TraceLane& L, f3 o, f3 d, float tmax, bool emptyScene)
 {
   L.o = o; L.d = d;
 #if PT_BVH_WIDTH != 2
   L.rbox = make_raybox(o, d);
-  if(cbound > 0.0f)
-    prebias_raybox(L.rbox, o, cbound);
 #else
   L.idir = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 #endif
   L.tmax = tmax; L.bt = tmax; L.bu = 0.f; L.bv = 0.f; L.bslot = BVH_NONE; L.bw = 0xffffffffu;
   L.cur = 0; L.sp = 0; L.flags = 0; L.cnt = 0; L.wLimit = 0; L.pass = 0; L.opaqueHit = false; L.done = emptyScene; L.zeroMaxT = -1.0f; L.zeroMaxT2 = -1.0f; L.zeroMaxT3 = -1.0f;
-  L.early = 0;
 #if PT_BVH_WIDTH != 2
   L.ic = InstCtx{BVH_NONE, 0, 0u}; L.steps = 0;
 #endif
@@ -80,14 +69,7 @@ PT_DEV void lane_begin_count(TraceLane& L)
 #endif
 }
 
-// EARLY (shadow rays of the flat structure; trace contract T6): what a shadow ray reports is (occluded or not, the RNG state after the draws of the
-// zero-opacity candidates in front of the nearest certain hit).  Once an OPAQUE hit at t0 is the best hit and no non-opaque candidate has been
-// seen, the answer can only change through a non-opaque candidate inside (0, t0) -- a nearer OPAQUE hit changes neither the verdict nor the (zero)
-// draws.  From then on the walk enters only references tagged BVH_ALPHA (subtrees / leaves that hold non-opaque triangles); opaque-only subtrees
-// in front of t0 are skipped.  If such a candidate does turn up in front of the hit (any opacity), the draws depend on which certain hit is the
-// nearest after all: the walk starts over as the plain front-to-back walk bounded by t0 (L.early = 2).  The reference's own shadow ray is
-// gl_RayFlagsTerminateOnFirstHitEXT (shaders/traceray_rq.glsl:157, traceray_rtx.glsl:56).
-template <bool TWO = false, bool EARLY = false>
+template <bool TWO = false>
 PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
 {
 #if PT_BVH_WIDTH != 2
@@ -98,23 +80,18 @@ PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
     L.rbox    = make_raybox(L.o, L.d);
   }
 #endif
-  for(;;)
+  if(L.sp == 0)
   {
-    if(L.sp == 0)
-    {
-      L.done = true;
-      return;
-    }
-    --L.sp;
-    L.cur = L.sp < STACK_LDS ? lds[L.sp * TRACE_BLOCK] : spill[L.sp - STACK_LDS];
-    if(!(EARLY && L.early == 1) || (L.cur & BVH_ALPHA))
-      return;  // (EARLY, after the opaque hit: references without non-opaque triangles below them are dropped unvisited)
+    L.done = true;
+    return;
   }
+  --L.sp;
+  L.cur = L.sp < STACK_LDS ? lds[L.sp * TRACE_BLOCK] : spill[L.sp - STACK_LDS];
 }
 
 // One inner-node visit.  SHADOW: true for shadow rays (they must keep looking for opaque triangles behind the best
 // alpha candidate, so only tmax prunes).
-template <bool SHADOW, bool TWO = false, bool EARLY = false>
+template <bool SHADOW, bool TWO = false>
 PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters)
 {
 #if PT_BVH_WIDTH != 2
@@ -135,39 +112,13 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   };
   // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
   const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
-  const bool     alphaOnly = L.pass == 1 || (EARLY && L.early == 1);
-  if(PT_SORTED_VISIT && S.cnodes)
-  {  // (wave-uniform) the round-4 form of the visit: sorted far-to-near list, straight-line pushes
-    uint32_t       far3[3];
-    const uint32_t amask = alphaOnly ? BVH_ALPHA : 0u;
-    const uint32_t nxt2  = TWO ? wide_node_step_cs<false>(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, amask, far3)
-                               : (S.cnodeBound > 0.0f ? wide_node_step_cs<true>(S.cnodes, L.cur, L.rbox, lim, amask, far3) : wide_node_step_cs<false>(S.cnodes, L.cur, L.rbox, lim, amask, far3));
-    if(!__ballot(L.sp > STACK_LDS - 3))
-    {  // every lane of the visit has room for three entries in the LDS part of its stack
-#pragma unroll
-      for(int i = 0; i < 3; ++i)
-        if(far3[i] != BVH_NONE)
-          lds[L.sp++ * TRACE_BLOCK] = far3[i];
-    }
-    else
-    {
-#pragma unroll
-      for(int i = 0; i < 3; ++i)
-        if(far3[i] != BVH_NONE)
-          pushChild(far3[i]);
-    }
-    if(nxt2 != BVH_NONE)
-      L.cur = nxt2;
-    else
-      lane_pop<TWO, EARLY>(L, lds, spill);
-    return;
-  }
-  const uint32_t nxt    = (!PT_SORTED_VISIT && S.cnodes) ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
-                                                         : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
+  const bool     alphaOnly = L.pass == 1;
+  const uint32_t nxt    = S.cnodes ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
+                                   : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else
-    lane_pop<TWO, EARLY>(L, lds, spill);
+    lane_pop<TWO>(L, lds, spill);
 }
 #else
   const BvhNode* np = S.bvh + (L.cur & BVH_SLOT_MASK);
@@ -209,10 +160,10 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
 }
 #endif
 
-template <bool SHADOW, bool TWO, bool EARLY>
+template <bool SHADOW, bool TWO>
 PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, uint32_t* lds, uint32_t* spill);
 // One leaf (triangle) visit; same candidate rules as traverse<TM_CLOSEST / TM_SHADOW / TM_COUNT>.
-template <bool SHADOW, bool TWO = false, bool EARLY = false>
+template <bool SHADOW, bool TWO = false>
 PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill)
 {
   const uint32_t slot  = L.cur & BVH_SLOT_MASK;
@@ -235,10 +186,10 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
   if(TWO && L.ic.inst != PT_INST_MERGED)
     tr = world_tri(S, L.ic, tr);
 #endif
-  lane_leaf_with<SHADOW, TWO, EARLY>(S, L, slot, tr, ar, lds, spill);
+  lane_leaf_with<SHADOW, TWO>(S, L, slot, tr, ar, lds, spill);
 }
 // the triangle step on records already in registers
-template <bool SHADOW, bool TWO, bool EARLY>
+template <bool SHADOW, bool TWO>
 PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, uint32_t* lds, uint32_t* spill)
 {
   const uint32_t wbits = __float_as_uint(tr.p0w.w);
@@ -267,14 +218,6 @@ PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, co
         L.done      = true;
         return;
       }
-      else if(EARLY && L.early == 1)
-      {  // only non-opaque leaves are visited in this state
-        if(key_less(t, w, L.bt, L.bw & TRI_INDEX_MASK))
-        {  // a non-opaque candidate in front of the opaque hit: which certain hit is the nearest matters after all -- the plain walk, bounded by the hit
-          L.early = 2; L.cur = 0; L.sp = 0;
-          return;
-        }
-      }
       else if(L.bslot == BVH_NONE || key_less(t, w, L.bt, L.bw & TRI_INDEX_MASK))
       {
         bool certain = opq;
@@ -295,74 +238,12 @@ PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, co
         if(certain)
         {
           L.bt = t; L.bu = u; L.bv = v; L.bslot = slot; L.bw = wbits;
-          if(EARLY && opq && L.early == 0 && L.cnt == 0 && L.flags == 0)
-            L.early = 1;
         }
       }
     }
   }
-  lane_pop<TWO, EARLY>(L, lds, spill);
+  lane_pop<TWO>(L, lds, spill);
 }
-
-#if PT_BVH_WIDTH != 2
-// ---- the same machine with ONE memory wait per iteration (round 4; flat-format structure with compact nodes) -----------------------------------------
-// lane_inner / lane_leaf each fetch what they need and wait for it: a loop iteration (node step for the lanes at an inner node, then triangle step
-// for the lanes at a leaf) has two dependent round trips, and the wavefront sits out both.  Here a lane's NEXT record -- the 80-byte node, or the
-// 48-byte triangle (+ the 32-byte any-hit record of a non-opaque one) -- is requested at the END of its step (lane_issue) into five quads that stay
-// in registers across the loop's back edge, and consumed at the start of the next iteration (lane_step): one wait per iteration, covering node
-// lanes and triangle lanes alike, and five request instructions per iteration instead of five plus three to five.  Arithmetic, candidate rules and
-// stack discipline are those of lane_inner / lane_leaf (the visit bodies are shared: cnode_visit, lane_leaf_with).
-struct LaneFetch {
-  uint4 q[5];  // node: header, X, Y, Z planes, children.  leaf: p0w, e1n, e2p, AlphaRec (two quads, non-opaque triangles only)
-};
-PT_DEV void lane_issue(const DeviceScene& S, const TraceLane& L, LaneFetch& F)
-{
-  const bool     leaf = (L.cur & BVH_LEAF) != 0;
-  const uint32_t slot = L.cur & BVH_SLOT_MASK;
-  const char*    a    = leaf ? reinterpret_cast<const char*>(S.tris) + size_t(slot) * sizeof(TriRec) : reinterpret_cast<const char*>(S.cnodes) + size_t(slot) * sizeof(CompactNode);
-  F.q[0]              = *reinterpret_cast<const uint4*>(a);
-  F.q[1]              = *reinterpret_cast<const uint4*>(a + 16);
-  F.q[2]              = *reinterpret_cast<const uint4*>(a + 32);
-  if(!leaf || (L.cur & BVH_ALPHA))
-  {
-    const char* b = leaf ? reinterpret_cast<const char*>(S.alphaRecs) + size_t(slot) * sizeof(AlphaRec) : a + 48;
-    F.q[3]        = *reinterpret_cast<const uint4*>(b);
-    F.q[4]        = *reinterpret_cast<const uint4*>(b + 16);
-  }
-}
-PT_DEV float4 quad_as_float4(uint4 q) { return make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); }
-template <bool EARLY = false>
-PT_DEV void lane_step(const DeviceScene& S, TraceLane& L, const LaneFetch& F, uint32_t* lds, uint32_t* spill, Counters* counters)
-{
-  if(!(L.cur & BVH_LEAF))
-  {
-    const float lim = L.pass == 1 ? L.tmax : L.bt;
-    auto pushChild = [&](uint32_t c) {
-      if(L.sp < STACK_LDS)
-        lds[L.sp++ * TRACE_BLOCK] = c;
-      else if(L.sp < STACK_LDS + STACK_SPILL)
-        spill[L.sp++ - STACK_LDS] = c;
-      else
-        atomicAdd(&counters->stackOverflow, 1u);
-    };
-    const bool     alphaOnly = L.pass == 1 || (EARLY && L.early == 1);
-    const uint32_t nxt       = cnode_visit(quad_as_float4(F.q[0]), F.q[1], F.q[2], F.q[3], F.q[4], L.rbox, lim, alphaOnly, pushChild);
-    if(nxt != BVH_NONE)
-      L.cur = nxt;
-    else
-      lane_pop<false, EARLY>(L, lds, spill);
-  }
-  else
-  {
-    TriRec tr;
-    tr.p0w = quad_as_float4(F.q[0]); tr.e1n = quad_as_float4(F.q[1]); tr.e2p = quad_as_float4(F.q[2]);
-    AlphaRec ar;
-    ar.uv0[0] = __uint_as_float(F.q[3].x); ar.uv0[1] = __uint_as_float(F.q[3].y); ar.uv1[0] = __uint_as_float(F.q[3].z); ar.uv1[1] = __uint_as_float(F.q[3].w);
-    ar.uv2[0] = __uint_as_float(F.q[4].x); ar.uv2[1] = __uint_as_float(F.q[4].y); ar.material = F.q[4].z; ar._pad = F.q[4].w;
-    lane_leaf_with<false, false, EARLY>(S, L, L.cur & BVH_SLOT_MASK, tr, ar, lds, spill);
-  }
-}
-#endif
 
 // Wave-uniform ray supply: a wave reserves PT_CHUNK consecutive queue entries with one atomic and hands them to
 // its idle lanes.  Returns the queue index for this lane or 0xffffffff.

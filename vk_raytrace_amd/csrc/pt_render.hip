@@ -50,19 +50,11 @@ namespace {
 #ifndef PT_TRACE_WAVES_TWO
 #define PT_TRACE_WAVES_TWO 4  // two-level instantiations: object-space ray constants + instance context are live on top of the flat state (128 VGPRs)
 #endif
-#ifndef PT_TRACE_WAVES_PIPE
-#define PT_TRACE_WAVES_PIPE 4  // the pipelined machine keeps a lane's next record (five quads) in registers across the loop's back edge
-#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4  // 128 VGPRs.  The first bounce's shade launch streams ~700 B per path and is HBM-bound: a fourth wave per SIMD keeps more
                           // loads in flight (+5 % on the 96-step bench against 3 waves / 137 VGPRs, profiles/r03h_*)
 #endif
 constexpr int SHADE_BLOCK = 256;
-#ifndef PT_SHADOW_EARLY
-#define PT_SHADOW_EARLY 0  // 1: k_shadow_p walks with the exact early-out of pt_machine.h (EARLY).  Measured before it was built: 0.965x node steps,
-                           // 0.96x triangle steps per shadow ray on the C3 stand-in (profiles/r04_shadow_earlyout_experiment.txt) -- the front-to-back walk
-                           // finds the nearest hit first almost always, so little is left to skip
-#endif
 
 // ---- wave-aggregated helpers ---------------------------------------------------------------------------
 PT_DEV void count_event(unsigned long long* ctr)
@@ -175,11 +167,9 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
 // waits for the next service round instead of dragging ~200 instructions of epilogue into every iteration.
 // HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
 // instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
-template <bool HEAT, bool TWO, bool PIPE = false>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE ? PT_TRACE_WAVES_PIPE : PT_TRACE_WAVES)) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
+template <bool HEAT, bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
-  static_assert(!(PIPE && TWO), "the pipelined machine walks the flat-format structure");
-  LaneFetch F;  // (PIPE) the lane's next record, requested one iteration ahead
   uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   uint32_t            spill[STACK_SPILL];
@@ -210,8 +200,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
       {
         lane_begin_count<TWO>(L);  // stay alive: pass B runs in the same loop
-        if(PIPE)
-          lane_issue(S, L, F);
       }
       else
       {
@@ -244,9 +232,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
       pslot           = queueIn[qi];
       const float4 dw = rb.ps.rayD[pslot];
       seed            = __float_as_uint(dw.w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
-      if(PIPE && !L.done)
-        lane_issue(S, L, F);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
       alive = true;
       ++nRays;
       if(HEAT)
@@ -264,16 +250,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
 #ifdef PT_HIST
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
-      if(PIPE)
-      {  // one wait per iteration: the records were requested at the end of the previous step (pt_machine.h lane_issue / lane_step)
-        if(!L.done)
-        {
-          lane_step<false>(S, L, F, lds, spill, rb.counters);
-          if(!L.done)
-            lane_issue(S, L, F);
-        }
-        continue;
-      }
       if(!L.done && !(L.cur & BVH_LEAF))
         lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
@@ -324,7 +300,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_PACKET_WAVES_TWO : PT_PA
     const bool     valid = i < count;
     uint32_t       slot = 0, seed = 0;
     f3             o = f3{0.f, 0.f, 0.f}, d = f3{0.f, 0.f, 1.f};
-    const bool regen = fp.regen != 0;
+    const bool regen = fp.regen != 0 && bounce == 0;  // (later bounces of a packetClosest >= 2 policy trace the rays k_shade wrote)
     if(valid)
     {
       slot = queueIn[i];
@@ -420,7 +396,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 __attribute__((amdgpu_num_vgpr(PT_SHADE_VGPRS)))
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth)
+__global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceScene S, RenderBuffers rb, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int depth, int cntNext)
 {
   __shared__ uint32_t sCnt[5], sBase[2];  // shadow, next, misses, hits, nee lookups
   uint32_t*      C     = rb.counts + depth * CNT_STRIDE;
@@ -467,7 +443,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK, PT_SHADE_WAVES) k_shade(DeviceSce
   if(threadIdx.x == 0)
   {
     if(sCnt[0]) sBase[0] = atomicAdd(&C[CNT_SHADOW], sCnt[0]);
-    if(sCnt[1]) sBase[1] = atomicAdd(&C[CNT_STRIDE + CNT_IN], sCnt[1]);
+    if(sCnt[1]) sBase[1] = atomicAdd(&C[cntNext], sCnt[1]);  // CNT_STRIDE + CNT_IN: the next bounce's input queue; CNT_NEXT: the fused stage's second queue
     if(sCnt[2]) atomicAdd(&rb.counters->misses, (unsigned long long)sCnt[2]);
     if(sCnt[3]) atomicAdd(&rb.counters->shadedHits, (unsigned long long)sCnt[3]);
     if(sCnt[4]) atomicAdd(&rb.counters->neeLookups, (unsigned long long)sCnt[4]);
@@ -487,12 +463,10 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
 
 // Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
 // zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
-template <bool HEAT, bool TWO, bool PIPE = false>
-__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE ? PT_TRACE_WAVES_PIPE : PT_TRACE_WAVES)) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
+template <bool HEAT, bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
-  static_assert(!(PIPE && TWO), "the pipelined machine walks the flat-format structure");
-  LaneFetch F;
   uint32_t heatT0 = 0;
   __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
   __shared__ uint32_t stage[STAGE_CAP];
@@ -526,8 +500,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
       if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
       {
         lane_begin_count<TWO>(L);
-        if(PIPE)
-          lane_issue(S, L, F);
       }
       else
       {
@@ -562,9 +534,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
     {
       pslot = queueIn[qi];
       seed  = __float_as_uint(rb.ps.rayD[pslot].w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0, (TWO || !PT_SORTED_VISIT) ? 0.0f : S.cnodeBound);
-      if(PIPE && !L.done)
-        lane_issue(S, L, F);
+      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
       alive = true;
       ++nRays;
       if(HEAT)
@@ -582,29 +552,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : (PIPE 
 #ifdef PT_HIST
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
-      constexpr bool EARLY = !TWO && PT_SHADOW_EARLY != 0;
-      if(PIPE)
-      {
-        if(!L.done)
-        {
-          const bool wasLeaf = (L.cur & BVH_LEAF) != 0;
-          lane_step<EARLY>(S, L, F, lds, spill, rb.counters);
-          if(wasLeaf && S.allOpaque && L.bslot != BVH_NONE)
-            L.done = true;  // (see below)
-          if(!L.done)
-            lane_issue(S, L, F);
-        }
-        continue;
-      }
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false, TWO, EARLY>(S, L, lds, spill, rb.counters);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
 #endif
       if(!L.done && (L.cur & BVH_LEAF))
       {
-        lane_leaf<false, TWO, EARLY>(S, L, lds, spill);
+        lane_leaf<false, TWO>(S, L, lds, spill);
         if(S.allOpaque && L.bslot != BVH_NONE)
           L.done = true;  // all-opaque scene: any hit inside (0, tmax) occludes and nothing draws -- the nearest one need not be found
       }
@@ -661,6 +617,203 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
       wPrev = h.w & TRI_INDEX_MASK;
     }
     finish_bounce(rb, slot, inShadow, variant == PT_VARIANT_RTX ? seed0 : seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+  }
+}
+
+// ---- shadow ray of bounce b and closest-hit ray of bounce b + 1 in ONE launch (round 5) --------------------------------------------------------
+// The reference runs AnyHit -> rand (Russian roulette) -> the next ClosestHit back to back in one invocation (shaders/pathtrace.glsl:319-338,
+// traceray_rq.glsl:108-185).  The staged chain cut that into k_shadow_p -> queue -> k_closest_p: two launches of the SAME trace machine on the same
+// path with a kernel boundary (every wave drained, as long as the slowest ray) and a queue round trip in between.  Here a lane that settles a
+// shadow ray adds the NEE contribution, draws the roulette (finish_bounce_core) and, if the path lives, begins the path's next closest-hit ray on
+// the spot -- the lane never goes idle, nothing is queued.  Paths that k_shade sent on WITHOUT a shadow ray (queueN) are pulled after the shadow
+// rays.  Closest-hit rays that settle are appended to the hit queue k_shade of bounce b + 1 reads.  A bounce then costs two launch drains (trace,
+// shade) instead of three.  Ray kinds differ only in their upper bound and in what the service round does with the result: the walk is the same
+// (trace contract T5 / T6).  Bit-identical to the staged chain by construction: the same functions on the same per-path state in the same order.
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_trace_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueS, const uint32_t* __restrict__ queueN,
+                                                                                                    uint32_t* __restrict__ queueHit, int bounce, int minRun, int chunk, int variant)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stage[STAGE_CAP];
+  uint32_t            nStage = 0;
+  uint32_t            spill[STACK_SPILL];
+  uint32_t*           C  = rb.counts + bounce * CNT_STRIDE;  // this bounce: shadow rays, paths without one
+  uint32_t*           C1 = C + CNT_STRIDE;                   // the next bounce: its hit queue, its closest-hit fallbacks
+  const uint32_t      nS = C[CNT_SHADOW], count = nS + C[CNT_NEXT];
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
+    return;
+  uint32_t* lds = stack + threadIdx.x;
+  TraceLane L;
+  RaySupply rs;
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
+  uint32_t pslot = 0, seed = 0, nShadow = 0, nClosest = 0, nAlpha = 0;
+  bool     alive = false, shadowRay = false;
+  L.done         = true;
+  L.cur          = 0;
+  for(;;)
+  {
+    // ---- service
+    bool settled = false;  // a closest-hit ray of bounce + 1 whose hit record is written: the path goes to k_shade
+    if(alive && L.done)
+    {
+      bool fallback = (L.flags & TF_SAW_FRAC) != 0;
+      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
+        lane_begin_count<TWO>(L);  // stay alive: pass B runs in the same loop
+      else
+      {
+        uint32_t s2 = seed, nDraw = L.cnt;
+        if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
+          ++nDraw;  // the certain non-opaque hit consumes its own (always passing) draw
+        if(!fallback && !consume_rejected_draws(s2, nDraw))
+          fallback = true;
+        if(!fallback)
+          nAlpha += nDraw;
+        if(shadowRay)
+        {
+          if(fallback)
+          {
+            enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
+            alive = false;
+          }
+          else
+          {
+            seed = variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
+            if(finish_bounce_core(rb, pslot, L.bslot != BVH_NONE, seed))
+            {  // the path lives: its next closest-hit ray (written by k_shade) starts in this lane right away
+              lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.rayD[pslot]), PT_INFINITY, S.numTris == 0);
+              shadowRay = false;
+              ++nClosest;
+            }
+            else
+              alive = false;
+          }
+        }
+        else
+        {
+          if(fallback)
+            enqueue(rb.queueX, &C1[CNT_X_CLOSEST], pslot);
+          else
+          {
+            store_hit(rb, pslot, L.bslot, L.bw, TWO, L.bt, L.bu, L.bv);
+            if(nDraw)
+              rb.ps.rayD[pslot].w = __uint_as_float(s2);
+            settled = true;
+          }
+          alive = false;
+        }
+      }
+    }
+    stage_push(stage, nStage, settled, pslot, queueHit, &C1[CNT_IN]);
+    const uint32_t qi = supply_next(rs, &C[CNT_CHUNK_SHADOW], count, !alive);
+    if(qi != 0xffffffffu)
+    {
+      shadowRay = qi < nS;
+      if(shadowRay)
+      {
+        pslot = queueS[qi];
+        seed  = __float_as_uint(rb.ps.rayD[pslot].w);
+        lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
+        ++nShadow;
+      }
+      else
+      {
+        pslot           = queueN[qi - nS];
+        const float4 dw = rb.ps.rayD[pslot];
+        seed            = __float_as_uint(dw.w);
+        lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
+        ++nClosest;
+      }
+      alive = true;
+    }
+    if(!__ballot(alive))
+      break;
+    // ---- run
+    const int target = rs.more ? minRun : 1;
+    while(__popcll(__ballot(!L.done)) >= target)
+    {
+      if(!L.done && !(L.cur & BVH_LEAF))
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
+      if(!L.done && (L.cur & BVH_LEAF))
+      {
+        lane_leaf<false, TWO>(S, L, lds, spill);
+        if(shadowRay && S.allOpaque && L.bslot != BVH_NONE)
+          L.done = true;  // all-opaque scene: any hit inside (0, tmax) occludes and nothing draws -- the nearest one need not be found
+      }
+    }
+  }
+  stage_flush(stage, nStage, queueHit, &C1[CNT_IN]);
+  wave_add(&rb.counters->shadowRays, nShadow);
+  wave_add(&rb.counters->closestRays, nClosest);
+  wave_add(&rb.counters->alphaTests, nAlpha);
+}
+
+// Exact fallbacks of the fused stage: the shadow rays of bounce b that k_trace_p could not settle (queueX2) -- a survivor of the roulette goes straight on
+// to the exact closest-hit loop of its next ray -- and the closest-hit rays of bounce b + 1 it could not settle (queueX).  Normally almost empty.
+template <bool TWO>
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_trace_x(DeviceScene S, RenderBuffers rb, uint32_t* __restrict__ queueHit, int bounce, int variant)
+{
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t*           C  = rb.counts + bounce * CNT_STRIDE;
+  uint32_t*           C1 = C + CNT_STRIDE;
+  const uint32_t      nXS = C[CNT_X_SHADOW], count = nXS + C1[CNT_X_CLOSEST];
+  for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
+  {
+    const uint32_t slot = i < nXS ? rb.queueX2[i] : rb.queueX[i - nXS];
+    uint32_t       seed = __float_as_uint(rb.ps.rayD[slot].w);
+    RayHit         h;
+    bool           dummy;
+    if(i < nXS)
+    {
+      const uint32_t seed0    = seed;
+      const f3       o        = xyz(rb.ps.rayO[slot]);
+      const f3       d        = xyz(rb.ps.neeDir[slot]);
+      const float    maxDist  = rb.ps.absorb[slot].w;
+      bool           inShadow = false;
+      float          tPrev    = 0.0f;
+      uint32_t       wPrev    = 0xffffffffu;
+      for(;;)
+      {
+        traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+        if(h.slot == BVH_NONE)
+          break;
+        if((h.w >> 29) & TRI_OPAQUE)
+        {
+          inShadow = true;
+          break;
+        }
+        atomicAdd(&rb.counters->alphaTests, 1ull);
+        if(alpha_test(S, h.slot, h.u, h.v, seed))
+        {
+          inShadow = true;
+          break;
+        }
+        tPrev = h.t;
+        wPrev = h.w & TRI_INDEX_MASK;
+      }
+      if(variant == PT_VARIANT_RTX)
+        seed = seed0;
+      if(!finish_bounce_core(rb, slot, inShadow, seed))
+        continue;
+      atomicAdd(&rb.counters->closestRays, 1ull);  // (the shadow ray was counted when k_trace_p fetched it; the next ray starts here)
+    }
+    const f3 o     = xyz(rb.ps.rayO[slot]);
+    const f3 d     = xyz(rb.ps.rayD[slot]);
+    float    tPrev = 0.0f;
+    uint32_t wPrev = 0xffffffffu;
+    for(;;)
+    {
+      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
+      if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
+        break;
+      atomicAdd(&rb.counters->alphaTests, 1ull);
+      if(alpha_test(S, h.slot, h.u, h.v, seed))
+        break;
+      tPrev = h.t;
+      wPrev = h.w & TRI_INDEX_MASK;
+    }
+    store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
+    rb.ps.rayD[slot].w = __uint_as_float(seed);
+    enqueue(queueHit, &C1[CNT_IN], slot);
   }
 }
 
@@ -738,74 +891,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBu
 }
 
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
-// ---- ray sorting (north_star: "per-wavefront ray compaction / sorting"; no reference counterpart: the Vulkan driver schedules rays) ------
-// After bounce 0 the rays of a queue are incoherent: consecutive entries start anywhere and point anywhere, so the 64 rays a wave of the trace
-// machine works on share no BVH nodes and leave its two loop phases half empty.  A queue is therefore binned by the key
-//   (direction octant : 3 bits) | (Morton code of the origin's cell in the scene bounds : 3 * cellBits bits)
-// with a counting sort: histogram (fire-and-forget atomics), one-block scan, scatter (one returning atomic per ray; the order inside a bin is
-// whatever the hardware makes it -- results never depend on queue order, tests/test_gpu_parity.py::test_launch_policy_never_changes_results).
-PT_DEV uint32_t spread3(uint32_t v)  // 5 bits -> every third bit
-{
-  v = (v | (v << 8)) & 0x0000f00fu;
-  v = (v | (v << 4)) & 0x000c30c3u;
-  v = (v | (v << 2)) & 0x00249249u;
-  return v;
-}
-PT_DEV uint32_t ray_sort_key(const DeviceScene& S, float4 o, float4 d, int cellBits)
-{
-  const float    n  = float(1 << cellBits);
-  const int      hi = (1 << cellBits) - 1;
-  const int      cx = min(max(int((o.x - S.boundsMin[0]) * S.boundsInvExt[0] * n), 0), hi);
-  const int      cy = min(max(int((o.y - S.boundsMin[1]) * S.boundsInvExt[1] * n), 0), hi);
-  const int      cz = min(max(int((o.z - S.boundsMin[2]) * S.boundsInvExt[2] * n), 0), hi);
-  const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
-  return (oct << (3 * cellBits)) | spread3(uint32_t(cx)) | (spread3(uint32_t(cy)) << 1) | (spread3(uint32_t(cz)) << 2);
-}
-__global__ void __launch_bounds__(256) k_raysort_hist(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countPtr, int useNee, int cellBits)
-{
-  const uint32_t count = *countPtr;
-  const float4*  dir   = useNee ? rb.ps.neeDir : rb.ps.rayD;
-  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-  {
-    const uint32_t slot = queueIn[i];
-    const uint32_t k    = ray_sort_key(S, rb.ps.rayO[slot], dir[slot], cellBits);
-    rb.sortKeys[i]      = k;
-    atomicAdd(&rb.sortHist[k], 1u);
-  }
-}
-__global__ void __launch_bounds__(1024) k_raysort_scan(uint32_t* __restrict__ hist, uint32_t bins)
-{
-  __shared__ uint32_t part[1024];
-  const uint32_t      per = (bins + 1023u) / 1024u, first = threadIdx.x * per;
-  uint32_t            sum = 0;
-  for(uint32_t i = 0; i < per && first + i < bins; ++i)
-    sum += hist[first + i];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for(uint32_t off = 1; off < 1024u; off <<= 1)
-  {
-    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's span
-  for(uint32_t i = 0; i < per && first + i < bins; ++i)
-  {
-    const uint32_t h = hist[first + i];
-    hist[first + i]  = run;
-    run += h;
-  }
-}
-__global__ void __launch_bounds__(256) k_raysort_scatter(RenderBuffers rb, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countPtr)
-{
-  const uint32_t count = *countPtr;
-  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-    rb.queueT[atomicAdd(&rb.sortHist[rb.sortKeys[i]], 1u)] = queueIn[i];
-}
-
+// The last kernel of a sample pass also hands the pass's per-bounce counter block over (queue-size feedback reads the copy) and leaves it zeroed for
+// the next pass on this frame slot: no runtime fill kernel per launch sequence (profiles/r04_final_kernel_stats_bench20.csv: one fillBufferAligned each).
 __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParams fp)
 {
+  if(blockIdx.x == 0)
+  {
+    const uint32_t words = CNT_STRIDE * uint32_t(fp.st.maxDepth + 2);
+    for(uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+    {
+      rb.countsDone[i] = rb.counts[i];
+      rb.counts[i]     = 0u;
+    }
+  }
   uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
   if(pslot >= fp.numSlots)
     return;
@@ -1066,24 +1164,15 @@ __global__ void k_mean(const float4* __restrict__ img, size_t n, double* out3)
 // ---- host-side launchers ----------------------------------------------------------------------------------------
 PtTuning g_tuning;
 
-// counting sort of queueIn[0 .. *countPtr) by ray_sort_key into rb.queueT (slots: the capacity of the queue, which sizes the grids)
-static void sort_queue(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const uint32_t* queueIn, const uint32_t* countPtr, int useNee, uint32_t slots)
-{
-  const int      cellBits = g_tuning.sortCellBits < 1 ? 1 : (g_tuning.sortCellBits > SORT_MAX_CELL_BITS ? SORT_MAX_CELL_BITS : g_tuning.sortCellBits);
-  const uint32_t bins     = 8u << (3 * cellBits);
-  const uint32_t grid     = std::min<uint32_t>((slots + 255u) / 256u, 2048u);
-  (void)hipMemsetAsync(rb.sortHist, 0, sizeof(uint32_t) * bins, stream);
-  k_raysort_hist<<<grid, 256, 0, stream>>>(scene, rb, queueIn, countPtr, useNee, cellBits);
-  k_raysort_scan<<<1, 1024, 0, stream>>>(rb.sortHist, bins);
-  k_raysort_scatter<<<grid, 256, 0, stream>>>(rb, queueIn, countPtr);
-}
-
-// One launch sequence (a batch of frames, all bounces) as a list of STEPS -- generate, then per bounce the closest-hit stage, the shade stage
-// and the shadow stage (or k_tail for all remaining bounces), then accumulate.  A step only enqueues work on `stream`.  The caller either runs
+// One launch sequence (a batch of frames, all bounces) as a list of STEPS.  A step only enqueues work on `stream`.  The caller either runs
 // the steps back to back (pt_launch_frame) or interleaves the steps of several sequences that go to different streams (pt_capi.hip
-// flush_pending): enqueueing ~55 launches costs the host ~1 ms, so with one sequence submitted after the other the fourth stream would start
+// flush_pending): enqueueing the launches costs the host ~1 ms, so with one sequence submitted after the other the fourth stream would start
 // 2-3 ms late -- a third of the whole run when a short run is cut into four pieces (profiles/r02b_shard_timeline_0of8.txt).
-// TWO: the kernels instantiated for the two-level acceleration structure (no packet stage: a packet would have to agree on the instance too)
+//   generate | closest(0) | shade(0) | trace(0 -> 1) | shade(1) | trace(1 -> 2) | ... | shade(t-1) | shadow(t-1) | k_tail(t ...) | accumulate
+// trace(b -> b+1) = k_trace_p + k_trace_x: the shadow rays of bounce b and the closest-hit rays of bounce b + 1 in one launch (PT_TUNE fuse=0: the
+// round-4 chain closest | shade | shadow per bounce).  The bounce before k_tail (and the last bounce of the path) ends with the plain shadow stage.
+// The counter block is zero on entry: pt_resize clears it once, k_accumulate leaves it cleared.
+// TWO: the kernels instantiated for the two-level acceleration structure
 template <bool TWO>
 static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
                        hipEvent_t recordAfterAccum, int tailFrom)
@@ -1094,11 +1183,8 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
-  const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the machine kernels, no packet / lock-step stage, no k_tail
-  // the pipelined trace machine (pt_machine.h lane_issue / lane_step): flat-format structure with compact nodes
-  const bool     pipe      = !TWO && g_tuning.pipe && scene.cnodes != nullptr && !heat;
-  const uint32_t pwPipe    = uint32_t(g_tuning.pipeWaves > 0 ? g_tuning.pipeWaves : 1);
-  const uint32_t gridPipe  = wavesAll < pwPipe ? wavesAll : pwPipe;
+  const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the staged machine kernels; no packet stage, no fused stage, no k_tail
+  const bool     fuse      = g_tuning.fuse != 0 && !heat;
   // camera rays computed by the packet kernel instead of written by k_generate: one sample per frame (the RNG stream of a second sample continues
   // from the stored state), a packet stage at bounce 0, no heat map (it keeps the path's cost in rayO.w), bounce 0 not already in k_tail
   const bool packetStage = !TWO || g_tuning.packetTwo;  // the two-level structure has a packet stage of its own since round 4 (pt_packet.h traverse_packet_two)
@@ -1107,18 +1193,18 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   {
     fp.sample = s;
     steps.push_back(PtStep{[=]() {
-      (void)hipMemsetAsync(rb.counts, 0, sizeof(uint32_t) * CNT_STRIDE * size_t(fp.st.maxDepth + 2), stream);
       pt_timers_begin(tm, stream, 0);
       k_generate<<<(n + 1023) / 1024, 1024, 0, stream>>>(scene, rb, fp);
       pt_timers_end(tm, stream, 0);
     }, false});
-    uint32_t* qIn  = rb.queueA;
-    uint32_t* qOut = rb.queueB;
+    uint32_t* qIn     = rb.queueA;
+    uint32_t* qOut    = rb.queueB;
+    bool      fusedIn = false;  // this bounce's closest-hit rays were traced by the previous bounce's fused stage (qIn is its hit queue)
     for(int depth = 0; depth < fp.st.maxDepth; ++depth)
     {
       const int last = depth == fp.st.maxDepth - 1 ? 1 : 0;
       if(depth >= tailFrom && !heat)
-      {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost three latency floors
+      {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost its latency floors
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 5);
           k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
@@ -1126,61 +1212,54 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         }, false});
         break;
       }
-      const bool      sortC   = depth >= 1 && g_tuning.sortClosest;
-      const uint32_t* traceIn = sortC ? rb.queueT : qIn;
-      steps.push_back(PtStep{[=]() {
-        pt_timers_begin(tm, stream, 1);
-        if(sortC)
-          sort_queue(stream, scene, rb, qIn, rb.counts + depth * CNT_STRIDE + CNT_IN, 0, n);
-        if(heat)
-          k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-        else if(packetStage && depth < g_tuning.packetClosestBounces)
-        {
-          const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
-          const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
-          k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
-          if(pipe)
-            k_closest_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
-          else
+      // the next bounce is a staged one too: this bounce's shadow rays and its closest-hit rays share a launch
+      const bool fusedOut = fuse && !last && depth + 1 < tailFrom;
+      if(!fusedIn)
+        steps.push_back(PtStep{[=]() {
+          pt_timers_begin(tm, stream, 1);
+          if(heat)
+            k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+          else if(packetStage && depth < g_tuning.packetClosestBounces)
+          {
+            const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+            const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
+            k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
             k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
-        }
-        else if(pipe)
-          k_closest_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-        else
-          k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, traceIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-        k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
-        pt_timers_end(tm, stream, 1);
-      }, false});
+          }
+          else
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+          k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
+          pt_timers_end(tm, stream, 1);
+        }, false});
       steps.push_back(PtStep{[=]() {
         pt_timers_begin(tm, stream, 2);
-        const dim3 sg((n + SHADE_BLOCK - 1) / SHADE_BLOCK), sb(SHADE_BLOCK);
-        const bool plain = g_tuning.shadeSpecialised && fp.st.debugging_mode == PT_DEBUG_NONE && scene.sunsky.in_use != 1 && scene.camera.nbLights == 0;
-        if(plain && fp.st.pbrMode == 0)
-          k_shade<0><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
-        else if(plain && fp.st.pbrMode == 1)
-          k_shade<1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
-        else
-          k_shade<-1><<<sg, sb, 0, stream>>>(scene, rb, fp, traceIn, qOut, depth);
+        // paths that go on without a shadow ray: the fused stage pulls them from qOut behind the shadow rays (CNT_NEXT); else they open the next bounce's queue
+        k_shade<-1><<<(n + SHADE_BLOCK - 1) / SHADE_BLOCK, SHADE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, qOut, depth, fusedOut ? CNT_NEXT : CNT_STRIDE + CNT_IN);
         pt_timers_end(tm, stream, 2);
       }, false});
-      steps.push_back(PtStep{[=]() {
-        pt_timers_begin(tm, stream, 3);
-        const uint32_t* shadowIn = rb.queueS;
-        if(g_tuning.sortShadow)
-        {
-          sort_queue(stream, scene, rb, rb.queueS, rb.counts + depth * CNT_STRIDE + CNT_SHADOW, 1, n);
-          shadowIn = rb.queueT;
-        }
-        if(heat)
-          k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-        else if(pipe)
-          k_shadow_p<false, false, !TWO><<<gridPipe, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-        else
-          k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, shadowIn, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-        k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
-        pt_timers_end(tm, stream, 3);
-      }, false});
-      std::swap(qIn, qOut);
+      if(fusedOut)
+      {  // qIn has been consumed by k_shade: it becomes the hit queue of bounce depth + 1 (no swap)
+        steps.push_back(PtStep{[=]() {
+          pt_timers_begin(tm, stream, 6);
+          k_trace_p<TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
+          k_trace_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, fp.variant);
+          pt_timers_end(tm, stream, 6);
+        }, false});
+      }
+      else
+      {
+        steps.push_back(PtStep{[=]() {
+          pt_timers_begin(tm, stream, 3);
+          if(heat)
+            k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          else
+            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+          k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
+          pt_timers_end(tm, stream, 3);
+        }, false});
+        std::swap(qIn, qOut);
+      }
+      fusedIn = fusedOut;
     }
     const bool waitHere = waitBeforeAccum && s == 0, recordHere = recordAfterAccum && s == fp.st.maxSamples - 1;
     steps.push_back(PtStep{[=]() {

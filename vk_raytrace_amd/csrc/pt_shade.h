@@ -431,8 +431,9 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 
 // ---- shadow + Russian roulette ---------------------------------------------------------------------------------
 // NEE contribution if unoccluded, then Russian roulette (pathtrace.glsl:327-338); survivors go to the next bounce.
-// Returns true when the path survives the roulette (the caller queues it for the next bounce).
-PT_DEV bool finish_bounce_core(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t seed)
+// Returns true when the path survives the roulette (the caller queues it for the next bounce, or traces its next ray right away: k_trace_p);
+// `seed` comes back as the RNG state after the roulette draw (also stored in the path state).
+PT_DEV bool finish_bounce_core(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t& seed)
 {
   if(!inShadow)
   {

@@ -88,100 +88,11 @@ PT_DEV bool key_less(float ta, uint32_t wa, float tb, uint32_t wb) { return ta <
 #ifdef PT_TRI_TEST_OVERRIDE
 // host experiments only (tests/cpp/trace_host.cpp -DTH_ROBUST_T2): a candidate replacement of T2 under evaluation takes the place of the contract's
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v) { return PT_TRI_TEST_OVERRIDE(tr, flags, o, d, t, u, v); }
-#elif defined(PT_ROBUST_T2)
-// MEASUREMENT BUILD ONLY (tools/build_variants.sh robust "-DPT_ROBUST_T2"): the candidate replacement of T2 that closes the
-// "accidental grazing hit" exception -- fp32 Moeller-Trumbore kept whenever a forward error bound shows that neither its verdict nor its t can
-// be a rounding artefact, the same formulas in fp64 otherwise (IEEE on every side, so still bit-reproducible).  Validated on the CPU harness
-// (profiles/r02c_t2_robust_experiment.txt: walks == brute force on all 240 000 adversarial rays); this build measures what it costs on the GPU,
-// where one ambiguous lane sends the whole wavefront through the fp64 branch.  Not the contract: oracle, _ref driver and goldens use T2 above.
-PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
-{
-  const f3    e1 = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
-  const f3    pv = cross3(d, e2);
-  const float det = dot3(e1, pv);
-  const f3    tv = o - p0;
-  const f3    qv = cross3(tv, e1);
-  const float nu = dot3(tv, pv), nv = dot3(d, qv), nt = dot3(e2, qv);
-  const f3    apv = f3{fabsf(d.y) * fabsf(e2.z) + fabsf(d.z) * fabsf(e2.y), fabsf(d.z) * fabsf(e2.x) + fabsf(d.x) * fabsf(e2.z), fabsf(d.x) * fabsf(e2.y) + fabsf(d.y) * fabsf(e2.x)};
-  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
-  const f3    aqv = f3{atv.y * fabsf(e1.z) + atv.z * fabsf(e1.y), atv.z * fabsf(e1.x) + atv.x * fabsf(e1.z), atv.x * fabsf(e1.y) + atv.y * fabsf(e1.x)};
-  const float k   = 8.0f * 5.9604645e-8f;
-  const float edet = k * (fabsf(e1.x) * apv.x + fabsf(e1.y) * apv.y + fabsf(e1.z) * apv.z);
-  const float eu   = k * (atv.x * apv.x + atv.y * apv.y + atv.z * apv.z);
-  const float ev   = k * (fabsf(d.x) * aqv.x + fabsf(d.y) * aqv.y + fabsf(d.z) * aqv.z);
-  const float et   = k * (fabsf(e2.x) * aqv.x + fabsf(e2.y) * aqv.y + fabsf(e2.z) * aqv.z);
-  const float adet = fabsf(det);
-  bool        sure = adet > 4.0f * edet;
-  if(sure)
-  {
-    const float s  = det < 0.0f ? -1.0f : 1.0f;
-    const float su = nu * s, sv = nv * s;
-    const bool  inside  = su > eu && sv > ev && (adet - su - sv) > (eu + ev + edet);
-    const bool  outside = su < -eu || sv < -ev || (su + sv - adet) > (eu + ev + edet);
-    const bool  tOk     = et <= 4.0e-6f * fabsf(nt);
-    sure = outside || (inside && tOk);
-  }
-  if(sure)
-  {
-    if(det == 0.0f)
-      return false;
-    if(!(flags & TRI_NOCULL))
-    {
-      const bool front = (flags & TRI_FLIP) ? (det < 0.0f) : (det > 0.0f);
-      if(!front)
-        return false;
-    }
-    const float inv = 1.0f / det;
-    u = nu * inv;
-    if(u < 0.0f || u > 1.0f)
-      return false;
-    v = nv * inv;
-    if(v < 0.0f || u + v > 1.0f)
-      return false;
-    t = nt * inv;
-    return true;
-  }
-  const double E1[3] = {e1.x, e1.y, e1.z}, E2[3] = {e2.x, e2.y, e2.z}, D[3] = {d.x, d.y, d.z}, TV[3] = {double(o.x) - p0.x, double(o.y) - p0.y, double(o.z) - p0.z};
-  const double PV[3] = {D[1] * E2[2] - D[2] * E2[1], D[2] * E2[0] - D[0] * E2[2], D[0] * E2[1] - D[1] * E2[0]};
-  const double DET   = E1[0] * PV[0] + E1[1] * PV[1] + E1[2] * PV[2];
-  if(DET == 0.0)
-    return false;
-  if(!(flags & TRI_NOCULL))
-  {
-    const bool front = (flags & TRI_FLIP) ? (DET < 0.0) : (DET > 0.0);
-    if(!front)
-      return false;
-  }
-  const double U = (TV[0] * PV[0] + TV[1] * PV[1] + TV[2] * PV[2]) / DET;
-  if(U < 0.0 || U > 1.0)
-    return false;
-  const double QV[3] = {TV[1] * E1[2] - TV[2] * E1[1], TV[2] * E1[0] - TV[0] * E1[2], TV[0] * E1[1] - TV[1] * E1[0]};
-  const double V     = (D[0] * QV[0] + D[1] * QV[1] + D[2] * QV[2]) / DET;
-  if(V < 0.0 || U + V > 1.0)
-    return false;
-  u = float(U);
-  v = float(V);
-  t = float((E2[0] * QV[0] + E2[1] * QV[1] + E2[2] * QV[2]) / DET);
-  return true;
-}
 #else
 // T2: Moeller-Trumbore in the fixed operation order of the trace contract.
-// MEASUREMENT BUILD -DPT_CERTIFIED_T2 (round 4; not the contract -- oracle, _ref driver and goldens use plain T2): an ACCEPTED candidate is kept only when a
-// forward error bound of the same fp32 evaluation certifies its barycentrics and its distance to PT_T2_TAU -- otherwise it is a miss, on every side.
-// Why: plain fp32 Moeller-Trumbore accepts, by cancellation, triangles a ray passes at a macroscopic distance when they are seen edge-on or from far
-// away (det ~ 0: u = v = 0 "accidental" hits); whether a walk ever tests such a triangle depends on the shape of the boxes around it, which made the
-// flat and the two-level structure differ in one pixel-sample of 6.6e7.  A certified candidate lies within PT_T2_TAU of its
-// triangle's extent of the triangle, i.e. inside every conservative box around it.  No fp64, no second code path: the bound is ~35 more fp32
-// operations on the accept path (absolute values are operand modifiers).  Component-wise bound of round 2's experiment: a cross product's component
-// a_i b_j - a_j b_i is off by at most 2 ulp of |a_i b_j| + |a_j b_i|, a 3-term dot by 3 ulp of sum |x_i y_i| plus |x| . (error of y); 8 ulp covers
-// every chain.  On the CPU harness it closes the exception completely -- walks == brute force on all 120 000 adversarial rays (48 disagreements under plain
-// T2) with today's boxes -- and removes 0 of 122 k camera-ray and 5 of 142 k bounce-ray candidates of the bench scene, all grazing
-// (profiles/r04_t2_certified_experiment.txt).  On the GPU it costs 7 % of the bench line: the bound's live values do not fit 96 VGPRs (-19 % when they
-// spill at 5 waves per SIMD), and at 4 waves it is -4.5 % on top of the -2.6 % of the fourth wave (profiles/r04k_t2_certified_gpu.txt) -- the triangle
-// step runs every iteration at 14 of 64 lanes, so 30 instructions there weigh like 130.  Above the 2 % it was allowed: stays a measurement build.
-#ifndef PT_T2_TAU
-#define PT_T2_TAU 0.0078125f  // 2^-7
-#endif
+// (A "certified" form -- accepted candidates kept only when a forward error bound of the same fp32 evaluation certifies them -- closes the one known
+// flat != two-level pixel-sample on the CPU harness and costs 7 % on the GPU: DESIGN.md section 3, profiles/r04k_t2_certified_gpu.txt; a robust fp32 / fp64
+// form costs 33 %, profiles/r03h_*.  The contract stays plain T2.)
 PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, float& u, float& v)
 {
   f3    e1  = xyz(tr.e1n), e2 = xyz(tr.e2p), p0 = xyz(tr.p0w);
@@ -206,23 +117,6 @@ PT_DEV bool tri_test(const TriRec& tr, uint32_t flags, f3 o, f3 d, float& t, flo
     return false;
   const float nt = dot3(e2, qv);
   t              = nt * inv;
-#ifdef PT_CERTIFIED_T2
-  // certification of the accepted candidate
-  const f3    ad = f3{fabsf(d.x), fabsf(d.y), fabsf(d.z)}, ae1 = f3{fabsf(e1.x), fabsf(e1.y), fabsf(e1.z)}, ae2 = f3{fabsf(e2.x), fabsf(e2.y), fabsf(e2.z)};
-  const f3    atv = f3{fabsf(tv.x), fabsf(tv.y), fabsf(tv.z)};
-  const f3    apv = f3{ad.y * ae2.z + ad.z * ae2.y, ad.z * ae2.x + ad.x * ae2.z, ad.x * ae2.y + ad.y * ae2.x};
-  const f3    aqv = f3{atv.y * ae1.z + atv.z * ae1.y, atv.z * ae1.x + atv.x * ae1.z, atv.x * ae1.y + atv.y * ae1.x};
-  const float k8   = 8.0f * 5.9604645e-8f;
-  const float edet = k8 * dot3(ae1, apv);
-  const float eu   = k8 * dot3(atv, apv);
-  const float ev   = k8 * dot3(ad, aqv);
-  const float et   = k8 * dot3(ae2, aqv);
-  const float adet = fabsf(det), ant = fabsf(nt);
-  if(!((eu + ev) + 2.0f * edet <= PT_T2_TAU * adet))
-    return false;
-  if(!(et * adet + ant * edet <= (PT_T2_TAU * ant) * adet))
-    return false;
-#endif
   return true;
 }
 #endif
@@ -359,7 +253,7 @@ PT_DEV uint32_t wide_node_step_c(const CompactNode* __restrict__ nodes, uint32_t
   const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 64u));
   return cnode_visit(h, X, Y, Z, ch, rb, lim, alphaOnly, push);
 }
-// the visit proper, on the five quads of the node already in registers (the pipelined machine of pt_machine.h fetches them one iteration ahead)
+// the visit proper, on the five quads of the node already in registers
 template <class Push>
 PT_DEV uint32_t cnode_visit(float4 h, uint4 X, uint4 Y, uint4 Z, uint4 ch, const RayBox& rb, float lim, bool alphaOnly, Push&& push)
 {
@@ -384,87 +278,6 @@ PT_DEV uint32_t cnode_visit(float4 h, uint4 X, uint4 Y, uint4 Z, uint4 ch, const
   const float    fz[4] = {__builtin_fmaf(cn_plane(fZ0, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ0, 1), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 1), sz, bhz)};
   const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
   return wide_node_decide(nx, fx, ny, fy, nz, fz, cc, lim, alphaOnly, push);
-}
-// ---- the node visit of the persistent kernels (round 4) -----------------------------------------------------------------------------------------
-// The trace machine is bound by VALU issue, not by memory (profiles/r03_valu.json: a VALU instruction in flight during 19 % of a wavefront's
-// cycles x 5 wavefronts per SIMD; fewer requests at more arithmetic per plane -- the 64-byte nodes -- measured 3 % slower, profiles/r04a_*), so
-// this form of the visit spends fewer instructions on the same decisions:
-//  * PREBIASED: the conservative slack of the compact planes, (|b| + 2047 |s|) x 8e-7 per node, axis and side, is replaced by ONE per-ray bound
-//    folded into RayBox::nlo / nhi by prebias_raybox -- E = (M + |o|) |idir| x 1e-6 with M >= |p| + 2047 step of every node of the structure
-//    (DeviceScene::cnodeBound, from the conversion kernel) -- 18 instructions per visit less; the boxes grow by ~1e-6 of the scene's size;
-//  * the hit children are ordered by a five-exchange sorting network on (entry distance, reference) pairs instead of the select-the-farthest
-//    loop (three divergent rounds of ~45 instructions per wave visit), and handed back as a far-to-near list that the caller pushes with
-//    straight-line stores.  Entry distances are compared with their two lowest mantissa bits cleared (the key carries nothing else): the
-//    order among children 4 ulp apart is immaterial, results never depend on the visiting order (trace contract).
-PT_DEV void prebias_raybox(RayBox& rb, f3 o, float bound)
-{
-  const f3 e = f3{(bound + fabsf(o.x)) * fabsf(rb.idir.x) * 1.0e-6f, (bound + fabsf(o.y)) * fabsf(rb.idir.y) * 1.0e-6f, (bound + fabsf(o.z)) * fabsf(rb.idir.z) * 1.0e-6f};
-  rb.nlo = rb.nlo - e;
-  rb.nhi = rb.nhi + e;
-}
-#define PT_CE(ka, ia, kb, ib)                \
-  {                                          \
-    const bool     sw_ = kb < ka;            \
-    const uint32_t lo_ = sw_ ? kb : ka, hi_ = sw_ ? ka : kb, li_ = sw_ ? ib : ia, hj_ = sw_ ? ia : ib; \
-    ka = lo_; kb = hi_; ia = li_; ib = hj_;  \
-  }
-// amask: BVH_ALPHA when only references tagged with it may be entered (pass B, EARLY state 1), else 0.  far3: the hit children other than the
-// nearest, farthest first (BVH_NONE where there is none).  Returns the nearest hit child (BVH_NONE: nothing hit).
-PT_DEV uint32_t wide_node_decide_sorted(const float* nx, const float* fx, const float* ny, const float* fy, const float* nz, const float* fz, const uint32_t* cc, float lim, uint32_t amask,
-                                        uint32_t (&far3)[3])
-{
-  uint32_t key[4], id[4];
-#pragma unroll
-  for(int k = 0; k < 4; ++k)
-  {
-    const float nr = fmaxf(fmaxf(nx[k], ny[k]), fmaxf(nz[k], 0.0f)) * 0.9999996f;
-    const float fr = fminf(fminf(fx[k], fy[k]), fminf(fz[k], lim)) * 1.0000004f;
-    const bool  h  = (nr <= fr) && (cc[k] != BVH_NONE) && ((cc[k] & amask) == amask);
-    key[k]         = h ? (__float_as_uint(nr) & ~3u) : 0xffffffffu;  // nr >= 0: unsigned order == float order
-    id[k]          = h ? cc[k] : BVH_NONE;
-  }
-  PT_CE(key[0], id[0], key[1], id[1]);
-  PT_CE(key[2], id[2], key[3], id[3]);
-  PT_CE(key[0], id[0], key[2], id[2]);
-  PT_CE(key[1], id[1], key[3], id[3]);
-  PT_CE(key[1], id[1], key[2], id[2]);
-  far3[0] = id[3];
-  far3[1] = id[2];
-  far3[2] = id[1];
-  return id[0];
-}
-template <bool PREBIASED>
-PT_DEV uint32_t wide_node_step_cs(const CompactNode* __restrict__ nodes, uint32_t node, const RayBox& rb, float lim, uint32_t amask, uint32_t (&far3)[3])
-{
-  const char*    nb = reinterpret_cast<const char*>(nodes);
-  const uint32_t at = (node & BVH_SLOT_MASK) * uint32_t(sizeof(CompactNode));
-  const float4   h  = *reinterpret_cast<const float4*>(nb + at);
-  const uint4    X = *reinterpret_cast<const uint4*>(nb + (at + 16u)), Y = *reinterpret_cast<const uint4*>(nb + (at + 32u)), Z = *reinterpret_cast<const uint4*>(nb + (at + 48u));
-  const uint4    ch = *reinterpret_cast<const uint4*>(nb + (at + 64u));
-  const uint32_t ex = __float_as_uint(h.w);
-  const float    sx = __uint_as_float((ex & 0xffu) << 23) * rb.idir.x, sy = __uint_as_float(((ex >> 8) & 0xffu) << 23) * rb.idir.y, sz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * rb.idir.z;
-  float          blx = __builtin_fmaf(h.x, rb.idir.x, rb.nlo.x), bhx = __builtin_fmaf(h.x, rb.idir.x, rb.nhi.x);
-  float          bly = __builtin_fmaf(h.y, rb.idir.y, rb.nlo.y), bhy = __builtin_fmaf(h.y, rb.idir.y, rb.nhi.y);
-  float          blz = __builtin_fmaf(h.z, rb.idir.z, rb.nlo.z), bhz = __builtin_fmaf(h.z, rb.idir.z, rb.nhi.z);
-  if(!PREBIASED)
-  {
-    const float gm = float(CN_GRID_MAX);
-    blx -= (fabsf(blx) + gm * fabsf(sx)) * 8.0e-7f; bhx += (fabsf(bhx) + gm * fabsf(sx)) * 8.0e-7f;
-    bly -= (fabsf(bly) + gm * fabsf(sy)) * 8.0e-7f; bhy += (fabsf(bhy) + gm * fabsf(sy)) * 8.0e-7f;
-    blz -= (fabsf(blz) + gm * fabsf(sz)) * 8.0e-7f; bhz += (fabsf(bhz) + gm * fabsf(sz)) * 8.0e-7f;
-  }
-  const bool     ngx = rb.nearOff[0] != 0, ngy = rb.nearOff[1] != 0, ngz = rb.nearOff[2] != 0;  // negative direction: the upper plane is the near one
-  const uint32_t nX0 = ngx ? X.z : X.x, nX1 = ngx ? X.w : X.y, fX0 = ngx ? X.x : X.z, fX1 = ngx ? X.y : X.w;
-  const uint32_t nY0 = ngy ? Y.z : Y.x, nY1 = ngy ? Y.w : Y.y, fY0 = ngy ? Y.x : Y.z, fY1 = ngy ? Y.y : Y.w;
-  const uint32_t nZ0 = ngz ? Z.z : Z.x, nZ1 = ngz ? Z.w : Z.y, fZ0 = ngz ? Z.x : Z.z, fZ1 = ngz ? Z.y : Z.w;
-  const float    nx[4] = {__builtin_fmaf(cn_plane(nX0, 0), sx, blx), __builtin_fmaf(cn_plane(nX0, 1), sx, blx), __builtin_fmaf(cn_plane(nX1, 0), sx, blx), __builtin_fmaf(cn_plane(nX1, 1), sx, blx)};
-  const float    fx[4] = {__builtin_fmaf(cn_plane(fX0, 0), sx, bhx), __builtin_fmaf(cn_plane(fX0, 1), sx, bhx), __builtin_fmaf(cn_plane(fX1, 0), sx, bhx), __builtin_fmaf(cn_plane(fX1, 1), sx, bhx)};
-  const float    ny[4] = {__builtin_fmaf(cn_plane(nY0, 0), sy, bly), __builtin_fmaf(cn_plane(nY0, 1), sy, bly), __builtin_fmaf(cn_plane(nY1, 0), sy, bly), __builtin_fmaf(cn_plane(nY1, 1), sy, bly)};
-  const float    fy[4] = {__builtin_fmaf(cn_plane(fY0, 0), sy, bhy), __builtin_fmaf(cn_plane(fY0, 1), sy, bhy), __builtin_fmaf(cn_plane(fY1, 0), sy, bhy), __builtin_fmaf(cn_plane(fY1, 1), sy, bhy)};
-  const float    nz[4] = {__builtin_fmaf(cn_plane(nZ0, 0), sz, blz), __builtin_fmaf(cn_plane(nZ0, 1), sz, blz), __builtin_fmaf(cn_plane(nZ1, 0), sz, blz), __builtin_fmaf(cn_plane(nZ1, 1), sz, blz)};
-  const float    fz[4] = {__builtin_fmaf(cn_plane(fZ0, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ0, 1), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 0), sz, bhz), __builtin_fmaf(cn_plane(fZ1, 1), sz, bhz)};
-  const uint32_t cc[4] = {ch.x, ch.y, ch.z, ch.w};
-  return wide_node_decide_sorted(nx, fx, ny, fy, nz, fz, cc, lim, amask, far3);
 }
 #endif
 

@@ -120,7 +120,8 @@ class Stats(C.Structure):
                 ("bytesScene", C.c_uint64), ("bytesAccel", C.c_uint64), ("numBlas", C.c_uint32), ("numTlasNodes", C.c_uint32),
                 ("msTail", C.c_double), ("batchFrames", C.c_uint32), ("framesInFlight", C.c_uint32),
                 ("tailClosestRays", C.c_uint64), ("tailShadowRays", C.c_uint64), ("tailShadedHits", C.c_uint64), ("tailMisses", C.c_uint64),
-                ("tailAlphaTests", C.c_uint64), ("launchesTail", C.c_uint64), ("numMergedTriangles", C.c_uint64)]
+                ("tailAlphaTests", C.c_uint64), ("launchesTail", C.c_uint64), ("numMergedTriangles", C.c_uint64),
+                ("msTraceFused", C.c_double), ("launchesTraceFused", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
