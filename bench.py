@@ -628,7 +628,8 @@ def main():
         nsamp = float(s2["samples"])
         serial = {"frames": nser, "wall_ms": tser * 1e3, "launches_per_stage": int(s2["launchesTraceClosest"]), "launches_tail": int(s2["launchesTail"]),
                   "stage_ms": {"generate": s2["msGenerate"], "closest": s2["msTraceClosest"], "shade": s2["msShade"], "shadow": s2["msTraceShadow"], "tail": s2["msTail"],
-                               "accumulate": s2["msAccumulate"]},
+                               "accumulate": s2["msAccumulate"], "fused": s2.get("msTraceFused", 0.0)},
+                  "launches_fused": int(s2.get("launchesTraceFused", 0)),
                   "rays": {k: s2[k] for k in RAY_KEYS}, "rays_in_tail": {k: s2["tail" + k[0].upper() + k[1:]] for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests")},
                   "samples": nsamp}
         out["serialised"] = serial

@@ -381,7 +381,7 @@ struct Scene {
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
   std::vector<TexRec>      texRecs;
-  std::vector<uint4>       matDesc;  // PT_TEX_BATCH flavour: per material the packed descriptors of its four common textures
+  std::vector<uint4>       matDesc;  // per material the packed descriptors of its four common textures
   std::vector<pt_GltfShadeMaterial> materials;
   std::vector<pt_Light>    lights;
   std::vector<float4>      env;
@@ -600,9 +600,7 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   d.alphaMats = s->alphaMats.data(); d.alphaMaps = s->alphaMaps.data(); d.texels = s->texels.data();
   d.materials = s->materials.empty() ? nullptr : s->materials.data(); d.lights = s->lights.empty() ? nullptr : s->lights.data();
   d.texRecs = s->texRecs.empty() ? nullptr : s->texRecs.data();
-#if PT_TEX_BATCH
   d.matDesc = s->matDesc.empty() ? nullptr : s->matDesc.data();
-#endif
   d.numTris = triTotal; d.numInstances = numInst;
   s->dsFlat           = d;
   s->dsFlat.wide      = s->flat.wide.data();

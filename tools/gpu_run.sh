@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: ONE parameterised script for the round's GPU calls (replaces the per-call gpu_r03*.sh scripts of round 3).
-#   gpurun -- 'bash tools/gpu_r04.sh <tag> <step> [<step> ...]'        output -> gpurun_out/<tag>/
+#   gpurun -- 'bash tools/gpu_run.sh <tag> <step> [<step> ...]'        output -> gpurun_out/<tag>/
 # steps (run in the order given; each under its own `timeout`):
 #   cold20              the driver's command with PT_TUNE=warm=0 and no evidence legs: what a first process on a fresh box does without the slot warm-up
 #   bench20 | bench256  the driver's command line / the 256-step line (bench256 without the CPU leg)

@@ -32,7 +32,7 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
-  DevBuf   dMatDesc;  // PT_TEX_BATCH builds only (16-byte texture descriptors, four per material); empty otherwise
+  DevBuf   dMatDesc;  // 16-byte texture descriptors, four per material (DeviceScene::matDesc)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   DevBuf   dShadeTris;
   bool     haveShadeTris = false;
@@ -277,9 +277,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.materials    = (const pt_GltfShadeMaterial*)c->dMaterials.p;
   s.lights       = (const pt_Light*)c->dLights.p;
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
-#if PT_TEX_BATCH
   s.matDesc      = (const uint4*)c->dMatDesc.p;
-#endif
   s.texels       = (const uint32_t*)c->dTexels.p;
   s.bvh          = (const BvhNode*)c->dBvh.p;
   s.wide         = (const WideNode*)c->dWide.p;
@@ -726,47 +724,45 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     return PT_ERR_HIP;
   }
   // every context starts from the defaults: a knob set for one context's creation does not leak into the next.  The string is parsed into a local
-  // and published with one assignment, so a context that is rendering on another thread never sees a half-parsed policy (the knobs are performance
-  // policy only; two contexts created under DIFFERENT PT_TUNE strings in one process share the later one)
+  // and published with one struct assignment below.  That assignment is NOT atomic: contexts must not be created while another thread renders
+  // (the knobs are performance policy only; two contexts created under DIFFERENT PT_TUNE strings in one process share the later one)
   PtTuning parsed;
-#define g_tuning parsed
   if(const char* tune = getenv("PT_TUNE"))
   {  // performance A/B knobs only
     int v;
-    if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) g_tuning.stateMB = v;
-    if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) g_tuning.packetClosestBounces = v;
-    if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) g_tuning.packetWaves = v;
-    if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) g_tuning.refillBelow = v;
-    if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) g_tuning.persistentWaves = v;
-    if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) g_tuning.chunk = v;
-    if(strstr(tune, "build=lbvh")) g_tuning.sahBuild = 0;
-    if(strstr(tune, "build=sah")) g_tuning.sahBuild = 1;
-    if(strstr(tune, "build=ploc")) g_tuning.sahBuild = 2;
-    if(strstr(tune, "build=sahdev")) g_tuning.sahBuild = 3;
-    if(strstr(tune, "accel=two")) g_tuning.accelTwoLevel = 1;
-    if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) g_tuning.mergeSingles = v;
-    if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) g_tuning.cnodes = v;
-    if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) g_tuning.shadeTris = v;
-    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) g_tuning.tailBelow = v;
-    if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) g_tuning.warm = v;
-    if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) g_tuning.texTile = v;
-    if(const char* p = strstr(tune, "regen=")) if(sscanf(p, "regen=%d", &v) == 1) g_tuning.regen = v;
-    if(const char* p = strstr(tune, "packetTwo=")) if(sscanf(p, "packetTwo=%d", &v) == 1) g_tuning.packetTwo = v;
-    if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) g_tuning.interleave = v;
-    if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) g_tuning.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
-    if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) g_tuning.rotatePasses = v;
-    if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) g_tuning.plocFull = v;
-    if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) g_tuning.plocRadius = v;
-    if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) g_tuning.splitFull = v;
-    if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) g_tuning.batch = v;
-    if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) g_tuning.framesInFlight = v;
-    if(const char* p = strstr(tune, "displaySlots=")) if(sscanf(p, "displaySlots=%d", &v) == 1) g_tuning.displaySlots = v;
-    if(const char* p = strstr(tune, "bands=")) if(sscanf(p, "bands=%d", &v) == 1) g_tuning.bands = v;
-    if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) g_tuning.bandTiles = v > 0 ? v : 1;
-    if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) g_tuning.stateGB = v;
-    if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) g_tuning.fuse = v;
+    if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) parsed.stateMB = v;
+    if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) parsed.packetClosestBounces = v;
+    if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) parsed.packetWaves = v;
+    if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) parsed.refillBelow = v;
+    if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) parsed.persistentWaves = v;
+    if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) parsed.chunk = v;
+    if(strstr(tune, "build=lbvh")) parsed.sahBuild = 0;
+    if(strstr(tune, "build=sah")) parsed.sahBuild = 1;
+    if(strstr(tune, "build=ploc")) parsed.sahBuild = 2;
+    if(strstr(tune, "build=sahdev")) parsed.sahBuild = 3;
+    if(strstr(tune, "accel=two")) parsed.accelTwoLevel = 1;
+    if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) parsed.mergeSingles = v;
+    if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) parsed.cnodes = v;
+    if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) parsed.shadeTris = v;
+    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) parsed.tailBelow = v;
+    if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) parsed.warm = v;
+    if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) parsed.texTile = v;
+    if(const char* p = strstr(tune, "regen=")) if(sscanf(p, "regen=%d", &v) == 1) parsed.regen = v;
+    if(const char* p = strstr(tune, "packetTwo=")) if(sscanf(p, "packetTwo=%d", &v) == 1) parsed.packetTwo = v;
+    if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) parsed.interleave = v;
+    if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) parsed.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
+    if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) parsed.rotatePasses = v;
+    if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) parsed.plocFull = v;
+    if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) parsed.plocRadius = v;
+    if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) parsed.splitFull = v;
+    if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) parsed.batch = v;
+    if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) parsed.framesInFlight = v;
+    if(const char* p = strstr(tune, "displaySlots=")) if(sscanf(p, "displaySlots=%d", &v) == 1) parsed.displaySlots = v;
+    if(const char* p = strstr(tune, "bands=")) if(sscanf(p, "bands=%d", &v) == 1) parsed.bands = v;
+    if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) parsed.bandTiles = v > 0 ? v : 1;
+    if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) parsed.stateGB = v;
+    if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) parsed.fuse = v;
   }
-#undef g_tuning
   g_tuning = parsed;
   pt_context* c = new pt_context();
   c->device     = device_ordinal;
@@ -1038,8 +1034,8 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
     const pt_TextureDesc& td = d->textures[t];
     if(!td.rgba8 || td.width <= 0 || td.height <= 0)
       return records_fail(err, "texture %u: empty image", t);
-    if(td.width > 65536 || td.height > 65536)  // (pt_device.h tex_index multiplies row x stride in 24 bits)
-      return records_fail(err, "texture %u: %d x %d exceeds 65536 texels a side", t, td.width, td.height);
+    if(td.width > 65535 || td.height > 65535)  // (pt_device.h tex_index multiplies row x stride in 24 bits)
+      return records_fail(err, "texture %u: %d x %d exceeds 65535 texels a side (tex_desc_pack keeps a side in 16 bits)", t, td.width, td.height);
     R.texRecs[t].tiled  = (g_tuning.texTile && td.width % PT_TEX_TILE_W == 0 && td.height % PT_TEX_TILE_H == 0) ? 1 : 0;
     if(R.texRecs[t].tiled)
       R.texels = (R.texels + 31u) & ~size_t(31);  // a tile = one 128-byte line (the pool itself is 256-byte aligned)
@@ -1135,7 +1131,6 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     }
   }
   if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
-#if PT_TEX_BATCH
   {
     std::vector<uint4> md(size_t(4) * std::max<size_t>(1, d->numMaterials), tex_desc_pack(R.texRecs[0]));
     for(uint32_t i = 0; i < d->numMaterials; ++i)
@@ -1147,7 +1142,6 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     }
     if((rc = upload(c, c->dMatDesc, md.data(), sizeof(uint4) * md.size())) != PT_OK) return rc;
   }
-#endif
   if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;
   c->numInstances = d->numNodes;
@@ -1437,8 +1431,21 @@ static int warm_slots(pt_context* c)
   const int nd = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);
   if(f0.hCounts)
     (void)hipMemcpyAsync(f0.hCounts, f0.rb.countsDone, sizeof(uint32_t) * CNT_STRIDE * size_t(nd), hipMemcpyDeviceToHost, f0.stream);
+  hipError_t werr = hipSuccess;
   for(int k = 0; k < slot_total(c); ++k)
-    HIP_TRY(c, hipStreamSynchronize(slot_at(c, k).stream));
+  {
+    const hipError_t e = hipStreamSynchronize(slot_at(c, k).stream);
+    werr               = werr == hipSuccess ? e : werr;
+  }
+  // whatever happened: the device counters and the accumulation image go back to what the caller left (best effort), and a failed warm-up is retried
+  // by the next pt_resize instead of being silently skipped for the life of the scene
+  const hipError_t r1 = hipMemcpy(c->dCounters.p, &saved, sizeof(Counters), hipMemcpyHostToDevice);
+  const hipError_t r2 = hipMemset(c->dFrame.p, 0, c->dFrame.bytes);
+  if(werr != hipSuccess || r1 != hipSuccess || r2 != hipSuccess)
+  {
+    c->warmPending = true;
+    HIP_TRY(c, werr != hipSuccess ? werr : (r1 != hipSuccess ? r1 : r2));
+  }
   if(f0.hCounts && c->qRatioDepths == 0)
   {
     const double paths = double(fp.batch) * double(c->numSlots);
@@ -1446,8 +1453,6 @@ static int warm_slots(pt_context* c)
       c->qRatio[d] = double(f0.hCounts[size_t(d) * CNT_STRIDE + CNT_IN]) / paths;
     c->qRatioDepths = nd;
   }
-  HIP_TRY(c, hipMemcpy(c->dCounters.p, &saved, sizeof(Counters), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
   return PT_OK;
 }
 

@@ -155,11 +155,8 @@ inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 #endif
 }
 
-// PT_TEX_BATCH (pt_surface.h, a measurement build): a texture's descriptor in 16 bytes, so that a material's four descriptors cost 16 registers, not 32:
+// A texture's descriptor in 16 bytes (pt_surface.h resolve_material), so that a material's four descriptors cost 16 registers, not 32:
 // x = texel offset, y = w | h << 16 (sides < 2^16, pt_set_scene checks), z = bit 0 NEAREST, bits 1-2 wrapS, bits 3-4 wrapT, bits 5-6 pot, bit 7 tiled.
-#ifndef PT_TEX_BATCH
-#define PT_TEX_BATCH 0
-#endif
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -197,10 +194,8 @@ struct DeviceScene {
   const pt_GltfShadeMaterial* materials;
   const pt_Light*             lights;
   const TexRec*               texRecs;
-#if PT_TEX_BATCH
   const uint4*                matDesc;  // per material the 16-byte descriptors (tex_desc_pack) of its normal / emissive / metallic-roughness / base-colour textures
                                         // (texture 0 for an absent one): they arrive WITH the material record instead of one round trip after it
-#endif
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
@@ -237,13 +232,23 @@ struct DeviceScene {
 };
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------
-// -DPT_NT_STATE=1 (measurement build): every access to the path state carries the non-temporal hint -- the state is streamed through once per
-// stage (11 GB per batch), the scene's working set (textures, structure, environment: a few hundred MB) is what the caches should keep.  The
-// arrays become thin proxies so that the access sites stay as they are.
-#ifndef PT_NT_STATE
-#define PT_NT_STATE 0
+// The state is streamed through once per stage (11 GB per batch); the scene's working set (textures, structure, environment: a few hundred MB) is
+// what the caches should keep.  PT_STATE_POLICY picks the cache policy of every path-state access; the arrays are thin proxies so that the access
+// sites read like plain arrays:
+//   0  plain loads / stores
+//   1  non-temporal (`nt`) loads and stores (round 4: +1.3 % at 96 steps; round 5: +4.6 %, profiles/r05a_*)
+//   2  buffer loads / stores with the cache-policy bits PT_STATE_LD_AUX / PT_STATE_ST_AUX (1 = sc0, 2 = nt, 16 = sc1; MI355X_MICROARCH.md "stores of
+//      each flavour": sc1 stores are write-through AND drop the line from the XCD's L2; sc1 loads bypass the L1)
+#ifndef PT_STATE_POLICY
+#define PT_STATE_POLICY 1
 #endif
-#if PT_NT_STATE && defined(__HIP_DEVICE_COMPILE__)
+#ifndef PT_STATE_LD_AUX
+#define PT_STATE_LD_AUX 2
+#endif
+#ifndef PT_STATE_ST_AUX
+#define PT_STATE_ST_AUX 16
+#endif
+#if PT_STATE_POLICY == 1 && defined(__HIP_DEVICE_COMPILE__)
 typedef float pt_nt_f4 __attribute__((ext_vector_type(4)));
 struct StateF1Ref {
   float* p;
@@ -273,8 +278,42 @@ struct StateArray {
   PT_DEV StateF4Ref operator[](size_t i) const { return StateF4Ref(p + i); }
   PT_DEV operator float4*() const { return p; }
 };
+#elif PT_STATE_POLICY == 2 && defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t pt_st_u4 __attribute__((ext_vector_type(4)));
+struct StateF1Ref {  // one 32-bit component of a slot
+  float4*  base;
+  uint32_t off;  // byte offset (a batch's state arrays stay below 2 GB: 2^26 slots x 16 B)
+  PT_DEV __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+  PT_DEV operator float() const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(), off, 0, PT_STATE_LD_AUX)); }
+  PT_DEV StateF1Ref& operator=(float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc(), off, 0, PT_STATE_ST_AUX); return *this; }
+  PT_DEV StateF1Ref& operator+=(float v) { return *this = float(*this) + v; }
+};
+struct StateF4Ref {
+  float4*    base;
+  uint32_t   off;
+  StateF1Ref x, y, z, w;
+  PT_DEV StateF4Ref(float4* b, uint32_t o) : base(b), off(o), x{b, o}, y{b, o + 4u}, z{b, o + 8u}, w{b, o + 12u} {}
+  PT_DEV __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+  PT_DEV operator float4() const
+  {
+    const pt_st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(), off, 0, PT_STATE_LD_AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+  PT_DEV StateF4Ref& operator=(const float4& v)
+  {
+    pt_st_u4 t;
+    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(t, rsrc(), off, 0, PT_STATE_ST_AUX);
+    return *this;
+  }
+};
+struct StateArray {
+  float4* p;
+  PT_DEV StateF4Ref operator[](size_t i) const { return StateF4Ref(p, uint32_t(i) << 4); }
+  PT_DEV operator float4*() const { return p; }
+};
 #else
-struct StateArray {  // the plain form: a pointer
+struct StateArray {  // the plain form: a pointer (and the host build of the shading source, tests/cpp/trace_host.cpp)
   float4* p;
   PT_DEV float4& operator[](size_t i) const { return p[i]; }
   PT_DEV operator float4*() const { return p; }

@@ -131,7 +131,8 @@ struct PtTuning {
   int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
   int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
   int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
-  int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p); 0: the round-4 chain
+  int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
+                                   // (the display loop), 2 = always, 0 = never (the round-4 chain)
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other

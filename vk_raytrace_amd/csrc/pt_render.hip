@@ -1184,7 +1184,9 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the staged machine kernels; no packet stage, no fused stage, no k_tail
-  const bool     fuse      = g_tuning.fuse != 0 && !heat;
+  // measured (profiles/r05a_*, r05b_*, r05c_*): serialised, the fused launch takes exactly the time of the two launches it replaces (21.3 ms per 32-frame
+  // batch either way) and k_shade reads a hit queue scrambled by two traversals instead of one (+6 %): -4 % on batches, +2.5 % on a frame the host waits for
+  const bool     fuse      = !heat && (g_tuning.fuse == 2 || (g_tuning.fuse == 1 && fp.batch == 1));
   // camera rays computed by the packet kernel instead of written by k_generate: one sample per frame (the RNG stream of a second sample continues
   // from the stored state), a packet stage at bounce 0, no heat map (it keeps the path's cost in rayO.w), bounce 0 not already in k_tail
   const bool packetStage = !TWO || g_tuning.packetTwo;  // the two-level structure has a packet stage of its own since round 4 (pt_packet.h traverse_packet_two)

@@ -58,11 +58,11 @@ PT_DEV f4 sample_rgba8_rec(const uint32_t* texels, const TexRec& tr, f2 uv)
 }
 PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv) { return sample_rgba8_rec(S.texels, S.texRecs[id], uv); }
 
-// -DPT_TEX_BATCH=1 (measurement build, never the product until measured): resolve_material reaches its four common textures -- normal, emissive,
+// Batched texture fetch (round 5: +1 % on the bench line, profiles/r05d_*): resolve_material reached its four common textures -- normal, emissive,
 // metallic-roughness, base colour -- through up to eight DEPENDENT round trips (descriptor, then texels, per texture, each behind its own `if`).
-// The flavour stores the four 16-byte descriptors per material (DeviceScene::matDesc), so that they arrive with the material record, and requests
-// the texels of the textures a material HAS up front, so that those requests are in flight together.  First forms that also fetched the absent
-// textures (as texture 0) were 7 % SLOWER on the bench line (profiles/r04tb_batched_texture_fetch.txt): k_shade is short of requests, not of latency.
+// The four 16-byte descriptors are stored per material (DeviceScene::matDesc), so that they arrive with the material record, and the texels of the
+// textures a material HAS are requested up front, so that those requests are in flight together.  First forms that also fetched the absent
+// textures (as texture 0) were 7 % SLOWER (profiles/r04tb_batched_texture_fetch.txt): k_shade is short of requests, not of latency.
 // The tap is sample_rgba8_rec cut in two: where the texels are (tex_tap) and what is made of them (tex_filter) -- the same expressions in the same order.
 struct TexTap {
   uint32_t i[4];  // texel indices into the pool: (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1); four times the nearest texel for a NEAREST tap
@@ -352,7 +352,6 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   sf.uv           = f2{((sf.uv.x * um[0] + sf.uv.y * um[1]) + 1.0f * um[2]) + 1.0f * um[3], ((sf.uv.x * um[4] + sf.uv.y * um[5]) + 1.0f * um[6]) + 1.0f * um[7]};
   const f3 T0 = sf.tangent, B0 = sf.bitangent, N0 = sf.normal;  // TBN before normal mapping
 
-#if PT_TEX_BATCH
   const bool      hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
   const uint4     dN = S.matDesc[4 * matIndex], dE = S.matDesc[4 * matIndex + 1], dM = S.matDesc[4 * matIndex + 2], dB = S.matDesc[4 * matIndex + 3];
   const uint32_t* tx = S.texels;
@@ -367,12 +366,6 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
 #define PT_TAP_E tex_filter(tE, e0, e1, e2, e3)
 #define PT_TAP_M tex_filter(tM, m0, m1, m2, m3)
 #define PT_TAP_B tex_filter(tB, b0, b1, b2, b3)
-#else
-#define PT_TAP_N sample_rgba8(S, m.normalTexture, sf.uv)
-#define PT_TAP_E sample_rgba8(S, m.emissiveTexture, sf.uv)
-#define PT_TAP_M sample_rgba8(S, m.pbrMetallicRoughnessTexture, sf.uv)
-#define PT_TAP_B sample_rgba8(S, m.pbrBaseColorTexture, sf.uv)
-#endif
   if(m.normalTexture > -1)
   {
     f3 nv       = xyz(PT_TAP_N);
