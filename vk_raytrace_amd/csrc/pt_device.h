@@ -233,39 +233,44 @@ struct DeviceScene {
 
 // ---- wavefront path state (SoA of float4, one slot per local pixel) --------------------------------
 // The state is streamed through once per stage (11 GB per batch); the scene's working set (textures, structure, environment: a few hundred MB) is
-// what the caches should keep.  PT_STATE_POLICY picks the cache policy of every path-state access; the arrays are thin proxies so that the access
-// sites read like plain arrays:
-//   0  plain loads / stores
-//   1  non-temporal (`nt`) loads and stores (round 4: +1.3 % at 96 steps; round 5: +4.6 %, profiles/r05a_*)
-//   2  buffer loads / stores with the cache-policy bits PT_STATE_LD_AUX / PT_STATE_ST_AUX (1 = sc0, 2 = nt, 16 = sc1; MI355X_MICROARCH.md "stores of
-//      each flavour": sc1 stores are write-through AND drop the line from the XCD's L2; sc1 loads bypass the L1)
+// what the caches should keep.  The arrays are thin proxies that carry the cache policy of every path-state access in their TYPE, so that the
+// access sites read like plain arrays and one function body (shade_path, finish_bounce_core, store_hit) serves kernels with different policies:
+//   PT_STATE_PLAIN     plain loads / stores (the host build of the shading source, tests/cpp/trace_host.cpp)
+//   PT_STATE_NT        non-temporal (`nt`) loads and stores: the staged kernels (+2 % at 96 steps against plain, profiles/r05d_*)
+//   PT_STATE_COHERENT  sc1 buffer loads and write-through sc1 stores: data handed from wavefront to wavefront INSIDE one launch (k_wave) -- per-XCD
+//                      L2s are not coherent with each other and a CU's L1 is never refreshed by other CUs' stores (MI355X_MICROARCH.md, "Workgroup
+//                      dispatch, XCD placement & inter-workgroup visibility": 16-byte sc1 stores + vmcnt drain + flag, sc1 loads on the reading side).
+//                      As the policy of EVERY kernel it measured 3.5 % slower than nt (sc1 stores drop the line from L2; profiles/r05d_*).
+#define PT_STATE_PLAIN 0
+#define PT_STATE_NT 1
+#define PT_STATE_COHERENT 2
 #ifndef PT_STATE_POLICY
-#define PT_STATE_POLICY 1
+#define PT_STATE_POLICY PT_STATE_NT
 #endif
-#ifndef PT_STATE_LD_AUX
-#define PT_STATE_LD_AUX 2
-#endif
-#ifndef PT_STATE_ST_AUX
-#define PT_STATE_ST_AUX 16
-#endif
-#if PT_STATE_POLICY == 1 && defined(__HIP_DEVICE_COMPILE__)
+template <int POL>
+struct StateArrayT {  // the plain form: a pointer
+  float4* p;
+  PT_DEV float4& operator[](size_t i) const { return p[i]; }
+  PT_DEV operator float4*() const { return p; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef float pt_nt_f4 __attribute__((ext_vector_type(4)));
-struct StateF1Ref {
+struct StateF1RefNt {
   float* p;
   PT_DEV operator float() const { return __builtin_nontemporal_load(p); }
-  PT_DEV StateF1Ref& operator=(float v) { __builtin_nontemporal_store(v, p); return *this; }
-  PT_DEV StateF1Ref& operator+=(float v) { __builtin_nontemporal_store(__builtin_nontemporal_load(p) + v, p); return *this; }
+  PT_DEV StateF1RefNt& operator=(float v) { __builtin_nontemporal_store(v, p); return *this; }
+  PT_DEV StateF1RefNt& operator+=(float v) { __builtin_nontemporal_store(__builtin_nontemporal_load(p) + v, p); return *this; }
 };
-struct StateF4Ref {
-  float4*    p;
-  StateF1Ref x, y, z, w;
-  PT_DEV explicit StateF4Ref(float4* q) : p(q), x{&q->x}, y{&q->y}, z{&q->z}, w{&q->w} {}
+struct StateF4RefNt {
+  float4*      p;
+  StateF1RefNt x, y, z, w;
+  PT_DEV explicit StateF4RefNt(float4* q) : p(q), x{&q->x}, y{&q->y}, z{&q->z}, w{&q->w} {}
   PT_DEV operator float4() const
   {
     const pt_nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const pt_nt_f4*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
   }
-  PT_DEV StateF4Ref& operator=(const float4& v)
+  PT_DEV StateF4RefNt& operator=(const float4& v)
   {
     pt_nt_f4 t;
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -273,63 +278,62 @@ struct StateF4Ref {
     return *this;
   }
 };
-struct StateArray {
+template <>
+struct StateArrayT<PT_STATE_NT> {
   float4* p;
-  PT_DEV StateF4Ref operator[](size_t i) const { return StateF4Ref(p + i); }
+  PT_DEV StateF4RefNt operator[](size_t i) const { return StateF4RefNt(p + i); }
   PT_DEV operator float4*() const { return p; }
 };
-#elif PT_STATE_POLICY == 2 && defined(__HIP_DEVICE_COMPILE__)
+// coherent form: raw buffer operations with aux = 16 (sc1).  A batch's state arrays stay below 2 GB (2^26 slots x 16 B), so 32-bit byte offsets do.
 typedef uint32_t pt_st_u4 __attribute__((ext_vector_type(4)));
-struct StateF1Ref {  // one 32-bit component of a slot
+#define PT_AUX_SC1 16
+PT_DEV __amdgpu_buffer_rsrc_t state_rsrc(float4* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+struct StateF1RefCo {  // one 32-bit component of a slot
   float4*  base;
-  uint32_t off;  // byte offset (a batch's state arrays stay below 2 GB: 2^26 slots x 16 B)
-  PT_DEV __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
-  PT_DEV operator float() const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc(), off, 0, PT_STATE_LD_AUX)); }
-  PT_DEV StateF1Ref& operator=(float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc(), off, 0, PT_STATE_ST_AUX); return *this; }
-  PT_DEV StateF1Ref& operator+=(float v) { return *this = float(*this) + v; }
+  uint32_t off;
+  PT_DEV operator float() const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(state_rsrc(base), off, 0, PT_AUX_SC1)); }
+  PT_DEV StateF1RefCo& operator=(float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), state_rsrc(base), off, 0, PT_AUX_SC1); return *this; }
+  PT_DEV StateF1RefCo& operator+=(float v) { return *this = float(*this) + v; }
 };
-struct StateF4Ref {
-  float4*    base;
-  uint32_t   off;
-  StateF1Ref x, y, z, w;
-  PT_DEV StateF4Ref(float4* b, uint32_t o) : base(b), off(o), x{b, o}, y{b, o + 4u}, z{b, o + 8u}, w{b, o + 12u} {}
-  PT_DEV __amdgpu_buffer_rsrc_t rsrc() const { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+struct StateF4RefCo {
+  float4*      base;
+  uint32_t     off;
+  StateF1RefCo x, y, z, w;
+  PT_DEV StateF4RefCo(float4* b, uint32_t o) : base(b), off(o), x{b, o}, y{b, o + 4u}, z{b, o + 8u}, w{b, o + 12u} {}
   PT_DEV operator float4() const
   {
-    const pt_st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(), off, 0, PT_STATE_LD_AUX);
+    const pt_st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(state_rsrc(base), off, 0, PT_AUX_SC1);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
-  PT_DEV StateF4Ref& operator=(const float4& v)
+  PT_DEV StateF4RefCo& operator=(const float4& v)
   {
     pt_st_u4 t;
     t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(t, rsrc(), off, 0, PT_STATE_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(t, state_rsrc(base), off, 0, PT_AUX_SC1);
     return *this;
   }
 };
-struct StateArray {
+template <>
+struct StateArrayT<PT_STATE_COHERENT> {
   float4* p;
-  PT_DEV StateF4Ref operator[](size_t i) const { return StateF4Ref(p, uint32_t(i) << 4); }
-  PT_DEV operator float4*() const { return p; }
-};
-#else
-struct StateArray {  // the plain form: a pointer (and the host build of the shading source, tests/cpp/trace_host.cpp)
-  float4* p;
-  PT_DEV float4& operator[](size_t i) const { return p[i]; }
+  PT_DEV StateF4RefCo operator[](size_t i) const { return StateF4RefCo(p, uint32_t(i) << 4); }
   PT_DEV operator float4*() const { return p; }
 };
 #endif
-struct PathState {
-  StateArray rayO;    // origin.xyz, -
-  StateArray rayD;    // direction.xyz, bits(seed)
-  StateArray thr;     // throughput.xyz, rrPcont
-  StateArray rad;     // radiance.xyz, -
-  StateArray absorb;  // absorption.xyz, lightDist
-  StateArray neeDir;  // lightDir.xyz, visible (1/0)
-  StateArray neeRad;  // vcontrib.radiance.xyz, -
-  StateArray hit;     // t, bits(tri slot in leaf order | 0xffffffff miss), u, v
-  StateArray sum;     // per-frame sample sum (maxSamples > 1)
+typedef StateArrayT<PT_STATE_POLICY> StateArray;
+template <int POL>
+struct PathStateT {
+  StateArrayT<POL> rayO;    // origin.xyz, -
+  StateArrayT<POL> rayD;    // direction.xyz, bits(seed)
+  StateArrayT<POL> thr;     // throughput.xyz, rrPcont
+  StateArrayT<POL> rad;     // radiance.xyz, -
+  StateArrayT<POL> absorb;  // absorption.xyz, lightDist
+  StateArrayT<POL> neeDir;  // lightDir.xyz, visible (1/0)
+  StateArrayT<POL> neeRad;  // vcontrib.radiance.xyz, -
+  StateArrayT<POL> hit;     // t, bits(tri slot in leaf order | 0xffffffff miss), u, v
+  StateArrayT<POL> sum;     // per-frame sample sum (maxSamples > 1)
 };
+typedef PathStateT<PT_STATE_POLICY> PathState;
 
 struct Counters {
   unsigned long long closestRays, shadowRays, shadedHits, misses, alphaTests, neeLookups, nodesVisited, trisTested;

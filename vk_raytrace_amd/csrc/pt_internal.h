@@ -90,20 +90,32 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
 #endif
 #define PT_PERSISTENT_WAVES (256u * 20u)
 
-struct RenderBuffers {
-  PathState ps;
+// POL: cache policy of the path-state accesses (pt_device.h); every instantiation has the same layout (plain pointers), so a kernel may view the
+// buffers it was handed under another policy (render_buffers_as)
+template <int POL>
+struct RenderBuffersT {
+  PathStateT<POL> ps;
   uint32_t* queueA;    // path-slot queues of the bounces (ping-pong)
   uint32_t* queueB;
   uint32_t* queueS;    // paths with a shadow ray
   uint32_t* queueX;    // exact-fallback queues (normally empty)
   uint32_t* queueX2;
   uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
+  uint32_t* ringT;     // k_wave: trace ring and shade ring (pt_render.hip); all 0xffffffff at rest
+  uint32_t* ringH;
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   uint32_t* countsDone;  // the counter block of the latest finished sample pass (k_accumulate copies it here and clears `counts`)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
   Counters* counters;
 };
+typedef RenderBuffersT<PT_STATE_POLICY> RenderBuffers;
+template <int POL, int FROM>
+PT_DEV const RenderBuffersT<POL>& render_buffers_as(const RenderBuffersT<FROM>& rb)
+{
+  static_assert(sizeof(RenderBuffersT<POL>) == sizeof(RenderBuffersT<FROM>), "same layout under every policy");
+  return reinterpret_cast<const RenderBuffersT<POL>&>(rb);
+}
 // Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
 // the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
 struct PtTuning {
@@ -131,6 +143,7 @@ struct PtTuning {
   int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
   int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
   int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
+  int wave                 = 1;    // the late bounces of a launch sequence: 1 = k_wave (independently scheduled wavefronts, in-launch rings), 0 = k_tail (lock step)
   int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
                                    // (the display loop), 2 = always, 0 = never (the round-4 chain)
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them

@@ -9,12 +9,70 @@
 
 // The hit record names the triangle by its leaf slot (flat structure: S.tris[slot] carries instance and primitive) or, with the two-level
 // structure (`two`: a BLAS leaf is shared by all instances of its mesh), by its world triangle index (k_shade: instance_of_world_tri).
-PT_DEV void store_hit(const RenderBuffers& rb, uint32_t slot, uint32_t bslot, uint32_t bw, bool two, float t, float u, float v)
+template <class RB>
+PT_DEV void store_hit(const RB& rb, uint32_t slot, uint32_t bslot, uint32_t bw, bool two, float t, float u, float v)
 {
   if(bslot == BVH_NONE)
     rb.ps.hit[slot] = make_float4(PT_INFINITY, __uint_as_float(BVH_NONE), 0.f, 0.f);
   else
     rb.ps.hit[slot] = make_float4(t, __uint_as_float(two ? (bw & TRI_INDEX_MASK) : bslot), u, v);
+}
+
+// The exact key-ordered loops (trace contract T5 / T6; k_closest_x / k_shadow_x spell the same steps out per stage): what a ray falls back to when the
+// two-pass scheme cannot settle it -- a candidate of fractional opacity in front of the hit, or a rejected-candidate draw of exactly 0.0.
+// `seed`: the path's RNG state before the ray's first draw; closest: hit record and the state afterwards go to the path state.
+template <bool TWO, class RB>
+PT_DEV void settle_closest_exact(const DeviceScene& S, const RB& rb, uint32_t slot, f3 o, f3 d, uint32_t seed, uint32_t* stack, uint32_t& nAlpha)
+{
+  RayHit   h;
+  bool     dummy;
+  float    tPrev = 0.0f;
+  uint32_t wPrev = 0xffffffffu;
+  for(;;)
+  {
+    traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
+    if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
+      break;
+    ++nAlpha;
+    if(alpha_test(S, h.slot, h.u, h.v, seed))
+      break;
+    tPrev = h.t;
+    wPrev = h.w & TRI_INDEX_MASK;
+  }
+  store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
+  rb.ps.rayD[slot].w = __uint_as_float(seed);
+}
+// shadow: returns inShadow; `seed` comes back as the path's state afterwards (RTX flavour: untouched, the any-hit shader draws from a copy)
+template <bool TWO>
+PT_DEV bool settle_shadow_exact(const DeviceScene& S, f3 o, f3 d, float maxDist, int variant, uint32_t& seed, uint32_t* stack, uint32_t& nAlpha, Counters* counters)
+{
+  const uint32_t seed0 = seed;
+  RayHit         h;
+  bool           dummy, inShadow = false;
+  float          tPrev = 0.0f;
+  uint32_t       wPrev = 0xffffffffu;
+  for(;;)
+  {
+    traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack, h, dummy, counters);
+    if(h.slot == BVH_NONE)
+      break;
+    if((h.w >> 29) & TRI_OPAQUE)
+    {
+      inShadow = true;
+      break;
+    }
+    ++nAlpha;
+    if(alpha_test(S, h.slot, h.u, h.v, seed))
+    {
+      inShadow = true;
+      break;
+    }
+    tPrev = h.t;
+    wPrev = h.w & TRI_INDEX_MASK;
+  }
+  if(variant == PT_VARIANT_RTX)
+    seed = seed0;
+  return inShadow;
 }
 
 // the closest-hit ray of a path: hit record -> rb.ps.hit[slot], RNG state after the alpha draws -> rb.ps.rayD[slot].w
@@ -52,22 +110,7 @@ PT_DEV void tail_closest(const DeviceScene& S, const RenderBuffers& rb, uint32_t
       return;
     }
   }
-  // exact key-ordered loop (k_closest_x)
-  float    tPrev = 0.0f;
-  uint32_t wPrev = 0xffffffffu;
-  for(;;)
-  {
-    traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
-    if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
-      break;
-    ++nAlpha;
-    if(alpha_test(S, h.slot, h.u, h.v, seed))
-      break;
-    tPrev = h.t;
-    wPrev = h.w & TRI_INDEX_MASK;
-  }
-  store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
-  rb.ps.rayD[slot].w = __uint_as_float(seed);
+  settle_closest_exact<TWO>(S, rb, slot, o, d, seed, stack, nAlpha);
 }
 
 // the shadow ray of a path (k_shadow_s / k_shadow_x): returns inShadow, `seed` = the path's seed afterwards
@@ -104,31 +147,7 @@ PT_DEV bool tail_shadow(const DeviceScene& S, const RenderBuffers& rb, uint32_t 
       return h.slot != BVH_NONE;
     }
   }
-  // exact key-ordered loop (k_shadow_x)
-  bool     inShadow = false;
-  float    tPrev    = 0.0f;
-  uint32_t wPrev    = 0xffffffffu;
-  for(;;)
-  {
-    traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack, h, dummy, rb.counters);
-    if(h.slot == BVH_NONE)
-      break;
-    if((h.w >> 29) & TRI_OPAQUE)
-    {
-      inShadow = true;
-      break;
-    }
-    ++nAlpha;
-    if(alpha_test(S, h.slot, h.u, h.v, seed))
-    {
-      inShadow = true;
-      break;
-    }
-    tPrev = h.t;
-    wPrev = h.w & TRI_INDEX_MASK;
-  }
-  if(variant == PT_VARIANT_RTX)
-    seed = seed0;
-  return inShadow;
+  seed = seed0;  // (the two-pass attempt above left it untouched unless it settled the ray)
+  return settle_shadow_exact<TWO>(S, o, d, maxDist, variant, seed, stack, nAlpha, rb.counters);
 }
 

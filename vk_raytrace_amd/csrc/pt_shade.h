@@ -175,8 +175,8 @@ PT_DEV f3 bsdf_sample(int pbrMode, const Surface& s, f3 V, f3 N, f3& L, float& p
 // MODE: 0 / 1 = the common case compiled on its own -- Disney / glTF BSDF, no debug output, no sun & sky, no punctual lights (the host picks the
 // kernel from the frame's uniform state), so that neither the other BSDF nor sun_and_sky() nor the debug / light branches cost registers or
 // instruction-cache space; -1 = everything decided at run time.  Same arithmetic in every instantiation.
-template <int MODE>
-PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const FrameParams& fp, uint32_t slot, int depth, uint32_t& events)
+template <int MODE, class RB>
+PT_DEV int shade_path(const DeviceScene& S, const RB& rb, const FrameParams& fp, uint32_t slot, int depth, uint32_t& events)
 {
   const pt_RtxState& st   = fp.st;
   const int          pbrMode  = MODE >= 0 ? MODE : st.pbrMode;
@@ -433,7 +433,8 @@ PT_DEV int shade_path(const DeviceScene& S, const RenderBuffers& rb, const Frame
 // NEE contribution if unoccluded, then Russian roulette (pathtrace.glsl:327-338); survivors go to the next bounce.
 // Returns true when the path survives the roulette (the caller queues it for the next bounce, or traces its next ray right away: k_trace_p);
 // `seed` comes back as the RNG state after the roulette draw (also stored in the path state).
-PT_DEV bool finish_bounce_core(const RenderBuffers& rb, uint32_t slot, bool inShadow, uint32_t& seed)
+template <class RB>
+PT_DEV bool finish_bounce_core(const RB& rb, uint32_t slot, bool inShadow, uint32_t& seed)
 {
   if(!inShadow)
   {
