@@ -72,7 +72,7 @@ struct pt_context {
   // frame's stage (a launch lasts as long as its slowest ray) is filled with the work of other frames.  Only the
   // running-mean accumulate is ordered across frames (events).
   struct FrameSlot {
-    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dRingT, dRingH, dCounts, dCountsDone;
+    DevBuf        dState[9], dQueueA, dQueueB, dQueueS, dQueueX, dQueueX2, dQueueR, dCounts, dCountsDone;
     RenderBuffers rb{};
     hipStream_t   stream    = nullptr;
     hipEvent_t    accumDone = nullptr;
@@ -253,16 +253,7 @@ int check_traversal(pt_context* c)
   c->renderedSinceCheck = false;
   if(n)
   {
-    // (a k_wave launch that gave up may have left entries in its rings and counts in its counter blocks: back to the state a launch expects)
-    for(int k = 0; k < PT_MAX_INFLIGHT; ++k)
-    {
-      pt_context::FrameSlot& fs = c->slots[k];
-      if(fs.dRingT.p) (void)hipMemset(fs.dRingT.p, 0xff, fs.dRingT.bytes);
-      if(fs.dRingH.p) (void)hipMemset(fs.dRingH.p, 0xff, fs.dRingH.bytes);
-      if(fs.dCounts.p) (void)hipMemset(fs.dCounts.p, 0, fs.dCounts.bytes);
-    }
-    return c->fail(PT_ERR_STATE, "traversal failed %u times (the image is invalid: the acceleration structure is deeper than the traversal stack, or a wavefront of the "
-                                 "late-bounce kernel found no work for ~1 s)", n);
+    return c->fail(PT_ERR_STATE, "BVH traversal stack overflowed %u times (the image is invalid: the acceleration structure is deeper than the traversal stack)", n);
   }
   return PT_OK;
 }
@@ -773,7 +764,6 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) parsed.bandTiles = v > 0 ? v : 1;
     if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) parsed.stateGB = v;
     if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) parsed.fuse = v;
-    if(const char* p = strstr(tune, "wave=")) if(sscanf(p, "wave=%d", &v) == 1) parsed.wave = v;
   }
   g_tuning = parsed;
   pt_context* c = new pt_context();
@@ -824,7 +814,7 @@ int pt_destroy(pt_context* c)
   {
     for(DevBuf& b : fs.dState)
       dev_free(b);
-    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dRingT, &fs.dRingH, &fs.dCounts, &fs.dCountsDone};
+    DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dCounts, &fs.dCountsDone};
     for(DevBuf* b : q)
       dev_free(*b);
     if(fs.accumDone)
@@ -1508,7 +1498,7 @@ int pt_resize(pt_context* c, int width, int height)
   // the defaults, sized for 288 GB of HBM.  It is a budget, not a requirement: PT_TUNE stateGB=<n> (or what hipMemGetInfo reports as free,
   // minus a reserve) caps it, and an allocation that still fails halves the batch / drops frame slots and retries, down to one frame on
   // one slot, before PT_ERR_OOM is reported.  Smaller batches only cost throughput, never results.
-  const size_t perPath = 9 * sizeof(float4) + 8 * sizeof(uint32_t);
+  const size_t perPath = 9 * sizeof(float4) + 6 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
   c->displaySlots      = c->displaySlotsMax;
   {
@@ -1521,7 +1511,7 @@ int pt_resize(pt_context* c, int width, int height)
     {
       pt_context::FrameSlot& fs = c->slots[i];
       for(DevBuf& bf : fs.dState) held += bf.bytes;
-      const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dRingT, &fs.dRingH};
+      const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(const DevBuf* bf : q) held += bf->bytes;
     }
     const double budget = g_tuning.stateMB > 0 ? g_tuning.stateMB * 1e6 : g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
@@ -1544,14 +1534,9 @@ int pt_resize(pt_context* c, int width, int height)
       const size_t           n  = size_t(c->numSlots ? c->numSlots : 1) * size_t(k < c->inflight ? c->batchMax : 1);
       for(DevBuf& bf : fs.dState)
         ok = ok && dev_alloc_quiet(bf, sizeof(float4) * n);
-      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dRingT, &fs.dRingH};
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(DevBuf* bf : q)
         ok = ok && dev_alloc_quiet(*bf, 4 * n);
-      if(ok)
-      {  // k_wave's rings are all WV_EMPTY at rest (every entry pushed is consumed before its launch ends)
-        HIP_TRY(c, hipMemset(fs.dRingT.p, 0xff, fs.dRingT.bytes));
-        HIP_TRY(c, hipMemset(fs.dRingH.p, 0xff, fs.dRingH.bytes));
-      }
       ok = ok && dev_alloc_quiet(fs.dCounts, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
       ok = ok && dev_alloc_quiet(fs.dCountsDone, sizeof(uint32_t) * CNT_STRIDE * (PT_MAX_DEPTH + 2));
       if(ok)
@@ -1569,7 +1554,7 @@ int pt_resize(pt_context* c, int width, int height)
           continue;
         pt_context::FrameSlot& fs = c->slots[i];
         for(DevBuf& bf : fs.dState) dev_free(bf);
-        DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dRingT, &fs.dRingH};
+        DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
         for(DevBuf* bf : q) dev_free(*bf);
       }
       break;
@@ -1579,7 +1564,7 @@ int pt_resize(pt_context* c, int width, int height)
     {  // release everything before retrying smaller
       pt_context::FrameSlot& fs = c->slots[i];
       for(DevBuf& bf : fs.dState) dev_free(bf);
-      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR, &fs.dRingT, &fs.dRingH};
+      DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(DevBuf* bf : q) dev_free(*bf);
     }
     if(c->displaySlots > 0)
@@ -1615,8 +1600,6 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.queueX   = (uint32_t*)fs.dQueueX.p;
     fs.rb.queueX2  = (uint32_t*)fs.dQueueX2.p;
     fs.rb.queueR   = (uint32_t*)fs.dQueueR.p;
-    fs.rb.ringT    = (uint32_t*)fs.dRingT.p;
-    fs.rb.ringH    = (uint32_t*)fs.dRingH.p;
     fs.rb.counts   = (uint32_t*)fs.dCounts.p;
     fs.rb.countsDone = (uint32_t*)fs.dCountsDone.p;
     fs.rb.frame    = (float4*)c->dFrame.p;

@@ -237,13 +237,11 @@ struct DeviceScene {
 // access sites read like plain arrays and one function body (shade_path, finish_bounce_core, store_hit) serves kernels with different policies:
 //   PT_STATE_PLAIN     plain loads / stores (the host build of the shading source, tests/cpp/trace_host.cpp)
 //   PT_STATE_NT        non-temporal (`nt`) loads and stores: the staged kernels (+2 % at 96 steps against plain, profiles/r05d_*)
-//   PT_STATE_COHERENT  sc1 buffer loads and write-through sc1 stores: data handed from wavefront to wavefront INSIDE one launch (k_wave) -- per-XCD
-//                      L2s are not coherent with each other and a CU's L1 is never refreshed by other CUs' stores (MI355X_MICROARCH.md, "Workgroup
-//                      dispatch, XCD placement & inter-workgroup visibility": 16-byte sc1 stores + vmcnt drain + flag, sc1 loads on the reading side).
-//                      As the policy of EVERY kernel it measured 3.5 % slower than nt (sc1 stores drop the line from L2; profiles/r05d_*).
+// (sc1 buffer loads / write-through sc1 stores -- what data handed from wavefront to wavefront INSIDE one launch needs, MI355X_MICROARCH.md "inter-workgroup
+// visibility" -- measured 3.5 % slower than nt as the policy of every kernel, sc1 stores alone 5.6 %: they drop the line from L2; profiles/r05d_*.  The
+// in-launch scheduler that needed them, k_wave, lost to k_tail: profiles/r05_kwave_experiment.txt, branch kwave-experiment.)
 #define PT_STATE_PLAIN 0
 #define PT_STATE_NT 1
-#define PT_STATE_COHERENT 2
 #ifndef PT_STATE_POLICY
 #define PT_STATE_POLICY PT_STATE_NT
 #endif
@@ -282,41 +280,6 @@ template <>
 struct StateArrayT<PT_STATE_NT> {
   float4* p;
   PT_DEV StateF4RefNt operator[](size_t i) const { return StateF4RefNt(p + i); }
-  PT_DEV operator float4*() const { return p; }
-};
-// coherent form: raw buffer operations with aux = 16 (sc1).  A batch's state arrays stay below 2 GB (2^26 slots x 16 B), so 32-bit byte offsets do.
-typedef uint32_t pt_st_u4 __attribute__((ext_vector_type(4)));
-#define PT_AUX_SC1 16
-PT_DEV __amdgpu_buffer_rsrc_t state_rsrc(float4* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
-struct StateF1RefCo {  // one 32-bit component of a slot
-  float4*  base;
-  uint32_t off;
-  PT_DEV operator float() const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(state_rsrc(base), off, 0, PT_AUX_SC1)); }
-  PT_DEV StateF1RefCo& operator=(float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), state_rsrc(base), off, 0, PT_AUX_SC1); return *this; }
-  PT_DEV StateF1RefCo& operator+=(float v) { return *this = float(*this) + v; }
-};
-struct StateF4RefCo {
-  float4*      base;
-  uint32_t     off;
-  StateF1RefCo x, y, z, w;
-  PT_DEV StateF4RefCo(float4* b, uint32_t o) : base(b), off(o), x{b, o}, y{b, o + 4u}, z{b, o + 8u}, w{b, o + 12u} {}
-  PT_DEV operator float4() const
-  {
-    const pt_st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(state_rsrc(base), off, 0, PT_AUX_SC1);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-  }
-  PT_DEV StateF4RefCo& operator=(const float4& v)
-  {
-    pt_st_u4 t;
-    t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(t, state_rsrc(base), off, 0, PT_AUX_SC1);
-    return *this;
-  }
-};
-template <>
-struct StateArrayT<PT_STATE_COHERENT> {
-  float4* p;
-  PT_DEV StateF4RefCo operator[](size_t i) const { return StateF4RefCo(p, uint32_t(i) << 4); }
   PT_DEV operator float4*() const { return p; }
 };
 #endif

@@ -101,8 +101,6 @@ struct RenderBuffersT {
   uint32_t* queueX;    // exact-fallback queues (normally empty)
   uint32_t* queueX2;
   uint32_t* queueR;    // rays the packet kernel could not settle (redone per lane on the trace machine)
-  uint32_t* ringT;     // k_wave: trace ring and shade ring (pt_render.hip); all 0xffffffff at rest
-  uint32_t* ringH;
   uint32_t* counts;    // (PT_MAX_DEPTH + 2) x CNT_STRIDE device counters
   uint32_t* countsDone;  // the counter block of the latest finished sample pass (k_accumulate copies it here and clears `counts`)
   float4*   frame;     // accumulation tiles, slot order
@@ -143,7 +141,6 @@ struct PtTuning {
   int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
   int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
   int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
-  int wave                 = 1;    // the late bounces of a launch sequence: 1 = k_wave (independently scheduled wavefronts, in-launch rings), 0 = k_tail (lock step)
   int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
                                    // (the display loop), 2 = always, 0 = never (the round-4 chain)
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them

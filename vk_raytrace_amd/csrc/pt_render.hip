@@ -890,359 +890,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, 2) k_tail(DeviceScene S, RenderBu
   wave_add(&rb.counters->tailShadedHits, nHit);
 }
 
-// ---- the late bounces as ONE launch of independently scheduled wavefronts (round 5) -----------------------------------------------------------
-// What a launch sequence loses on a short run is not work but waiting: every staged bounce ends when its SLOWEST ray ends (the longest of
-// 10^5 rays needs ~250 loop iterations, 0.3-0.6 ms, profiles/r03r_lane_hist_batch32.txt), three such floors per bounce, and k_tail -- which
-// removed the kernel boundaries -- still walks in lock step: a wavefront's 64 paths wait for each other at every ray.  Here the stages talk through
-// two rings in HBM instead of kernel boundaries, and nothing waits for a stage to drain:
-//   tracer wavefronts (3 of 4) run the refilling trace machine (pt_machine.h).  Their lanes first take the paths of the input queue (closest-hit rays
-//                of bounce depth0), then entries of the TRACE RING: closest-hit (entry = slot | relative depth << 26) or shadow rays (| 1 << 31).  A
-//                shadow ray that settles adds the NEE contribution, draws the roulette and -- if the path lives -- starts the path's next closest-hit
-//                ray in the same lane (k_trace_p's fusion); a closest-hit ray that settles goes to the SHADE RING;
-//   shader wavefronts (1 of 4) take entries of the shade ring, run shade_path and push the paths that go on back to the trace ring.
-// The launch ends when every path has ended (`done` counter).  Its critical path is the longest single PATH, not the sum over stages of the longest ray.
-// Rings: positions grow monotonically.  A producer reserves a span with one atomic per wavefront and writes its entries; a consumer LANE draws one
-// ticket (= position; one atomic per wavefront and service round), polls that entry -- its own address, no hot spot -- until it is there, and writes
-// WV_EMPTY back.  No compare-and-swap (a first version claimed spans with one: 64 entries per serialised round trip, 20 x slower than k_tail), no
-// ordered commit.  A ring is all WV_EMPTY at rest: pt_resize fills it once, every entry pushed is consumed before the last path ends.  At most count0
-// paths exist, each in at most one ring, and both rings hold n >= count0 entries: they cannot overflow.
-// Visibility: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by other CUs' stores (MI355X_MICROARCH.md, "inter-workgroup
-// visibility"), so every path-state access of this kernel is sc1 (PT_STATE_COHERENT: write-through stores, L1-bypassing loads), ring entries and
-// counters are agent-scope atomics, and a wavefront drains its stores (s_waitcnt vmcnt(0)) before it writes the entries that announce them.
-// Every wait is bounded: a wavefront that finds nothing to do for ~1 s raises Counters::stackOverflow (reported as an error) and leaves.
-#define WV_RESERVE 8   // counter words of a ring inside a per-bounce counter block (trace ring: block depth0, shade ring: block depth0 + 1)
-#define WV_TICKET 9
-#define WV_DONE 11     // (block depth0) paths that have ended -- words 8 .. 11 of that block are read together
-#define WV_EMPTY 0xffffffffu
-#define WV_SLOT_MASK 0x03ffffffu
-#define WV_MAX_REL_DEPTH 31
-PT_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-PT_DEV void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-struct WaveRing {
-  uint32_t* buf;
-  uint32_t  cap;
-  uint32_t* ctr;  // counter block: ctr[WV_RESERVE] positions handed to producers, ctr[WV_TICKET] positions handed to consumers
-};
-// appends the n (wave-uniform) entries of `stage` (LDS); false: a position was still occupied after the bounded wait (cannot happen: see above)
-PT_DEV bool ring_push(const WaveRing& r, const uint32_t* stage, uint32_t n)
-{
-  if(n == 0)
-    return true;
-  const int lane = threadIdx.x & 63;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every path-state store of this wavefront has left the CU before an entry announces it
-  uint32_t pos = 0;
-  if(lane == 0)
-    pos = atomicAdd(&r.ctr[WV_RESERVE], n);
-  pos         = __builtin_amdgcn_readfirstlane(pos);
-  uint32_t ok = 1;
-  for(uint32_t k = lane; k < n; k += 64)
-  {
-    uint32_t* at    = &r.buf[(pos + k) % r.cap];
-    uint32_t  spins = 0;
-    while(ld_agent(at) != WV_EMPTY && ok)
-    {
-      __builtin_amdgcn_s_sleep(8);
-      if(++spins > (1u << 18))
-        ok = 0;
-    }
-    st_agent(at, stage[k]);
-  }
-  return __ballot(ok == 0) == 0;
-}
-// Per-lane ticket: a lane that wants an entry and holds no ticket draws one -- but only as many tickets are drawn as entries have been reserved
-// beyond the tickets already out (`avail`, from the caller's look at the counters): a wavefront without tickets owes the ring nothing and may
-// leave the launch.  A lane that holds a ticket looks at its position; the entry is taken with an exchange, because a ticket one lap of the ring
-// ahead polls the same position (entries are interchangeable: whoever gets one, every entry is consumed exactly once).  Returns the entry or WV_EMPTY.
-PT_DEV uint32_t ring_take(const WaveRing& r, bool wants, uint32_t& ticket, int32_t avail)
-{
-  const int          lane = threadIdx.x & 63;
-  unsigned long long draw = __ballot(wants && ticket == WV_EMPTY);
-  if(draw && avail > 0)
-  {
-    const uint32_t want = (uint32_t)__popcll(draw), take = uint32_t(avail) < want ? uint32_t(avail) : want;
-    uint32_t       base = 0;
-    if(lane == 0)
-      base = atomicAdd(&r.ctr[WV_TICKET], take);
-    base                = __builtin_amdgcn_readfirstlane(base);
-    const uint32_t rank = (uint32_t)__popcll(draw & ((1ull << lane) - 1ull));
-    if(wants && ticket == WV_EMPTY && rank < take)
-      ticket = base + rank;
-  }
-  uint32_t e = WV_EMPTY;
-  if(wants && ticket != WV_EMPTY)
-  {
-    uint32_t* at = &r.buf[ticket % r.cap];
-    if(ld_agent(at) != WV_EMPTY)
-    {
-      e = __hip_atomic_exchange(at, WV_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if(e != WV_EMPTY)
-        ticket = WV_EMPTY;
-    }
-  }
-  return e;
-}
-// the four words a wavefront looks at to decide what to do: entries reserved, tickets out, (chunk counter of the input queue), paths ended
-struct WaveLook {
-  uint32_t reserve, ticket, _chunk, done;
-};
-PT_DEV WaveLook ring_look(const uint32_t* ctr)
-{
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(ctr), 0, 0x7fffffff, 0x00020000), WV_RESERVE * 4u, 0, 16 /* sc1 */);
-  return WaveLook{v.x, v.y, v.z, v.w};
-}
-
-template <bool TWO>
-__global__ void __launch_bounds__(TRACE_BLOCK, 2) k_wave(DeviceScene S, RenderBuffers rbIn, FrameParams fp, const uint32_t* __restrict__ queueIn, uint32_t* ringT, uint32_t* ringH, uint32_t cap, int depth0, int minRun)
-{
-  const RenderBuffersT<PT_STATE_COHERENT>& rb = render_buffers_as<PT_STATE_COHERENT>(rbIn);
-  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
-  __shared__ uint32_t stage[STAGE_CAP];  // tracer: settled closest-hit rays on their way to the shade ring; shader: what a shading round sends to the trace ring
-  uint32_t*           C0     = rb.counts + depth0 * CNT_STRIDE;
-  const uint32_t      count0 = C0[CNT_IN];
-  // wavefronts the launch starts with: one per 48 paths (a tracer lane per path, a shader lane per three), at least four
-  if(count0 == 0 || (blockIdx.x >= 4 && (unsigned long long)blockIdx.x * 48ull >= count0))
-    return;
-  const WaveRing T{ringT, cap, C0}, H{ringH, cap, C0 + CNT_STRIDE};
-  uint32_t*      doneCtr = &C0[WV_DONE];
-  const int      lane    = threadIdx.x & 63;
-  const bool     shader  = (blockIdx.x & 3u) == 1u;
-  // a wavefront that is idle, holds no ticket and finds the rings without unclaimed entries leaves the launch once the paths still alive would not
-  // fill the lanes of the wavefronts of its role with a lower rank: the launch shrinks with its work instead of spinning on the whole chip
-  // (the first version kept 2048 polling wavefronts resident to the end: nothing of the other frame slots' launches got onto the GPU)
-  const uint32_t rank    = shader ? (blockIdx.x >> 2) : (blockIdx.x - ((blockIdx.x + 2u) >> 2));
-  uint32_t       nDone = 0, idle = 0, ticket = WV_EMPTY;
-  uint32_t       nClosest = 0, nShadow = 0, nAlpha = 0, nMiss = 0, nHit = 0, nNee = 0;
-  bool           failed = false;
-  if(shader)
-  {
-#pragma unroll 1
-    for(;;)
-    {
-      const WaveLook lookH = ring_look(H.ctr);
-      const uint32_t eh    = ring_take(H, true, ticket, int32_t(lookH.reserve - lookH.ticket));
-      if(__ballot(eh != WV_EMPTY))
-      {
-        idle            = 0;
-        int      to     = SHADE_DONE;
-        uint32_t events = 0, slot = 0, r = 0;
-        if(eh != WV_EMPTY)
-        {
-          slot = eh & WV_SLOT_MASK;
-          r    = (eh >> 26) & 31u;
-          to   = shade_path<-1>(S, rb, fp, slot, depth0 + int(r), events);
-        }
-        nMiss += (events & EV_MISS) ? 1u : 0u;
-        nHit += (events & EV_HIT) ? 1u : 0u;
-        nNee += (events & EV_NEE) ? 1u : 0u;
-        nDone                       = (uint32_t)__popcll(__ballot(eh != WV_EMPTY && to == SHADE_DONE));
-        const bool               on = to == SHADE_TO_SHADOW || to == SHADE_TO_NEXT;
-        const unsigned long long m  = __ballot(on);
-        if(on)
-          stage[__popcll(m & ((1ull << lane) - 1ull))] = to == SHADE_TO_SHADOW ? (slot | (r << 26) | 0x80000000u) : (slot | ((r + 1u) << 26));
-        failed = !ring_push(T, stage, (uint32_t)__popcll(m));
-        if(nDone && lane == 0)
-          atomicAdd(doneCtr, nDone);
-        if(failed)
-          break;
-        continue;
-      }
-      // nothing there yet: the launch is over, or the tracers still hold the remaining paths
-      const uint32_t doneNow = ld_agent(doneCtr);
-      if(doneNow >= count0 || (__ballot(ticket != WV_EMPTY) == 0 && int32_t(lookH.reserve - lookH.ticket) <= 0 && count0 - doneNow < rank * 128u))
-        break;
-      if(idle < 64)
-        __builtin_amdgcn_s_sleep(16);
-      else
-        __builtin_amdgcn_s_sleep(127);
-      if(++idle > (1u << 19))
-      {
-        failed = true;
-        break;
-      }
-    }
-  }
-  else
-  {
-    uint32_t  spill[STACK_SPILL];
-    uint32_t* lds       = stack + threadIdx.x;
-    const int lastDepth = fp.st.maxDepth - 1;
-    TraceLane L;
-    RaySupply rs;  // the input queue: closest-hit rays of bounce depth0
-    rs.chunk = 64;
-    uint32_t pslot = 0, seed = 0, rel = 0, nStage = 0;
-    bool     alive = false, shadowRay = false;
-    L.done = true;
-    L.cur  = 0;
-#pragma unroll 1
-    for(;;)
-    {
-      // ---- service: settle the rays that have finished
-      bool settled = false, ended = false;
-      if(alive && L.done)
-      {
-        bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-        if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
-          lane_begin_count<TWO>(L);  // pass B in the same lane
-        else
-        {
-          uint32_t s2 = seed, nDraw = L.cnt;
-          if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
-            ++nDraw;
-          if(!fallback && !consume_rejected_draws(s2, nDraw))
-            fallback = true;
-          if(!fallback)
-            nAlpha += nDraw;
-          if(shadowRay)
-          {
-            bool inShadow = L.bslot != BVH_NONE;
-            if(fallback)
-              inShadow = settle_shadow_exact<TWO>(S, L.o, L.d, rb.ps.absorb[pslot].w, fp.variant, seed, lds, nAlpha, rb.counters);
-            else
-              seed = fp.variant == PT_VARIANT_RTX ? seed : s2;  // RTX: the any-hit shader draws from a copy (traceray_rtx.glsl:54-55)
-            if(finish_bounce_core(rb, pslot, inShadow, seed) && int(depth0 + rel) != lastDepth)
-            {  // the path lives: its next closest-hit ray starts in this lane
-              lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.rayD[pslot]), PT_INFINITY, S.numTris == 0);
-              shadowRay = false;
-              ++rel;
-              ++nClosest;
-            }
-            else
-            {
-              alive = false;
-              ended = true;
-            }
-          }
-          else
-          {
-            if(fallback)
-              settle_closest_exact<TWO>(S, rb, pslot, L.o, L.d, seed, lds, nAlpha);
-            else
-            {
-              store_hit(rb, pslot, L.bslot, L.bw, TWO, L.bt, L.bu, L.bv);
-              if(nDraw)
-                rb.ps.rayD[pslot].w = __uint_as_float(s2);
-            }
-            settled = true;
-            alive   = false;
-          }
-        }
-      }
-      nDone += (uint32_t)__popcll(__ballot(ended));
-      {  // settled closest-hit rays -> stage (flushed to the shade ring when full, and whenever the supply of rays runs dry)
-        const unsigned long long m = __ballot(settled);
-        if(m)
-        {
-          if(nStage + 64 > STAGE_CAP)
-          {
-            failed = failed || !ring_push(H, stage, nStage);
-            nStage = 0;
-          }
-          if(settled)
-            stage[nStage + __popcll(m & ((1ull << lane) - 1ull))] = pslot | (rel << 26);
-          nStage += (uint32_t)__popcll(m);
-        }
-      }
-      // ---- idle lanes: the input queue first, then the trace ring
-      uint32_t e = WV_EMPTY;
-      if(rs.more)
-      {
-        const uint32_t qi = supply_next(rs, &C0[CNT_CHUNK_TAIL], count0, !alive);
-        if(qi != 0xffffffffu)
-          e = queueIn[qi];  // a plain path slot = closest-hit ray, relative depth 0
-      }
-      WaveLook lookT{0u, 0u, 0u, 0u};
-      if(!rs.more && __ballot(!alive && e == WV_EMPTY))
-      {
-        lookT             = ring_look(T.ctr);
-        const uint32_t er = ring_take(T, !alive && e == WV_EMPTY, ticket, int32_t(lookT.reserve - lookT.ticket));
-        e                 = e == WV_EMPTY ? er : e;
-      }
-      if(e != WV_EMPTY)
-      {
-        pslot     = e & WV_SLOT_MASK;
-        rel       = (e >> 26) & 31u;
-        shadowRay = (e >> 31) != 0;
-        if(shadowRay)
-        {
-          seed = __float_as_uint(rb.ps.rayD[pslot].w);
-          lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
-          ++nShadow;
-        }
-        else
-        {
-          const float4 dw = rb.ps.rayD[pslot];
-          seed            = __float_as_uint(dw.w);
-          lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
-          ++nClosest;
-        }
-        alive = true;
-      }
-      // dry: an idle lane found nothing -- the launch is running out of rays and latency counts: what this wavefront holds back (settled rays
-      // staged for the shade ring, its share of the `done` count) goes out now, not when the staging buffer is full
-      const bool dry = __ballot(!alive) != 0;
-      if(dry)
-      {
-        failed = failed || !ring_push(H, stage, nStage);
-        nStage = 0;
-        if(nDone)
-        {
-          if(lane == 0)
-            atomicAdd(doneCtr, nDone);
-          nDone = 0;
-        }
-      }
-      if(failed)
-        break;
-      if(__ballot(alive))
-      {
-        // ---- run: until fewer than minRun lanes are traversing or, when the supply is dry, until all are done; at most 64 iterations (16 when idle
-        // lanes are waiting for entries), so that they look at the ring again
-        idle             = 0;
-        const int target = dry ? 1 : minRun, burst = dry ? 16 : 64;
-        for(int it = 0; it < burst && __popcll(__ballot(!L.done)) >= target; ++it)
-        {
-          if(!L.done && !(L.cur & BVH_LEAF))
-            lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
-          if(!L.done && (L.cur & BVH_LEAF))
-          {
-            lane_leaf<false, TWO>(S, L, lds, spill);
-            if(shadowRay && S.allOpaque && L.bslot != BVH_NONE)
-              L.done = true;  // all-opaque scene: any hit inside (0, tmax) occludes and nothing draws
-          }
-        }
-        continue;
-      }
-      // ---- no ray in this wavefront: the launch is over, or shaders / other tracers hold the remaining paths
-      if(lookT.done >= count0 || (!rs.more && __ballot(ticket != WV_EMPTY) == 0 && int32_t(lookT.reserve - lookT.ticket) <= 0 && count0 - lookT.done < rank * 32u))
-        break;
-      if(idle < 64)
-        __builtin_amdgcn_s_sleep(16);
-      else
-        __builtin_amdgcn_s_sleep(127);
-      if(++idle > (1u << 19))
-      {
-        failed = true;
-        break;
-      }
-    }
-  }
-  if(failed && lane == 0)
-    atomicAdd(&rb.counters->stackOverflow, 1u);  // (reported by pt_synchronize / pt_get_stats as a traversal error)
-  wave_add(&rb.counters->closestRays, nClosest);
-  wave_add(&rb.counters->shadowRays, nShadow);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-  wave_add(&rb.counters->misses, nMiss);
-  wave_add(&rb.counters->shadedHits, nHit);
-  wave_add(&rb.counters->neeLookups, nNee);
-  // the same again as "of which in the tail": per-stage byte / ray accounting of bench.py
-  wave_add(&rb.counters->tailClosestRays, nClosest);
-  wave_add(&rb.counters->tailShadowRays, nShadow);
-  wave_add(&rb.counters->tailAlphaTests, nAlpha);
-  wave_add(&rb.counters->tailMisses, nMiss);
-  wave_add(&rb.counters->tailShadedHits, nHit);
-}
-
 // ---- k_accumulate ---------------------------------------------------------------------------------------------
 // The last kernel of a sample pass also hands the pass's per-bounce counter block over (queue-size feedback reads the copy) and leaves it zeroed for
 // the next pass on this frame slot: no runtime fill kernel per launch sequence (profiles/r04_final_kernel_stats_bench20.csv: one fillBufferAligned each).
@@ -1562,11 +1209,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       {  // the remaining bounces in one launch (k_tail): the queue is small, a staged bounce would cost its latency floors
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 5);
-          // k_wave's ring entries keep the path slot in 26 bits and the depth relative to this bounce in 5
-          if(g_tuning.wave && n <= (1u << 26) && fp.st.maxDepth - depth <= WV_MAX_REL_DEPTH + 1)
-            k_wave<TWO><<<std::max(4u, wavesAll < 2048u ? wavesAll : 2048u), TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, rb.ringT, rb.ringH, n, depth, g_tuning.refillBelow);
-          else
-            k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
+          k_tail<TWO><<<wavesAll < 2048u ? wavesAll : 2048u, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
           pt_timers_end(tm, stream, 5);
         }, false});
         break;
