@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--emulate-shard", default="", help="R/N: render only rank R's tiles of an N-GPU run on this one GPU (scaling estimate; value = this shard's rate)")
     ap.add_argument("--accel", default="flat", choices=["flat", "two"], help="acceleration structure: flat world-space hierarchy (default) or the reference's BLAS per prim-mesh + TLAS (pt_set_accel_mode)")
     ap.add_argument("--refit", type=int, default=0, help="with --accel two: time this many pt_update_instances calls (TLAS refit) after the run")
+    ap.add_argument("--single-process", action="store_true", help="one process drives all --gpus N GPUs (N contexts, pt_comm_init_all) instead of one process per GPU; also the automatic "
+                    "fallback when the self-launched ranks of --gpus N fail to come up")
+    ap.add_argument("--no-fallback", action="store_true", help="with --gpus N: do not fall back to --single-process when the self-launched ranks fail")
+    ap.add_argument("--from-gltf", default="", help="time a .glb / .gltf file through libptmi's own importer (pt_gltf_load) instead of building the stand-in scene in memory: data = \"gltf\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the serialised profiling pass (roofline fields become null)")
     ap.add_argument("--no-interactive", action="store_true", help="skip the frame-by-frame (render + tonemap) measurement")
@@ -139,7 +143,7 @@ def usable_cores():
 
 def latest_profile(kind):
     """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", f"{rnd}_{kind}.json")
         if os.path.exists(p):
             try:
@@ -280,11 +284,11 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
         stage_bytes = {
             "closest": bc, "shadow": bs, "shade": shade_bytes(alg, st_hits, st_miss, st_hits),
             "tail": tc + ts + shade_bytes(alg, tl["shadedHits"], tl["misses"], tl["shadedHits"]),
-            "generate": 0.0,
+            "generate": 0.0, "fused": 0.0,  # (k_trace_p runs in launch sequences of ONE frame only: the serialised batch has none; its rays are priced under closest / shadow)
             # per sample the radiance handed over (16 B); per launch the running mean of the local framebuffer read and written ONCE (32 B per pixel)
             "accumulate": serial["samples"] * 16.0 + serial["samples"] / max(1, serial["frames"]) * 32.0,
         }
-        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate",
+        kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate", "fused": "k_trace_p (+ k_trace_x)",
                    "accumulate": "k_accumulate"}
         launches = max(1, serial["launches_per_stage"])
         cache, cache_src = latest_profile("cache")
@@ -367,57 +371,176 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
             pass
 
 
-def main():
-    args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(self_launch(args.gpus))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    args.gpus = world  # under a launcher the launcher's world size is the truth
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver: dmabuf IPC only (RCCL reads it at init)
-
+def build_workload(args):
     from vk_raytrace_amd import capi, workloads
-    from vk_raytrace_amd.renderer import HipRenderer
-    from vk_raytrace_amd import shard
-    from vk_raytrace_amd import host_device as hd
-
-    # bind the GPU first: "device ordinal R out of range: K HIP device(s) visible" comes from pt_create, before any rendezvous can hang
-    same_device = os.environ.get("PT_BENCH_SAME_DEVICE") == "1"  # TEST HOOK (tests/test_comm.py): every rank on device 0, so that the multi-process flow --
-    if same_device:                                              # rendezvous, barriers around the windows, MAX of the ranks' times, counters summed -- runs
-        local_rank = 0                                           # on a one-GPU box; RCCL refuses two ranks on one device, so the gather is skipped
-    r = HipRenderer()
-    r.setup(local_rank)
-
-    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"  # exercise the group / RCCL plumbing with one rank
-    dist = None
-    if world > 1 or force_dist:
-        from vk_raytrace_amd.rendezvous import LocalGroup
-        dist = LocalGroup(rank, world)  # control plane only (see the module docstring)
-
-    t_setup = time.time()
-    if args.workload == "c3":
+    if args.from_gltf:
+        # the FILE route as the timed route (reference: Scene::load, src/scene.cpp:57-118): the .glb / .gltf goes through libptmi's own importer
+        from vk_raytrace_amd.scene import GltfFileScene
+        from vk_raytrace_amd import synth
+        sc = GltfFileScene(args.from_gltf)
+        wl = workloads.Workload(f"C3 configuration on the glTF file {os.path.basename(args.from_gltf)} ({sc.num_triangles} tris) {args.width}x{args.height} {args.steps}spp depth8 Disney + HDR env",
+                                sc, synth.procedural_sky(2048, 1024), args.width, args.height, args.steps, 8, 0, note="gltf")
+    elif args.workload == "c3":
         wl = workloads.c3_sponza(args.width, args.height, args.steps, tex_size=args.tex_size, target_tris=args.tris)
     else:
         wl = {"c2": workloads.c2_helmet, "c4": workloads.c4_sponza_4k, "c5": workloads.c5_bistro}[args.workload]()
         wl.name = wl.name.replace(f"{wl.spp}spp", f"{args.steps}spp")
         args.no_cpu_baseline = True  # the CPU leg and its algorithmic-byte model are sized for the bench line only
     wl.scene.finalize(capi.pack_vertices)
-    W, H = wl.width, wl.height
+    return wl
 
+
+def setup_renderer(args, wl, device, shard_rank, shard_n):
+    """One context on `device` that renders rank `shard_rank`'s tiles of `shard_n`: scene, environment, camera, acceleration structure, frame slots."""
+    from vk_raytrace_amd import capi
+    from vk_raytrace_amd.renderer import HipRenderer
+    from vk_raytrace_amd import host_device as hd
+    r = HipRenderer()
+    r.setup(device)
     if args.accel == "two":
         r.set_accel_mode(capi.PT_ACCEL_TWO_LEVEL)
+    r.set_shard(shard_rank, shard_n)
+    r.set_scene(wl.scene)
+    integral, _ = r.set_env(wl.env)
+    cam = capi.camera_lookat(wl.scene.camera, wl.width / wl.height, nb_lights=len(wl.scene.lights))
+    r.set_camera(cam)
+    r.set_sunsky(hd.default_sun_and_sky())
+    r.create((wl.width, wl.height))
+    return r, integral, cam
+
+
+def rccl_version():
+    import ctypes as C
+    from vk_raytrace_amd import capi
+    v = C.c_int(0)
+    rc = capi.lib().pt_comm_version(C.byref(v))
+    return v.value if rc == capi.PT_OK else None
+
+
+def with_timeout(fn, seconds, what):
+    """fn() on a helper thread; a collective that never returns (a wedged RCCL) must not take the line with it.  Returns (ok, result | error text)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except Exception as e:  # noqa: BLE001
+            box["e"] = repr(e)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return False, f"{what}: no answer after {seconds:.0f} s"
+    return ("e" not in box), box.get("e", box.get("v"))
+
+
+def single_process(args):
+    """`--single-process`: ONE process drives all N GPUs -- N contexts, pt_comm_init_all, the shards gathered inside one pt_comm_group_begin / end
+    (SURVEY.md 8(e) "single process ... one stream per device"; include/pt_api.h).  Also what `--gpus N` falls back to when its self-launched ranks fail
+    to come up (rendezvous, RCCL bootstrap between processes)."""
+    import ctypes as C
+    from vk_raytrace_amd import capi
+    from vk_raytrace_amd import host_device as hd
+    n = args.gpus
+    t_setup = time.time()
+    wl = build_workload(args)
+    W, H = wl.width, wl.height
+    rs, integral, cam = [], None, None
+    for i in range(n):
+        r, integral, cam = setup_renderer(args, wl, i, i, n)
+        rs.append(r)
+    L = capi.lib()
+    comms = (C.c_void_p * n)()
+    dev = (C.c_int * n)(*range(n))
+    rc = L.pt_comm_init_all(n, dev, comms)
+    if rc != capi.PT_OK:
+        raise capi.PtError(rc, "pt_comm_init_all: " + L.pt_comm_last_error().decode())
+    cnt = C.c_int(0)
+    L.pt_comm_count(comms[0], C.byref(cnt))
+    print(f"bench.py preflight: single process, {n} context(s), RCCL {rccl_version()}, communicator spans {cnt.value} rank(s)", file=sys.stderr)
+    st = hd.default_rtx_state()
+    st.size[0], st.size[1] = W, H
+    st.maxDepth, st.pbrMode, st.maxSamples = wl.depth, wl.pbr_mode, 1
+    st.fireflyClampThreshold = 4.0 * integral
+    t_setup = time.time() - t_setup
+
+    def gather():
+        t0 = time.perf_counter()
+        for r in rs:
+            r.synchronize()
+        rs[0]._check(L.pt_comm_group_begin())
+        for i, r in enumerate(rs):
+            r._check(L.pt_gather_shards(r._ctx, comms[i], 0))
+        rs[0]._check(L.pt_comm_group_end())
+        for r in rs[1:]:
+            r.synchronize()
+        rs[0]._check(L.pt_gather_finish(rs[0]._ctx))
+        img = rs[0].read_accum()
+        return img, (time.perf_counter() - t0) * 1e3
+
+    frame = 0
+
+    def frames(k):
+        nonlocal frame
+        for _ in range(k):
+            st.frame = frame
+            for r in rs:
+                r.setPushContants(st)
+                r.run()
+            frame += 1
+    frames(args.warmup)
+    for r in rs:
+        r.synchronize()
+        r.reset_stats()
+    windows, per_rank_ms, img_first, stats = [], None, None, None
+    for rep in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        frames(args.steps)
+        done = []
+        for r in rs:
+            r.synchronize()
+            done.append((time.perf_counter() - t0) * 1e3 / args.steps)
+        windows.append(time.perf_counter() - t0)
+        if rep == 0:
+            per_rank_ms = done
+            stats = [r.stats() for r in rs]
+            img_first, _ = gather()
+    img, gather_ms = gather()
+    RAY_KEYS = ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")
+    total = dict(stats[0])
+    for k in RAY_KEYS:
+        total[k] = int(sum(s_[k] for s_ in stats))
+    return {"wl": wl, "W": W, "H": H, "windows": windows, "img_first": img_first, "img": img, "gather_ms": gather_ms, "stats": total, "ranks_seen": cnt.value, "t_setup": t_setup,
+            "integral": integral, "cam": cam, "renderer": rs[0], "st": st, "frame": frame, "per_rank_ms": per_rank_ms, "gather": "rccl (pt_comm_init_all, one process)",
+            "cleanup": lambda: [L.pt_comm_destroy(c) for c in comms]}
+
+
+def multi_process(args, rank, local_rank, world):
+    """One process per GPU (the driver's launch, or bench.py's self-launch): this rank's part of the job.  Returns the same record as single_process on
+    rank 0, None on the other ranks."""
+    from vk_raytrace_amd import capi
+    from vk_raytrace_amd import shard
+    from vk_raytrace_amd import host_device as hd
+
+    # bind the GPU first: "device ordinal R out of range: K HIP device(s) visible" comes from pt_create, before any rendezvous can hang
+    same_device = os.environ.get("PT_BENCH_SAME_DEVICE") == "1"  # TEST HOOK (tests/test_comm.py): every rank on device 0, so that the multi-process flow --
+    if same_device:                                              # rendezvous, barriers around the windows, MAX of the ranks' times, counters summed, the gathered
+        local_rank = 0                                           # image's parity -- runs on a one-GPU box; RCCL refuses two ranks on one device: host gather
+    t_setup = time.time()
+    wl = build_workload(args)
+    W, H = wl.width, wl.height
     shard_rank, shard_n = rank, world
     if args.emulate_shard:
         shard_rank, shard_n = (int(x) for x in args.emulate_shard.split("/"))
         args.no_cpu_baseline = True
-    r.set_shard(shard_rank, shard_n)
-    r.set_scene(wl.scene)
-    integral, _ = r.set_env(wl.env)
-    cam = capi.camera_lookat(wl.scene.camera, W / H, nb_lights=len(wl.scene.lights))
-    r.set_camera(cam)
-    r.set_sunsky(hd.default_sun_and_sky())
-    r.create((W, H))
+    r, integral, cam = setup_renderer(args, wl, local_rank, shard_rank, shard_n)
+
+    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"  # exercise the group / RCCL plumbing with one rank
+    dist = None
+    if world > 1 or force_dist:
+        from vk_raytrace_amd.rendezvous import LocalGroup
+        dist = LocalGroup(rank, world)  # control plane only (see the module docstring)
     st = hd.default_rtx_state()
     st.size[0], st.size[1] = W, H
     st.maxDepth, st.pbrMode, st.maxSamples = wl.depth, wl.pbr_mode, 1
@@ -428,6 +551,45 @@ def main():
         r.synchronize()  # pt_synchronize: every stream of the context has drained (the device-side bracket of the timed region)
         if dist is not None:
             dist.barrier()
+
+    # ---- the one collective of the path, set up and tried BEFORE anything is timed (preflight): libptmi's own RCCL gather behind the C ABI
+    # (pt_gather_shards / pt_gather_finish).  If the communicator cannot be built, or the first gather does not come back, every rank agrees on the
+    # host route instead (the shards travel through the control-plane socket): slower, untimed either way, and the line says which one it was.
+    gatherer, how = None, "none (one rank)"
+    if world > 1 or force_dist:
+        ok, res = (False, "PT_BENCH_SAME_DEVICE: two ranks on one device") if (same_device and world > 1) else with_timeout(lambda: shard.NativeGather(rank, world, local_rank, dist), 120, "pt_comm_init_rank")
+        all_ok = dist.all_reduce([1.0 if ok else 0.0], "sum")[0] == world
+        if all_ok:
+            gatherer, how = res, "rccl (pt_comm_init_rank, one process per GPU)"
+        else:
+            how = f"host (control-plane socket); RCCL route unavailable: {res if not ok else 'another rank failed'}"
+        if rank == 0:
+            print(f"bench.py preflight: {world} process(es), RCCL {rccl_version()}, gather route: {how}", file=sys.stderr)
+    ranks_seen = gatherer.ranks_seen() if gatherer is not None else (world if (world > 1 and dist is not None) else 1)
+
+    def gather():
+        """the full image on rank 0 (None elsewhere) and the milliseconds it took"""
+        nonlocal gatherer, how
+        r.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        if world == 1 and not force_dist:
+            return r.read_accum(), (time.perf_counter() - t0) * 1e3
+        if gatherer is not None:
+            ok, res = with_timeout(lambda: gatherer.gather(r), 120, "pt_gather_shards")
+            if dist.all_reduce([1.0 if ok else 0.0], "sum")[0] == world:
+                return res, (time.perf_counter() - t0) * 1e3
+            gatherer, how = None, f"host (control-plane socket); the RCCL gather failed: {res if not ok else 'on another rank'}"
+        mine = r.read_accum()  # this rank's pixels are valid in it
+        ids = shard.local_pixel_ids(W, H, shard_rank, shard_n)
+        parts = dist.gather_bytes(np.ascontiguousarray(mine.reshape(-1, 4)[ids]).tobytes())
+        if rank != 0:
+            return None, (time.perf_counter() - t0) * 1e3
+        out = np.zeros((H * W, 4), np.float32)
+        for q, blob in enumerate(parts):
+            out[shard.local_pixel_ids(W, H, q, world)] = np.frombuffer(blob, np.float32).reshape(-1, 4)
+        return out.reshape(H, W, 4), (time.perf_counter() - t0) * 1e3
 
     frame = 0
     for _ in range(args.warmup):
@@ -441,9 +603,7 @@ def main():
     # The timed window: exactly --steps frames between two (device synchronisation + barrier) brackets, MAX over the ranks.  It is run --repeats
     # times back to back on the same accumulation image (frames keep counting up); `value` is the MEDIAN window and every window is reported, so
     # that one 30 ms window on a box that has just come up (clocks, first use of a frame slot) cannot decide the line on its own.
-    windows = []
-    img_first = None
-    stats = None
+    windows, img_first, stats, per_rank_ms = [], None, None, None
     for rep in range(max(1, args.repeats)):
         sync()
         t0 = time.perf_counter()
@@ -453,6 +613,7 @@ def main():
             r.run()
             frame += 1
         r.synchronize()
+        mine = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -461,43 +622,68 @@ def main():
         windows.append(dt)
         if rep == 0:
             stats = r.stats()  # ray counters of ONE window (the per-sample figures below are per window)
-            if world == 1 and not force_dist:
-                img_first = r.read_accum()  # frames 0 .. warmup+steps-1: what the parity leg below re-renders on the CPU (untimed: between two windows)
-    elapsed = float(np.median(windows))
-    frames_first = args.warmup + args.steps
-
-    # the one collective of the path (untimed, reported): libptmi's own RCCL gather behind the C ABI (pt_gather_shards / pt_gather_finish)
-    ranks_seen = 1
-    if same_device and world > 1:
-        ranks_seen, img, gather_ms = world, None, None  # (test hook: no collective between two ranks on one device)
-        r.synchronize()
-    elif world > 1 or force_dist:
-        gatherer = shard.NativeGather(rank, world, local_rank, dist)
-        ranks_seen = gatherer.ranks_seen()
-        r.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        img = gatherer.gather(r)
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        gatherer.close()
-    else:
-        t0 = time.perf_counter()
-        img = r.read_accum()
-        gather_ms = (time.perf_counter() - t0) * 1e3
+            if dist is not None:
+                slot = [0.0] * world
+                slot[rank] = mine * 1e3 / args.steps
+                per_rank_ms = dist.all_reduce(slot, "sum")   # every rank's own time for the window (before the barrier): who is the slowest
+            # frames 0 .. warmup+steps-1 of the WHOLE image: what the parity leg re-renders on the CPU (untimed: between two windows)
+            img_first, _ = gather()
+    img, gather_ms = gather()
 
     RAY_KEYS = ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")
     if dist is not None:
-        # whole-job counters
-        v = dist.all_reduce([float(stats[k]) for k in RAY_KEYS], "sum")
+        v = dist.all_reduce([float(stats[k]) for k in RAY_KEYS], "sum")  # whole-job counters
         for i, k in enumerate(RAY_KEYS):
             stats[k] = int(v[i])
-
+    if gatherer is not None:
+        gatherer.close()
     if rank != 0:
         if dist is not None:
-            dist.barrier()  # rank 0 may still be reading the gathered image
+            dist.barrier()  # rank 0 finishes its evidence legs, then everybody leaves
             dist.close()
-        return
+        return None
+    return {"wl": wl, "W": W, "H": H, "windows": windows, "img_first": img_first, "img": img, "gather_ms": gather_ms, "stats": stats, "ranks_seen": ranks_seen, "t_setup": t_setup,
+            "integral": integral, "cam": cam, "renderer": r, "st": st, "frame": frame, "per_rank_ms": per_rank_ms, "gather": how, "shard": (shard_rank, shard_n),
+            "cleanup": (lambda: (dist.barrier(), dist.close())) if dist is not None else (lambda: None)}
+
+
+def main():
+    args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver: dmabuf IPC only (RCCL reads it at init)
+    launched = "WORLD_SIZE" in os.environ
+    if args.single_process and not launched:
+        job = single_process(args)
+        world, local_rank, mode = args.gpus, 0, "single-process"
+    else:
+        if not launched and args.gpus > 1:
+            rc = self_launch(args.gpus)
+            if rc == 0 or args.no_fallback:
+                raise SystemExit(rc)
+            # the ranks did not come up (rendezvous, RCCL bootstrap between processes, ...): the same job from ONE process instead of no line at all
+            print(f"bench.py: the self-launched ranks failed (exit code {rc}); falling back to --single-process", file=sys.stderr)
+            job = single_process(args)
+            world, local_rank, mode = args.gpus, 0, "single-process (fallback: the self-launched ranks failed)"
+        else:
+            rank = int(os.environ.get("RANK", "0"))
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+            world = int(os.environ.get("WORLD_SIZE", "1"))
+            args.gpus = world  # under a launcher the launcher's world size is the truth
+            job = multi_process(args, rank, local_rank, world)
+            mode = "one process per GPU"
+            if job is None:
+                return
+    from vk_raytrace_amd import capi
+    from vk_raytrace_amd.renderer import HipRenderer
+    from vk_raytrace_amd import host_device as hd
+    wl, W, H, windows, img_first, img, gather_ms, stats = (job[k] for k in ("wl", "W", "H", "windows", "img_first", "img", "gather_ms", "stats"))
+    r, st, frame, integral, cam, ranks_seen, t_setup = (job[k] for k in ("renderer", "st", "frame", "integral", "cam", "ranks_seen", "t_setup"))
+    shard_rank, shard_n = job.get("shard", (0, world))
+    elapsed = float(np.median(windows))
+    frames_first = args.warmup + args.steps
+    RAY_KEYS = ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")
+    if job.get("per_rank_ms") and world > 1:
+        pr = job["per_rank_ms"]
+        print(f"bench.py preflight: ms/frame per rank in the first window {[round(x, 4) for x in pr]}; slowest rank {int(np.argmax(pr))} at {max(pr) / (sum(pr) / len(pr)):.3f} x the mean", file=sys.stderr)
 
     # pixels actually rendered by this job (an emulated shard renders one rank's tiles only)
     job_pixels = W * H if not args.emulate_shard else int(stats["samples"] // max(1, args.steps))
@@ -523,6 +709,9 @@ def main():
                    "width": W, "height": H, "spp": args.steps, "max_depth": wl.depth, "bsdf": "disney" if wl.pbr_mode == 0 else "gltf", "env": f"{wl.env.shape[1]}x{wl.env.shape[0]} procedural HDR",
                    "parallelism": f"image tiles {hd.TILE}x{hd.TILE} over {world} GPU(s), scene replicated" + (f"; this run = shard {args.emulate_shard} on one GPU" if args.emulate_shard else "")},
         "ranks_seen": ranks_seen,
+        "launch": mode,
+        "gather": job.get("gather"),
+        "ms_per_step_per_rank": job.get("per_rank_ms"),
         "setup_s": t_setup,
         "gather_ms": gather_ms,
         "bvh_build_ms": stats["msBuildAccel"],
@@ -545,11 +734,14 @@ def main():
     # kind "reference": oracle/_ref/libref.so = shaders/pathtrace.comp:87-134 with everything it includes, compiled for the host by the committed
     # recipe (oracle/ref_glue), dispatched over a bounded pixel sample on the host cores; what the Vulkan driver would supply (ray queries,
     # texture filtering) is bound to the oracle's trace contract.  `port_value`: the oracle's own restatement on the same sample.
+    # N > 1: the same leg on rank 0, against the GATHERED image of the first window -- the line of a multi-GPU run carries both halves of the metric too
     alg = None
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         out["cpu_baseline"], par, alg = cpu_leg(wl, cam, integral, W, H, frames_first, img_first, args.cpu_seconds)
         if par is not None:
             out["parity"] = par
+            if world > 1:
+                par["note"] = f"image GATHERED from {world} ranks ({job.get('gather')}) after the first timed window vs CPU renders of the same frames on the sampled pixels"
     elif os.path.exists(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")):
         alg = json.load(open(os.path.join(ROOT, "profiles", "alg_bytes_c3.json")))
 
@@ -568,7 +760,7 @@ def main():
                           "hbm_read_GBps": peaks["hbmReadBytesPerSec"] / 1e9, "compute_units": peaks["computeUnits"], "clock_MHz": peaks["clockMHz"],
                           "note": "pt_measure_peaks on this device; theoretical VALU issue = CUs x 4 SIMDs x clock / 2 cycles (MI355X_MICROARCH.md), tools/valu_peak.hip shows 0.45-0.8 of it depending on the instruction form"}
     # (2) the interactive path: SampleExample's loop tonemaps after every frame, so every frame is its own batch of one
-    if not args.no_interactive and world == 1:
+    if not args.no_interactive and world == 1 and not args.emulate_shard:
         tm = hd.default_tonemapper()
         n_i = 24
         for _ in range(4):
@@ -603,7 +795,7 @@ def main():
     if not args.no_profile:
         os.environ["PT_TUNE"] = (os.environ.get("PT_TUNE", "") + ",inflight=1").lstrip(",")
         r2 = HipRenderer()
-        r2.setup(local_rank)
+        r2.setup(local_rank if mode == "one process per GPU" and os.environ.get("PT_BENCH_SAME_DEVICE") != "1" else 0)
         if args.accel == "two":
             r2.set_accel_mode(capi.PT_ACCEL_TWO_LEVEL)
         r2.set_shard(shard_rank, shard_n)
@@ -640,9 +832,7 @@ def main():
         out["evidence_error"] = repr(e)
     print(json.dumps(out))
     sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.close()
+    job["cleanup"]()
     if out.get("parity") and not (out["parity"]["l2"] <= out["parity"]["tolerance"]):
         print(f"bench.py: parity FAILED: per-pixel L2 {out['parity']['l2']} against {out['parity']['against']} exceeds {out['parity']['tolerance']}", file=sys.stderr)
         raise SystemExit(3)

@@ -199,6 +199,8 @@ int pt_comm_init_all(int ndev, const int* device_ordinals, pt_comm** out_comms);
 int pt_comm_destroy(pt_comm* comm);
 /* ranks of the communicator as RCCL reports them (ncclCommCount): what a launcher prints to show that N processes really met */
 int pt_comm_count(pt_comm* comm, int* out_nranks);
+/* ncclGetVersion of the RCCL that was opened (e.g. 22707), 0 when the library does not say; a preflight of a multi-GPU run prints it */
+int pt_comm_version(int* out_version);
 /* why the last pt_comm_* call of this thread's process failed (e.g. "librccl.so not found: ..."); never NULL */
 const char* pt_comm_last_error(void);
 int pt_comm_group_begin(void);

@@ -81,24 +81,50 @@ def test_bench_gpus_2_on_a_one_gpu_box():
 
 @pytest.mark.gpu
 def test_bench_two_processes_share_one_gpu():
-    """The multi-process flow of bench.py for real -- two self-launched ranks, the torch-free rendezvous, barriers around every timed window, the MAX
-    of the ranks' times, counters summed over the ranks -- with both ranks on device 0 (PT_BENCH_SAME_DEVICE=1: RCCL refuses two ranks on one device,
-    so only the gather is left to the one-rank tests below and to the driver's 8-GPU run)."""
+    """The multi-process flow of bench.py for real -- two self-launched ranks, the torch-free rendezvous, the gather route agreed in a preflight, barriers
+    around every timed window, the MAX of the ranks' times, counters summed over the ranks, and BOTH halves of the metric in the N > 1 line: the image
+    gathered from the two ranks after the first window is bit-identical to the reference's shader compiled for the host (parity.l2 == 0).  Both ranks sit
+    on device 0 (PT_BENCH_SAME_DEVICE=1); RCCL refuses two ranks on one device, so the preflight settles on the host route -- which is also what a run
+    falls back to when RCCL cannot be brought up -- and the RCCL route is left to the one-rank tests below and to the driver's 8-GPU run."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["PT_BENCH_SAME_DEVICE"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "256", "--height", "160", "--tex-size", "32",
-           "--tris", "2000", "--no-profile", "--no-interactive"]
+           "--tris", "2000", "--no-profile", "--no-interactive", "--cpu-seconds", "2"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and len(line["repeats"]) == 2 and line["value"] > 0
-    assert line["scaling"] == "strong" and "parity" not in line and "cpu_baseline" not in line   # the CPU leg is rank 0 at N = 1 only
+    assert line["scaling"] == "strong" and line["launch"] == "one process per GPU" and line["gather"].startswith("host")
+    assert len(line["ms_per_step_per_rank"]) == 2 and "preflight" in p.stderr
+    par = line["parity"]
+    assert par["l2"] == 0.0 and par["pixels_bit_identical"] == par["pixels"] > 0 and par["frames"] == 4 and "GATHERED from 2 ranks" in par["note"]
+    assert line["cpu_baseline"]["value"] > 0
     one = subprocess.run(cmd[:3] + ["1"] + cmd[4:] + ["--no-cpu-baseline"], env={k: v for k, v in env.items() if k != "PT_BENCH_SAME_DEVICE"}, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads(one.stdout.strip().splitlines()[-1])
     for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests"):
         assert line["rays"][k] == ref["rays"][k], k   # the two shards together trace exactly the rays of the whole image
+    assert abs(line["image_mean"] - ref["image_mean"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_single_process_flavour():
+    """`bench.py --single-process`: one process, N contexts, pt_comm_init_all, the shards gathered inside one RCCL group -- with N = 1 on this box (everything
+    but the peer-to-peer transfers runs); the line says how it was launched and carries the parity of the gathered image.  `--gpus 2` falls back to this
+    flavour when its self-launched ranks fail; on a one-GPU box the fallback then fails for the same reason and says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-process", "--steps", "3", "--warmup", "1", "--repeats", "2", "--width", "256", "--height", "160",
+           "--tex-size", "32", "--tris", "2000", "--no-profile", "--no-interactive", "--cpu-seconds", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["launch"] == "single-process" and line["ranks_seen"] == 1 and line["gather"].startswith("rccl") and "RCCL" in p.stderr
+    assert line["parity"]["l2"] == 0.0 and line["parity"]["pixels_bit_identical"] == line["parity"]["pixels"] > 0
+    if _visible_devices() == 1:
+        p = subprocess.run(cmd[:2] + ["--gpus", "2"] + cmd[5:], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "falling back to --single-process" in p.stderr and "device ordinal 1 out of range" in p.stderr, p.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -56,6 +56,7 @@ API = [
     ("pt_comm_init_all", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     ("pt_comm_destroy", C.c_int, [_P]),
     ("pt_comm_count", C.c_int, [_P, C.POINTER(C.c_int)]),
+    ("pt_comm_version", C.c_int, [C.POINTER(C.c_int)]),
     ("pt_comm_last_error", C.c_char_p, []),
     ("pt_comm_group_begin", C.c_int, []),
     ("pt_comm_group_end", C.c_int, []),

@@ -39,6 +39,7 @@ struct Rccl {
   rcclResult_t (*Send)(const void*, size_t, int, int, rcclComm_t, hipStream_t)           = nullptr;
   rcclResult_t (*Recv)(void*, size_t, int, int, rcclComm_t, hipStream_t)                 = nullptr;
   const char* (*GetErrorString)(rcclResult_t)                                            = nullptr;
+  rcclResult_t (*GetVersion)(int*)                                                       = nullptr;  // optional
   std::string err;  // why the library is unavailable / the last failure
 };
 Rccl&      rccl() { static Rccl r; return r; }
@@ -78,6 +79,7 @@ bool load()
   }
   SYM(GetUniqueId) SYM(CommInitRank) SYM(CommInitAll) SYM(CommDestroy) SYM(CommCount) SYM(CommUserRank) SYM(GroupStart) SYM(GroupEnd) SYM(Send) SYM(Recv) SYM(GetErrorString)
 #undef SYM
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
   r.handle = h;
   r.err.clear();
   return true;
@@ -182,6 +184,19 @@ int pt_comm_count(pt_comm* comm, int* out_nranks)
     return PT_ERR_UNAVAILABLE;
   rcclResult_t r = rccl().CommCount(reinterpret_cast<rcclComm_t>(comm), out_nranks);
   return r == 0 ? PT_OK : fail(PT_ERR_HIP, "ncclCommCount", r);
+}
+
+int pt_comm_version(int* out_version)
+{
+  if(!out_version)
+    return fail(PT_ERR_INVALID, "pt_comm_version: null argument");
+  if(!load())
+    return PT_ERR_UNAVAILABLE;
+  *out_version = 0;
+  if(!rccl().GetVersion)
+    return PT_OK;  // (an RCCL without ncclGetVersion: 0)
+  rcclResult_t r = rccl().GetVersion(out_version);
+  return r == 0 ? PT_OK : fail(PT_ERR_HIP, "ncclGetVersion", r);
 }
 
 int pt_comm_group_begin(void)

@@ -143,6 +143,16 @@ class LocalGroup:
         """rank `src`'s bytes on every rank (the others pass anything)"""
         return self._exchange(bytes(data) if self.rank == src else b"", lambda parts: parts[src])
 
+    def gather_bytes(self, data):
+        """every rank's bytes on rank 0, as a list in rank order (None on the other ranks)"""
+        got = []
+
+        def combine(parts):
+            got.extend(parts)
+            return b""
+        self._exchange(bytes(data), combine)
+        return got if self.rank == 0 else None
+
     def close(self):
         for c in self.peers.values():
             c.close()
