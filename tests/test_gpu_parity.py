@@ -201,21 +201,50 @@ def test_c2_full_size_64spp():
     check_sparse(cfg, 64, 64)
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=1)
+def _c5_workload():
+    return workloads.c5_bistro()   # (built once for the two tests that use it: 3.8 M triangles take a while to synthesise)
+
+
 @pytest.mark.parametrize("which", ["c4", "c5"])
 def test_c4_c5_full_size_sampled(which):
-    """C4 (the C3 scene at 3840x2160) and C5 (bistro-like, 3.8 M instanced triangles, 1 793 instances, 3840x2160): a few frames at full size
-    against the oracle on a sparse pixel sample (their 1024 / 4096 spp only repeat the per-frame arithmetic checked here) -- on the flat
-    structure AND on the two-level structure (BLAS per prim-mesh + TLAS, the reference's shape, src/accelstruct.cpp:110-162), and the two
-    whole 4K images against each other."""
-    if which == "c4":
-        wl = workloads.c3_sponza(3840, 2160, 1024, tex_size=256, env_w=1024)
-    else:
-        wl = workloads.c5_bistro(tex_size=128)
+    """C4 (the C3 scene at 3840x2160) and C5 (bistro-like, 3.8 M instanced triangles, 1 793 instances, 3840x2160) ON THE DATA bench.py TIMES (the
+    workloads' own texture and environment sizes: 1024^2 / 2048 x 1024 and 512^2): a few frames at full size against the oracle on a sparse pixel
+    sample (their 1024 / 4096 spp only repeat the per-frame arithmetic checked here) -- on the flat structure AND on the two-level structure (BLAS per
+    prim-mesh + TLAS, the reference's shape, src/accelstruct.cpp:110-162), and the two whole 4K images against each other."""
+    wl = workloads.c4_sponza_4k() if which == "c4" else _c5_workload()
     cfg = Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0)
     flat = check_sparse(cfg, 4, 1024)
     two = render_hip(cfg, 4, accel=capi.PT_ACCEL_TWO_LEVEL)
     check_sparse(cfg, 4, 1024, hip_image=two)
     assert_identical(two, flat, f"{which}: two-level vs flat, 3840x2160 x 4 spp")
+
+
+def test_known_two_level_exception_c5_8spp():
+    """The ONE documented difference between the flat and the two-level structure: on the C5 stand-in at 3840x2160 x 8 spp, pixel
+    (1948, 1135) -- frame 5, instance 282, primitive 1326: plain fp32 Moeller-Trumbore accepts, by cancellation, a triangle the ray passes edge-on
+    (det = 2e-5, true v = -0.0137, fp32 u = v = 0); the world-space hierarchy reaches that triangle's leaf (as brute force does: the oracle agrees
+    with it), the object-space boxes of the two-level walk do not.  Asserted EXACTLY, so that a second such pixel-sample fails loudly
+    (profiles/r02_two_level_c5_diff.txt; reference shape: src/accelstruct.cpp:110-162)."""
+    wl = _c5_workload()
+    cfg = Config(wl.scene, wl.env, 3840, 2160, depth=8, pbr=0)
+    flat = render_hip(cfg, 8)
+    two = render_hip(cfg, 8, accel=capi.PT_ACCEL_TWO_LEVEL)
+    diff = np.argwhere(np.any(flat.view(np.uint32) != two.view(np.uint32), axis=-1))
+    assert [tuple(int(v) for v in d[::-1]) for d in diff] == [(1948, 1135)], diff[:10]
+    ids = np.array([1135 * 3840 + 1948], np.uint32)
+    o = orc.Oracle()
+    o.set_scene(cfg.scene); integ, _ = o.set_env(cfg.env); o.set_camera(cfg.camera); o.set_sunsky(cfg.sunsky)
+    st = cfg.state(integ)
+    acc = np.zeros((2160, 3840, 4), np.float32)
+    for f in range(8):
+        st.frame = f
+        o.render_frame(st, acc, ids)
+    o.close()
+    assert np.array_equal(acc[1135, 1948].view(np.uint32), flat[1135, 1948].view(np.uint32))   # the flat structure is the contract's answer here
 
 
 def test_path_state_budget_shrinks_the_batch(env_small):
