@@ -830,9 +830,19 @@ def main():
         evidence_fields(out, serial, alg, samples, elapsed, world, args.workload)
     except Exception as e:  # the evidence fields are additions: a failure in their post-processing must never cost the line itself
         out["evidence_error"] = repr(e)
+    try:  # RCCL writes a version banner through C stdio, which a pipe holds back until exit -- AFTER the line.  Out with it now: the line is the last thing on stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out))
     sys.stdout.flush()
     job["cleanup"]()
+    try:
+        sys.stdout.flush()
+        os.close(1)  # nothing a library prints at exit may follow the line
+    except Exception:
+        pass
     if out.get("parity") and not (out["parity"]["l2"] <= out["parity"]["tolerance"]):
         print(f"bench.py: parity FAILED: per-pixel L2 {out['parity']['l2']} against {out['parity']['against']} exceeds {out['parity']['tolerance']}", file=sys.stderr)
         raise SystemExit(3)

@@ -40,6 +40,14 @@ print("ok")
 """
 
 
+def _last_json(text):
+    """the bench line: the last line of stdout that is a JSON object (RCCL prints a version banner through C stdio)"""
+    import json
+    lines = [ln for ln in text.strip().splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
 def _visible_devices():
     """HIP devices this process can create contexts on, asked through libptmi itself (torch.cuda must not be initialised next to it: capi.lib())"""
     L, n = capi.lib(), 0
@@ -93,7 +101,7 @@ def test_bench_two_processes_share_one_gpu():
            "--tris", "2000", "--no-profile", "--no-interactive", "--cpu-seconds", "2"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    line = _last_json(p.stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and len(line["repeats"]) == 2 and line["value"] > 0
     assert line["scaling"] == "strong" and line["launch"] == "one process per GPU" and line["gather"].startswith("host")
     assert len(line["ms_per_step_per_rank"]) == 2 and "preflight" in p.stderr
@@ -102,7 +110,7 @@ def test_bench_two_processes_share_one_gpu():
     assert line["cpu_baseline"]["value"] > 0
     one = subprocess.run(cmd[:3] + ["1"] + cmd[4:] + ["--no-cpu-baseline"], env={k: v for k, v in env.items() if k != "PT_BENCH_SAME_DEVICE"}, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
-    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    ref = _last_json(one.stdout)
     for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests"):
         assert line["rays"][k] == ref["rays"][k], k   # the two shards together trace exactly the rays of the whole image
     assert abs(line["image_mean"] - ref["image_mean"]) < 1e-6
@@ -119,7 +127,7 @@ def test_bench_single_process_flavour():
            "--tex-size", "32", "--tris", "2000", "--no-profile", "--no-interactive", "--cpu-seconds", "2"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    line = _last_json(p.stdout)
     assert line["launch"] == "single-process" and line["ranks_seen"] == 1 and line["gather"].startswith("rccl") and "RCCL" in p.stderr
     assert line["parity"]["l2"] == 0.0 and line["parity"]["pixels_bit_identical"] == line["parity"]["pixels"] > 0
     if _visible_devices() == 1:
