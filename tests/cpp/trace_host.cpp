@@ -381,7 +381,7 @@ struct Scene {
   std::vector<AlphaMat>    alphaMats;   // th_create_scene: the product's own records (pt_debug_scene_records)
   std::vector<uint32_t>    alphaMaps, texels;
   std::vector<TexRec>      texRecs;
-  std::vector<uint4>       matDesc;  // per material the packed descriptors of its four common textures
+  std::vector<uint4>       matLines;  // per material its 128-byte line (pt_device.h mat_line_pack)
   std::vector<pt_GltfShadeMaterial> materials;
   std::vector<pt_Light>    lights;
   std::vector<float4>      env;
@@ -600,7 +600,7 @@ static void build_structures(Scene* s, const std::vector<float>& padC0, const st
   d.alphaMats = s->alphaMats.data(); d.alphaMaps = s->alphaMaps.data(); d.texels = s->texels.data();
   d.materials = s->materials.empty() ? nullptr : s->materials.data(); d.lights = s->lights.empty() ? nullptr : s->lights.data();
   d.texRecs = s->texRecs.empty() ? nullptr : s->texRecs.data();
-  d.matDesc = s->matDesc.empty() ? nullptr : s->matDesc.data();
+  d.matLines = s->matLines.empty() ? nullptr : s->matLines.data();
   d.numTris = triTotal; d.numInstances = numInst;
   s->dsFlat           = d;
   s->dsFlat.wide      = s->flat.wide.data();
@@ -771,14 +771,9 @@ void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
     delete s;
     return nullptr;
   }
-  s->matDesc.assign(size_t(4) * std::max<size_t>(1, s->materials.size()), tex_desc_pack(s->texRecs[0]));
+  s->matLines.assign(size_t(PT_MAT_LINE_QUADS) * std::max<size_t>(1, s->materials.size()), uint4{0u, 0u, 0u, 0u});
   for(size_t i = 0; i < s->materials.size(); ++i)
-  {
-    const pt_GltfShadeMaterial& mt = s->materials[i];
-    const int ids[4] = {mt.normalTexture, mt.emissiveTexture, mt.pbrMetallicRoughnessTexture, mt.pbrBaseColorTexture};
-    for(int k = 0; k < 4; ++k)
-      s->matDesc[4 * i + k] = tex_desc_pack(s->texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
-  }
+    mat_line_pack(s->materials[i], s->texRecs.data(), &s->matLines[size_t(PT_MAT_LINE_QUADS) * i]);
   std::vector<float> padC0(counts[0]), padC1(counts[0]);
   for(size_t i = 0; i < counts[0]; ++i)
   {

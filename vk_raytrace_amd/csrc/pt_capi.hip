@@ -32,7 +32,7 @@ struct pt_context {
   std::string err;
 
   // scene (host copies kept only for what build_accel needs)
-  DevBuf   dMatDesc;  // 16-byte texture descriptors, four per material (DeviceScene::matDesc)
+  DevBuf   dMatLines;  // one 128-byte line per material (DeviceScene::matLines)
   DevBuf   dVertices, dIndices, dInstances, dMaterials, dLights, dTexRecs, dTexels, dBvh, dWide, dTris, dAlphaRecs, dAlphaMats, dAlphaMaps, dEnv, dEnvAccel;
   DevBuf   dShadeTris;
   bool     haveShadeTris = false;
@@ -279,7 +279,7 @@ void refresh_scene_ptrs(pt_context* c)
   s.materials    = (const pt_GltfShadeMaterial*)c->dMaterials.p;
   s.lights       = (const pt_Light*)c->dLights.p;
   s.texRecs      = (const TexRec*)c->dTexRecs.p;
-  s.matDesc      = (const uint4*)c->dMatDesc.p;
+  s.matLines     = (const uint4*)c->dMatLines.p;
   s.texels       = (const uint32_t*)c->dTexels.p;
   s.bvh          = (const BvhNode*)c->dBvh.p;
   s.wide         = (const WideNode*)c->dWide.p;
@@ -805,7 +805,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dMatDesc, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dMatLines, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -1134,15 +1134,10 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   }
   if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
   {
-    std::vector<uint4> md(size_t(4) * std::max<size_t>(1, d->numMaterials), tex_desc_pack(R.texRecs[0]));
+    std::vector<uint4> ml(size_t(PT_MAT_LINE_QUADS) * std::max<size_t>(1, d->numMaterials), uint4{0u, 0u, 0u, 0u});
     for(uint32_t i = 0; i < d->numMaterials; ++i)
-    {
-      const pt_GltfShadeMaterial& mt = d->materials[i];
-      const int ids[4] = {mt.normalTexture, mt.emissiveTexture, mt.pbrMetallicRoughnessTexture, mt.pbrBaseColorTexture};
-      for(int k = 0; k < 4; ++k)
-        md[size_t(4) * i + k] = tex_desc_pack(R.texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
-    }
-    if((rc = upload(c, c->dMatDesc, md.data(), sizeof(uint4) * md.size())) != PT_OK) return rc;
+      mat_line_pack(d->materials[i], R.texRecs.data(), &ml[size_t(PT_MAT_LINE_QUADS) * i]);
+    if((rc = upload(c, c->dMatLines, ml.data(), sizeof(uint4) * ml.size())) != PT_OK) return rc;
   }
   if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/pt_types.h"
 #include "pt_math.h"
+#include <cstring>
 
 // ---- acceleration structure -------------------------------------------------------------------
 // World-space triangle record, 48 B, three aligned 16-byte loads.  Built on device from the node
@@ -186,6 +187,46 @@ inline TexRec tex_desc_unpack(const uint4& d)
   return t;
 }
 
+// One aligned 128-byte line per material for k_shade (round 5): quads 0-2 the "hot" part of the 216-byte pt_GltfShadeMaterial -- base colour factor |
+// emissive factor, normal-texture scale | roughness, metallic, ior, flags -- and quads 3-6 the 16-byte descriptors of its normal / emissive /
+// metallic-roughness / base-colour textures (texture 0 for an absent one).  A material whose remaining fields are the importer's defaults (no KHR
+// transmission / clearcoat / sheen / anisotropy / volume, identity texture transform, lit: MAT_SIMPLE) is shaded from the line alone -- seven requests
+// in one cache line instead of fourteen into the 216-byte record plus four descriptors; any other material still reads its full record.
+// The values are the record's own floats and the shading code is the same function on a record rebuilt in registers: identical results.
+#define PT_MAT_LINE_QUADS 8
+#define MAT_HAS_NORMAL 1u
+#define MAT_HAS_EMISSIVE 2u
+#define MAT_HAS_MR 4u
+#define MAT_HAS_BASE 8u
+#define MAT_SIMPLE 16u
+inline bool mat_is_simple(const pt_GltfShadeMaterial& m)
+{
+  const float id[8] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f};  // the two rows of uvTransform the shading reads (pt_surface.h resolve_material)
+  for(int k = 0; k < 8; ++k)
+    if(std::memcmp(&m.uvTransform[k], &id[k], 4) != 0)
+      return false;
+  const float one = 1.0f, zero = 0.0f, big = 3.4028235e38f;
+  auto eq = [](float a, float b) { return std::memcmp(&a, &b, 4) == 0; };
+  return m.unlit == 0 && eq(m.transmissionFactor, zero) && m.transmissionTexture == -1 && eq(m.anisotropy, zero) && eq(m.anisotropyDirection[0], zero) &&
+         eq(m.anisotropyDirection[1], one) && eq(m.anisotropyDirection[2], zero) && eq(m.attenuationColor[0], one) && eq(m.attenuationColor[1], one) &&
+         eq(m.attenuationColor[2], one) && eq(m.thicknessFactor, zero) && eq(m.attenuationDistance, big) && eq(m.clearcoatFactor, zero) &&
+         eq(m.clearcoatRoughness, zero) && m.clearcoatTexture == -1 && m.clearcoatRoughnessTexture == -1 && m.sheen == 0u;
+}
+// texRecs: the scene's texture records (at least one: record 0 stands in for absent textures)
+inline void mat_line_pack(const pt_GltfShadeMaterial& m, const TexRec* texRecs, uint4 out[PT_MAT_LINE_QUADS])
+{
+  auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  const int      ids[4] = {m.normalTexture, m.emissiveTexture, m.pbrMetallicRoughnessTexture, m.pbrBaseColorTexture};
+  const uint32_t flags  = (ids[0] > -1 ? MAT_HAS_NORMAL : 0u) | (ids[1] > -1 ? MAT_HAS_EMISSIVE : 0u) | (ids[2] > -1 ? MAT_HAS_MR : 0u) | (ids[3] > -1 ? MAT_HAS_BASE : 0u) |
+                         (mat_is_simple(m) ? MAT_SIMPLE : 0u);
+  out[0] = uint4{bits(m.pbrBaseColorFactor[0]), bits(m.pbrBaseColorFactor[1]), bits(m.pbrBaseColorFactor[2]), bits(m.pbrBaseColorFactor[3])};
+  out[1] = uint4{bits(m.emissiveFactor[0]), bits(m.emissiveFactor[1]), bits(m.emissiveFactor[2]), bits(m.normalTextureScale)};
+  out[2] = uint4{bits(m.pbrRoughnessFactor), bits(m.pbrMetallicFactor), bits(m.ior), flags};
+  for(int k = 0; k < 4; ++k)
+    out[3 + k] = tex_desc_pack(texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
+  out[7] = uint4{0u, 0u, 0u, 0u};
+}
+
 #define PT_SHADE_REC_QUADS 8
 struct DeviceScene {
   const float4*               vertices;  // pt_VertexAttributes as 2 x float4
@@ -194,8 +235,7 @@ struct DeviceScene {
   const pt_GltfShadeMaterial* materials;
   const pt_Light*             lights;
   const TexRec*               texRecs;
-  const uint4*                matDesc;  // per material the 16-byte descriptors (tex_desc_pack) of its normal / emissive / metallic-roughness / base-colour textures
-                                        // (texture 0 for an absent one): they arrive WITH the material record instead of one round trip after it
+  const uint4*                matLines;  // per material one 128-byte line (mat_line_pack): hot fields + the descriptors of its four common textures
   const uint32_t*             texels;  // RGBA8 pool
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH

@@ -263,7 +263,7 @@ PT_DEV int shade_path(const DeviceScene& S, const RB& rb, const FrameParams& fp,
   const f3 hitPos = sf.position;
   sf.ffnormal     = dot3(sf.normal, rdir) <= 0.0f ? sf.normal : -sf.normal;
   const int matIndex = hitMat != -2 ? hitMat : I.materialIndex;
-  resolve_material(S, S.materials[matIndex < 0 ? 0 : matIndex], rdir, sf, matIndex < 0 ? 0 : matIndex);
+  resolve_material_at(S, matIndex < 0 ? 0 : matIndex, rdir, sf);
   sf.albedo *= vcolor;
 
   if(dbg != PT_DEBUG_NONE && dbg < PT_DEBUG_RADIANCE)  // pathtrace.glsl:61-83,255-256

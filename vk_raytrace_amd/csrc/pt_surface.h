@@ -60,7 +60,7 @@ PT_DEV f4 sample_rgba8(const DeviceScene& S, int id, f2 uv) { return sample_rgba
 
 // Batched texture fetch (round 5: +1 % on the bench line, profiles/r05d_*): resolve_material reached its four common textures -- normal, emissive,
 // metallic-roughness, base colour -- through up to eight DEPENDENT round trips (descriptor, then texels, per texture, each behind its own `if`).
-// The four 16-byte descriptors are stored per material (DeviceScene::matDesc), so that they arrive with the material record, and the texels of the
+// The four 16-byte descriptors are stored per material (DeviceScene::matLines, in the material's 128-byte line), so that they arrive with the material, and the texels of the
 // textures a material HAS are requested up front, so that those requests are in flight together.  First forms that also fetched the absent
 // textures (as texture 0) were 7 % SLOWER (profiles/r04tb_batched_texture_fetch.txt): k_shade is short of requests, not of latency.
 // The tap is sample_rgba8_rec cut in two: where the texels are (tex_tap) and what is made of them (tex_filter) -- the same expressions in the same order.
@@ -342,7 +342,8 @@ PT_DEV f4 srgb_to_linear(f4 c)
 }
 
 // glTF material + KHR extensions -> Surface (everything the BSDFs need).  `rayDir` is the incoming ray.
-PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m, f3 rayDir, Surface& sf, int matIndex = 0)
+// md: the material's four texture descriptors (quads 3-6 of its line)
+PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m, const uint4* md, f3 rayDir, Surface& sf)
 {
   sf.specular     = 0.5f;
   sf.subsurface   = 0.0f;
@@ -353,7 +354,7 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   const f3 T0 = sf.tangent, B0 = sf.bitangent, N0 = sf.normal;  // TBN before normal mapping
 
   const bool      hasN = m.normalTexture > -1, hasE = m.emissiveTexture > -1, hasM = m.pbrMetallicRoughnessTexture > -1, hasB = m.pbrBaseColorTexture > -1;
-  const uint4     dN = S.matDesc[4 * matIndex], dE = S.matDesc[4 * matIndex + 1], dM = S.matDesc[4 * matIndex + 2], dB = S.matDesc[4 * matIndex + 3];
+  const uint4     dN = md[0], dE = md[1], dM = md[2], dB = md[3];
   const uint32_t* tx = S.texels;
   // each texture behind its `if`, but nothing waits inside the blocks
   TexTap   tN{}, tE{}, tM{}, tB{};
@@ -436,4 +437,35 @@ PT_DEV void resolve_material(const DeviceScene& S, const pt_GltfShadeMaterial& m
   f4 sh        = unpack_unorm4(m.sheen);
   sf.sheenTint = f3{sh.x, sh.y, sh.z};
   sf.sheen     = sh.w;
+}
+
+// The material of a hit, by index: from its 128-byte line alone when the material is MAT_SIMPLE (pt_device.h), else from the full record.
+PT_DEV void resolve_material_at(const DeviceScene& S, int matIndex, f3 rayDir, Surface& sf)
+{
+  const uint4* line = S.matLines + size_t(matIndex) * PT_MAT_LINE_QUADS;
+  const uint4  q0 = line[0], q1 = line[1], q2 = line[2];
+  const uint4  md[4] = {line[3], line[4], line[5], line[6]};
+  if(q2.w & MAT_SIMPLE)
+  {
+    pt_GltfShadeMaterial m;
+    m.pbrBaseColorFactor[0] = __uint_as_float(q0.x); m.pbrBaseColorFactor[1] = __uint_as_float(q0.y); m.pbrBaseColorFactor[2] = __uint_as_float(q0.z); m.pbrBaseColorFactor[3] = __uint_as_float(q0.w);
+    m.emissiveFactor[0] = __uint_as_float(q1.x); m.emissiveFactor[1] = __uint_as_float(q1.y); m.emissiveFactor[2] = __uint_as_float(q1.z);
+    m.normalTextureScale = __uint_as_float(q1.w);
+    m.pbrRoughnessFactor = __uint_as_float(q2.x); m.pbrMetallicFactor = __uint_as_float(q2.y); m.ior = __uint_as_float(q2.z);
+    m.normalTexture = (q2.w & MAT_HAS_NORMAL) ? 0 : -1; m.emissiveTexture = (q2.w & MAT_HAS_EMISSIVE) ? 0 : -1;
+    m.pbrMetallicRoughnessTexture = (q2.w & MAT_HAS_MR) ? 0 : -1; m.pbrBaseColorTexture = (q2.w & MAT_HAS_BASE) ? 0 : -1;
+    // what mat_is_simple checked, as constants
+    for(int k = 0; k < 16; ++k)
+      m.uvTransform[k] = 0.0f;
+    m.uvTransform[0] = 1.0f; m.uvTransform[5] = 1.0f;
+    m.unlit = 0; m.transmissionFactor = 0.0f; m.transmissionTexture = -1;
+    m.anisotropy = 0.0f; m.anisotropyDirection[0] = 0.0f; m.anisotropyDirection[1] = 1.0f; m.anisotropyDirection[2] = 0.0f;
+    m.attenuationColor[0] = m.attenuationColor[1] = m.attenuationColor[2] = 1.0f;
+    m.thicknessFactor = 0.0f; m.thicknessTexture = -1; m.attenuationDistance = 3.4028235e38f;
+    m.clearcoatFactor = 0.0f; m.clearcoatRoughness = 0.0f; m.clearcoatTexture = -1; m.clearcoatRoughnessTexture = -1; m.sheen = 0u;
+    m.alphaMode = 0; m.alphaCutoff = 0.0f; m.doubleSided = 0; m._pad0 = 0; m._pad1 = 0;  // (not read by the shading)
+    resolve_material(S, m, md, rayDir, sf);
+  }
+  else
+    resolve_material(S, S.materials[matIndex], md, rayDir, sf);
 }
