@@ -426,6 +426,8 @@ static std::atomic<unsigned long long> g_innerSteps{0};  // node steps of the ma
 extern "C" unsigned long long th_take_inner_steps() { return g_innerSteps.exchange(0); }
 static std::atomic<unsigned long long> g_leafSteps{0};  // triangle steps, same bracket
 extern "C" unsigned long long th_take_leaf_steps() { return g_leafSteps.exchange(0); }
+static std::atomic<unsigned long long> g_spHist[65];  // machine walks: rays by the deepest traversal-stack level they used (tools/stack_depth_experiment.py)
+extern "C" void th_take_sp_hist(unsigned long long* out65) { for(int i = 0; i < 65; ++i) out65[i] = g_spHist[i].exchange(0); }
 static int g_compactNodes = 0, g_compactOk = 0;  // PT_TUNE cnodes (pt_internal.h)
 extern "C" void th_set_compact_nodes(int on) { g_compactNodes = on; }
 extern "C" int  th_compact_ok() { return g_compactOk; }
@@ -908,7 +910,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
   std::memset(&total, 0, sizeof(total));
 #pragma omp parallel
   {
-    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * std::max(TRACE_BLOCK, MACHINE_BLOCK));
     Counters              cnt;
     std::memset(&cnt, 0, sizeof(cnt));
     RenderBuffers rb;
@@ -925,7 +927,9 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       if(exact == 2)
       {
         TraceLane             L;
-        std::vector<uint32_t> spill(STACK_SPILL);
+        std::vector<uint32_t> spill(MACHINE_SPILL);
+        int                   maxSp = 0;
+        const uint4*          treelet = (PT_TREELET > 0 && !two && S.cnodes) ? reinterpret_cast<const uint4*>(S.cnodes) : nullptr;  // (the kernels copy the first PT_TREELET nodes to LDS)
         lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
         for(;;)
         {
@@ -935,7 +939,8 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
             {
               ++innerSteps;
               if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt);
-              else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
+              else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt, treelet);
+              maxSp = L.sp > maxSp ? L.sp : maxSp;
             }
             if(!L.done && (L.cur & BVH_LEAF))
             {
@@ -977,6 +982,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
               fallback = true;
           }
           machineFallback = fallback;  // queueX / queueX2: the exact kernels take over (below)
+          g_spHist[maxSp < 64 ? maxSp : 64]++;
           g_innerSteps += innerSteps;
           g_leafSteps += leafSteps;
           break;
