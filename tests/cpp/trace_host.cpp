@@ -910,7 +910,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
   std::memset(&total, 0, sizeof(total));
 #pragma omp parallel
   {
-    std::vector<uint32_t> stack(size_t(STACK_LDS) * std::max(TRACE_BLOCK, MACHINE_BLOCK));
+    std::vector<uint32_t> stack(size_t(STACK_LDS) * TRACE_BLOCK);
     Counters              cnt;
     std::memset(&cnt, 0, sizeof(cnt));
     RenderBuffers rb;
@@ -927,9 +927,8 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
       if(exact == 2)
       {
         TraceLane             L;
-        std::vector<uint32_t> spill(MACHINE_SPILL);
+        std::vector<uint32_t> spill(STACK_SPILL);
         int                   maxSp = 0;
-        const uint4*          treelet = (PT_TREELET > 0 && !two && S.cnodes) ? reinterpret_cast<const uint4*>(S.cnodes) : nullptr;  // (the kernels copy the first PT_TREELET nodes to LDS)
         lane_begin(L, o, d, kind == 0 ? PT_INFINITY : absorb[r].w, S.numTris == 0);
         for(;;)
         {
@@ -939,7 +938,7 @@ uint32_t th_settle(void* p, int kind, int two, int exact, int variant, uint32_t 
             {
               ++innerSteps;
               if(two) lane_inner<false, true>(S, L, stack.data(), spill.data(), &cnt);
-              else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt, treelet);
+              else lane_inner<false, false>(S, L, stack.data(), spill.data(), &cnt);
               maxSp = L.sp > maxSp ? L.sp : maxSp;
             }
             if(!L.done && (L.cur & BVH_LEAF))

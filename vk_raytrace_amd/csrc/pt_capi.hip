@@ -42,7 +42,6 @@ struct pt_context {
   uint32_t nodeCapacity = 0;          // nodes dWide was sized for (two-level mode: the BLASes sit at their node bases)
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
-  uint32_t numCNodes = 0;  // compact nodes of the flat-format structure (0 in two-level mode: the treelet of the machine kernels is a flat-structure thing)
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
   // two-level acceleration structure (pt_set_accel_mode): dWide / dTris / dAlphaRecs hold the concatenated BLASes, dTlas the instance hierarchy
   int      accelMode = PT_ACCEL_FLAT;
@@ -287,7 +286,6 @@ void refresh_scene_ptrs(pt_context* c)
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
-  s.numCNodes    = c->haveCNodes ? c->numCNodes : 0u;
   s.ctlas        = c->haveCNodes ? (const CompactNode*)c->dCTlas.p : nullptr;
   s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
@@ -463,7 +461,6 @@ int build_tlas(pt_context* c)
 void build_cnodes_two_level(pt_context* c)
 {
   c->haveCNodes = false;
-  c->numCNodes  = 0;
   if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
   {
     dev_free(c->dCNodes);
@@ -500,7 +497,6 @@ void build_cnodes(pt_context* c, uint32_t n)
     return;
   }
   c->haveCNodes = pt_compact_nodes(c->stream, n, (const WideNode*)c->dWide.p, (CompactNode*)c->dCNodes.p) == 0;
-  c->numCNodes  = c->haveCNodes ? n : 0u;
 }
 // DeviceScene::shadeTris over the first n leaf records of a flat-format structure (best effort: without the memory k_shade takes the indexed route)
 void build_shade_tris(pt_context* c, uint32_t n)

@@ -240,7 +240,6 @@ struct DeviceScene {
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
-  uint32_t                    numCNodes;  // compact nodes of a flat-format structure (the first of them are the top of the tree: pt_machine.h treelet)
   const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot ONE 128-byte line (PT_SHADE_REC_QUADS float4): the six float4 of the
                                           // triangle's three pt_VertexAttributes, then (instance, primitive) -- everything k_shade needs of the hit
                                           // triangle in one aligned line instead of a 48-byte TriRec (1.4 lines) + 96 bytes at a 96-byte stride (1.7 lines).  Was: next to

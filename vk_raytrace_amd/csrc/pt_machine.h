@@ -13,24 +13,6 @@
 #pragma once
 #include "pt_trace.h"
 
-// Workgroup shape of the persistent machine kernels (k_closest_p, k_shadow_p, k_trace_p).  MACHINE_BLOCK threads = MACHINE_BLOCK / 64 independent
-// wavefronts that share one thing: the TREELET, the first PT_TREELET compact nodes of the flat structure copied into LDS at kernel start (k_collapse
-// numbers the wide nodes level by level, so the first 85 are the root and its next three levels).  A lane whose current node is one of them reads its
-// five quads with ds_read_b128 instead of five per-lane vector-memory requests (the L1 request path is the memory-side resource these kernels load
-// most: DESIGN.md section 5, "what bounds the trace kernels").  LDS per CU: 5 workgroups x (stack + staging + treelet) must stay below 160 KB, hence
-// 20 LDS levels per lane with four wavefronts per workgroup (deeper levels go to the private spill array; tools/stack_depth_experiment.py: 0.01 % of
-// the walks go beyond 20 levels, none beyond 22).
-#ifndef PT_MACHINE_BLOCK
-#define PT_MACHINE_BLOCK 64
-#endif
-#ifndef PT_TREELET
-#define PT_TREELET 0
-#endif
-#define MACHINE_BLOCK PT_MACHINE_BLOCK
-#define MACHINE_WAVES (MACHINE_BLOCK / 64)
-#define MACHINE_STACK_LDS (MACHINE_BLOCK > 64 ? 20 : STACK_LDS)
-#define MACHINE_SPILL (64 - MACHINE_STACK_LDS)
-
 // refill threshold: PT_REFILL_BELOW_DEFAULT in pt_internal.h (lanes still running below which idle lanes pull new rays)
 
 struct TraceLane {
@@ -104,14 +86,13 @@ PT_DEV void lane_pop(TraceLane& L, const uint32_t* lds, const uint32_t* spill)
     return;
   }
   --L.sp;
-  L.cur = L.sp < MACHINE_STACK_LDS ? lds[L.sp * MACHINE_BLOCK] : spill[L.sp - MACHINE_STACK_LDS];
+  L.cur = L.sp < STACK_LDS ? lds[L.sp * TRACE_BLOCK] : spill[L.sp - STACK_LDS];
 }
 
 // One inner-node visit.  SHADOW: true for shadow rays (they must keep looking for opaque triangles behind the best
 // alpha candidate, so only tmax prunes).
-// treelet: the first PT_TREELET compact nodes of the flat structure in LDS (nullptr: none)
 template <bool SHADOW, bool TWO = false>
-PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters, const uint4* treelet = nullptr)
+PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_t* spill, Counters* counters)
 {
 #if PT_BVH_WIDTH != 2
   if(TWO && ++L.steps > PT_TWO_GUARD)
@@ -122,36 +103,18 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
   }
   const float    lim = (SHADOW || L.pass == 1) ? L.tmax : L.bt;
   auto pushChild = [&](uint32_t c) {
-    if(L.sp < MACHINE_STACK_LDS)
-      lds[L.sp++ * MACHINE_BLOCK] = c;
-    else if(L.sp < MACHINE_STACK_LDS + MACHINE_SPILL)
-      spill[L.sp++ - MACHINE_STACK_LDS] = c;
+    if(L.sp < STACK_LDS)
+      lds[L.sp++ * TRACE_BLOCK] = c;
+    else if(L.sp < STACK_LDS + STACK_SPILL)
+      spill[L.sp++ - STACK_LDS] = c;
     else
       atomicAdd(&counters->stackOverflow, 1u);
   };
   // compact nodes when the structure has them (wave-uniform choice): five requests per node instead of seven
   const bool     atTlas = TWO && L.ic.inst == BVH_NONE;
   const bool     alphaOnly = L.pass == 1;
-  uint32_t nxt;
-  if(!TWO && PT_TREELET > 0 && treelet)
-  {  // (wave-uniform: a flat-format structure with compact nodes) only the FETCH differs between the top of the tree and the rest: one visit body
-    const uint32_t idx = L.cur & BVH_SLOT_MASK;
-    uint4          q0, q1, q2, q3, q4;
-    if(idx < uint32_t(PT_TREELET))
-    {
-      const uint4* q = treelet + idx * 5u;
-      q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
-    }
-    else
-    {
-      const uint4* q = reinterpret_cast<const uint4*>(S.cnodes) + size_t(idx) * 5u;
-      q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
-    }
-    nxt = cnode_visit(make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)), q1, q2, q3, q4, L.rbox, lim, alphaOnly, pushChild);
-  }
-  else
-    nxt = S.cnodes ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
-                   : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
+  const uint32_t nxt    = S.cnodes ? wide_node_step_c(atTlas ? S.ctlas : S.cnodes, L.cur, L.rbox, lim, alphaOnly, pushChild)
+                                   : wide_node_step(atTlas ? S.tlas : S.wide, L.cur, L.rbox, lim, alphaOnly, pushChild);
   if(nxt != BVH_NONE)
     L.cur = nxt;
   else
@@ -182,10 +145,10 @@ PT_DEV void lane_inner(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32
       nearC = ch.y;
       farC  = ch.x;
     }
-    if(L.sp < MACHINE_STACK_LDS)
-      lds[L.sp++ * MACHINE_BLOCK] = farC;
-    else if(L.sp < MACHINE_STACK_LDS + MACHINE_SPILL)
-      spill[L.sp++ - MACHINE_STACK_LDS] = farC;
+    if(L.sp < STACK_LDS)
+      lds[L.sp++ * TRACE_BLOCK] = farC;
+    else if(L.sp < STACK_LDS + STACK_SPILL)
+      spill[L.sp++ - STACK_LDS] = farC;
     else
       atomicAdd(&counters->stackOverflow, 1u);
     L.cur = nearC;

@@ -158,24 +158,6 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
     atomicAdd(ctr, (unsigned long long)v);
 }
 
-// LDS of a machine kernel's workgroup: per-lane traversal stacks, one staging buffer per wavefront, the treelet
-#define MACHINE_LDS(WITH_STAGE)                                                                                                   \
-  __shared__ uint32_t stack[MACHINE_STACK_LDS * MACHINE_BLOCK];                                                                  \
-  __shared__ uint32_t stageAll[(WITH_STAGE) ? MACHINE_WAVES * STAGE_CAP : 1];                                                    \
-  __shared__ uint4    treeletLds[PT_TREELET > 0 ? PT_TREELET * 5 : 1];                                                          \
-  uint32_t*           stage   = stageAll + ((WITH_STAGE) ? (threadIdx.x >> 6) * STAGE_CAP : 0);                                  \
-  const uint4*        treelet = nullptr;                                                                                         \
-  (void)stage;                                                                                                                   \
-  if(PT_TREELET > 0 && !TWO && S.cnodes)                                                                                         \
-  {                                                                                                                              \
-    const uint4*   src = reinterpret_cast<const uint4*>(S.cnodes);                                                               \
-    const uint32_t nq  = (S.numCNodes < uint32_t(PT_TREELET) ? S.numCNodes : uint32_t(PT_TREELET)) * 5u;                         \
-    for(uint32_t i = threadIdx.x; i < nq; i += MACHINE_BLOCK)                                                                    \
-      treeletLds[i] = src[i];                                                                                                    \
-    treelet = treeletLds;                                                                                                        \
-    __syncthreads();                                                                                                             \
-  }
-
 // Persistent wavefronts on the trace machine (pt_machine.h).  The loop alternates between
 //   service: lanes whose ray has finished settle it (pass A -> pass B transition, RNG draws, hit record) and every
 //            idle lane pulls the next ray from the queue;
@@ -186,22 +168,22 @@ PT_DEV void wave_add(unsigned long long* ctr, uint32_t v)
 // HEAT: the heat-map debug mode (shaders/pathtrace.comp:89,108-119 colours a pixel by the real time its invocation took): the instrumented
 // instantiation stamps every ray with the wall-clock time it spent in this kernel (fetch -> settled), added to the path's cost in rayO.w
 template <bool HEAT, bool TWO>
-__global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_closest_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
-  uint32_t            spill[MACHINE_SPILL];
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[cntIn];
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (MACHINE_BLOCK * PT_MIN_GENERATIONS) >= count)
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves with full lanes.  Spreading such a queue over MORE waves (8 .. 56 rays each, so that the SIMDs hold more
              // resident waves and a wave waits for fewer rays) measured 4-7 % slower on the 20-step run and on an 8-GPU rank's shard
              // (profiles/r04d_*): a wave-instruction costs the same with 16 lanes as with 64
-  MACHINE_LDS(0)
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
   // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
-  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * MACHINE_WAVES * 8u)) & ~63u));
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -269,7 +251,7 @@ __global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_T
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false, TWO>(S, L, lds, spill, rb.counters, treelet);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
@@ -482,24 +464,25 @@ PT_DEV void finish_bounce(const RenderBuffers& rb, uint32_t slot, bool inShadow,
 // Shadow rays (trace contract T6): the closest-hit walk bounded by the light distance -- the nearest certain hit, opaque or not, ends the ray;
 // zero-opacity candidates in front of it consume their draws (pass A / pass B like k_closest_p)
 template <bool HEAT, bool TWO>
-__global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_shadow_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk, int variant,
                                                                              int cntIn, int cntChunk)
 {
   uint32_t heatT0 = 0;
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
-  uint32_t            spill[MACHINE_SPILL];
+  uint32_t            spill[STACK_SPILL];
   uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
   const uint32_t      count = C[cntIn];
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (MACHINE_BLOCK * PT_MIN_GENERATIONS) >= count)
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;  // small queue: fewer waves with full lanes.  Spreading such a queue over MORE waves (8 .. 56 rays each, so that the SIMDs hold more
              // resident waves and a wave waits for fewer rays) measured 4-7 % slower on the 20-step run and on an 8-GPU rank's shard
              // (profiles/r04d_*): a wave-instruction costs the same with 16 lanes as with 64
-  MACHINE_LDS(1)
   uint32_t*           lds   = stack + threadIdx.x;
   TraceLane           L;
   RaySupply           rs;
   // rays reserved per queue atomic: ~8 reservations per wave over the launch, at least `chunk`
-  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * MACHINE_WAVES * 8u)) & ~63u));
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t            pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
   bool                alive = false;
   L.done                    = true;
@@ -570,7 +553,7 @@ __global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_T
       const uint32_t ni = __popcll(__ballot(!L.done && !(L.cur & BVH_LEAF)));
 #endif
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false, TWO>(S, L, lds, spill, rb.counters, treelet);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
 #ifdef PT_HIST
       const uint32_t nl = __popcll(__ballot(!L.done && (L.cur & BVH_LEAF)));
       ++hIter; hInner += ni; hLeaf += nl; hBoth += (ni && nl) ? 1 : 0; hInnerIt += ni ? 1 : 0; hLeafIt += nl ? 1 : 0;
@@ -647,21 +630,22 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
 // shade) instead of three.  Ray kinds differ only in their upper bound and in what the service round does with the result: the walk is the same
 // (trace contract T5 / T6).  Bit-identical to the staged chain by construction: the same functions on the same per-path state in the same order.
 template <bool TWO>
-__global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_trace_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueS, const uint32_t* __restrict__ queueN,
+__global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRACE_WAVES) k_trace_p(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueS, const uint32_t* __restrict__ queueN,
                                                                                                     uint32_t* __restrict__ queueHit, int bounce, int minRun, int chunk, int variant)
 {
+  __shared__ uint32_t stack[STACK_LDS * TRACE_BLOCK];
+  __shared__ uint32_t stage[STAGE_CAP];
   uint32_t            nStage = 0;
-  uint32_t            spill[MACHINE_SPILL];
+  uint32_t            spill[STACK_SPILL];
   uint32_t*           C  = rb.counts + bounce * CNT_STRIDE;  // this bounce: shadow rays, paths without one
   uint32_t*           C1 = C + CNT_STRIDE;                   // the next bounce: its hit queue, its closest-hit fallbacks
   const uint32_t      nS = C[CNT_SHADOW], count = nS + C[CNT_NEXT];
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (MACHINE_BLOCK * PT_MIN_GENERATIONS) >= count)
+  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * (TRACE_BLOCK * PT_MIN_GENERATIONS) >= count)
     return;
-  MACHINE_LDS(1)
   uint32_t* lds = stack + threadIdx.x;
   TraceLane L;
   RaySupply rs;
-  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * MACHINE_WAVES * 8u)) & ~63u));
+  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
   uint32_t pslot = 0, seed = 0, nShadow = 0, nClosest = 0, nAlpha = 0;
   bool     alive = false, shadowRay = false;
   L.done         = true;
@@ -748,7 +732,7 @@ __global__ void __launch_bounds__(MACHINE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_T
     while(__popcll(__ballot(!L.done)) >= target)
     {
       if(!L.done && !(L.cur & BVH_LEAF))
-        lane_inner<false, TWO>(S, L, lds, spill, rb.counters, treelet);
+        lane_inner<false, TWO>(S, L, lds, spill, rb.counters);
       if(!L.done && (L.cur & BVH_LEAF))
       {
         lane_leaf<false, TWO>(S, L, lds, spill);
@@ -1198,7 +1182,6 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
   const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
-  const uint32_t gridMachine = (gridTrace + MACHINE_WAVES - 1) / MACHINE_WAVES;  // workgroups of the machine kernels
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the staged machine kernels; no packet stage, no fused stage, no k_tail
   // measured (profiles/r05a_*, r05b_*, r05c_*): serialised, the fused launch takes exactly the time of the two launches it replaces (21.3 ms per 32-frame
@@ -1237,16 +1220,16 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 1);
           if(heat)
-            k_closest_p<true, TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+            k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
           else if(packetStage && depth < g_tuning.packetClosestBounces)
           {
             const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
             const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
             k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
-            k_closest_p<false, TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
           }
           else
-            k_closest_p<false, TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
           k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
           pt_timers_end(tm, stream, 1);
         }, false});
@@ -1260,7 +1243,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       {  // qIn has been consumed by k_shade: it becomes the hit queue of bounce depth + 1 (no swap)
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 6);
-          k_trace_p<TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
+          k_trace_p<TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
           k_trace_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, fp.variant);
           pt_timers_end(tm, stream, 6);
         }, false});
@@ -1270,9 +1253,9 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 3);
           if(heat)
-            k_shadow_p<true, TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+            k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           else
-            k_shadow_p<false, TWO><<<gridMachine, MACHINE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
           pt_timers_end(tm, stream, 3);
         }, false});
