@@ -187,6 +187,7 @@ static inline bool th_tri_test_certified(const TriRec& tr, uint32_t flags, f3 o,
 
 extern "C" int pt_debug_sahdev_topology(uint32_t n, const float* tri9, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);
 extern "C" int pt_debug_two_level_pad(const float* worldMatrix16, float Bo, float* out27);
+extern "C" int pt_debug_mat_lines(const pt_SceneDesc* d, void* linesOut, char* err, size_t errLen);
 extern "C" int pt_debug_scene_records(const pt_SceneDesc* d, unsigned long long* counts5, void* instOut, float* padOut, void* alphaMatsOut, uint32_t* alphaMapsOut, uint32_t* texelsOut,
                                       void* texRecsOut, char* err, size_t errLen);
 extern "C" int pt_build_env_accel(const float* rgba32f, int width, int height, pt_EnvAccel* out, float* out_integral, float* out_average);
@@ -774,8 +775,11 @@ void* th_create_scene(const pt_SceneDesc* d, char* err, size_t errLen)
     return nullptr;
   }
   s->matLines.assign(size_t(PT_MAT_LINE_QUADS) * std::max<size_t>(1, s->materials.size()), uint4{0u, 0u, 0u, 0u});
-  for(size_t i = 0; i < s->materials.size(); ++i)
-    mat_line_pack(s->materials[i], s->texRecs.data(), &s->matLines[size_t(PT_MAT_LINE_QUADS) * i]);
+  if(pt_debug_mat_lines(d, s->matLines.data(), err, errLen) != 0)  // the product's own lines: their descriptors point into the pool fetched above (plain copies + interleaved groups)
+  {
+    delete s;
+    return nullptr;
+  }
   std::vector<float> padC0(counts[0]), padC1(counts[0]);
   for(size_t i = 0; i < counts[0]; ++i)
   {

@@ -764,6 +764,7 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) parsed.bandTiles = v > 0 ? v : 1;
     if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) parsed.stateGB = v;
     if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) parsed.fuse = v;
+    if(const char* p = strstr(tune, "texGroups=")) if(sscanf(p, "texGroups=%d", &v) == 1) parsed.texGroups = v;
   }
   g_tuning = parsed;
   pt_context* c = new pt_context();
@@ -938,6 +939,14 @@ struct SceneRecords {
   size_t                   texels = 0; // texels of the RGBA8 pool
   std::vector<AlphaMat>    alphaMats;
   std::vector<uint32_t>    alphaMaps;
+  // interleaved texture groups (pt_device.h TexRec::tiled): the pool holds every texture in its plain form first, then the groups
+  struct TexGroup {
+    int      tex[4];  // texture ids in layer order (-1: unused layer)
+    int      layers;
+    uint32_t offset;  // first texel word of the group in the pool
+  };
+  std::vector<TexGroup> groups;
+  std::vector<uint4>    matLines;  // PT_MAT_LINE_QUADS per material (pt_device.h mat_line_pack)
 };
 __attribute__((format(printf, 2, 3))) static int records_fail(std::string& err, const char* fmt, ...)
 {
@@ -961,6 +970,19 @@ static void store_texture(uint32_t* dst, const TexRec& tr, const void* rgba8RowM
   for(int y = 0; y < tr.h; ++y)
     for(int x = 0; x < tr.w; x += PT_TEX_TILE_W)
       std::memcpy(dst + tex_index(tr.w, x, y, true), src + size_t(y) * tr.w + x, PT_TEX_TILE_W * 4);
+}
+
+// the texels of a group: texel (x, y) of layer l at tex_index(...) x layers + l
+static void store_group(uint32_t* dst, const SceneRecords::TexGroup& g, const std::vector<TexRec>& texRecs, const pt_SceneDesc* d)
+{
+  for(int l = 0; l < g.layers; ++l)
+  {
+    const TexRec&   tr  = texRecs[size_t(g.tex[l])];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d->textures[g.tex[l]].rgba8);
+    for(int y = 0; y < tr.h; ++y)
+      for(int x = 0; x < tr.w; ++x)
+        dst[size_t(tex_index(tr.w, x, y, (tr.tiled & 1) != 0)) * size_t(g.layers) + size_t(l)] = src[size_t(y) * tr.w + x];
+  }
 }
 
 static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::string& err)
@@ -1057,6 +1079,57 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
     R.texRecs[0] = TexRec{0, 1, 1, PT_FILTER_LINEAR, PT_WRAP_REPEAT, PT_WRAP_REPEAT, 3, 0};
     R.texels     = 1;
   }
+  // ---- material lines, and the interleaved groups their descriptors point into.  The textures a material samples with one (u, v) -- normal, emissive,
+  // metallic-roughness, base colour -- are ALSO stored texel by texel next to each other when they share size and sampler (the first present one sets the
+  // shape): the 2 x 2 footprints of a shading's taps then share cache lines instead of pulling one or two 128-byte lines per texture for 16 bytes of texels
+  // each (k_shade is the kernel next to the read-bandwidth ceiling).  Texel values and filter arithmetic are untouched; the plain copies stay for the any-hit
+  // evaluation and the other texture roles.  PT_TUNE texGroups=0: descriptors point at the plain copies.
+  R.matLines.assign(size_t(PT_MAT_LINE_QUADS) * std::max<size_t>(1, d->numMaterials), uint4{0u, 0u, 0u, 0u});
+  for(uint32_t m = 0; m < d->numMaterials; ++m)
+  {
+    const pt_GltfShadeMaterial& mt = d->materials[m];
+    const int ids[4] = {mt.normalTexture, mt.emissiveTexture, mt.pbrMetallicRoughnessTexture, mt.pbrBaseColorTexture};
+    TexRec    rec[4];
+    for(int k = 0; k < 4; ++k)
+      rec[k] = R.texRecs[ids[k] > -1 ? size_t(ids[k]) : 0];
+    SceneRecords::TexGroup g{{-1, -1, -1, -1}, 0, 0u};
+    if(g_tuning.texGroups && d->numTextures)
+      for(int k = 0; k < 4; ++k)
+      {
+        if(ids[k] < 0 || std::find(g.tex, g.tex + g.layers, ids[k]) != g.tex + g.layers)
+          continue;
+        const TexRec &a = R.texRecs[size_t(ids[k])], &b = R.texRecs[size_t(g.layers ? g.tex[0] : ids[k])];
+        if(a.w == b.w && a.h == b.h && a.mag == b.mag && a.wrapS == b.wrapS && a.wrapT == b.wrapT)
+          g.tex[g.layers++] = ids[k];
+      }
+    if(g.layers >= 2)
+    {
+      size_t at = R.groups.size();
+      for(size_t q = 0; q < R.groups.size(); ++q)
+        if(std::equal(g.tex, g.tex + 4, R.groups[q].tex))
+          at = q;
+      if(at == R.groups.size())
+      {
+        const TexRec& sh = R.texRecs[size_t(g.tex[0])];
+        R.texels = (R.texels + 31u) & ~size_t(31);
+        g.offset = uint32_t(R.texels);
+        R.texels += size_t(sh.w) * sh.h * size_t(g.layers);
+        if(R.texels > 0xffffffffull)
+          return records_fail(err, "texture pool exceeds 2^32 texels");
+        R.groups.push_back(g);
+      }
+      const SceneRecords::TexGroup& G = R.groups[at];
+      for(int k = 0; k < 4; ++k)
+      {
+        const int* hit = ids[k] < 0 ? G.tex + G.layers : std::find(G.tex, G.tex + G.layers, ids[k]);
+        if(hit == G.tex + G.layers)
+          continue;  // absent, or of another shape: its plain copy
+        rec[k].offset = G.offset;
+        rec[k].tiled  = (rec[k].tiled & 1) | ((G.layers - 1) << 8) | (int(hit - G.tex) << 10);
+      }
+    }
+    mat_line_pack(mt, rec, &R.matLines[size_t(PT_MAT_LINE_QUADS) * m]);
+  }
   // ---- compact alpha view of every material (what the any-hit evaluation reads)
   R.alphaMats.assign(d->numMaterials, AlphaMat{});
   for(uint32_t m = 0; m < d->numMaterials; ++m)
@@ -1132,13 +1205,18 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
       HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + tr.offset, src, size_t(tr.w) * tr.h * 4, hipMemcpyHostToDevice));
     }
   }
-  if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
   {
-    std::vector<uint4> ml(size_t(PT_MAT_LINE_QUADS) * std::max<size_t>(1, d->numMaterials), uint4{0u, 0u, 0u, 0u});
-    for(uint32_t i = 0; i < d->numMaterials; ++i)
-      mat_line_pack(d->materials[i], R.texRecs.data(), &ml[size_t(PT_MAT_LINE_QUADS) * i]);
-    if((rc = upload(c, c->dMatLines, ml.data(), sizeof(uint4) * ml.size())) != PT_OK) return rc;
+    std::vector<uint32_t> staged;  // one interleaved group at a time
+    for(const SceneRecords::TexGroup& g : R.groups)
+    {
+      const TexRec& sh = R.texRecs[size_t(g.tex[0])];
+      staged.assign(size_t(sh.w) * sh.h * size_t(g.layers), 0u);
+      store_group(staged.data(), g, R.texRecs, d);
+      HIP_TRY(c, hipMemcpy((uint32_t*)c->dTexels.p + g.offset, staged.data(), staged.size() * 4, hipMemcpyHostToDevice));
+    }
   }
+  if((rc = upload(c, c->dTexRecs, R.texRecs.data(), sizeof(TexRec) * R.texRecs.size())) != PT_OK) return rc;
+  if((rc = upload(c, c->dMatLines, R.matLines.data(), sizeof(uint4) * R.matLines.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMaps, R.alphaMaps.data(), 4 * R.alphaMaps.size())) != PT_OK) return rc;
   if((rc = upload(c, c->dAlphaMats, R.alphaMats.data(), sizeof(AlphaMat) * R.alphaMats.size())) != PT_OK) return rc;
   c->numInstances = d->numNodes;
@@ -2351,7 +2429,25 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(con
       texelsOut[0] = 0xffffffffu;
     for(uint32_t t = 0; t < d->numTextures; ++t)
       store_texture(texelsOut + R.texRecs[t].offset, R.texRecs[t], d->textures[t].rgba8);
+    for(const SceneRecords::TexGroup& g : R.groups)
+      store_group(texelsOut + g.offset, g, R.texRecs, d);
   }
+  return PT_OK;
+}
+// ... and the material lines (PT_MAT_LINE_QUADS x 16 bytes per material) whose descriptors point into that pool
+extern "C" __attribute__((visibility("default"))) int pt_debug_mat_lines(const pt_SceneDesc* d, void* linesOut, char* err, size_t errLen)
+{
+  SceneRecords R;
+  std::string  msg;
+  const int    rc = build_scene_records(d, R, msg);
+  if(rc != PT_OK)
+  {
+    if(err && errLen)
+      snprintf(err, errLen, "%s", msg.c_str());
+    return rc;
+  }
+  if(linesOut)
+    std::memcpy(linesOut, R.matLines.data(), sizeof(uint4) * R.matLines.size());
   return PT_OK;
 }
 

@@ -132,7 +132,10 @@ struct TexRec {
   int32_t  w, h;
   int32_t  mag, wrapS, wrapT;
   int32_t  pot;  // bit0: w is a power of two, bit1: h is
-  int32_t  tiled;  // 1: block-linear storage (see tex_index), 0: row-major
+  int32_t  tiled;  // bit 0: block-linear storage (see tex_index), else row-major; bits 8-9: layers - 1, bits 10-11: this texture's layer of an
+                   // INTERLEAVED group (round 5): the textures a material samples with one (u, v) -- normal, emissive, metallic-roughness, base colour --
+                   // stored texel by texel next to each other when they have the same size and sampler, so that the 2 x 2 footprints of a shading's
+                   // taps share cache lines (texel (ix, iy) of layer l: offset + tex_index(...) x layers + l)
 };
 // Texel (ix, iy) of a w-texel-wide image -> index into its storage.  Block-linear images (w % 8 == 0, h % 4 == 0) keep every 8 x 4-texel tile in one
 // 128-byte line, so the 2 x 2 footprint of a bilinear tap is ONE line two times out of three instead of always two (rows w texels apart).
@@ -157,7 +160,8 @@ inline uint32_t tex_index(int32_t w, int32_t ix, int32_t iy, bool tiled)
 }
 
 // A texture's descriptor in 16 bytes (pt_surface.h resolve_material), so that a material's four descriptors cost 16 registers, not 32:
-// x = texel offset, y = w | h << 16 (sides < 2^16, pt_set_scene checks), z = bit 0 NEAREST, bits 1-2 wrapS, bits 3-4 wrapT, bits 5-6 pot, bit 7 tiled.
+// x = texel offset, y = w | h << 16 (sides < 2^16, pt_set_scene checks), z = bit 0 NEAREST, bits 1-2 wrapS, bits 3-4 wrapT, bits 5-6 pot, bit 7 tiled,
+// bits 8-9 layers - 1, bits 10-11 layer (TexRec::tiled).
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -166,7 +170,7 @@ inline uint4 tex_desc_pack(const TexRec& t)
   uint4 d;
   d.x = t.offset;
   d.y = uint32_t(t.w) | (uint32_t(t.h) << 16);
-  d.z = (t.mag == 0 ? 1u : 0u) | (uint32_t(t.wrapS) << 1) | (uint32_t(t.wrapT) << 3) | (uint32_t(t.pot & 3) << 5) | (t.tiled ? 128u : 0u);
+  d.z = (t.mag == 0 ? 1u : 0u) | (uint32_t(t.wrapS) << 1) | (uint32_t(t.wrapT) << 3) | (uint32_t(t.pot & 3) << 5) | ((t.tiled & 1) ? 128u : 0u) | (uint32_t(t.tiled) & 0xf00u);
   d.w = 0;
   return d;
 }
@@ -183,7 +187,7 @@ inline TexRec tex_desc_unpack(const uint4& d)
   t.wrapS  = int32_t((d.z >> 1) & 3u);
   t.wrapT  = int32_t((d.z >> 3) & 3u);
   t.pot    = int32_t((d.z >> 5) & 3u);
-  t.tiled  = int32_t((d.z >> 7) & 1u);
+  t.tiled  = int32_t(((d.z >> 7) & 1u) | (d.z & 0xf00u));
   return t;
 }
 
@@ -212,8 +216,9 @@ inline bool mat_is_simple(const pt_GltfShadeMaterial& m)
          eq(m.attenuationColor[2], one) && eq(m.thicknessFactor, zero) && eq(m.attenuationDistance, big) && eq(m.clearcoatFactor, zero) &&
          eq(m.clearcoatRoughness, zero) && m.clearcoatTexture == -1 && m.clearcoatRoughnessTexture == -1 && m.sheen == 0u;
 }
-// texRecs: the scene's texture records (at least one: record 0 stands in for absent textures)
-inline void mat_line_pack(const pt_GltfShadeMaterial& m, const TexRec* texRecs, uint4 out[PT_MAT_LINE_QUADS])
+// rec[k]: the record through which the material's normal / emissive / metallic-roughness / base-colour texture is read (its plain storage or its layer of
+// an interleaved group; the scene's record 0 for an absent one)
+inline void mat_line_pack(const pt_GltfShadeMaterial& m, const TexRec rec[4], uint4 out[PT_MAT_LINE_QUADS])
 {
   auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
   const int      ids[4] = {m.normalTexture, m.emissiveTexture, m.pbrMetallicRoughnessTexture, m.pbrBaseColorTexture};
@@ -223,7 +228,7 @@ inline void mat_line_pack(const pt_GltfShadeMaterial& m, const TexRec* texRecs, 
   out[1] = uint4{bits(m.emissiveFactor[0]), bits(m.emissiveFactor[1]), bits(m.emissiveFactor[2]), bits(m.normalTextureScale)};
   out[2] = uint4{bits(m.pbrRoughnessFactor), bits(m.pbrMetallicFactor), bits(m.ior), flags};
   for(int k = 0; k < 4; ++k)
-    out[3 + k] = tex_desc_pack(texRecs[ids[k] > -1 ? size_t(ids[k]) : 0]);
+    out[3 + k] = tex_desc_pack(rec[k]);
   out[7] = uint4{0u, 0u, 0u, 0u};
 }
 

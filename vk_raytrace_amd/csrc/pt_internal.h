@@ -144,6 +144,7 @@ struct PtTuning {
   int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
                                    // (the display loop), 2 = always, 0 = never (the round-4 chain)
   int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
+  int texGroups            = 1;    // the textures a material samples with one (u, v) are also stored interleaved when they share size and sampler (pt_device.h TexRec::tiled)
   int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently

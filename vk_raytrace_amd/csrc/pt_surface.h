@@ -33,9 +33,11 @@ PT_DEV int wrap_index(int i, int n, int mode, bool pot)
   return m < 0 ? m + n : m;
 }
 
+PT_DEV uint32_t tex_layers(const TexRec& tr) { return ((uint32_t(tr.tiled) >> 8) & 3u) + 1u; }
+PT_DEV uint32_t tex_layer(const TexRec& tr) { return (uint32_t(tr.tiled) >> 10) & 3u; }
 PT_DEV f4 texel_bytes(const uint32_t* pool, const TexRec& tr, int ix, int iy)
 {
-  uint32_t p = pool[tr.offset + tex_index(tr.w, wrap_index(ix, tr.w, tr.wrapS, (tr.pot & 1) != 0), wrap_index(iy, tr.h, tr.wrapT, (tr.pot & 2) != 0), tr.tiled != 0)];
+  uint32_t p = pool[tr.offset + tex_index(tr.w, wrap_index(ix, tr.w, tr.wrapS, (tr.pot & 1) != 0), wrap_index(iy, tr.h, tr.wrapT, (tr.pot & 2) != 0), (tr.tiled & 1) != 0) * tex_layers(tr) + tex_layer(tr)];
   return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)};
 }
 
@@ -74,11 +76,12 @@ PT_DEV TexTap tex_tap(const TexRec& tr, f2 uv)
   TexTap t;
   float  x = uv.x * float(tr.w), y = uv.y * float(tr.h);
   t.nearest = tr.mag == PT_FILTER_NEAREST;
-  const bool ps = (tr.pot & 1) != 0, pt = (tr.pot & 2) != 0, tiled = tr.tiled != 0;
+  const bool     ps = (tr.pot & 1) != 0, pt = (tr.pot & 2) != 0, tiled = (tr.tiled & 1) != 0;
+  const uint32_t K = tex_layers(tr), base = tr.offset + tex_layer(tr);
   if(t.nearest)
   {
     t.a = t.b = 0.0f;
-    t.i[0] = t.i[1] = t.i[2] = t.i[3] = tr.offset + tex_index(tr.w, wrap_index((int)floorf(x), tr.w, tr.wrapS, ps), wrap_index((int)floorf(y), tr.h, tr.wrapT, pt), tiled);
+    t.i[0] = t.i[1] = t.i[2] = t.i[3] = base + tex_index(tr.w, wrap_index((int)floorf(x), tr.w, tr.wrapS, ps), wrap_index((int)floorf(y), tr.h, tr.wrapT, pt), tiled) * K;
     return t;
   }
   x -= 0.5f;
@@ -88,10 +91,10 @@ PT_DEV TexTap tex_tap(const TexRec& tr, f2 uv)
   t.b = y - fy;
   const int x0 = (int)fx, y0 = (int)fy;
   const int wx0 = wrap_index(x0, tr.w, tr.wrapS, ps), wx1 = wrap_index(x0 + 1, tr.w, tr.wrapS, ps), wy0 = wrap_index(y0, tr.h, tr.wrapT, pt), wy1 = wrap_index(y0 + 1, tr.h, tr.wrapT, pt);
-  t.i[0] = tr.offset + tex_index(tr.w, wx0, wy0, tiled);
-  t.i[1] = tr.offset + tex_index(tr.w, wx1, wy0, tiled);
-  t.i[2] = tr.offset + tex_index(tr.w, wx0, wy1, tiled);
-  t.i[3] = tr.offset + tex_index(tr.w, wx1, wy1, tiled);
+  t.i[0] = base + tex_index(tr.w, wx0, wy0, tiled) * K;
+  t.i[1] = base + tex_index(tr.w, wx1, wy0, tiled) * K;
+  t.i[2] = base + tex_index(tr.w, wx0, wy1, tiled) * K;
+  t.i[3] = base + tex_index(tr.w, wx1, wy1, tiled) * K;
   return t;
 }
 PT_DEV f4 texel_unpack(uint32_t p) { return f4{float(p & 0xffu), float((p >> 8) & 0xffu), float((p >> 16) & 0xffu), float(p >> 24)}; }
