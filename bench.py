@@ -7,18 +7,23 @@ accumulated into the RGBA32F framebuffer exactly like shaders/pathtrace.comp:122
 and environment are resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps 256 --warmup 8
-  python bench.py --gpus N ...          (self-launching: spawns one process per GPU on 127.0.0.1 and relays rank 0's line)
+  python bench.py --gpus N ...          (self-launching: spawns one process per GPU on 127.0.0.1 and relays rank 0's line; falls back to --single-process
+                                         when those ranks fail to come up)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N --single-process     (one process, N contexts, pt_comm_init_all)
+  python bench.py --from-gltf scene.glb ...     (the scene through libptmi's own importer: data = "gltf")
 
 With N > 1 the image tiles are sharded over the ranks (vk_raytrace_amd/shard.py); the ranks do not communicate while rendering and
-the single framebuffer gather -- libptmi's own RCCL path over xGMI, pt_gather_shards / pt_gather_finish -- happens after the timed loop (its
-time is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).  `ranks_seen` is
-ncclCommCount of that communicator.  Every rank binds its GPU through pt_create BEFORE any rendezvous, so a box with fewer than N
-devices fails with pt_create's device-count message.  The control plane (rendezvous of the launcher's ranks, barriers around the timed
-region, the MAX of the ranks' times, handing out the ncclUniqueId) is vk_raytrace_amd/rendezvous.py -- a Unix-domain socket between the
-ranks of this node; a rank imports nothing of torch, because the PyTorch wheel's bundled HIP / RCCL libraries break the system RCCL that
-libptmi opens (rendezvous.py).  Device work and the data-path collective are libptmi's; pt_synchronize is the device synchronisation that
-brackets the timed region.
+the single framebuffer gather -- libptmi's own RCCL path over xGMI, pt_gather_shards / pt_gather_finish -- happens outside the timed loop (its
+time is reported as gather_ms, like the reference metric which times the frame loop only - BASELINE.md section 2).  The communicator is built and the
+gather route agreed in a PREFLIGHT before anything is timed (RCCL calls under a watchdog; rank 0 prints the RCCL version, the route and every rank's
+time per frame to stderr); when RCCL cannot be brought up the shards travel through the control-plane socket instead and the line's `gather` field
+says so.  `ranks_seen` is ncclCommCount of the communicator.  Every rank binds its GPU through pt_create BEFORE any rendezvous, so a box with fewer
+than N devices fails with pt_create's device-count message.  The control plane (rendezvous of the launcher's ranks, barriers around the timed region,
+the MAX of the ranks' times, handing out the ncclUniqueId) is vk_raytrace_amd/rendezvous.py -- a Unix-domain socket between the ranks of this node;
+a rank imports nothing of torch, because the PyTorch wheel's bundled HIP / RCCL libraries break the system RCCL that libptmi opens (rendezvous.py).
+The image gathered after the FIRST timed window is what the parity leg compares: the line of an N > 1 run carries `parity`, `cpu_baseline` and
+`roofline` like the N = 1 line.  The JSON line is the last thing written to stdout.
 
 After the timed region (never part of `value`), rank 0 measures what the JSON line's evidence fields need, all in this run:
   calibration        pt_measure_peaks: the VALU-issue and HBM-streaming ceilings of this box
@@ -27,12 +32,12 @@ After the timed region (never part of `value`), rank 0 measures what the JSON li
                      standalone stage durations (HIP events on the launching stream, nothing overlapped)
   roofline           the stage with the largest standalone time: `achieved` / `frac` = SURVEY.md 8(d) ALGORITHMIC bytes per launch / its average
                      launch duration vs 8 TB/s (may exceed 1: most algorithmic bytes are served by L2 / Infinity Cache); `traffic` /
-                     `traffic_frac` = HBM bytes per launch from this round's PMC passes (profiles/r03_traffic.json, tools/pmc_passes.sh);
-                     `l2_*` = L2 requests of the same stage (profiles/r03_cache.json) against the 34.5 TB/s L2 ceiling
+                     `traffic_frac` = HBM bytes per launch from the newest round's PMC passes (profiles/rNN_traffic.json, tools/pmc_passes.sh);
+                     `l2_*` = L2 requests of the same stage (profiles/rNN_cache.json) against the 34.5 TB/s L2 ceiling
   hbm_measured       measured HBM bytes per sample x this run's rate
-  issue_roofline     VALU wave-instructions per sample (profiles/r03_valu.json, same PMC run) x this run's rate / the calibrated ceiling
+  issue_roofline     VALU wave-instructions per sample (profiles/rNN_valu.json, same PMC run) x this run's rate / the calibrated ceiling
   cpu_baseline       oracle/_ref (the reference's own pathtrace.comp compiled for the host, kind "reference") and the CPU oracle (the
-                     restatement, `port_value`) on a bounded sample of the same workload, N = 1 only
+                     restatement, `port_value`) on a bounded sample of the same workload, on rank 0; the same renders are the parity reference
 """
 import argparse
 import json
