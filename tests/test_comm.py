@@ -189,6 +189,8 @@ assert g.all_reduce([rank + 1.0, -rank], "max") == [float(world), 0.0]
 assert g.all_reduce([rank + 1.0, 2.0], "sum") == [world * (world + 1) / 2.0, 2.0 * world]
 blob = bytes(range(128)) if rank == 1 %% world else b"junk"
 assert g.broadcast_bytes(blob, 1 %% world) == bytes(range(128))
+parts = g.gather_bytes(bytes([rank]) * (rank + 1))   # the host route of bench.py's gather: every rank's shard on rank 0, in rank order
+assert parts == ([bytes([r]) * (r + 1) for r in range(world)] if rank == 0 else None)
 for _ in range(50):
     g.barrier()
 g.close()
@@ -198,9 +200,35 @@ print("ok", rank)
 
 @pytest.mark.parametrize("world", [1, 3])
 def test_local_group_control_plane(world, tmp_path):
-    """vk_raytrace_amd/rendezvous.py: the torch-free control plane of bench.py's ranks (barrier, MAX / SUM all-reduce, byte broadcast)."""
+    """vk_raytrace_amd/rendezvous.py: the torch-free control plane of bench.py's ranks (barrier, MAX / SUM all-reduce, byte broadcast, byte gather)."""
     procs = [subprocess.Popen([sys.executable, "-c", _GROUP % ROOT, str(r), str(world), f"test{os.getpid()}_{world}"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in reversed(range(world))]  # rank 0 (the server) starts last: the peers wait for it
     for p in procs:
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0 and out.startswith("ok"), (out, err)
+
+
+def test_bench_watchdog_and_stdout_contract():
+    """bench.py's guard around the RCCL calls of the preflight (a collective that never returns must not take the line with it) and the promise that the
+    JSON line is the LAST thing on stdout (RCCL prints a version banner through C stdio, which a pipe holds back until exit)."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ok, res = bench.with_timeout(lambda: 41 + 1, 5, "quick")
+    assert ok and res == 42
+    ok, res = bench.with_timeout(lambda: 1 / 0, 5, "raises")
+    assert not ok and "ZeroDivisionError" in res
+    t0 = time.monotonic()
+    ok, res = bench.with_timeout(lambda: time.sleep(30), 0.3, "pt_gather_shards")
+    assert not ok and "pt_gather_shards: no answer" in res and time.monotonic() - t0 < 5
+    code = ("import ctypes, json, os, sys\n"
+            "libc = ctypes.CDLL(None)\n"
+            "libc.printf(b'RCCL version : banner held back by C stdio\\n')\n"      # what librccl does at init
+            "ctypes.CDLL(None).fflush(None)\n"                                      # bench.py, before the line
+            "print(json.dumps({'value': 1})); sys.stdout.flush()\n"
+            "os.dup2(os.open(os.devnull, os.O_WRONLY), 1)\n"                        # bench.py, after the line
+            "libc.printf(b'late noise\\n')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == '{"value": 1}', (out.stdout, out.stderr)
