@@ -12,6 +12,7 @@
 #   tests[:<-k expression>]     pytest -m gpu
 #   smoke               __graft_entry__.smoke()
 #   pmc[:<frames>]      tools/pmc_passes.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
+#   binders[:<frames>[:<PT_TUNE>]]  tools/pmc_binders.sh passes -> binders.json (lane occupancy, I-cache, VMEM issue, waits per kernel)
 #   shards:<wl>:<steps> every rank's shard of N = 1, 2, 4, 8 on this one GPU (bench.py --emulate-shard R/N); max over ranks per N
 #   shardtune:<wl>:<steps>:<R/N>:<A>;<B>;...   one rank's shard under each PT_TUNE string, two alternating rounds
 #   sh:<command>        anything else
@@ -46,6 +47,7 @@ for step in "$@"; do
     tests)   if [ -n "$a" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$a" > $O/gputest.txt 2>&1; else timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; fi; tail -5 $O/gputest.txt | tee -a $O/log.txt ;;
     smoke)   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a $O/log.txt ;;
     pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_passes.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;
+    binders) PMC_FRAMES=${a:-64} PMC_TUNE=${b:-inflight=1,warm=0} timeout 1500 bash tools/pmc_binders.sh $TAG > $O/binders.txt 2>&1; cp gpurun_out/pmc_$TAG/binders.json $O/binders.json 2>/dev/null; tail -14 $O/binders.txt | tee -a $O/log.txt ;;
     shards)  for n in 1 2 4 8; do worst=0; for ((r = 0; r < n; r++)); do
                timeout 300 python bench.py --workload $a --emulate-shard $r/$n --steps $b --warmup 5 --no-cpu-baseline --no-profile --no-interactive > $O/shard_${a}_${r}of${n}_$b.json 2>/dev/null
                ms=$(python -c "import json; print(json.loads(open('$O/shard_${a}_${r}of${n}_$b.json').readline())['ms_per_step'])" 2>/dev/null || echo 0)
