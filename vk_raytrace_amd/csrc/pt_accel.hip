@@ -1518,30 +1518,6 @@ int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, Compact
   return bad[0] ? -1 : 0;
 }
 
-// WideNode -> QuadNode (pt_device.h): the same planes and child references, child by child
-__global__ void k_quad_nodes(uint32_t n, const WideNode* __restrict__ in, QuadNode* __restrict__ out)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if(i >= n * 4u)
-    return;
-  const WideNode& w = in[i >> 2];
-  const uint32_t  k = i & 3u;
-  auto            pick = [k](const float4& v) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; };
-  QuadNode::Child c;
-  c.lox = pick(w.minx[0]); c.loy = pick(w.miny[0]); c.loz = pick(w.minz[0]);
-  c.hix = pick(w.maxx[0]); c.hiy = pick(w.maxy[0]); c.hiz = pick(w.maxz[0]);
-  c.child = k == 0 ? w.child[0].x : k == 1 ? w.child[0].y : k == 2 ? w.child[0].z : w.child[0].w;
-  c._pad  = 0u;
-  out[i >> 2].c[k] = c;
-}
-int pt_quad_nodes(hipStream_t stream, uint32_t n, const WideNode* in, QuadNode* out)
-{
-  if(n == 0)
-    return 0;
-  k_quad_nodes<<<(n * 4u + 255) / 256, 256, 0, stream>>>(n, in, out);
-  return (hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -1;
-}
-
 // DeviceScene::shadeTris of a flat-format structure: per leaf slot the three vertices' attribute pairs, copied from where the record's instance and
 // primitive point
 __global__ void k_shade_tris(uint32_t n, const TriRec* __restrict__ tris, const InstanceRec* __restrict__ inst, const float4* __restrict__ vertices,

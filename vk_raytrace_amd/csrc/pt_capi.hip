@@ -42,8 +42,6 @@ struct pt_context {
   uint32_t nodeCapacity = 0;          // nodes dWide was sized for (two-level mode: the BLASes sit at their node bases)
   DevBuf   dCNodes;  // DeviceScene::cnodes (flat-format structures, PT_TUNE cnodes=1)
   bool     haveCNodes = false;
-  DevBuf   dQNodes;  // DeviceScene::qnodes (flat-format structures, PT_TUNE quad=1: the sub-group trace machine, pt_quad.h)
-  bool     haveQNodes = false;
   uint32_t numTris = 0, numInstances = 0, numBvhNodes = 0, numWideNodes = 0, numLights = 0;
   // two-level acceleration structure (pt_set_accel_mode): dWide / dTris / dAlphaRecs hold the concatenated BLASes, dTlas the instance hierarchy
   int      accelMode = PT_ACCEL_FLAT;
@@ -288,7 +286,6 @@ void refresh_scene_ptrs(pt_context* c)
   s.tris         = (const TriRec*)c->dTris.p;
   s.alphaRecs    = (const AlphaRec*)c->dAlphaRecs.p;
   s.cnodes       = c->haveCNodes ? (const CompactNode*)c->dCNodes.p : nullptr;
-  s.qnodes       = c->haveQNodes ? (const QuadNode*)c->dQNodes.p : nullptr;
   s.ctlas        = c->haveCNodes ? (const CompactNode*)c->dCTlas.p : nullptr;
   s.shadeTris    = c->haveShadeTris ? (const float4*)c->dShadeTris.p : nullptr;
   s.alphaMats    = (const AlphaMat*)c->dAlphaMats.p;
@@ -464,8 +461,6 @@ int build_tlas(pt_context* c)
 void build_cnodes_two_level(pt_context* c)
 {
   c->haveCNodes = false;
-  c->haveQNodes = false;  // the sub-group machine walks flat-format structures only
-  dev_free(c->dQNodes);
   if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
   {
     dev_free(c->dCNodes);
@@ -491,14 +486,6 @@ void build_cnodes_two_level(pt_context* c)
 void build_cnodes(pt_context* c, uint32_t n)
 {
   c->haveCNodes = false;
-  c->haveQNodes = false;
-  if(g_tuning.quad && n != 0 && dev_alloc(c, c->dQNodes, sizeof(QuadNode) * size_t(n)) == PT_OK)
-    c->haveQNodes = pt_quad_nodes(c->stream, n, (const WideNode*)c->dWide.p, (QuadNode*)c->dQNodes.p) == 0;
-  else
-  {
-    (void)hipGetLastError();
-    dev_free(c->dQNodes);
-  }
   if(!g_tuning.cnodes || n == 0)
   {
     dev_free(c->dCNodes);
@@ -758,7 +745,6 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     if(strstr(tune, "accel=two")) parsed.accelTwoLevel = 1;
     if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) parsed.mergeSingles = v;
     if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) parsed.cnodes = v;
-    if(const char* p = strstr(tune, "quad=")) if(sscanf(p, "quad=%d", &v) == 1) parsed.quad = v;
     if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) parsed.shadeTris = v;
     if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) parsed.tailBelow = v;
     if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) parsed.warm = v;
@@ -820,7 +806,7 @@ int pt_destroy(pt_context* c)
   CTX_CHECK(c);
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
-  DevBuf* all[] = {&c->dMatLines, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dQNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
+  DevBuf* all[] = {&c->dMatLines, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
                    &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
@@ -2376,7 +2362,7 @@ int pt_get_stats(pt_context* c, pt_Stats* out)
   s.numTlasNodes = c->numTlasNodes;
   s.batchFrames    = uint32_t(c->batchMax);
   s.framesInFlight = uint32_t(c->inflight);
-  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes + c->dCNodes.bytes + c->dQNodes.bytes + c->dCTlas.bytes + c->dShadeTris.bytes;
+  s.bytesAccel   = c->dBvh.bytes + c->dWide.bytes + c->dTris.bytes + c->dAlphaRecs.bytes + c->dTlas.bytes + c->dTlasLeaves.bytes + c->dInstTriBase.bytes + c->dCNodes.bytes + c->dCTlas.bytes + c->dShadeTris.bytes;
   uint64_t bytes = 0;
   const DevBuf* sb[] = {&c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dAlphaMats, &c->dAlphaMaps, &c->dEnv, &c->dEnvAccel,
                         &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase};

@@ -90,19 +90,6 @@ struct CompactNode {
 };
 #define CN_GRID_MAX 2047
 
-// The same node child by child, 128 B, for the sub-group trace machine (pt_quad.h; PT_TUNE quad=1): lane k of the four lanes that share a ray reads
-// the 32 bytes of child k -- two 16-byte requests per lane, the quad's 128 bytes contiguous -- and tests that one box.  The planes are the
-// WideNode's fp32 planes (same decisions as wide_node_step), same node numbering; an empty slot keeps its inverted box and BVH_NONE.
-struct QuadNode {
-  struct Child {
-    float    lox, loy, loz, hix;
-    float    hiy, hiz;
-    uint32_t child;  // as WideNode::child
-    uint32_t _pad;
-  } c[4];
-};
-static_assert(sizeof(QuadNode) == 128, "QuadNode is read as 4 x 2 aligned 16-byte quads");
-
 // ---- two-level acceleration structure (PT_ACCEL_TWO_LEVEL; reference: src/accelstruct.cpp:110-162) -----------------
 // One BLAS per prim-mesh in OBJECT space (its WideNodes and leaf records are shared by every instance of the mesh) and one TLAS over
 // the instances' world boxes.  DeviceScene::wide / tris / alphaRecs then hold the concatenated BLASes (child references and leaf slots
@@ -258,7 +245,6 @@ struct DeviceScene {
   const BvhNode*              bvh;   // binary LBVH (build product; traversed only when PT_BVH_WIDTH == 2)
   const WideNode*             wide;  // collapsed wide BVH
   const CompactNode*          cnodes;  // its nodes in the compact form (nullptr: none)
-  const QuadNode*             qnodes;  // its nodes child by child for the sub-group trace machine (pt_quad.h; nullptr: none)
   const float4*               shadeTris;  // flat structure only (else nullptr): per leaf slot ONE 128-byte line (PT_SHADE_REC_QUADS float4): the six float4 of the
                                           // triangle's three pt_VertexAttributes, then (instance, primitive) -- everything k_shade needs of the hit
                                           // triangle in one aligned line instead of a 48-byte TriRec (1.4 lines) + 96 bytes at a 96-byte stride (1.7 lines).  Was: next to

@@ -64,7 +64,6 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
 // WideNode -> CompactNode for the first n nodes; -1 when a node cannot be represented (the caller keeps the WideNode walk)
 void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, const InstanceRec* inst, const float4* vertices, const uint32_t* indices, float4* out);
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out, float* reachOut = nullptr);  // reachOut: max |p| + 2047 step over the nodes
-int pt_quad_nodes(hipStream_t stream, uint32_t n, const WideNode* in, QuadNode* out);  // WideNode -> QuadNode for the first n nodes (pt_quad.h)
 // ... over numRanges node ranges given as (base, count) pairs
 int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint32_t numRanges, const WideNode* in, CompactNode* out);
 int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
@@ -150,8 +149,6 @@ struct PtTuning {
   int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
   int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
   int shadeTris            = 1;    // flat-format structures: per-slot shading line for k_shade: the triangle's vertex attributes + (instance, primitive), 128 B per triangle (0: none)
-  int quad                 = 0;    // flat-format structures: the staged closest-hit / shadow machines give every ray FOUR lanes (pt_quad.h k_closest_q / k_shadow_q on QuadNodes);
-                                   // round-6 experiment, measured in profiles/r06_quad_*; 0: one ray per lane (k_closest_p / k_shadow_p)
   int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (measurement; see pt_device.h CompactNode)
   int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
   int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)

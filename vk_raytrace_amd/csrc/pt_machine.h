@@ -188,17 +188,9 @@ PT_DEV void lane_leaf(const DeviceScene& S, TraceLane& L, uint32_t* lds, uint32_
 #endif
   lane_leaf_with<SHADOW, TWO>(S, L, slot, tr, ar, lds, spill);
 }
-// the triangle step on records already in registers; `pop` takes the lane to its next stack entry (per-lane stack: lane_pop; the sub-group machine of
-// pt_quad.h has a stack per ray)
-template <bool SHADOW, bool TWO, class Pop>
-PT_DEV void lane_leaf_core(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, Pop&& pop);
+// the triangle step on records already in registers
 template <bool SHADOW, bool TWO>
 PT_DEV void lane_leaf_with(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, uint32_t* lds, uint32_t* spill)
-{
-  lane_leaf_core<SHADOW, TWO>(S, L, slot, tr, ar, [&]() { lane_pop<TWO>(L, lds, spill); });
-}
-template <bool SHADOW, bool TWO, class Pop>
-PT_DEV void lane_leaf_core(const DeviceScene& S, TraceLane& L, uint32_t slot, const TriRec& tr, const AlphaRec& ar, Pop&& pop)
 {
   const uint32_t wbits = __float_as_uint(tr.p0w.w);
   const uint32_t flags = wbits >> 29;
@@ -250,7 +242,7 @@ PT_DEV void lane_leaf_core(const DeviceScene& S, TraceLane& L, uint32_t slot, co
       }
     }
   }
-  pop();
+  lane_pop<TWO>(L, lds, spill);
 }
 
 // Wave-uniform ray supply: a wave reserves PT_CHUNK consecutive queue entries with one atomic and hands them to

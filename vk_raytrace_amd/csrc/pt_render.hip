@@ -38,7 +38,6 @@
 #include "pt_sky.h"
 #include "pt_machine.h"
 #include "pt_packet.h"
-#include "pt_quad.h"
 #include "pt_settle.h"
 #include "pt_shade.h"
 
@@ -574,178 +573,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
     atomicAdd(&g_hist[6][4], hBoth); atomicAdd(&g_hist[6][5], hInnerIt); atomicAdd(&g_hist[6][6], hLeafIt);
   }
 #endif
-  stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
-  wave_add(&rb.counters->shadowRays, nRays);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-}
-
-// ---- the sub-group trace machine (pt_quad.h): persistent wavefronts of 16 rays, four lanes per ray --------------------------------------------
-// The loop of k_closest_p / k_shadow_p: a service round settles finished rays and refills idle QUADS, the run loop alternates node visits (one child
-// box per lane) and triangle visits.  The four lanes of a quad hold identical ray state; the quad leader (lane & 3 == 0) does the path-state stores,
-// the queue appends and the counting.  Flat-format structures only (PT_TUNE quad=1; measured in profiles/r06_quad_*).
-#ifndef PT_QUAD_WAVES
-#define PT_QUAD_WAVES 8  // 64 VGPRs
-#endif
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_QUAD_WAVES) k_closest_q(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, int bounce, int minRun, int chunk, int cntIn, int cntChunk)
-{
-  __shared__ uint32_t stack[QUAD_STACK * QUAD_RAYS];
-  uint32_t*           C     = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      count = C[cntIn];
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * QUAD_RAYS >= count)
-    return;
-  const uint32_t lane = threadIdx.x & 63u, k = lane & 3u;
-  const bool     leader = k == 0u;
-  uint32_t*      qstack = stack + (lane >> 2);
-  TraceLane      L;
-  RaySupply      rs;
-  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
-  uint32_t pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
-  bool     alive = false;
-  L.done         = true;
-  L.cur          = 0;
-  for(;;)
-  {
-    // ---- service (see k_closest_p)
-    if(alive && L.done)
-    {
-      bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
-        lane_begin_count<false>(L);
-      else
-      {
-        if(!fallback)
-        {
-          uint32_t nDraw = L.cnt;
-          if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
-            ++nDraw;
-          uint32_t s2 = seed;
-          if(consume_rejected_draws(s2, nDraw))
-          {
-            if(leader)
-            {
-              store_hit(rb, pslot, L.bslot, L.bw, false, L.bt, L.bu, L.bv);
-              if(nDraw)
-                rb.ps.rayD[pslot].w = __uint_as_float(s2);
-              nAlpha += nDraw;
-            }
-          }
-          else
-            fallback = true;
-        }
-        if(fallback && leader)
-          enqueue(rb.queueX, &C[CNT_X_CLOSEST], pslot);
-        alive = false;
-      }
-    }
-    const uint32_t qi = quad_first(supply_next(rs, &C[cntChunk], count, !alive && leader));
-    if(qi != 0xffffffffu)
-    {
-      pslot           = queueIn[qi];
-      const float4 dw = rb.ps.rayD[pslot];
-      seed            = __float_as_uint(dw.w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(dw), PT_INFINITY, S.numTris == 0);
-      alive = true;
-      nRays += leader ? 1u : 0u;
-    }
-    if(!__ballot(alive))
-      break;
-    // ---- run
-    const int target = rs.more ? minRun : 1;
-    while(__popcll(__ballot(!L.done)) >= target)
-    {
-      if(!L.done && !(L.cur & BVH_LEAF))
-        quad_inner<false>(S, L, k, qstack, rb.counters);
-      if(!L.done && (L.cur & BVH_LEAF))
-        quad_leaf<false>(S, L, qstack);
-    }
-  }
-  wave_add(&rb.counters->closestRays, nRays);
-  wave_add(&rb.counters->alphaTests, nAlpha);
-}
-
-__global__ void __launch_bounds__(TRACE_BLOCK, PT_QUAD_WAVES) k_shadow_q(DeviceScene S, RenderBuffers rb, const uint32_t* __restrict__ queueIn, uint32_t* __restrict__ queueOut, int bounce, int lastBounce, int minRun, int chunk,
-                                                                        int variant, int cntIn, int cntChunk)
-{
-  __shared__ uint32_t stack[QUAD_STACK * QUAD_RAYS];
-  __shared__ uint32_t stage[STAGE_CAP];
-  uint32_t            nStage = 0;
-  uint32_t*           C      = rb.counts + bounce * CNT_STRIDE;
-  const uint32_t      count  = C[cntIn];
-  if(blockIdx.x > 0 && (unsigned long long)blockIdx.x * QUAD_RAYS >= count)
-    return;
-  const uint32_t lane = threadIdx.x & 63u, k = lane & 3u;
-  const bool     leader = k == 0u;
-  uint32_t*      qstack = stack + (lane >> 2);
-  TraceLane      L;
-  RaySupply      rs;
-  rs.chunk = max(uint32_t(chunk), min(2048u, (count / (gridDim.x * 8u)) & ~63u));
-  uint32_t pslot = 0, seed = 0, nRays = 0, nAlpha = 0;
-  bool     alive = false;
-  L.done         = true;
-  L.cur          = 0;
-  for(;;)
-  {
-    // ---- service (see k_shadow_p)
-    bool survivor = false;
-    if(alive && L.done)
-    {
-      bool fallback = (L.flags & TF_SAW_FRAC) != 0;
-      if(!fallback && L.pass == 0 && (L.flags & TF_SAW_ZERO) && !pass_a_settles(L.bslot, L.bt, L.zeroMaxT, L.zeroMaxT2, L.zeroMaxT3, L.cnt))
-        lane_begin_count<false>(L);
-      else
-      {
-        bool inShadow = false;
-        if(!fallback)
-        {
-          uint32_t nDraw = L.cnt;
-          if(L.bslot != BVH_NONE && !((L.bw >> 29) & TRI_OPAQUE))
-            ++nDraw;
-          uint32_t s2 = seed;
-          if(consume_rejected_draws(s2, nDraw))
-          {
-            seed     = variant == PT_VARIANT_RTX ? seed : s2;
-            inShadow = L.bslot != BVH_NONE;
-            nAlpha += leader ? nDraw : 0u;
-          }
-          else
-            fallback = true;
-        }
-        if(leader)
-        {
-          if(fallback)
-            enqueue(rb.queueX2, &C[CNT_X_SHADOW], pslot);
-          else
-            survivor = finish_bounce_core(rb, pslot, inShadow, seed) && !lastBounce;
-        }
-        alive = false;
-      }
-    }
-    stage_push(stage, nStage, survivor, pslot, queueOut, &C[CNT_STRIDE + CNT_IN]);
-    const uint32_t qi = quad_first(supply_next(rs, &C[cntChunk], count, !alive && leader));
-    if(qi != 0xffffffffu)
-    {
-      pslot = queueIn[qi];
-      seed  = __float_as_uint(rb.ps.rayD[pslot].w);
-      lane_begin(L, xyz(rb.ps.rayO[pslot]), xyz(rb.ps.neeDir[pslot]), rb.ps.absorb[pslot].w, S.numTris == 0);
-      alive = true;
-      nRays += leader ? 1u : 0u;
-    }
-    if(!__ballot(alive))
-      break;
-    // ---- run
-    const int target = rs.more ? minRun : 1;
-    while(__popcll(__ballot(!L.done)) >= target)
-    {
-      if(!L.done && !(L.cur & BVH_LEAF))
-        quad_inner<false>(S, L, k, qstack, rb.counters);
-      if(!L.done && (L.cur & BVH_LEAF))
-      {
-        quad_leaf<false>(S, L, qstack);
-        if(S.allOpaque && L.bslot != BVH_NONE)
-          L.done = true;
-      }
-    }
-  }
   stage_flush(stage, nStage, queueOut, &C[CNT_STRIDE + CNT_IN]);
   wave_add(&rb.counters->shadowRays, nRays);
   wave_add(&rb.counters->alphaTests, nAlpha);
@@ -1356,9 +1183,6 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
-  const bool     quad      = !TWO && g_tuning.quad && scene.qnodes;  // four lanes per ray (pt_quad.h): 16 rays per wavefront, 8 wavefronts per SIMD
-  const uint32_t wavesQ    = (n + QUAD_RAYS - 1) / QUAD_RAYS;
-  const uint32_t gridQuad  = wavesQ < 8192u ? wavesQ : 8192u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the staged machine kernels; no packet stage, no fused stage, no k_tail
   // measured (profiles/r05a_*, r05b_*, r05c_*): serialised, the fused launch takes exactly the time of the two launches it replaces (21.3 ms per 32-frame
   // batch either way) and k_shade reads a hit queue scrambled by two traversals instead of one (+6 %): -4 % on batches, +2.5 % on a frame the host waits for
@@ -1402,13 +1226,8 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
             const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
             const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
             k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
-            if(quad)
-              k_closest_q<<<gridQuad, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
-            else
-              k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
           }
-          else if(quad)
-            k_closest_q<<<gridQuad, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
           else
             k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
           k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
@@ -1435,8 +1254,6 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
           pt_timers_begin(tm, stream, 3);
           if(heat)
             k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
-          else if(quad)
-            k_shadow_q<<<gridQuad, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           else
             k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
