@@ -436,8 +436,13 @@ def with_timeout(fn, seconds, what):
     t.start()
     t.join(seconds)
     if t.is_alive():
-        return False, f"{what}: no answer after {seconds:.0f} s"
+        # the helper thread is still INSIDE the call (and inside the pt_context it was given): that context must not be touched again
+        return False, TimedOut(f"{what}: no answer after {seconds:.0f} s")
     return ("e" not in box), box.get("e", box.get("v"))
+
+
+class TimedOut(str):
+    """error text of a with_timeout() call whose helper thread never came back: the objects it was using are poisoned"""
 
 
 def single_process(args):
@@ -560,7 +565,7 @@ def multi_process(args, rank, local_rank, world):
     # ---- the one collective of the path, set up and tried BEFORE anything is timed (preflight): libptmi's own RCCL gather behind the C ABI
     # (pt_gather_shards / pt_gather_finish).  If the communicator cannot be built, or the first gather does not come back, every rank agrees on the
     # host route instead (the shards travel through the control-plane socket): slower, untimed either way, and the line says which one it was.
-    gatherer, how = None, "none (one rank)"
+    gatherer, how, poisoned = None, "none (one rank)", False
     if world > 1 or force_dist:
         ok, res = (False, "PT_BENCH_SAME_DEVICE: two ranks on one device") if (same_device and world > 1) else with_timeout(lambda: shard.NativeGather(rank, world, local_rank, dist), 120, "pt_comm_init_rank")
         all_ok = dist.all_reduce([1.0 if ok else 0.0], "sum")[0] == world
@@ -574,7 +579,9 @@ def multi_process(args, rank, local_rank, world):
 
     def gather():
         """the full image on rank 0 (None elsewhere) and the milliseconds it took"""
-        nonlocal gatherer, how
+        nonlocal gatherer, how, poisoned
+        if poisoned:
+            return None, 0.0
         r.synchronize()
         if dist is not None:
             dist.barrier()
@@ -583,8 +590,15 @@ def multi_process(args, rank, local_rank, world):
             return r.read_accum(), (time.perf_counter() - t0) * 1e3
         if gatherer is not None:
             ok, res = with_timeout(lambda: gatherer.gather(r), 120, "pt_gather_shards")
-            if dist.all_reduce([1.0 if ok else 0.0], "sum")[0] == world:
+            votes = dist.all_reduce([1.0 if ok else 0.0, 1.0 if isinstance(res, TimedOut) else 0.0], "sum")
+            if votes[0] == world:
                 return res, (time.perf_counter() - t0) * 1e3
+            if votes[1] > 0:
+                # a rank's helper thread is still inside pt_gather_shards / RCCL on its context: pt_context is not thread-safe, so no rank reads an image
+                # (the collective may still be writing it) -- the line is emitted with the gather error and without the parity leg
+                poisoned = True
+                gatherer, how = None, f"FAILED: pt_gather_shards did not return on {int(votes[1])} rank(s) (contexts poisoned; no image, no parity): {res if not ok else 'on another rank'}"
+                return None, (time.perf_counter() - t0) * 1e3
             gatherer, how = None, f"host (control-plane socket); the RCCL gather failed: {res if not ok else 'on another rank'}"
         mine = r.read_accum()  # this rank's pixels are valid in it
         ids = shard.local_pixel_ids(W, H, shard_rank, shard_n)
@@ -648,7 +662,7 @@ def multi_process(args, rank, local_rank, world):
             dist.close()
         return None
     return {"wl": wl, "W": W, "H": H, "windows": windows, "img_first": img_first, "img": img, "gather_ms": gather_ms, "stats": stats, "ranks_seen": ranks_seen, "t_setup": t_setup,
-            "integral": integral, "cam": cam, "renderer": r, "st": st, "frame": frame, "per_rank_ms": per_rank_ms, "gather": how, "shard": (shard_rank, shard_n),
+            "integral": integral, "cam": cam, "renderer": r, "st": st, "frame": frame, "per_rank_ms": per_rank_ms, "gather": how, "poisoned": poisoned, "shard": (shard_rank, shard_n),
             "cleanup": (lambda: (dist.barrier(), dist.close())) if dist is not None else (lambda: None)}
 
 
@@ -760,6 +774,12 @@ def main():
 
     # ---- measurement passes after the timed region (never part of `value`) ---------------------------------------------------------
     # (1) ceilings measured on this box: VALU issue (independent wave64 v_fmac_f32, 8 waves/SIMD on every CU) and HBM streaming
+    if job.get("poisoned"):
+        # a collective never returned on this context (helper thread still inside it): nothing below may touch the renderer again -- the line goes out as it is
+        out["gather_error"] = job.get("gather")
+        print(json.dumps(out))
+        sys.stdout.flush()
+        os._exit(4)
     peaks = r.measure_peaks()
     out["calibration"] = {"valu_G_wave_instr_per_s": peaks["valuWaveInstrPerSec"] / 1e9, "hbm_copy_GBps": peaks["hbmCopyBytesPerSec"] / 1e9,
                           "hbm_read_GBps": peaks["hbmReadBytesPerSec"] / 1e9, "compute_units": peaks["computeUnits"], "clock_MHz": peaks["clockMHz"],

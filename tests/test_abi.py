@@ -92,3 +92,32 @@ def test_product_never_imports_the_oracle():
                 for line in txt.splitlines():
                     if "oracle" in line and ("#include" in line or "import" in line):
                         raise AssertionError(f"{f}: {line}")
+
+
+def _parse_tuning(s):
+    L = capi.lib()
+    out = (C.c_int * 32)()
+    unk = C.create_string_buffer(512)
+    L.pt_debug_parse_tuning.restype = C.c_int
+    n = L.pt_debug_parse_tuning(s.encode() if s is not None else None, out, 32, unk, 512)
+    keys = ["stateMB", "stateGB", "packetClosest", "mergeSingles", "cnodes", "shadeTris", "tail", "warm", "texTile", "texGroups", "regen", "packetTwo", "blasWorkers", "batch",
+            "inflight", "displaySlots", "bands", "bandTiles", "fuse", "build", "accel"]
+    assert n == len(keys)
+    return dict(zip(keys, list(out)[:n])), unk.value.decode()
+
+
+def test_pt_tune_is_parsed_key_by_key():
+    """PT_TUNE (read by pt_create into the CONTEXT's knobs since round 6): exact key matches, every knob reachable, unknown tokens reported -- the removed knobs
+    (waves, refill, chunk, packetWaves, ...) among them, and "waves=" no longer matches inside "packetWaves="."""
+    d, unk = _parse_tuning(None)
+    assert unk == "" and (d["tail"], d["batch"], d["inflight"], d["build"], d["accel"], d["fuse"], d["bands"], d["bandTiles"]) == (65536, 64, 4, 3, 0, 1, 3, 64)
+    d, unk = _parse_tuning("tail=0, batch=4,build=sah,accel=two,inflight=3,stateMB=12,packetClosest=2,fuse=2")
+    assert unk == "" and (d["tail"], d["batch"], d["build"], d["accel"], d["inflight"], d["stateMB"], d["packetClosest"], d["fuse"]) == (0, 4, 1, 1, 3, 12, 2, 2)
+    d, unk = _parse_tuning("packetWaves=7,waves=16,refill=8,chunk=64,bogus,fuse=x,build=quick,tail=5")
+    assert unk == "packetWaves=7,waves=16,refill=8,chunk=64,bogus,fuse=x,build=quick" and d["tail"] == 5 and d["fuse"] == 1 and d["build"] == 3
+    for k, v in (("build=lbvh", 0), ("build=sah", 1), ("build=ploc", 2), ("build=sahdev", 3)):
+        assert _parse_tuning(k)[0]["build"] == v
+    assert _parse_tuning("bandTiles=0")[0]["bandTiles"] == 1
+    every = "stateMB=1,stateGB=2,packetClosest=3,mergeSingles=0,cnodes=0,shadeTris=0,tail=7,warm=0,texTile=0,texGroups=0,regen=0,packetTwo=0,blasWorkers=2,batch=9,inflight=2,displaySlots=1,bands=5,bandTiles=6,fuse=0"
+    d, unk = _parse_tuning(every)
+    assert unk == "" and [d[t.split("=")[0]] for t in every.split(",")] == [int(t.split("=")[1]) for t in every.split(",")]

@@ -1061,7 +1061,7 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
 // dProxies (may be null): the primitives are given as ready-made records instead of (instance, triangle) pairs -- the TLAS of the two-level
 // structure is built over one "diagonal" record per instance (p0 = box min, e1 = box extent, e2 = 0: its bounding box is the instance's box).
 // scratch (may be null): temporaries come out of the caller's arena instead of one device allocation each (a scene of hundreds of BLASes).
-int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
+int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
                    TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen, const TriRec* dProxies,
                    PtScratch* scratch)
 {
@@ -1113,9 +1113,9 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
   }
   else
     k_world_tris<<<G, B, 0, stream>>>(n, dInst, numInst, dVertices, dIndices, dUnsorted, dAlphaUnsorted, dCen, dBounds);
-  sah = g_tuning.sahBuild == 1 && n >= 2;  // sahBuild: 0 device LBVH (Karras), 1 host SAH topology, 2 device PLOC, 3 device binned SAH (default)
-  ploc = g_tuning.sahBuild == 2 && n >= 2;
-  sahDev = g_tuning.sahBuild == 3 && n >= 2;
+  sah = tune.sahBuild == 1 && n >= 2;  // sahBuild: 0 device LBVH (Karras), 1 host SAH topology, 2 device PLOC, 3 device binned SAH (default)
+  ploc = tune.sahBuild == 2 && n >= 2;
+  sahDev = tune.sahBuild == 3 && n >= 2;
   if(sahDev)
   {
     // ---- device binned SAH (pt_sahdev.h): level-synchronous; the number of open nodes comes back to the host between levels
@@ -1231,7 +1231,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
     bool done = false;
     if(okAlloc)
     {
-      const int radius = g_tuning.plocRadius < 1 ? 1 : (g_tuning.plocRadius > 64 ? 64 : g_tuning.plocRadius);
+      const int radius = PT_PLOC_RADIUS;
       (void)hipMemsetAsync(dCnt, 0, 8, stream);
       k_ploc_init<<<G, B, 0, stream>>>(n, dLeafLo, dLeafHi, cidA, cloA, chiA);
       uint32_t m = n;
@@ -1244,7 +1244,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
         const uint32_t g = (m + 255) / 256, nb = (m + 1023) / 1024;
         // the top of the tree decides how many subtrees a ray enters: once few clusters are left every cluster considers ALL others
         // (exact agglomerative clustering), not just its Morton neighbourhood
-        const int rad = m <= uint32_t(g_tuning.plocFull) ? int(m) : radius;
+        const int rad = radius;
         k_ploc_nn<<<g, 256, 0, stream>>>(m, rad, cloA, chiA, dNn);
         k_ploc_merge<<<g, 256, 0, stream>>>(m, n - 1, dNn, cidA, cloA, chiA, dValid, dCnt, dChildL, dChildR, dParI, dParL, dNodeLo, dNodeHi);
         k_ploc_scan_blocks<<<nb, 1024, 0, stream>>>(m, dValid, dPos, dBlockSum);
@@ -1277,7 +1277,7 @@ int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numIns
       k_hierarchy<<<G, B, 0, stream>>>(int(n), dKeysA, dChildL, dChildR, dParI, dParL);
     if(!ploc)  // PLOC wrote the inner boxes while merging
       k_refit<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
-    for(int pass = 0; pass < g_tuning.rotatePasses && !sah; ++pass)
+    for(int pass = 0; pass < PT_ROTATE_PASSES && !sah; ++pass)
     {
       (void)hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream);
       k_rotate<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
@@ -1325,7 +1325,7 @@ fail:
 // ---- two-level structure: the builds -------------------------------------------------------------------------------------------------
 // Every BLAS is an ordinary pt_accel_build over ONE pseudo-instance with the identity transform (object space), written at its bases in the
 // shared arrays; then its leaf records are turned into vertex form and its references made global.
-int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
+int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
                   char* err, size_t errLen)
 {
   if(numBlas == 0)
@@ -1366,7 +1366,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
   // A build is a chain of small level-synchronous launches with a host round trip per level: one mesh alone leaves the GPU and the host idle
   // most of the time.  A few host threads, each with its own stream, arena and binary-node scratch, take the meshes from a shared counter
   // (largest first would balance better; the meshes of a scene are usually of similar size).
-  const unsigned       numWorkers = std::max(1u, std::min(std::min(numBlas, 16u), uint32_t(g_tuning.blasWorkers > 0 ? g_tuning.blasWorkers : 1)));
+  const unsigned       numWorkers = std::max(1u, std::min(std::min(numBlas, 16u), uint32_t(tune.blasWorkers > 0 ? tune.blasWorkers : 1)));
   std::atomic<uint32_t> next{0};
   std::atomic<int>      failed{0};
   std::mutex            errLock;
@@ -1395,7 +1395,7 @@ int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const 
         break;
       PtBlasDesc&    d = blas[b];
       const uint32_t n = d.triCount;
-      if(pt_accel_build(ws, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, msg, sizeof(msg), nullptr, &arena) != 0)
+      if(pt_accel_build(ws, tune, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, msg, sizeof(msg), nullptr, &arena) != 0)
       {
         ok = false;
         break;
@@ -1558,7 +1558,7 @@ __global__ void k_merged_identity(uint32_t n, TriRec* __restrict__ tris, const u
   tris[i].p0w.w    = __uint_as_float((w & ~TRI_INDEX_MASK) | (worldBase[j] + prim));
   tris[i].e1n.w    = __uint_as_float(ids[j]);
 }
-int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
+int pt_merged_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
                     const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide, uint32_t slotBase, uint32_t nodeBase, uint32_t* numWideOut, float* boxOut6, char* err,
                     size_t errLen)
 {
@@ -1589,7 +1589,7 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
     snprintf(err, errLen, "merged BLAS build: upload failed");
     goto done;
   }
-  if(pt_accel_build(stream, dInst, numInst, dVertices, dIndices, numTris, dTris + slotBase, dAlpha + slotBase, dNodes, dWide + nodeBase, numWideOut, err, errLen, nullptr, &arena) != 0)
+  if(pt_accel_build(stream, tune, dInst, numInst, dVertices, dIndices, numTris, dTris + slotBase, dAlpha + slotBase, dNodes, dWide + nodeBase, numWideOut, err, errLen, nullptr, &arena) != 0)
     goto done;
   k_merged_identity<<<(numTris + 255) / 256, 256, 0, stream>>>(numTris, dTris + slotBase, dIds, dIds + numInst);
   k_blas_rebase<<<(*numWideOut + 255) / 256, 256, 0, stream>>>(*numWideOut, dWide + nodeBase, nodeBase, slotBase);
@@ -1619,7 +1619,7 @@ done:
   return rc;
 }
 
-int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
+int pt_tlas_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
                   const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen,
                   const float* mergedBox, uint32_t mergedNodeBase)
 {
@@ -1654,7 +1654,7 @@ int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* 
       goto done;
     }
   }
-  if(pt_accel_build(stream, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, numWideOut, err, errLen, dProx, nullptr) != 0)
+  if(pt_accel_build(stream, tune, nullptr, 0, nullptr, nullptr, n, dLeafOrder, dAlpha, dNodes, dTlasOut, numWideOut, err, errLen, dProx, nullptr) != 0)
     goto done;
   k_tlas_leaves<<<(n + 255) / 256, 256, 0, stream>>>(n, dLeafOrder, dInst, dInstNodeBase, dInstPad, dLeavesOut, mergedNodeBase);
   if(hipMemcpyAsync(rootOut, dNodes, sizeof(BvhNode), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess)

@@ -4,6 +4,7 @@
 // Renderer implementations (src/rayquery.cpp, src/rtx_pipeline.cpp) -- behind one opaque pt_context.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -27,6 +28,7 @@ struct DevBuf {
 }  // namespace
 
 struct pt_context {
+  PtTuning    tune;  // launch-policy knobs of THIS context (PT_TUNE at pt_create)
   int         device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -133,8 +135,11 @@ struct pt_context {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     err = buf;
+    if(code == PT_ERR_HIP)
+      countsDirty = true;  // a launch sequence may have died before its k_accumulate cleared the per-bounce counters: flush_pending repairs them first
     return code;
   }
+  bool countsDirty = false;
 };
 
 #define CTX_CHECK(ctx)       \
@@ -439,7 +444,7 @@ int build_tlas(pt_context* c)
   auto    t0 = std::chrono::steady_clock::now();
   char    msg[256];
   BvhNode root{};
-  if(pt_tlas_build(c->stream, (const InstanceRec*)c->dInstances.p, (const uint32_t*)c->dActive.p, c->numActive, (const uint32_t*)c->dInstNodeBase.p, (const float*)c->dInstPad.p,
+  if(pt_tlas_build(c->stream, c->tune, (const InstanceRec*)c->dInstances.p, (const uint32_t*)c->dActive.p, c->numActive, (const uint32_t*)c->dInstNodeBase.p, (const float*)c->dInstPad.p,
                    (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (WideNode*)c->dTlas.p, (TlasLeaf*)c->dTlasLeaves.p, &root, &c->numTlasNodes, msg, sizeof(msg),
                    c->mergedTris ? c->mergedBox : nullptr, 0u) != 0)
     return c->fail(PT_ERR_HIP, "TLAS build: %s", msg);
@@ -461,7 +466,7 @@ int build_tlas(pt_context* c)
 void build_cnodes_two_level(pt_context* c)
 {
   c->haveCNodes = false;
-  if(!g_tuning.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
+  if(!c->tune.cnodes || c->nodeCapacity == 0 || c->numTlasNodes == 0)
   {
     dev_free(c->dCNodes);
     dev_free(c->dCTlas);
@@ -486,7 +491,7 @@ void build_cnodes_two_level(pt_context* c)
 void build_cnodes(pt_context* c, uint32_t n)
 {
   c->haveCNodes = false;
-  if(!g_tuning.cnodes || n == 0)
+  if(!c->tune.cnodes || n == 0)
   {
     dev_free(c->dCNodes);
     return;
@@ -502,7 +507,7 @@ void build_cnodes(pt_context* c, uint32_t n)
 void build_shade_tris(pt_context* c, uint32_t n)
 {
   c->haveShadeTris = false;
-  if(!g_tuning.shadeTris || n == 0)
+  if(!c->tune.shadeTris || n == 0)
   {
     dev_free(c->dShadeTris);
     return;
@@ -541,7 +546,7 @@ int build_merged(pt_context* c)
     sub.push_back(I);
   }
   char msg[256];
-  if(pt_merged_build(c->stream, sub.data(), c->hMerged.data(), worldBase.data(), uint32_t(sub.size()), n, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p,
+  if(pt_merged_build(c->stream, c->tune, sub.data(), c->hMerged.data(), worldBase.data(), uint32_t(sub.size()), n, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p,
                      (AlphaRec*)c->dAlphaRecs.p, (WideNode*)c->dWide.p, 0u, 0u, &c->mergedWide, c->mergedBox, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel (two-level, merged structure): %s", msg);
   return PT_OK;
@@ -561,7 +566,7 @@ int build_two_level(pt_context* c)
   c->mergedTris = 0;
   c->mergedOnly = false;
   std::vector<char> isMerged(inst.size(), 0);
-  if(g_tuning.mergeSingles)
+  if(c->tune.mergeSingles)
   {
     std::map<int32_t, uint32_t> uses;
     for(const InstanceRec& I : inst)
@@ -605,7 +610,7 @@ int build_two_level(pt_context* c)
   dev_free(c->dBvh);  // the binary nodes are a build temporary here
   auto t0 = std::chrono::steady_clock::now();
   char msg[256];
-  if(pt_blas_build(c->stream, blas.data(), uint32_t(blas.size()), (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p,
+  if(pt_blas_build(c->stream, c->tune, blas.data(), uint32_t(blas.size()), (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p,
                    (WideNode*)c->dWide.p, msg, sizeof(msg)) != 0)
     return c->fail(PT_ERR_HIP, "pt_build_accel (two-level): %s", msg);
   if((rc = build_merged(c)) != PT_OK)
@@ -684,6 +689,87 @@ void pt_timers_collect(StageTimers* t)
   t->npend = 0;
 }
 
+// PT_TUNE -> PtTuning, key by key (pt_internal.h)
+void pt_parse_tuning(const char* tune, PtTuning& t, std::string& unknown)
+{
+  if(!tune)
+    return;
+  struct Key { const char* name; int PtTuning::*field; };
+  static const Key keys[] = {{"stateMB", &PtTuning::stateMB}, {"stateGB", &PtTuning::stateGB}, {"packetClosest", &PtTuning::packetClosestBounces}, {"mergeSingles", &PtTuning::mergeSingles},
+                             {"cnodes", &PtTuning::cnodes}, {"shadeTris", &PtTuning::shadeTris}, {"tail", &PtTuning::tailBelow}, {"warm", &PtTuning::warm}, {"texTile", &PtTuning::texTile},
+                             {"texGroups", &PtTuning::texGroups}, {"regen", &PtTuning::regen}, {"packetTwo", &PtTuning::packetTwo}, {"blasWorkers", &PtTuning::blasWorkers},
+                             {"batch", &PtTuning::batch}, {"inflight", &PtTuning::framesInFlight}, {"displaySlots", &PtTuning::displaySlots}, {"bands", &PtTuning::bands},
+                             {"bandTiles", &PtTuning::bandTiles}, {"fuse", &PtTuning::fuse}};
+  const std::string all(tune);
+  size_t            at = 0;
+  while(at <= all.size())
+  {
+    size_t end = all.find(',', at);
+    if(end == std::string::npos)
+      end = all.size();
+    std::string tok = all.substr(at, end - at);
+    at              = end + 1;
+    while(!tok.empty() && (tok.front() == ' ' || tok.front() == '\t'))
+      tok.erase(tok.begin());
+    while(!tok.empty() && (tok.back() == ' ' || tok.back() == '\t'))
+      tok.pop_back();
+    if(tok.empty())
+      continue;
+    const size_t      eq  = tok.find('=');
+    const std::string key = tok.substr(0, eq), val = eq == std::string::npos ? std::string() : tok.substr(eq + 1);
+    bool              ok  = false;
+    if(key == "build")
+    {
+      ok = true;
+      if(val == "lbvh") t.sahBuild = 0;
+      else if(val == "sah") t.sahBuild = 1;
+      else if(val == "ploc") t.sahBuild = 2;
+      else if(val == "sahdev") t.sahBuild = 3;
+      else ok = false;
+    }
+    else if(key == "accel")
+    {
+      ok = val == "two" || val == "flat";
+      if(ok)
+        t.accelTwoLevel = val == "two" ? 1 : 0;
+    }
+    else
+      for(const Key& k : keys)
+        if(key == k.name)
+        {
+          char*      e = nullptr;
+          const long v = std::strtol(val.c_str(), &e, 10);
+          if(!val.empty() && e && *e == 0)
+          {
+            t.*(k.field) = int(v);
+            ok           = true;
+          }
+          break;
+        }
+    if(!ok)
+      unknown += (unknown.empty() ? "" : ",") + tok;
+  }
+  if(t.bandTiles < 1)
+    t.bandTiles = 1;
+}
+
+// test hook (no GPU involved): parses `tune` as pt_create would and reports the knobs in the order of the keys below plus build / accel;
+// `unknown` receives the tokens that name no knob.  Returns the number of values written.
+extern "C" __attribute__((visibility("default"))) int pt_debug_parse_tuning(const char* tune, int* out, int maxOut, char* unknownOut, size_t unknownLen)
+{
+  PtTuning    t;
+  std::string unknown;
+  pt_parse_tuning(tune, t, unknown);
+  const int v[] = {t.stateMB, t.stateGB, t.packetClosestBounces, t.mergeSingles, t.cnodes, t.shadeTris, t.tailBelow, t.warm, t.texTile, t.texGroups, t.regen, t.packetTwo,
+                   t.blasWorkers, t.batch, t.framesInFlight, t.displaySlots, t.bands, t.bandTiles, t.fuse, t.sahBuild, t.accelTwoLevel};
+  const int n   = int(sizeof(v) / sizeof(v[0]));
+  for(int i = 0; i < n && i < maxOut; ++i)
+    out[i] = v[i];
+  if(unknownOut && unknownLen)
+    snprintf(unknownOut, unknownLen, "%s", unknown.c_str());
+  return n < maxOut ? n : maxOut;
+}
+
 extern "C" {
 
 const char* pt_renderer_name(void) { return "HIP"; }
@@ -725,51 +811,20 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     g_createError = "hipSetDevice failed";
     return PT_ERR_HIP;
   }
-  // every context starts from the defaults: a knob set for one context's creation does not leak into the next.  The string is parsed into a local
-  // and published with one struct assignment below.  That assignment is NOT atomic: contexts must not be created while another thread renders
-  // (the knobs are performance policy only; two contexts created under DIFFERENT PT_TUNE strings in one process share the later one)
-  PtTuning parsed;
-  if(const char* tune = getenv("PT_TUNE"))
-  {  // performance A/B knobs only
-    int v;
-    if(const char* p = strstr(tune, "stateMB=")) if(sscanf(p, "stateMB=%d", &v) == 1) parsed.stateMB = v;
-    if(const char* p = strstr(tune, "packetClosest=")) if(sscanf(p, "packetClosest=%d", &v) == 1) parsed.packetClosestBounces = v;
-    if(const char* p = strstr(tune, "packetWaves=")) if(sscanf(p, "packetWaves=%d", &v) == 1) parsed.packetWaves = v;
-    if(const char* p = strstr(tune, "refill=")) if(sscanf(p, "refill=%d", &v) == 1) parsed.refillBelow = v;
-    if(const char* p = strstr(tune, "waves=")) if(sscanf(p, "waves=%d", &v) == 1) parsed.persistentWaves = v;
-    if(const char* p = strstr(tune, "chunk=")) if(sscanf(p, "chunk=%d", &v) == 1) parsed.chunk = v;
-    if(strstr(tune, "build=lbvh")) parsed.sahBuild = 0;
-    if(strstr(tune, "build=sah")) parsed.sahBuild = 1;
-    if(strstr(tune, "build=ploc")) parsed.sahBuild = 2;
-    if(strstr(tune, "build=sahdev")) parsed.sahBuild = 3;
-    if(strstr(tune, "accel=two")) parsed.accelTwoLevel = 1;
-    if(const char* p = strstr(tune, "mergeSingles=")) if(sscanf(p, "mergeSingles=%d", &v) == 1) parsed.mergeSingles = v;
-    if(const char* p = strstr(tune, "cnodes=")) if(sscanf(p, "cnodes=%d", &v) == 1) parsed.cnodes = v;
-    if(const char* p = strstr(tune, "shadeTris=")) if(sscanf(p, "shadeTris=%d", &v) == 1) parsed.shadeTris = v;
-    if(const char* p = strstr(tune, "tail=")) if(sscanf(p, "tail=%d", &v) == 1) parsed.tailBelow = v;
-    if(const char* p = strstr(tune, "warm=")) if(sscanf(p, "warm=%d", &v) == 1) parsed.warm = v;
-    if(const char* p = strstr(tune, "texTile=")) if(sscanf(p, "texTile=%d", &v) == 1) parsed.texTile = v;
-    if(const char* p = strstr(tune, "regen=")) if(sscanf(p, "regen=%d", &v) == 1) parsed.regen = v;
-    if(const char* p = strstr(tune, "packetTwo=")) if(sscanf(p, "packetTwo=%d", &v) == 1) parsed.packetTwo = v;
-    if(const char* p = strstr(tune, "interleave=")) if(sscanf(p, "interleave=%d", &v) == 1) parsed.interleave = v;
-    if(const char* p = strstr(tune, "blasWorkers=")) if(sscanf(p, "blasWorkers=%d", &v) == 1) parsed.blasWorkers = v;  // contexts start in PT_ACCEL_TWO_LEVEL (A/B runs of unmodified callers)
-    if(const char* p = strstr(tune, "rotate=")) if(sscanf(p, "rotate=%d", &v) == 1) parsed.rotatePasses = v;
-    if(const char* p = strstr(tune, "plocFull=")) if(sscanf(p, "plocFull=%d", &v) == 1) parsed.plocFull = v;
-    if(const char* p = strstr(tune, "plocRadius=")) if(sscanf(p, "plocRadius=%d", &v) == 1) parsed.plocRadius = v;
-    if(const char* p = strstr(tune, "splitFull=")) if(sscanf(p, "splitFull=%d", &v) == 1) parsed.splitFull = v;
-    if(const char* p = strstr(tune, "batch=")) if(sscanf(p, "batch=%d", &v) == 1) parsed.batch = v;
-    if(const char* p = strstr(tune, "inflight=")) if(sscanf(p, "inflight=%d", &v) == 1) parsed.framesInFlight = v;
-    if(const char* p = strstr(tune, "displaySlots=")) if(sscanf(p, "displaySlots=%d", &v) == 1) parsed.displaySlots = v;
-    if(const char* p = strstr(tune, "bands=")) if(sscanf(p, "bands=%d", &v) == 1) parsed.bands = v;
-    if(const char* p = strstr(tune, "bandTiles=")) if(sscanf(p, "bandTiles=%d", &v) == 1) parsed.bandTiles = v > 0 ? v : 1;
-    if(const char* p = strstr(tune, "stateGB=")) if(sscanf(p, "stateGB=%d", &v) == 1) parsed.stateGB = v;
-    if(const char* p = strstr(tune, "fuse=")) if(sscanf(p, "fuse=%d", &v) == 1) parsed.fuse = v;
-    if(const char* p = strstr(tune, "texGroups=")) if(sscanf(p, "texGroups=%d", &v) == 1) parsed.texGroups = v;
+  // every context has its own knobs (round 6): parsed key by key, defaults otherwise; tokens that name no knob are reported once per process
+  PtTuning    parsed;
+  std::string unknown;
+  pt_parse_tuning(getenv("PT_TUNE"), parsed, unknown);
+  if(!unknown.empty())
+  {
+    static std::atomic<bool> warned{false};
+    if(!warned.exchange(true))
+      fprintf(stderr, "libptmi: PT_TUNE tokens that name no knob (ignored; removed knobs are constants now, see csrc/pt_internal.h PtTuning): %s\n", unknown.c_str());
   }
-  g_tuning = parsed;
   pt_context* c = new pt_context();
+  c->tune       = parsed;
   c->device     = device_ordinal;
-  c->accelMode  = g_tuning.accelTwoLevel ? PT_ACCEL_TWO_LEVEL : PT_ACCEL_FLAT;
+  c->accelMode  = c->tune.accelTwoLevel ? PT_ACCEL_TWO_LEVEL : PT_ACCEL_FLAT;
   if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
   {
     g_createError = "hipStreamCreate failed";
@@ -777,9 +832,9 @@ int pt_create(int device_ordinal, pt_context** out_ctx)
     return PT_ERR_HIP;
   }
   c->timers.stream = c->stream;
-  c->inflight      = g_tuning.framesInFlight < 1 ? 1 : (g_tuning.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : g_tuning.framesInFlight);
+  c->inflight      = c->tune.framesInFlight < 1 ? 1 : (c->tune.framesInFlight > PT_MAX_INFLIGHT ? PT_MAX_INFLIGHT : c->tune.framesInFlight);
   c->inflightMax = c->inflight;
-  c->displaySlotsMax = std::max(0, std::min(g_tuning.displaySlots, PT_MAX_INFLIGHT - c->inflightMax));
+  c->displaySlotsMax = std::max(0, std::min(c->tune.displaySlots, PT_MAX_INFLIGHT - c->inflightMax));
   for(int i = 0; i < c->inflightMax + c->displaySlotsMax; ++i)
     if(hipStreamCreateWithFlags(&c->slots[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->slots[i].accumDone, hipEventDisableTiming) != hipSuccess ||
        hipEventCreateWithFlags(&c->slots[i].countsDone, hipEventDisableTiming) != hipSuccess ||
@@ -985,7 +1040,7 @@ static void store_group(uint32_t* dst, const SceneRecords::TexGroup& g, const st
   }
 }
 
-static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::string& err)
+static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::string& err, int texTile, int texGroups)
 {
   if(!d || !d->vertices || !d->indices || !d->primMeshes || !d->nodes || !d->materials || d->numMaterials == 0)
     return records_fail(err, "pt_set_scene: null array or no material");
@@ -1060,7 +1115,7 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
       return records_fail(err, "texture %u: empty image", t);
     if(td.width > 65535 || td.height > 65535)  // (pt_device.h tex_index multiplies row x stride in 24 bits)
       return records_fail(err, "texture %u: %d x %d exceeds 65535 texels a side (tex_desc_pack keeps a side in 16 bits)", t, td.width, td.height);
-    R.texRecs[t].tiled  = (g_tuning.texTile && td.width % PT_TEX_TILE_W == 0 && td.height % PT_TEX_TILE_H == 0) ? 1 : 0;
+    R.texRecs[t].tiled  = (texTile && td.width % PT_TEX_TILE_W == 0 && td.height % PT_TEX_TILE_H == 0) ? 1 : 0;
     if(R.texRecs[t].tiled)
       R.texels = (R.texels + 31u) & ~size_t(31);  // a tile = one 128-byte line (the pool itself is 256-byte aligned)
     R.texRecs[t].offset = uint32_t(R.texels);
@@ -1093,7 +1148,7 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
     for(int k = 0; k < 4; ++k)
       rec[k] = R.texRecs[ids[k] > -1 ? size_t(ids[k]) : 0];
     SceneRecords::TexGroup g{{-1, -1, -1, -1}, 0, 0u};
-    if(g_tuning.texGroups && d->numTextures)
+    if(texGroups && d->numTextures)
       for(int k = 0; k < 4; ++k)
       {
         if(ids[k] < 0 || std::find(g.tex, g.tex + g.layers, ids[k]) != g.tex + g.layers)
@@ -1110,12 +1165,17 @@ static int build_scene_records(const pt_SceneDesc* d, SceneRecords& R, std::stri
           at = q;
       if(at == R.groups.size())
       {
-        const TexRec& sh = R.texRecs[size_t(g.tex[0])];
-        R.texels = (R.texels + 31u) & ~size_t(31);
-        g.offset = uint32_t(R.texels);
-        R.texels += size_t(sh.w) * sh.h * size_t(g.layers);
-        if(R.texels > 0xffffffffull)
-          return records_fail(err, "texture pool exceeds 2^32 texels");
+        // the interleaved copy is an EXTRA on top of the plain copies (which serve the any-hit evaluation and the other texture roles): a group that
+        // would take the pool past 2^32 texels is simply not made -- its material reads the plain copies, as with texGroups=0
+        const TexRec& sh    = R.texRecs[size_t(g.tex[0])];
+        const size_t  start = (R.texels + 31u) & ~size_t(31), after = start + size_t(sh.w) * sh.h * size_t(g.layers);
+        if(after > 0xffffffffull)
+        {
+          mat_line_pack(mt, rec, &R.matLines[size_t(PT_MAT_LINE_QUADS) * m]);
+          continue;
+        }
+        g.offset = uint32_t(start);
+        R.texels = after;
         R.groups.push_back(g);
       }
       const SceneRecords::TexGroup& G = R.groups[at];
@@ -1164,7 +1224,7 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
   SceneRecords R;
   {
     std::string msg;
-    const int   vrc = build_scene_records(d, R, msg);
+    const int   vrc = build_scene_records(d, R, msg, c->tune.texTile, c->tune.texGroups);
     if(vrc != PT_OK)
       return c->fail(vrc, "%s", msg.c_str());
   }
@@ -1184,7 +1244,18 @@ int pt_set_scene(pt_context* c, const pt_SceneDesc* d)
     if((rc = upload(c, c->dLights, d->numLights ? d->lights : &dummy, sizeof(pt_Light) * size_t(d->numLights ? d->numLights : 1))) != PT_OK) return rc;
     c->numLights = d->numLights;
   }
-  if((rc = dev_alloc(c, c->dTexels, R.texels * 4)) != PT_OK) return rc;
+  if((rc = dev_alloc(c, c->dTexels, R.texels * 4)) != PT_OK)
+  {  // the interleaved groups double the pool: without the memory for them the scene loads as with texGroups=0
+    if(R.groups.empty())
+      return rc;
+    (void)hipGetLastError();
+    std::string msg;
+    R = SceneRecords();
+    if((rc = build_scene_records(d, R, msg, c->tune.texTile, 0)) != PT_OK)
+      return c->fail(rc, "%s", msg.c_str());
+    if((rc = dev_alloc(c, c->dTexels, R.texels * 4)) != PT_OK)
+      return rc;
+  }
   if(d->numTextures == 0)
   {
     uint32_t white = 0xffffffffu;
@@ -1266,7 +1337,7 @@ int pt_build_accel(pt_context* c)
       (void)hipGetLastError();
     }
   }
-  const int brc = pt_accel_build(c->stream, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
+  const int brc = pt_accel_build(c->stream, c->tune, (const InstanceRec*)c->dInstances.p, c->numInstances, (const float4*)c->dVertices.p, (const uint32_t*)c->dIndices.p, c->numTris,
                                  (TriRec*)c->dTris.p, (AlphaRec*)c->dAlphaRecs.p, (BvhNode*)c->dBvh.p, (WideNode*)c->dWide.p, &c->numWideNodes, msg, sizeof(msg), nullptr, &arena);
   arena.release();
   if(arena.base)
@@ -1467,7 +1538,7 @@ int pt_set_shard(pt_context* c, int rank, int nranks)
 // clears it anyway), the device counters are put back, statistics and frame numbering are untouched.  PT_TUNE warm=0 skips it.
 static int warm_slots(pt_context* c)
 {
-  if(!g_tuning.warm || !c->warmPending || !c->haveScene || !c->haveAccel || !c->haveCamera || !(c->haveEnv || c->scene.sunsky.in_use == 1) || c->numSlots == 0)
+  if(!c->tune.warm || !c->warmPending || !c->haveScene || !c->haveAccel || !c->haveCamera || !(c->haveEnv || c->scene.sunsky.in_use == 1) || c->numSlots == 0)
     return PT_OK;
   c->warmPending = false;  // once per scene: the de-scaling resizes of an interactive session (sample_example.cpp:410-413) must not stall on it
   if(c->scene.camera.nbLights < 0 || uint32_t(c->scene.camera.nbLights) > c->numLights)
@@ -1481,7 +1552,7 @@ static int warm_slots(pt_context* c)
   fp.numLocalTiles = c->numLocalTiles; fp.numSlots = c->numSlots; fp.variant = c->variant; fp.sample = 0;
   fp.batch = uint32_t(std::min(c->batchMax, 8));
   StageTimers off;  // disabled: the warm-up never shows in the stage timings
-  const int tailFrom = tail_from_depth(double(fp.batch) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, 0);
+  const int tailFrom = tail_from_depth(double(fp.batch) * double(c->numSlots), fp.st.maxDepth, c->tune.tailBelow, c->qRatio, 0);
   for(int k = 0; k < slot_total(c); ++k)
   {
     pt_context::FrameSlot& fs = slot_at(c, k);
@@ -1498,9 +1569,9 @@ static int warm_slots(pt_context* c)
     if(k >= c->inflight)
     {  // a display slot holds one frame
       fk.batch = 1;
-      tk       = tail_from_depth(double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, 0);
+      tk       = tail_from_depth(double(c->numSlots), fp.st.maxDepth, c->tune.tailBelow, c->qRatio, 0);
     }
-    pt_launch_frame(slot_at(c, k).stream, c->scene, slot_at(c, k).rb, fk, &off, nullptr, nullptr, tk);
+    pt_launch_frame(slot_at(c, k).stream, c->tune, c->scene, slot_at(c, k).rb, fk, &off, nullptr, nullptr, tk);
   }
   pt_context::FrameSlot& f0 = c->slots[0];
   const int nd = std::min(std::min(tailFrom + 1, int(fp.st.maxDepth)), PT_MAX_DEPTH);
@@ -1566,7 +1637,7 @@ int pt_resize(pt_context* c, int width, int height)
   int rc;
   // frames per batch: the tuning value, bounded so that one frame slot's path state stays below 2^26 paths (~11 GB):
   // 32 frames of a full 1080p image, 64 of an 8-GPU shard (measured best for both, profiles/r01_scaling_estimate.txt)
-  c->batchMax = std::max(1, std::min(g_tuning.batch, int((1u << 26) / (c->numSlots ? c->numSlots : 1u))));
+  c->batchMax = std::max(1, std::min(c->tune.batch, int((1u << 26) / (c->numSlots ? c->numSlots : 1u))));
   // In-flight path state: 9 float4 arrays + 9 index queues per path slot, times the batch, times the frame slots -- 38 GB for a 1080p image at
   // the defaults, sized for 288 GB of HBM.  It is a budget, not a requirement: PT_TUNE stateGB=<n> (or what hipMemGetInfo reports as free,
   // minus a reserve) caps it, and an allocation that still fails halves the batch / drops frame slots and retries, down to one frame on
@@ -1587,7 +1658,7 @@ int pt_resize(pt_context* c, int width, int height)
       const DevBuf* q[] = {&fs.dQueueA, &fs.dQueueB, &fs.dQueueS, &fs.dQueueX, &fs.dQueueX2, &fs.dQueueR};
       for(const DevBuf* bf : q) held += bf->bytes;
     }
-    const double budget = g_tuning.stateMB > 0 ? g_tuning.stateMB * 1e6 : g_tuning.stateGB > 0 ? g_tuning.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
+    const double budget = c->tune.stateMB > 0 ? c->tune.stateMB * 1e6 : c->tune.stateGB > 0 ? c->tune.stateGB * 1e9 : (haveInfo ? (double(freeB) + double(held)) * 0.85 : 1e30);
     auto need = [&]() { return double(perPath) * double(c->numSlots ? c->numSlots : 1) * (double(c->batchMax) * c->inflight + c->displaySlots); };
     if(need() > budget)
       c->displaySlots = 0;  // the one-frame display slots go first
@@ -1595,7 +1666,7 @@ int pt_resize(pt_context* c, int width, int height)
       c->batchMax = (c->batchMax + 1) / 2;
     while(c->inflight > 1 && need() > budget)
       c->inflight = (c->inflight + 1) / 2;
-    if((g_tuning.stateMB > 0 || g_tuning.stateGB > 0) && need() > budget)  // an explicit cap that one frame on one slot exceeds (a cap derived
+    if((c->tune.stateMB > 0 || c->tune.stateGB > 0) && need() > budget)  // an explicit cap that one frame on one slot exceeds (a cap derived
       return c->fail(PT_ERR_OOM, "pt_resize: the path state of one %dx%d frame (%.0f bytes) exceeds the configured budget (%.0f bytes)", width, height, need(), budget);  // from the free memory is left to the allocations below)
   }
   for(;;)
@@ -1726,6 +1797,16 @@ int flush_pending(pt_context* c)
 {
   if(c->pendCount == 0)
     return PT_OK;
+  if(c->countsDirty)
+  {  // The counter block of a frame slot is zero when a pass starts because the PREVIOUS pass's k_accumulate left it so (no fill kernel per sequence).  After a
+     // HIP error a sequence may have stopped short of that: stale queue sizes would make the next pass append past its queues.  Clear every slot's block.
+    (void)sync_all(c);
+    (void)hipGetLastError();
+    for(int i = 0; i < PT_MAX_INFLIGHT; ++i)
+      if(c->slots[i].dCounts.p)
+        HIP_TRY(c, hipMemset(c->slots[i].dCounts.p, 0, c->slots[i].dCounts.bytes));
+    c->countsDirty = false;
+  }
   FrameParams fp{};
   fp.st            = c->pendState;
   fp.width         = c->width;
@@ -1755,14 +1836,14 @@ int flush_pending(pt_context* c)
     const int freeSlots = c->inflight - busy;
     // a partial flush (the caller is waiting) is cut fine; a full batch only when the GPU is idle (the first batch of a run) -- later ones
     // find busy slots and go out whole, so the steady state of a long run works on full batches
-    const int minPart = total < c->batchMax ? 2 : ((g_tuning.splitFull > 0 && busy == 0) ? g_tuning.splitFull : total);
+    const int minPart = total < c->batchMax ? 2 : total;  // a full batch is never split (2-7 % slower at 96-256 frames, profiles/README.md)
     parts = std::max(1, std::min(freeSlots, total / minPart));
   }
   // A launch of ONE frame while nothing else runs (a display loop that waits for every image) is cut the other way: into bands of the frame's
   // tiles, one launch sequence per idle slot.  A band addresses its part of the tile list, of the accumulation image and of nothing else, so it
   // is an ordinary launch with shifted base pointers; the bands' late, thin bounces overlap each other's full ones (profiles/r04z_*).
   int bands = 1;
-  if(total == 1 && g_tuning.bands > 1 && !c->timers.enabled)
+  if(total == 1 && c->tune.bands > 1 && !c->timers.enabled)
   {
     int idle = 0;
     for(int k = 0; k < slot_total(c); ++k)
@@ -1775,7 +1856,7 @@ int flush_pending(pt_context* c)
     }
     (void)hipGetLastError();
     if(idle == slot_total(c))  // with frames in flight the slots are the pipeline: one sequence per frame
-      bands = std::max(1, std::min(std::min(idle, g_tuning.bands), int(c->numLocalTiles / uint32_t(g_tuning.bandTiles))));
+      bands = std::max(1, std::min(std::min(idle, c->tune.bands), int(c->numLocalTiles / uint32_t(c->tune.bandTiles))));
   }
   c->pendCount          = 0;
   c->renderedSinceCheck = true;
@@ -1795,7 +1876,7 @@ int flush_pending(pt_context* c)
   (void)hipGetLastError();  // hipErrorNotReady is not an error
   int done              = 0;
   // interleaved submission needs every piece to have exactly one accumulate step, and the stage timers record their events in launch order
-  const bool                       interleave = g_tuning.interleave && (parts > 1 || bands > 1) && fp.st.maxSamples == 1 && !c->timers.enabled;
+  const bool                       interleave = (parts > 1 || bands > 1) && fp.st.maxSamples == 1 && !c->timers.enabled;
   std::vector<std::vector<PtStep>> plans;
   std::vector<pt_context::FrameSlot*> planSlot;
   std::vector<int>                 planTail;
@@ -1809,14 +1890,14 @@ int flush_pending(pt_context* c)
     fb.batch          = 1;
     fb.numLocalTiles  = t1 - t0;
     fb.numSlots       = (t1 - t0) * 1024u;
-    const int tailFrom = tail_from_depth(double(fb.numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, c->qRatioDepths);
+    const int tailFrom = tail_from_depth(double(fb.numSlots), fp.st.maxDepth, c->tune.tailBelow, c->qRatio, c->qRatioDepths);
     pt_context::FrameSlot& fs = slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c))));
     RenderBuffers  rbb = fs.rb;
     rbb.slotTile += t0;
     rbb.frame += size_t(t0) * 1024u;
     plans.emplace_back();
     planSlot.push_back(&fs);
-    pt_plan_frame(plans.back(), fs.stream, c->scene, rbb, fb, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
+    pt_plan_frame(plans.back(), fs.stream, c->tune, c->scene, rbb, fb, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
     c->lastAccum = fs.accumDone;
     fs.launched  = true;
     if(!interleave)
@@ -1839,12 +1920,12 @@ int flush_pending(pt_context* c)
     // where k_tail takes over: the first bounce whose queue is expected to hold <= tailBelow paths.  Expectation = this launch's paths x the
     // alive fraction observed at that bounce; bounces beyond the observed ones continue the last observed shrink factor; before anything was
     // observed a shrink of 0.3 per bounce is assumed.  A wrong guess costs time, never results.
-    const int tailFrom = tail_from_depth(double(n) * double(c->numSlots), fp.st.maxDepth, g_tuning.tailBelow, c->qRatio, c->qRatioDepths);
+    const int tailFrom = tail_from_depth(double(n) * double(c->numSlots), fp.st.maxDepth, c->tune.tailBelow, c->qRatio, c->qRatioDepths);
     // a launch of ONE frame (the display loop flushes per frame) rotates over the batch slots and the display slots, a batch over the batch slots
     pt_context::FrameSlot& fs = (total == 1 && c->displaySlots > 0) ? slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c)))) : c->slots[c->frameCounter++ % uint64_t(c->inflight)];
     plans.emplace_back();
     planSlot.push_back(&fs);
-    pt_plan_frame(plans.back(), fs.stream, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
+    pt_plan_frame(plans.back(), fs.stream, c->tune, c->scene, fs.rb, fp, &c->timers, c->lastAccum, fs.accumDone, tailFrom);
     c->lastAccum = fs.accumDone;
     fs.launched  = true;
     if(!interleave)
@@ -2400,8 +2481,10 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(con
                                                                             uint32_t* alphaMapsOut, uint32_t* texelsOut, void* texRecsOut, char* err, size_t errLen)
 {
   SceneRecords R;
-  std::string  msg;
-  const int    rc = build_scene_records(d, R, msg);
+  std::string  msg, unknown;
+  PtTuning     tune;  // the knobs a context created now would get
+  pt_parse_tuning(getenv("PT_TUNE"), tune, unknown);
+  const int    rc = build_scene_records(d, R, msg, tune.texTile, tune.texGroups);
   if(rc != PT_OK)
   {
     if(err && errLen)
@@ -2438,8 +2521,10 @@ extern "C" __attribute__((visibility("default"))) int pt_debug_scene_records(con
 extern "C" __attribute__((visibility("default"))) int pt_debug_mat_lines(const pt_SceneDesc* d, void* linesOut, char* err, size_t errLen)
 {
   SceneRecords R;
-  std::string  msg;
-  const int    rc = build_scene_records(d, R, msg);
+  std::string  msg, unknown;
+  PtTuning     tune;  // the knobs a context created now would get
+  pt_parse_tuning(getenv("PT_TUNE"), tune, unknown);
+  const int    rc = build_scene_records(d, R, msg, tune.texTile, tune.texGroups);
   if(rc != PT_OK)
   {
     if(err && errLen)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <functional>
+#include <string>
 #include <vector>
 #include "pt_device.h"
 #define PT_REFILL_BELOW_DEFAULT 48
@@ -42,7 +43,45 @@ struct PtScratch {
     off      = 0;
   }
 };
-int pt_accel_build(hipStream_t stream, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
+// Launch-policy knobs (performance only, never results): one set PER CONTEXT, parsed key by key from the PT_TUNE environment variable when the context is
+// created ("tail=0,batch=4,build=sah"; unknown keys are reported on stderr once).  Defaults chosen from measurements.  Knobs whose sweeps said "the default is
+// best" for two rounds became constants in round 6 (PT_PERSISTENT_WAVES, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, PT_PACKET_WAVES_LAUNCH, PT_ROTATE_PASSES,
+// PT_PLOC_RADIUS; the pieces of a cut batch are always interleaved, a full batch is never split): profiles/README.md has their sweeps.
+struct PtTuning {
+  int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
+  int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
+  int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
+  int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
+  int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
+  int tailBelow            = 65536;  // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
+                                   // queue is expected to hold at most this many paths (0: never)
+  int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
+                                   // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
+  int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
+  int bandTiles            = 64;   // a band of a single frame holds at least this many 32x32 tiles (65 k pixels); the tests lower it to reach the band path on small images
+  int bands                = 3;    // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
+  int displaySlots         = 2;    // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
+  int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
+                                   // (the display loop), 2 = always, 0 = never (the round-4 chain)
+  int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
+  int texGroups            = 1;    // the textures a material samples with one (u, v) are also stored interleaved when they share size and sampler (pt_device.h TexRec::tiled)
+  int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
+  int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
+  int shadeTris            = 1;    // flat-format structures: per-slot shading line for k_shade: the triangle's vertex attributes + (instance, primitive), 128 B per triangle (0: none)
+  int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (see pt_device.h CompactNode)
+  int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
+  int accelTwoLevel        = 0;    // 1: the context starts with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
+  int batch                = 64;   // upper bound of the frames traced as one wavefront; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p)
+};
+// Parses a PT_TUNE string key by key ("key=value" tokens separated by commas) into `t`; every token whose key is not a knob is appended to `unknown`
+// (comma separated).  Exact key matches only: "waves=" no longer matches inside "packetWaves=".
+void pt_parse_tuning(const char* tune, PtTuning& t, std::string& unknown);
+#define PT_SUPPLY_CHUNK 64            // rays a persistent wave reserves per queue atomic (at least)
+#define PT_PACKET_WAVES_LAUNCH 8192u  // persistent waves of the packet kernel (8 per SIMD)
+#define PT_ROTATE_PASSES 2            // device builders: bottom-up tree-rotation passes after the topology is built
+#define PT_PLOC_RADIUS 16             // PLOC: clusters examined on either side of a cluster per round
+
+int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
                    TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen,
                    const TriRec* dProxies = nullptr, PtScratch* scratch = nullptr);
 // Two-level structure (reference: src/accelstruct.cpp:110-162).  One BLAS per prim-mesh in object space ...
@@ -52,11 +91,11 @@ struct PtBlasDesc {
   uint32_t slotBase, nodeBase;  // where its leaf records / wide nodes start in the shared arrays (nodeBase + max(1, triCount - 1) nodes reserved)
   uint32_t numWide;             // out: wide nodes used
 };
-int pt_blas_build(hipStream_t stream, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
+int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, uint32_t numBlas, const float4* dVertices, const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide,
                   char* err, size_t errLen);
 // ... and one TLAS over the world boxes of the `numActive` non-empty instances listed in dActive (exact bounds of the T1 world triangles).
 // dInstNodeBase[inst]: root node of the instance's BLAS; dInstPad[2 * inst + {0,1}]: TlasLeaf::padC0 / padC1.  rootOut: the binary root (world bounds).
-int pt_tlas_build(hipStream_t stream, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
+int pt_tlas_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, const uint32_t* dActive, uint32_t numActive, const uint32_t* dInstNodeBase, const float* dInstPad,
                   const float4* dVertices, const uint32_t* dIndices, WideNode* dTlasOut, TlasLeaf* dLeavesOut, BvhNode* rootOut, uint32_t* numWideOut, char* err, size_t errLen,
                   const float* mergedBox = nullptr, uint32_t mergedNodeBase = 0);
 // ... with mergedBox (lo xyz, hi xyz) one more TLAS primitive: the merged world-space structure of the prim-meshes instantiated once
@@ -66,7 +105,7 @@ void pt_launch_shade_tris(hipStream_t stream, uint32_t n, const TriRec* tris, co
 int pt_compact_nodes(hipStream_t stream, uint32_t n, const WideNode* in, CompactNode* out, float* reachOut = nullptr);  // reachOut: max |p| + 2047 step over the nodes
 // ... over numRanges node ranges given as (base, count) pairs
 int pt_compact_node_ranges(hipStream_t stream, const uint32_t* hBaseCount, uint32_t numRanges, const WideNode* in, CompactNode* out);
-int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
+int pt_merged_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* hInst, const uint32_t* hIds, const uint32_t* hWorldBase, uint32_t numInst, uint32_t numTris, const float4* dVertices,
                     const uint32_t* dIndices, TriRec* dTris, AlphaRec* dAlpha, WideNode* dWide, uint32_t slotBase, uint32_t nodeBase, uint32_t* numWideOut, float* boxOut6, char* err,
                     size_t errLen);
 
@@ -88,10 +127,9 @@ int pt_merged_build(hipStream_t stream, const InstanceRec* hInst, const uint32_t
 #ifndef PT_DISPLAY_RING
 #define PT_DISPLAY_RING 8  // images pt_tonemap_begin may have in flight before pt_tonemap_end collects the oldest
 #endif
-#define PT_PERSISTENT_WAVES (256u * 20u)
+#define PT_PERSISTENT_WAVES (256u * 20u)  // persistent trace kernels: waves per launch = what the chip holds at 5 waves / SIMD (profiles/r03h_tune_96.txt, r03i_*)
 
-// POL: cache policy of the path-state accesses (pt_device.h); every instantiation has the same layout (plain pointers), so a kernel may view the
-// buffers it was handed under another policy (render_buffers_as)
+// POL: cache policy of the path-state accesses (pt_device.h)
 template <int POL>
 struct RenderBuffersT {
   PathStateT<POL> ps;
@@ -108,53 +146,6 @@ struct RenderBuffersT {
   Counters* counters;
 };
 typedef RenderBuffersT<PT_STATE_POLICY> RenderBuffers;
-template <int POL, int FROM>
-PT_DEV const RenderBuffersT<POL>& render_buffers_as(const RenderBuffersT<FROM>& rb)
-{
-  static_assert(sizeof(RenderBuffersT<POL>) == sizeof(RenderBuffersT<FROM>), "same layout under every policy");
-  return reinterpret_cast<const RenderBuffersT<POL>&>(rb);
-}
-// Launch-policy knobs (performance only, never results); defaults chosen from measurements, overridable with
-// the PT_TUNE environment variable ("simpleClosest=1,simpleShadow=0,refill=16") for A/B runs.
-struct PtTuning {
-  int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
-  int packetWaves          = 8192; // persistent waves of the packet kernel (8 per SIMD)
-  int refillBelow          = PT_REFILL_BELOW_DEFAULT;  // persistent kernels: service round when fewer lanes are traversing
-  int persistentWaves      = 5120; // persistent kernels: waves per launch = what the chip holds at 5 waves / SIMD.  2048 (round 1-2: "several frames'
-                                   // launches share the GPU") left SIMDs short of waves whenever fewer than four launch sequences overlapped:
-                                   // 1395 -> 1515 Msamples/s at 96 steps, 4096 .. 8192 within 1 % (profiles/r03h_tune_96.txt, r03i_launch_policy_sweep.txt)
-  int chunk                = 64;   // rays a persistent wave reserves per queue atomic
-  int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
-  int splitFull            = 0;    // > 0: a full batch that finds the GPU idle is cut into pieces of at least this many frames.  Off: helps runs of
-                                   // 33-64 frames (+25 % at 40) but costs 2-7 % at 96-256 (the small first pieces unbalance the pipeline)
-  int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
-  int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
-  int rotatePasses         = 2;    // device builders: bottom-up tree-rotation passes after the topology is built
-  int plocFull             = 0;    // PLOC: below this many clusters the search covers all of them (exact agglomerative clustering of the top levels)
-  int plocRadius           = 16;   // PLOC: clusters examined on either side of a cluster per round
-  int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
-  int tailBelow            = 65536;  // a launch sequence hands the remaining bounces to k_tail (one launch, paths carried to their end) from the first bounce whose
-                                   // queue is expected to hold at most this many paths (0: never)
-  int warm                 = 1;    // pt_resize with scene, camera and environment in place: write every frame slot's path state once and run one throw-away launch
-                                   // sequence per slot (Renderer::create is where the reference builds its pipelines; 0: the first frames pay instead)
-  int packetTwo            = 1;    // two-level structure: bounce 0 walks one traversal per wavefront through TLAS and BLASes (pt_packet.h traverse_packet_two); 0: per lane
-  int bandTiles    = 64;  // ... each of at least this many 32x32 tiles (65 k pixels)
-  int bands        = 3;  // a single frame launched on an idle GPU is cut into up to this many bands of its tiles, one launch sequence each (1 = off); 3: +7 %, 6: -7 % (profiles/r04z_*)
-  int displaySlots = 2;  // extra frame slots holding ONE frame each, used only by single-frame launches (the display loop); 0 = none
-  int fuse                 = 1;    // shadow rays of bounce b and closest-hit rays of bounce b + 1 share one persistent launch (k_trace_p): 1 = launch sequences of ONE frame
-                                   // (the display loop), 2 = always, 0 = never (the round-4 chain)
-  int regen                = 1;    // bounce 0: the packet kernel computes the camera rays itself (k_generate only builds the queue); 0: k_generate writes them
-  int texGroups            = 1;    // the textures a material samples with one (u, v) are also stored interleaved when they share size and sampler (pt_device.h TexRec::tiled)
-  int texTile              = 1;    // RGBA8 images whose size allows it are stored block-linear (8 x 4-texel tiles = one 128-byte line; pt_device.h tex_index)
-  int interleave           = 1;    // the pieces of a cut batch are enqueued stage by stage in turn (all streams start together) instead of one piece after the other
-  int blasWorkers          = 8;    // two-level build: host threads (own stream + arena each) that build the BLASes concurrently
-  int shadeTris            = 1;    // flat-format structures: per-slot shading line for k_shade: the triangle's vertex attributes + (instance, primitive), 128 B per triangle (0: none)
-  int cnodes               = 1;    // flat-format structures: 80-byte compact nodes for the persistent trace kernels (measurement; see pt_device.h CompactNode)
-  int mergeSingles         = 1;    // two-level structure: prim-meshes instantiated once share one world-space bottom-level structure (0: a BLAS each)
-  int accelTwoLevel        = 0;    // 1: new contexts start with the two-level acceleration structure (PT_TUNE accel=two; pt_set_accel_mode overrides)
-  int batch                = 64;   // upper bound; the per-context value also keeps a batch below 2^26 paths (32 frames at 1080p, 64 for an 8-GPU shard)   // consecutive frames traced as one wavefront (bigger queues: the persistent kernels stay full)
-};
-extern PtTuning g_tuning;
 void pt_sah_topology(uint32_t n, const struct TriRec* tris, uint32_t* vals, uint32_t* childL, uint32_t* childR, uint32_t* parI, uint32_t* parL);  // pt_sah.hip
 struct StageTimers;  // pt_capi.hip
 // waitBeforeAccum (may be null): accumDone event of the previous frame; recordAfterAccum: this frame's
@@ -164,10 +155,10 @@ struct PtStep {
   std::function<void()> fn;
   bool                  accum;
 };
-void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
+void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const PtTuning& tune, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
                    hipEvent_t recordAfterAccum, int tailFrom);
 // tailFrom: first bounce handed to k_tail (>= maxDepth: none)
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
+void pt_launch_frame(hipStream_t stream, const PtTuning& tune, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* timers, hipEvent_t waitBeforeAccum,
                      hipEvent_t recordAfterAccum, int tailFrom);
 void pt_launch_retile(hipStream_t stream, const float4* rowMajor, const uint32_t* slotTile, uint32_t numLocalTiles, int tilesX, int width, int height, float4* frameTiles);
 void pt_launch_pick(hipStream_t stream, const DeviceScene& scene, float px, float py, const float* viewInv, const float* projInv, pt_PickResult* dOut, Counters* counters);

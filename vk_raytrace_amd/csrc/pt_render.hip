@@ -368,27 +368,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
   {
     const uint32_t slot = rb.queueX[i];
-    const f3       o    = xyz(rb.ps.rayO[slot]);
     const float4   dw   = rb.ps.rayD[slot];
-    const f3       d    = xyz(dw);
-    uint32_t       seed = __float_as_uint(dw.w);
-    float          tPrev = 0.0f;
-    uint32_t       wPrev = 0xffffffffu;
-    RayHit         h;
-    bool           dummy;
-    for(;;)
-    {
-      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-      if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
-        break;
-      atomicAdd(&rb.counters->alphaTests, 1ull);
-      if(alpha_test(S, h.slot, h.u, h.v, seed))
-        break;
-      tPrev = h.t;
-      wPrev = h.w & TRI_INDEX_MASK;
-    }
-    store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
-    rb.ps.rayD[slot].w = __uint_as_float(seed);
+    uint32_t       nAlpha = 0;
+    settle_closest_exact<TWO>(S, rb, slot, xyz(rb.ps.rayO[slot]), xyz(dw), __float_as_uint(dw.w), stack + threadIdx.x, nAlpha);  // pt_settle.h: THE key-ordered loop (T5)
+    if(nAlpha)
+      atomicAdd(&rb.counters->alphaTests, (unsigned long long)nAlpha);
   }
 }
 
@@ -587,36 +571,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   const uint32_t      count = C[CNT_X_SHADOW];
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
   {
-    const uint32_t slot    = rb.queueX2[i];
-    uint32_t       seed    = __float_as_uint(rb.ps.rayD[slot].w);
-    const uint32_t seed0   = seed;
-    const f3       o       = xyz(rb.ps.rayO[slot]);
-    const f3       d       = xyz(rb.ps.neeDir[slot]);
-    const float    maxDist = rb.ps.absorb[slot].w;
-    bool           inShadow = false, dummy;
-    RayHit         h;
-    float          tPrev = 0.0f;
-    uint32_t       wPrev = 0xffffffffu;
-    for(;;)
-    {
-      traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-      if(h.slot == BVH_NONE)
-        break;
-      if((h.w >> 29) & TRI_OPAQUE)
-      {
-        inShadow = true;
-        break;
-      }
-      atomicAdd(&rb.counters->alphaTests, 1ull);
-      if(alpha_test(S, h.slot, h.u, h.v, seed))
-      {
-        inShadow = true;
-        break;
-      }
-      tPrev = h.t;
-      wPrev = h.w & TRI_INDEX_MASK;
-    }
-    finish_bounce(rb, slot, inShadow, variant == PT_VARIANT_RTX ? seed0 : seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
+    const uint32_t slot     = rb.queueX2[i];
+    uint32_t       seed     = __float_as_uint(rb.ps.rayD[slot].w), nAlpha = 0;
+    const bool     inShadow = settle_shadow_exact<TWO>(S, xyz(rb.ps.rayO[slot]), xyz(rb.ps.neeDir[slot]), rb.ps.absorb[slot].w, variant, seed, stack + threadIdx.x, nAlpha, rb.counters);  // pt_settle.h (T6)
+    if(nAlpha)
+      atomicAdd(&rb.counters->alphaTests, (unsigned long long)nAlpha);
+    finish_bounce(rb, slot, inShadow, seed, queueOut, &C[CNT_STRIDE + CNT_IN], lastBounce != 0);
   }
 }
 
@@ -759,60 +719,21 @@ __global__ void __launch_bounds__(TRACE_BLOCK, TWO ? PT_TRACE_WAVES_TWO : PT_TRA
   for(uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < count; i += gridDim.x * TRACE_BLOCK)
   {
     const uint32_t slot = i < nXS ? rb.queueX2[i] : rb.queueX[i - nXS];
-    uint32_t       seed = __float_as_uint(rb.ps.rayD[slot].w);
-    RayHit         h;
-    bool           dummy;
+    uint32_t       seed = __float_as_uint(rb.ps.rayD[slot].w), nAlpha = 0;
+    bool           alive = true;
     if(i < nXS)
-    {
-      const uint32_t seed0    = seed;
-      const f3       o        = xyz(rb.ps.rayO[slot]);
-      const f3       d        = xyz(rb.ps.neeDir[slot]);
-      const float    maxDist  = rb.ps.absorb[slot].w;
-      bool           inShadow = false;
-      float          tPrev    = 0.0f;
-      uint32_t       wPrev    = 0xffffffffu;
-      for(;;)
-      {
-        traverse<TM_RAW_ALL, TWO>(S, o, d, maxDist, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-        if(h.slot == BVH_NONE)
-          break;
-        if((h.w >> 29) & TRI_OPAQUE)
-        {
-          inShadow = true;
-          break;
-        }
-        atomicAdd(&rb.counters->alphaTests, 1ull);
-        if(alpha_test(S, h.slot, h.u, h.v, seed))
-        {
-          inShadow = true;
-          break;
-        }
-        tPrev = h.t;
-        wPrev = h.w & TRI_INDEX_MASK;
-      }
-      if(variant == PT_VARIANT_RTX)
-        seed = seed0;
-      if(!finish_bounce_core(rb, slot, inShadow, seed))
-        continue;
-      atomicAdd(&rb.counters->closestRays, 1ull);  // (the shadow ray was counted when k_trace_p fetched it; the next ray starts here)
+    {  // the shadow ray (T6), the roulette, and -- for a survivor -- straight on to its next closest-hit ray
+      const bool inShadow = settle_shadow_exact<TWO>(S, xyz(rb.ps.rayO[slot]), xyz(rb.ps.neeDir[slot]), rb.ps.absorb[slot].w, variant, seed, stack + threadIdx.x, nAlpha, rb.counters);
+      alive               = finish_bounce_core(rb, slot, inShadow, seed);
+      if(alive)
+        atomicAdd(&rb.counters->closestRays, 1ull);  // (the shadow ray was counted when k_trace_p fetched it; the next ray starts here)
     }
-    const f3 o     = xyz(rb.ps.rayO[slot]);
-    const f3 d     = xyz(rb.ps.rayD[slot]);
-    float    tPrev = 0.0f;
-    uint32_t wPrev = 0xffffffffu;
-    for(;;)
-    {
-      traverse<TM_RAW_ALL, TWO>(S, o, d, PT_INFINITY, tPrev, wPrev, 0u, stack + threadIdx.x, h, dummy, rb.counters);
-      if(h.slot == BVH_NONE || ((h.w >> 29) & TRI_OPAQUE))
-        break;
-      atomicAdd(&rb.counters->alphaTests, 1ull);
-      if(alpha_test(S, h.slot, h.u, h.v, seed))
-        break;
-      tPrev = h.t;
-      wPrev = h.w & TRI_INDEX_MASK;
-    }
-    store_hit(rb, slot, h.slot, h.w, TWO, h.t, h.u, h.v);
-    rb.ps.rayD[slot].w = __uint_as_float(seed);
+    if(alive)
+      settle_closest_exact<TWO>(S, rb, slot, xyz(rb.ps.rayO[slot]), xyz(rb.ps.rayD[slot]), seed, stack + threadIdx.x, nAlpha);  // (T5; stores the hit and the RNG state)
+    if(nAlpha)
+      atomicAdd(&rb.counters->alphaTests, (unsigned long long)nAlpha);
+    if(!alive)
+      continue;
     enqueue(queueHit, &C1[CNT_IN], slot);
   }
 }
@@ -897,7 +818,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderBuffers rb, FrameParam
 {
   if(blockIdx.x == 0)
   {
-    const uint32_t words = CNT_STRIDE * uint32_t(fp.st.maxDepth + 2);
+    const uint32_t words = CNT_STRIDE * uint32_t((fp.st.maxDepth < PT_MAX_DEPTH ? fp.st.maxDepth : PT_MAX_DEPTH) + 2);  // (pt_render_frame rejects maxDepth > PT_MAX_DEPTH; the buffers hold PT_MAX_DEPTH + 2 blocks)
     for(uint32_t i = threadIdx.x; i < words; i += blockDim.x)
     {
       rb.countsDone[i] = rb.counts[i];
@@ -1162,7 +1083,6 @@ __global__ void k_mean(const float4* __restrict__ img, size_t n, double* out3)
 }  // namespace
 
 // ---- host-side launchers ----------------------------------------------------------------------------------------
-PtTuning g_tuning;
 
 // One launch sequence (a batch of frames, all bounces) as a list of STEPS.  A step only enqueues work on `stream`.  The caller either runs
 // the steps back to back (pt_launch_frame) or interleaves the steps of several sequences that go to different streams (pt_capi.hip
@@ -1174,23 +1094,24 @@ PtTuning g_tuning;
 // The counter block is zero on entry: pt_resize clears it once, k_accumulate leaves it cleared.
 // TWO: the kernels instantiated for the two-level acceleration structure
 template <bool TWO>
-static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
+static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const PtTuning& tune, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fpIn, StageTimers* tm, hipEvent_t waitBeforeAccum,
                        hipEvent_t recordAfterAccum, int tailFrom)
 {
   FrameParams    fp        = fpIn;
   const uint32_t n         = fp.numSlots * fp.batch;  // path slots of the batch
   const uint32_t wavesAll  = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-  const uint32_t pw        = uint32_t(g_tuning.persistentWaves > 0 ? g_tuning.persistentWaves : 1);
+  const uint32_t pw        = PT_PERSISTENT_WAVES;
   const uint32_t gridTrace = wavesAll < pw ? wavesAll : pw;
   const uint32_t gridX     = wavesAll < 512u ? wavesAll : 512u;
   const bool     heat      = fp.st.debugging_mode == PT_DEBUG_HEATMAP;  // instrumented instantiations of the staged machine kernels; no packet stage, no fused stage, no k_tail
   // measured (profiles/r05a_*, r05b_*, r05c_*): serialised, the fused launch takes exactly the time of the two launches it replaces (21.3 ms per 32-frame
   // batch either way) and k_shade reads a hit queue scrambled by two traversals instead of one (+6 %): -4 % on batches, +2.5 % on a frame the host waits for
-  const bool     fuse      = !heat && (g_tuning.fuse == 2 || (g_tuning.fuse == 1 && fp.batch == 1));
+  const bool     fuse      = !heat && (tune.fuse == 2 || (tune.fuse == 1 && fp.batch == 1));
   // camera rays computed by the packet kernel instead of written by k_generate: one sample per frame (the RNG stream of a second sample continues
   // from the stored state), a packet stage at bounce 0, no heat map (it keeps the path's cost in rayO.w), bounce 0 not already in k_tail
-  const bool packetStage = !TWO || g_tuning.packetTwo;  // the two-level structure has a packet stage of its own since round 4 (pt_packet.h traverse_packet_two)
-  fp.regen = (g_tuning.regen && packetStage && !heat && fp.st.maxSamples == 1 && g_tuning.packetClosestBounces >= 1 && tailFrom > 0 && fp.st.maxDepth > 0) ? 1 : 0;
+  const int  packetBounces = tune.packetClosestBounces;
+  const bool packetStage = !TWO || tune.packetTwo;  // the two-level structure has a packet stage of its own since round 4 (pt_packet.h traverse_packet_two)
+  fp.regen = (tune.regen && packetStage && !heat && fp.st.maxSamples == 1 && packetBounces >= 1 && tailFrom > 0 && fp.st.maxDepth > 0) ? 1 : 0;
   for(int s = 0; s < fp.st.maxSamples; ++s)
   {
     fp.sample = s;
@@ -1220,16 +1141,16 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 1);
           if(heat)
-            k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
-          else if(packetStage && depth < g_tuning.packetClosestBounces)
+            k_closest_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, CNT_IN, CNT_CHUNK_CLOSEST);
+          else if(packetStage && depth < packetBounces)
           {
-            const uint32_t kwAll = uint32_t(g_tuning.packetWaves > 0 ? g_tuning.packetWaves : 1);
+            const uint32_t kwAll = PT_PACKET_WAVES_LAUNCH;
             const uint32_t kw    = TWO ? kwAll * PT_PACKET_WAVES_TWO / PT_PACKET_WAVES : kwAll;
             k_closest_k<TWO><<<wavesAll < kw ? wavesAll : kw, TRACE_BLOCK, 0, stream>>>(scene, rb, fp, qIn, depth);
-            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_REDO, CNT_CHUNK_REDO);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueR, depth, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, CNT_REDO, CNT_CHUNK_REDO);
           }
           else
-            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, CNT_IN, CNT_CHUNK_CLOSEST);
+            k_closest_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, CNT_IN, CNT_CHUNK_CLOSEST);
           k_closest_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, depth);
           pt_timers_end(tm, stream, 1);
         }, false});
@@ -1243,7 +1164,7 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
       {  // qIn has been consumed by k_shade: it becomes the hit queue of bounce depth + 1 (no swap)
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 6);
-          k_trace_p<TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, qIn, depth, g_tuning.refillBelow, g_tuning.chunk, fp.variant);
+          k_trace_p<TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, qIn, depth, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, fp.variant);
           k_trace_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qIn, depth, fp.variant);
           pt_timers_end(tm, stream, 6);
         }, false});
@@ -1253,9 +1174,9 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
         steps.push_back(PtStep{[=]() {
           pt_timers_begin(tm, stream, 3);
           if(heat)
-            k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+            k_shadow_p<true, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           else
-            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, g_tuning.refillBelow, g_tuning.chunk, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
+            k_shadow_p<false, TWO><<<gridTrace, TRACE_BLOCK, 0, stream>>>(scene, rb, rb.queueS, qOut, depth, last, PT_REFILL_BELOW_DEFAULT, PT_SUPPLY_CHUNK, fp.variant, CNT_SHADOW, CNT_CHUNK_SHADOW);
           k_shadow_x<TWO><<<gridX, TRACE_BLOCK, 0, stream>>>(scene, rb, qOut, depth, last, fp.variant);
           pt_timers_end(tm, stream, 3);
         }, false});
@@ -1277,20 +1198,20 @@ static void plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const Dev
   }
 }
 
-void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum,
+void pt_plan_frame(std::vector<PtStep>& steps, hipStream_t stream, const PtTuning& tune, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum,
                    hipEvent_t recordAfterAccum, int tailFrom)
 {
   if(scene.twoLevel)
-    plan_frame<true>(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+    plan_frame<true>(steps, stream, tune, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
   else
-    plan_frame<false>(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+    plan_frame<false>(steps, stream, tune, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
 }
 
-void pt_launch_frame(hipStream_t stream, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum,
+void pt_launch_frame(hipStream_t stream, const PtTuning& tune, const DeviceScene& scene, const RenderBuffers& rb, const FrameParams& fp, StageTimers* tm, hipEvent_t waitBeforeAccum, hipEvent_t recordAfterAccum,
                      int tailFrom)
 {
   std::vector<PtStep> steps;
-  pt_plan_frame(steps, stream, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
+  pt_plan_frame(steps, stream, tune, scene, rb, fp, tm, waitBeforeAccum, recordAfterAccum, tailFrom);
   for(PtStep& st : steps)
     st.fn();
 }
