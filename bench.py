@@ -146,10 +146,31 @@ def usable_cores():
     return n
 
 
-def latest_profile(kind):
-    """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
-        p = os.path.join(ROOT, "profiles", f"{rnd}_{kind}.json")
+def mix_ceilings():
+    """VALU issue ceilings measured for the kernels' own instruction mixes (tools/valu_mix.hip, output committed as profiles/rNN_valu_mix.txt):
+    G wave-instructions/s for the trace-machine mix at 5 waves per SIMD and the k_shade mix at 4."""
+    import re
+    for rnd in ("r06",):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_valu_mix.txt")
+        if not os.path.exists(p):
+            continue
+        txt, out = open(p).read(), {}
+        for key, pat in (("trace", r"trace-machine mix \(k_closest_p: 5\)\s+waves/SIMD 5:\s+([0-9.]+) G"), ("packet", r"trace-machine mix \(80 VALU \+ 28 SALU\)\s+waves/SIMD 8:\s+([0-9.]+) G"),
+                         ("shade", r"k_shade mix \(k_shade: 4\)\s+waves/SIMD 4:\s+([0-9.]+) G"), ("fmac", r"independent v_fmac_f32\s+waves/SIMD 8:\s+([0-9.]+) G")):
+            m = re.search(pat, txt)
+            if m:
+                out[key] = float(m.group(1))
+        if out:
+            return out, f"profiles/{rnd}_valu_mix.txt"
+    return None, None
+
+
+def latest_profile(kind, workload="c3"):
+    """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's); the other BASELINE configurations
+    have summaries of their own, profiles/rNN_<kind>_<workload>.json (per-sample figures are a property of code AND workload)."""
+    suffix = "" if workload == "c3" else f"_{workload}"
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{kind}{suffix}.json")
         if os.path.exists(p):
             try:
                 return json.load(open(p)), f"profiles/{rnd}_{kind}.json"
@@ -296,8 +317,8 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
         kernels = {"closest": "k_closest_k + k_closest_p (+ k_closest_x)", "shadow": "k_shadow_p (+ k_shadow_x)", "shade": "k_shade", "tail": "k_tail", "generate": "k_generate", "fused": "k_trace_p (+ k_trace_x)",
                    "accumulate": "k_accumulate"}
         launches = max(1, serial["launches_per_stage"])
-        cache, cache_src = latest_profile("cache")
-        traffic_j, traffic_src = latest_profile("traffic")
+        cache, cache_src = latest_profile("cache", workload)
+        traffic_j, traffic_src = latest_profile("traffic", workload)
         table = {}
         for k, ms in serial["stage_ms"].items():
             n_l = launches if k in ("closest", "shade", "shadow") else max(1, serial["launches_tail"]) if k == "tail" else 1
@@ -316,7 +337,7 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
         #   closest, shadow  L1 (TCP) accesses (PMC, 64-byte accesses after the texture addresser's coalescing) / standalone time against one access per
         #                    clock and CU -- the per-lane request path of divergent rays -- next to the share of a wavefront's cycles spent waiting
         #                    (SQ_WAIT_ANY / SQ_WAVE_CYCLES of the stage's kernels): these stages are latency-chained, neither ceiling is reached
-        valu_b, valu_b_src = latest_profile("valu")
+        valu_b, valu_b_src = latest_profile("valu", workload)
         cu, clk = out["calibration"]["compute_units"], out["calibration"]["clock_MHz"] * 1e6
         stage_kernels = {"closest": ("k_closest_k", "k_closest_p"), "shadow": ("k_shadow_p",), "shade": ("k_shade",), "tail": ("k_tail",)}
         for k, row in table.items():
@@ -347,25 +368,56 @@ def evidence_fields(out, serial, alg, samples, elapsed, world, workload):
             out["hbm_measured"] = {"bytes_per_sample": tot, "GBps": tot * samples / max(1, world) / elapsed / 1e9, "frac": tot * samples / max(1, world) / elapsed / 1e9 / HBM_PEAK_GBS,
                                    "source": f"{traffic_src} (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh on the timed pipeline incl. k_tail, gfx950 corrections) x this run's rate",
                                    "note": "what actually crosses the HBM interface per sample, against the 8 TB/s peak: the scene's working set lives in L2 / Infinity Cache"}
-        # `achieved` / `frac`: SURVEY.md 8(d) -- algorithmic bytes per launch over the stage's average standalone launch duration, against the HBM peak.
-        # The algorithmic bytes are reference-layout node / triangle / material records; most of them are served by L2 / Infinity Cache (scene + BVH
-        # ~115 MB), so this fraction can exceed 1 while the HBM interface (`traffic`, `traffic_frac`: PMC-measured bytes) is far from saturated;
-        # `l2_frac` prices the same stage's L2 requests against the L2 ceiling.
-        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
-                           "achieved_basis": "SURVEY 8(d) algorithmic bytes per launch / average standalone launch duration (HIP events on the launching stream, serialised pass of this run)",
-                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
-                           "traffic": traffic, "traffic_GBps": d.get("hbm_GBps"), "traffic_frac": d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None, "traffic_source": traffic_src,
+        # ---- what binds, measured (round 6).  Per stage: VALU wave-instructions per sample (rocprofv3 SQ_INSTS_VALU, profiles/rNN_valu.json) x the samples of
+        # the serialised pass / the stage's standalone time = achieved issue rate, against the ceiling tools/valu_mix.hip reaches for THAT kernel's instruction mix
+        # at that kernel's occupancy (no memory instruction at all); next to it the hardware lane occupancy of those instructions
+        # (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, profiles/rNN_binders.json) and the HBM and L1 fractions, which do NOT bind.
+        mix, mix_src = mix_ceilings()
+        binders, binders_src = latest_profile("binders", workload)
+        valu_k = (valu_b or {}).get("kernels", {})
+        mix_of = {"k_closest_k": "packet", "k_closest_p": "trace", "k_shadow_p": "trace", "k_shade": "shade"}
+        for k, row in table.items():
+            if not row.get("ms") or k not in stage_kernels or not mix:
+                continue
+            ks = [kn for kn in stage_kernels[k] if kn in valu_k and "SQ_INSTS_VALU" in valu_k[kn]]
+            if not ks:
+                continue
+            instr = sum(valu_k[kn]["SQ_INSTS_VALU"] for kn in ks)                       # per sample
+            ceil = sum(valu_k[kn]["SQ_INSTS_VALU"] * mix.get(mix_of.get(kn, "trace"), 0.0) for kn in ks) / instr  # instruction-weighted when a stage has two kernels
+            ach = instr * serial["samples"] / (row["ms"] * 1e-3) / 1e9
+            iss = {"valu_wave_instr_per_sample": instr, "achieved_G_per_s": ach, "mix_ceiling_G_per_s": ceil, "frac": ach / ceil if ceil else None, "ceiling_source": mix_src, "instr_source": valu_b_src}
+            if binders:
+                bk = binders.get("kernels", {})
+                iss["lanes_per_valu_instr"] = {kn: bk[kn].get("lanes_per_valu_instr") for kn in stage_kernels[k] if kn in bk}
+                iss["lanes_source"] = binders_src
+            row["issue"] = iss
+        # `roofline`: the dominant stage against the ceiling that binds it.  SURVEY.md 8(d)'s HBM accounting moves to `alg_*` (it exceeds 1: the numerator prices
+        # BVH2-equivalent visits whose bytes are cache-served); the HBM interface itself is `traffic` / `hbm`.
+        iss = d.get("issue")
+        out["roofline"] = {"bound": "valu_issue" if iss else "hbm", "kernel": d["kernel"], "stage": dom,
+                           "achieved": iss["achieved_G_per_s"] if iss else d.get("hbm_GBps"), "peak": iss["mix_ceiling_G_per_s"] if iss else HBM_PEAK_GBS,
+                           "unit": "G wave-instructions/s" if iss else "GB/s", "frac": iss["frac"] if iss else (d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None),
+                           "basis": ("VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU) / average standalone launch duration (HIP events on the launching stream, serialised pass of this run) "
+                                     "against the issue rate tools/valu_mix.hip reaches for this kernel's instruction mix at its occupancy") if iss else "HBM-side bytes (PMC) / standalone duration",
+                           "lanes_per_valu_instr": iss.get("lanes_per_valu_instr") if iss else None,
+                           "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "hbm": {"achieved": d.get("hbm_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["hbm_GBps"] / HBM_PEAK_GBS if d.get("hbm_GBps") else None,
+                                   "note": "HBM-side bytes of this stage (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 corrections) / its standalone time: the HBM interface does not bind"},
+                           "alg_bytes_per_launch": d["alg_bytes"] / d["launches"], "alg_achieved_GBps": d["alg_GBps"], "alg_frac": d["alg_GBps"] / HBM_PEAK_GBS if d["alg_GBps"] else None,
+                           "alg_note": "SURVEY 8(d) accounting: algorithmic bytes per launch (BVH2-EQUIVALENT node visits of the oracle's binary tree, ~110 per ray x 32 B, + triangle, shading, "
+                                       "any-hit, NEE records) / the launch duration vs 8 TB/s.  It exceeds 1 because those bytes are served by L2 / Infinity Cache: an accounting figure, not a speed",
                            "l2_GBps": d.get("l2_GBps"), "l2_frac": d["l2_GBps"] / L2_PEAK_GBS if d.get("l2_GBps") else None, "l2_hit_rate": d.get("l2_hit_rate"), "l2_source": cache_src,
+                           "l1_request_path": d.get("binding") if dom in ("closest", "shadow") else None,
                            "measured_hbm_copy_GBps": out["calibration"]["hbm_copy_GBps"],
-                           "binding": d.get("binding"),
-                           "alg_model_note": "the numerator prices BVH2-EQUIVALENT node visits of the oracle's binary tree (about 110 per ray, SURVEY 8(d)) at 32 B each; the kernels "
-                                             "make about 22 four-wide visits per ray on nodes that live in L2 / Infinity Cache, so frac is an accounting figure, not a speed -- `binding` is the ceiling",
-                           "note": "dominant stage = largest STANDALONE time; frac > 1 means the algorithmic bytes are cache-served, traffic_frac is the HBM interface, l2_frac the L2"}
+                           "per_stage": {k: {"ms": row["ms"], "valu_issue_frac": (row.get("issue") or {}).get("frac"), "lanes_per_valu_instr": (row.get("issue") or {}).get("lanes_per_valu_instr"),
+                                             "hbm_frac": row["hbm_GBps"] / HBM_PEAK_GBS if row.get("hbm_GBps") else None} for k, row in table.items() if row.get("ms")},
+                           "note": "dominant stage = largest STANDALONE time.  Every kernel of the pipeline sits at 0.6-0.8 of the VALU issue ceiling of its own mix with a third (trace machine) to "
+                                   "three quarters (k_shade) of the lanes active per instruction; HBM 0.17-0.5, L1 request path 0.3-0.44: issue binds, lane occupancy is what it is spent on"}
     # ---- VALU issue: instruction counts per sample are a property of the code and the workload (rocprofv3 PMC pass of this round); the rate is
     # this run's; the ceiling is the one measured above on this box.
-    valu_j, valu_src = latest_profile("valu")
-    if workload == "c3" and valu_j:
+    valu_j, valu_src = latest_profile("valu", workload)
+    if valu_j:
         try:
             per_sample = valu_j["valu_wave_instr_per_sample"]
             peak = out["calibration"]["valu_G_wave_instr_per_s"] * 1e9
@@ -390,7 +442,6 @@ def build_workload(args):
     else:
         wl = {"c2": workloads.c2_helmet, "c4": workloads.c4_sponza_4k, "c5": workloads.c5_bistro}[args.workload]()
         wl.name = wl.name.replace(f"{wl.spp}spp", f"{args.steps}spp")
-        args.no_cpu_baseline = True  # the CPU leg and its algorithmic-byte model are sized for the bench line only
     wl.scene.finalize(capi.pack_vertices)
     return wl
 

@@ -11,6 +11,8 @@
 #   libs5:<steps>:<a>,<b>,...   the same on the C5 stand-in with the two-level structure
 #   tests[:<-k expression>]     pytest -m gpu
 #   smoke               __graft_entry__.smoke()
+#   pmcwl:<workload>:<frames>  reduced PMC passes on c2 / c4 / c5 -> traffic_<wl>.json, valu_<wl>.json, binders_<wl>.json
+#   valumix             tools/valu_mix.hip: the VALU issue ceiling for the kernels' instruction mixes -> valu_mix.txt
 #   pmc[:<frames>]      tools/pmc_passes.sh passes -> traffic / valu / cache json (copied to profiles/r04_*.json by hand)
 #   binders[:<frames>[:<PT_TUNE>]]  tools/pmc_binders.sh passes -> binders.json (lane occupancy, I-cache, VMEM issue, waits per kernel)
 #   shards:<wl>:<steps> every rank's shard of N = 1, 2, 4, 8 on this one GPU (bench.py --emulate-shard R/N); max over ranks per N
@@ -47,6 +49,10 @@ for step in "$@"; do
     tests)   if [ -n "$a" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$a" > $O/gputest.txt 2>&1; else timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; fi; tail -5 $O/gputest.txt | tee -a $O/log.txt ;;
     smoke)   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a $O/log.txt ;;
     pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_passes.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;
+    pmcwl)   # pmcwl:<workload>:<frames>  the reduced pass set (traffic, instruction mix, cycles, lane occupancy) on another BASELINE configuration -> <kind>_<workload>.json
+             PMC_WORKLOAD=$a PMC_FRAMES=${b:-32} PMC_SET=min timeout 1500 bash tools/pmc_passes.sh ${TAG}_$a > $O/pmc_$a.txt 2>&1
+             PMC_WORKLOAD=$a PMC_FRAMES=${b:-32} PMC_SET=min timeout 900 bash tools/pmc_binders.sh ${TAG}_$a >> $O/pmc_$a.txt 2>&1
+             for k in traffic valu binders; do [ -s gpurun_out/pmc_${TAG}_$a/$k.json ] && cp gpurun_out/pmc_${TAG}_$a/$k.json $O/${k}_$a.json; done; tail -6 $O/pmc_$a.txt | tee -a $O/log.txt ;;
     binders) PMC_FRAMES=${a:-64} PMC_TUNE=${b:-inflight=1,warm=0} timeout 1500 bash tools/pmc_binders.sh $TAG > $O/binders.txt 2>&1; cp gpurun_out/pmc_$TAG/binders.json $O/binders.json 2>/dev/null; tail -14 $O/binders.txt | tee -a $O/log.txt ;;
     shards)  for n in 1 2 4 8; do worst=0; for ((r = 0; r < n; r++)); do
                timeout 300 python bench.py --workload $a --emulate-shard $r/$n --steps $b --warmup 5 --no-cpu-baseline --no-profile --no-interactive > $O/shard_${a}_${r}of${n}_$b.json 2>/dev/null
@@ -57,6 +63,7 @@ for step in "$@"; do
              for round in 1 2; do IFS=';' read -ra TS <<< "$st_tunes"; for t in "${TS[@]}"; do tt=$t; [ "$t" = "-" ] && tt=""
                echo -n "$a shard $st_rn steps $st_steps PT_TUNE=$tt : " | tee -a $O/log.txt
                PT_TUNE=$tt timeout 300 python bench.py --workload $a --emulate-shard $st_rn --steps $st_steps --warmup 5 --no-cpu-baseline --no-profile --no-interactive 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(round(d["ms_per_step"],4), "ms/frame  windows:", [round(x) for x in d["repeats"]])' | tee -a $O/log.txt; done; done ;;
+    valumix) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/valu_mix.hip -o /tmp/valu_mix 2>/dev/null && timeout 300 /tmp/valu_mix | tee $O/valu_mix.txt | tee -a $O/log.txt ;;
     sh)      timeout 900 bash -c "${step#sh:}" 2>&1 | tail -20 | tee -a $O/log.txt ;;
     *)       echo "unknown step $step" | tee -a $O/log.txt ;;
   esac

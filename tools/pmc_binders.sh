@@ -22,13 +22,14 @@ GROUPS_=(
  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVE_CYCLES"
  "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_REQ SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ"
 )
+[ "${PMC_SET:-full}" = "min" ] && GROUPS_=("SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES")
 i=20
 for G in "${GROUPS_[@]}"; do
   i=$((i+1)); CTRS=""; n=0
   for c in $G; do if have $c && [ $n -lt 8 ]; then CTRS="$CTRS $c"; n=$((n+1)); else echo "not collected: $c" >> $OUT/binders_missing.txt; fi; done
   [ -z "$CTRS" ] && continue
   PT_TUNE=${PMC_TUNE:-inflight=1,warm=0} timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw$i -o p -- \
-    python $REPO/bench.py --workload $WL --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
+    python $REPO/bench.py --workload $WL --accel ${PMC_ACCEL:-flat} --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
   echo "pass $i ($CTRS): rc $?"
   find $OUT/raw$i -name '*counter_collection.csv' -exec cp {} $OUT/counters$i.csv \;
   rm -rf $OUT/raw$i

@@ -12,12 +12,16 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 FRAMES=${PMC_FRAMES:-96}
+WL=${PMC_WORKLOAD:-c3}     # BASELINE configuration (bench.py --workload); the summaries of c2 / c4 / c5 are committed as profiles/rNN_<kind>_<workload>.json
+ACCEL=${PMC_ACCEL:-flat}
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 i=0
-for CTRS in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
+GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU")
+[ "${PMC_SET:-full}" = "min" ] && GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU")
+for CTRS in "${GROUPS_[@]}"; do
   i=$((i+1))
   PT_TUNE=inflight=1,warm=0 timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw$i -o p -- \
-    python $REPO/bench.py --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
+    python $REPO/bench.py --workload $WL --accel $ACCEL --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
   echo "pass $i ($CTRS): rc $?"
   find $OUT/raw$i -name '*counter_collection.csv' -exec cp {} $OUT/counters$i.csv \;
   rm -rf $OUT/raw$i

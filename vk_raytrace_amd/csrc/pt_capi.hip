@@ -743,6 +743,8 @@ void pt_parse_tuning(const char* tune, PtTuning& t, std::string& unknown)
           {
             t.*(k.field) = int(v);
             ok           = true;
+            if(k.field == &PtTuning::framesInFlight)
+              t.inflightSet = 1;
           }
           break;
         }
@@ -1645,6 +1647,11 @@ int pt_resize(pt_context* c, int width, int height)
   const size_t perPath = 9 * sizeof(float4) + 6 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
   c->displaySlots      = c->displaySlotsMax;
+  // Shard policy by shard size (round 6; was left to PT_TUNE): a rank that renders a small shard -- 1/8 of a 1080p image is 259 k pixels -- keeps TWO
+  // frame slots: the pieces of its short batches are then large enough to fill the persistent kernels (3-4 % better at 20 steps, worse on a 1/4 shard:
+  // profiles/r05o_shard_pieces.txt).  An explicit PT_TUNE inflight= wins.
+  if(!c->tune.inflightSet && c->nranks > 1 && c->localPixels > 0 && c->localPixels <= 300000)
+    c->inflight = std::min(c->inflight, 2);
   {
     // what is free now PLUS what the frame slots already hold (those buffers are re-used or released below): a repeated pt_resize at the same
     // size must arrive at the same batch, not at half of it.  A failed query means "no cap" -- the retry loop below still shrinks on a failed allocation.

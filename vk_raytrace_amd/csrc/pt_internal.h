@@ -50,6 +50,7 @@ struct PtScratch {
 struct PtTuning {
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
+  int inflightSet          = 0;    // (parser) PT_TUNE named inflight=: pt_resize then leaves the slot count alone instead of choosing it by shard size
   int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
   int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
