@@ -165,6 +165,29 @@ def mix_ceilings():
     return None, None
 
 
+def scaling_prediction(workload, steps, world, ms_per_step):
+    """The N > 1 line next to what the all-rank emulation on ONE GPU predicted for it (tools/shard_table.py: every rank's shard rendered alone, job time =
+    slowest rank; profiles/rNN_shard_table_<workload>.json): predicted ms per step and efficiency for this N at the nearest tabulated step count, and the
+    measured time against it.  The N = 1 time of THIS run is not known inside an N > 1 run: the driver computes the measured efficiency from its own lines."""
+    table, src = latest_profile("shard_table_" + workload)
+    if not table:
+        return None
+    rows = table.get("rows", [])
+    tab_steps = sorted({r["steps"] for r in rows})
+    if not tab_steps:
+        return None
+    near = min(tab_steps, key=lambda t: abs(np.log(t / max(1, steps))))
+    one = next((r for r in rows if r["steps"] == near and r["ranks"] == 1), None)
+    mine = next((r for r in rows if r["steps"] == near and r["ranks"] == world), None)
+    if not one or not mine:
+        return None
+    return {"source": src, "tabulated_steps": near, "n1_ms_per_step_predicted": one["ms_per_frame_slowest_rank"], "ms_per_step_predicted": mine["ms_per_frame_slowest_rank"],
+            "efficiency_predicted": mine["efficiency"], "imbalance_predicted": mine["imbalance_max_over_mean"], "ms_per_step_measured": ms_per_step,
+            "measured_over_predicted": ms_per_step / mine["ms_per_frame_slowest_rank"],
+            "efficiency_vs_n1_prediction": one["ms_per_frame_slowest_rank"] / (world * ms_per_step),
+            "note": "prediction = every rank's shard rendered alone on one GPU (no host sharing, no gather); efficiency_vs_n1_prediction = the table's N = 1 time / (N x this run's time)"}
+
+
 def latest_profile(kind, workload="c3"):
     """profiles/rNN_<kind>.json of the newest round that has one (this round's PMC passes, else the previous round's); the other BASELINE configurations
     have summaries of their own, profiles/rNN_<kind>_<workload>.json (per-sample figures are a property of code AND workload)."""
@@ -790,6 +813,12 @@ def main():
         "rays": {k: stats[k] for k in RAY_KEYS},
         "image_mean": float(np.mean(img[..., :3])) if img is not None else None,
     }
+
+    if world > 1 and not args.emulate_shard:
+        try:
+            out["scaling_prediction"] = scaling_prediction(args.workload, args.steps, world, out["ms_per_step"])
+        except Exception as e:  # noqa: BLE001
+            out["scaling_prediction"] = {"error": repr(e)}
 
     if args.refit > 0:
         # instance update (pt_update_instances): every node's world matrix is re-sent; two-level mode redoes only the instance boxes + TLAS

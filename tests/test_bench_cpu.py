@@ -82,3 +82,70 @@ def test_evidence_fields_never_cost_the_line():
     out = {"calibration": {"valu_G_wave_instr_per_s": 800.0, "hbm_read_GBps": 6000.0, "hbm_copy_GBps": 4500.0, "compute_units": 256, "clock_MHz": 2400}, "rays": {}}
     bench.evidence_fields(out, None, None, 1000, 1.0, 1, "c3")
     assert "roofline" not in out
+
+
+_FALLBACK = r"""
+import json, sys, types
+sys.path.insert(0, %r)
+import numpy as np
+import bench
+
+calls = []
+def fake_launch(n):
+    calls.append(("self_launch", n))
+    return 7   # a rank died (rendezvous, RCCL bootstrap between processes, ...)
+
+class FakeRenderer:
+    def measure_peaks(self):
+        return {"valuWaveInstrPerSec": 8.0e11, "hbmCopyBytesPerSec": 4.5e12, "hbmReadBytesPerSec": 6.0e12, "computeUnits": 256, "clockMHz": 2400}
+
+def fake_single(args):
+    calls.append(("single_process", args.gpus))
+    wl = types.SimpleNamespace(name="C3 stand-in (stub)", scene=types.SimpleNamespace(num_triangles=12, materials=[0], textures=[]), depth=8, pbr_mode=0, env=np.zeros((4, 8, 4), np.float32), note="")
+    W, H = 64, 32
+    stats = {k: 10 for k in ("closestRays", "shadowRays", "shadedHits", "misses", "alphaTests", "neeLookups")}
+    stats.update({"msBuildAccel": 1.0, "bytesAccel": 1000, "numBlas": 0, "numTlasNodes": 0, "numBvhNodes": 3, "batchFrames": 2, "framesInFlight": 2, "samples": W * H * args.steps})
+    img = np.ones((H, W, 4), np.float32)
+    return {"wl": wl, "W": W, "H": H, "windows": [0.002, 0.001, 0.003], "img_first": img, "img": img, "gather_ms": 0.5, "stats": stats, "ranks_seen": args.gpus, "t_setup": 0.1,
+            "integral": 1.0, "cam": None, "renderer": FakeRenderer(), "st": None, "frame": 0, "per_rank_ms": [0.4, 0.5], "gather": "rccl (pt_comm_init_all, one process)", "shard": (0, args.gpus),
+            "cleanup": lambda: calls.append(("cleanup",))}
+
+bench.self_launch, bench.single_process = fake_launch, fake_single
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-profile", "--no-interactive", "--no-cpu-baseline"] + sys.argv[1:]
+try:
+    bench.main()
+finally:
+    print(json.dumps(calls), file=sys.stderr)
+"""
+
+
+def _run_fallback(extra=()):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", _FALLBACK % root] + list(extra), env=env, capture_output=True, text=True, timeout=300)
+    calls = json.loads([ln for ln in p.stderr.strip().splitlines() if ln.startswith("[")][-1])
+    return p, calls
+
+
+def test_failed_self_launch_falls_back_to_single_process():
+    """`bench.py --gpus 2` without a launcher: the self-launched ranks fail -> the same job from ONE process (--single-process) instead of no line at all, and the
+    line says so; `--no-fallback` turns the failure into the exit code.  The launch and the renderer are stubs here (no GPU): what is under test is main()'s flow
+    -- the fallback, the median window, the N > 1 fields incl. the prediction of tools/shard_table.py, the line being the last thing on stdout."""
+    import json
+    p, calls = _run_fallback()
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert [c[0] for c in calls] == ["self_launch", "single_process", "cleanup"] and calls[0][1] == 2
+    assert "falling back to --single-process" in p.stderr and "exit code 7" in p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["launch"].startswith("single-process (fallback") and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert abs(line["ms_per_step"] - 1.0) < 1e-9 and len(line["repeats"]) == 3       # the median window (2 ms for 2 steps)
+    assert line["scaling"] == "strong" and line["ms_per_step_per_rank"] == [0.4, 0.5] and line["gather"].startswith("rccl")
+    sp = line["scaling_prediction"]
+    assert sp["tabulated_steps"] == 20 and 0.0 < sp["efficiency_predicted"] <= 1.0 and sp["ms_per_step_measured"] == line["ms_per_step"]
+    assert abs(sp["efficiency_vs_n1_prediction"] - sp["n1_ms_per_step_predicted"] / (2 * line["ms_per_step"])) < 1e-12
+    p, calls = _run_fallback(["--no-fallback"])
+    assert p.returncode == 7 and [c[0] for c in calls] == ["self_launch"] and p.stdout.strip() == ""
