@@ -62,13 +62,19 @@ def test_evidence_fields_on_a_recorded_run():
     elapsed = rec["ms_per_step"] * rec["steps"] * 1e-3
     bench.evidence_fields(out, rec["serialised"], rec["alg_model"], samples, elapsed, 1, "c3")
     r = out["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    # round 6: the line names the MEASURED binder -- VALU issue against the ceiling tools/valu_mix.hip reaches for the stage's own instruction mix --
+    # and SURVEY 8(d)'s algorithmic-byte figure moves to alg_* (it exceeds 1: cache-served bytes); the HBM interface is `traffic` / `hbm`
+    assert r["bound"] == "valu_issue" and r["unit"] == "G wave-instructions/s" and 300.0 < r["peak"] < 1300.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     assert r["avg_launch_ms"] * r["launches"] / rec["steps"] <= rec["ms_per_step"]  # the dominant stage fits inside a step
-    b = r["binding"]
-    assert b is not None and 0.0 < b["frac"] < 1.0, "the binding ceiling of the dominant stage is a measured fraction below 1"
-    assert "alg_model_note" in r
+    assert abs(r["alg_achieved_GBps"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["alg_achieved_GBps"]
+    assert abs(r["alg_frac"] - r["alg_achieved_GBps"] / 8000.0) < 1e-12 and "alg_note" in r
+    assert r["hbm"]["peak"] == 8000.0 and 0.0 < r["hbm"]["frac"] < 1.0 and r["traffic"] > 0
+    lanes = r["lanes_per_valu_instr"]
+    assert lanes and all(0.0 < v <= 64.0 for v in lanes.values())  # hardware lane occupancy of the stage's kernels (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)
+    per = r["per_stage"]
+    for k in ("closest", "shade", "shadow"):
+        assert 0.0 < per[k]["valu_issue_frac"] < 1.0 and 0.0 < per[k]["hbm_frac"] < 1.0, k
     sh = out["stages_serialised"]["shade"]["binding"]
     assert 0.0 < sh["frac"] < 1.5 and sh["peak_GBps"] == rec["calibration"]["hbm_read_GBps"]
     for k in ("closest", "shadow"):

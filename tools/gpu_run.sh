@@ -3,7 +3,8 @@
 #   gpurun -- 'bash tools/gpu_run.sh <tag> <step> [<step> ...]'        output -> gpurun_out/<tag>/
 # steps (run in the order given; each under its own `timeout`):
 #   cold20              the driver's command with PT_TUNE=warm=0 and no evidence legs: what a first process on a fresh box does without the slot warm-up
-#   bench20 | bench256  the driver's command line / the 256-step line (bench256 without the CPU leg)
+#   bench20 | bench256  the driver's command line / the 256-step line (both with the CPU leg: parity in the line)
+#   line:<workload>:<steps>[:two]  a full line of c2 / c4 / c5 (flat or two-level structure)
 #   quick:<steps>       bench without evidence legs (rate only)
 #   prof20              rocprofv3 --kernel-trace --stats over the driver's command line -> kernel_stats_bench20.csv
 #   tune:<steps>:<A>;<B>;...    bench under each PT_TUNE string, two alternating rounds ("-" = the defaults)
@@ -33,7 +34,10 @@ for step in "$@"; do
   case $kind in
     cold20)  PT_TUNE=warm=0 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-interactive > $O/cold20.json 2> $O/cold20.err; val < $O/cold20.json | tee -a $O/log.txt ;;
     bench20) timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "rc $?" | tee -a $O/log.txt; val < $O/bench_20.json | tee -a $O/log.txt ;;
-    bench256) timeout 600 python bench.py --gpus 1 --steps 256 --warmup 8 --no-cpu-baseline > $O/bench_256.json 2> $O/bench_256.err; val < $O/bench_256.json | tee -a $O/log.txt ;;
+    bench256) timeout 900 python bench.py --gpus 1 --steps 256 --warmup 8 > $O/bench_256.json 2> $O/bench_256.err; val < $O/bench_256.json | tee -a $O/log.txt ;;
+    line)    # line:<workload>:<steps>[:two]  a full line (parity, cpu_baseline, roofline) of another BASELINE configuration
+             IFS=: read -r ln_steps ln_accel <<< "$b"; ACC=flat; SUF=""; [ "$ln_accel" = "two" ] && ACC=two && SUF=_two
+             timeout 1500 python bench.py --gpus 1 --workload $a --accel $ACC --steps $ln_steps --warmup 5 > $O/bench_${a}_${ln_steps}$SUF.json 2> $O/bench_${a}_${ln_steps}$SUF.err; echo "rc $?" | tee -a $O/log.txt; val < $O/bench_${a}_${ln_steps}$SUF.json | tee -a $O/log.txt ;;
     quick)   timeout 300 python bench.py --steps $a --warmup 8 --no-cpu-baseline --no-profile --no-interactive > $O/quick_$a.json 2> $O/quick_$a.err; val < $O/quick_$a.json | tee -a $O/log.txt ;;
     prof20)  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof20 -o p -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-interactive > $O/bench_20_profiled.json 2> $O/prof20.err)
              find $O/prof20 -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_bench20.csv \; ; rm -rf $O/prof20; head -12 $O/kernel_stats_bench20.csv | cut -c1-150 | tee -a $O/log.txt ;;

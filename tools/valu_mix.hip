@@ -13,7 +13,6 @@
 //   MIX 2  independent v_fmac_f32 (the form bench.py calibrates with), as the cross-check against tools/valu_peak.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#define ITERS 2048
 
 #define TRACE_BLOCK_ASM                                                                                                                      \
   "v_fma_f32 %0, %8, %21, %22\n v_fma_f32 %1, %9, %21, %22\n v_mul_f32 %2, %0, %23\n v_mul_f32 %3, %1, %23\n v_add_f32 %4, %2, %3\n"          \
@@ -56,9 +55,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_boun
                      "+s"(s0), "+s"(s1), "+s"(s2), "+s"(u0), "+s"(u1)
                    : "v"(q), "v"(r), "v"(m)
                    : "vcc", "scc");
-    if(MIX == 2)
-      asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
-                   "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+#define FMAC8 "v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+    if(MIX == 2)  // 64 per loop iteration (a loop of 8 pays a branch per 8 instructions: 620 G/s instead of the ceiling)
+      asm volatile(FMAC8 FMAC8 FMAC8 FMAC8 FMAC8 FMAC8 FMAC8 FMAC8
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(q), "v"(r));
   }
   float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + p0 + p1 + t0 + t1 + float(i0 + i1 + i2 + i3);
@@ -69,6 +68,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_boun
 template <int MIX, int WAVES>
 void run(const char* name, int cus, int valuPerIter, int saluPerIter)
 {
+  const int ITERS = 2400000 / valuPerIter;  // ~2.4 M VALU per wave and launch: a launch lasts milliseconds, its start-up does not show
   float* out;
   (void)hipMalloc(&out, 64);
   hipEvent_t e0, e1;
@@ -96,8 +96,8 @@ int main()
   (void)hipGetDeviceProperties(&p, 0);
   printf("%s, %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
   const int cus = p.multiProcessorCount;
-  run<2, 8>("independent v_fmac_f32", cus, 8, 0);
-  run<2, 5>("independent v_fmac_f32", cus, 8, 0);
+  run<2, 8>("independent v_fmac_f32", cus, 64, 0);
+  run<2, 5>("independent v_fmac_f32", cus, 64, 0);
   run<0, 8>("trace-machine mix (80 VALU + 28 SALU)", cus, 80, 28);
   run<0, 5>("trace-machine mix (k_closest_p: 5)", cus, 80, 28);
   run<0, 4>("trace-machine mix (two-level: 4)", cus, 80, 28);
