@@ -932,7 +932,7 @@ def main():
         out["serialised"] = serial
 
     try:
-        evidence_fields(out, serial, alg, samples, elapsed, world, args.workload)
+        evidence_fields(out, serial, alg, samples, elapsed, world, args.workload + ("two" if args.accel == "two" else ""))  # (the PMC summaries are per workload AND structure)
     except Exception as e:  # the evidence fields are additions: a failure in their post-processing must never cost the line itself
         out["evidence_error"] = repr(e)
     try:  # RCCL writes a version banner through C stdio, which a pipe holds back until exit -- AFTER the line.  Out with it now: the line is the last thing on stdout.

@@ -53,10 +53,11 @@ for step in "$@"; do
     tests)   if [ -n "$a" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$a" > $O/gputest.txt 2>&1; else timeout 1500 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; fi; tail -5 $O/gputest.txt | tee -a $O/log.txt ;;
     smoke)   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee -a $O/log.txt ;;
     pmc)     PMC_FRAMES=${a:-96} timeout 1500 bash tools/pmc_passes.sh $TAG > $O/pmc.txt 2>&1; for k in traffic valu cache; do [ -s gpurun_out/pmc_$TAG/$k.json ] && cp gpurun_out/pmc_$TAG/$k.json $O/$k.json; done; tail -4 $O/pmc.txt | tee -a $O/log.txt ;;
-    pmcwl)   # pmcwl:<workload>:<frames>  the reduced pass set (traffic, instruction mix, cycles, lane occupancy) on another BASELINE configuration -> <kind>_<workload>.json
-             PMC_WORKLOAD=$a PMC_FRAMES=${b:-32} PMC_SET=min timeout 1500 bash tools/pmc_passes.sh ${TAG}_$a > $O/pmc_$a.txt 2>&1
-             PMC_WORKLOAD=$a PMC_FRAMES=${b:-32} PMC_SET=min timeout 900 bash tools/pmc_binders.sh ${TAG}_$a >> $O/pmc_$a.txt 2>&1
-             for k in traffic valu binders; do [ -s gpurun_out/pmc_${TAG}_$a/$k.json ] && cp gpurun_out/pmc_${TAG}_$a/$k.json $O/${k}_$a.json; done; tail -6 $O/pmc_$a.txt | tee -a $O/log.txt ;;
+    pmcwl)   # pmcwl:<workload>:<frames>[:two]  the reduced pass set (traffic, instruction mix, cycles, lane occupancy) on another BASELINE configuration -> <kind>_<workload>.json
+             IFS=: read -r pw_frames pw_accel <<< "$b"; PACC=flat; PSUF=$a; [ "$pw_accel" = "two" ] && PACC=two && PSUF=${a}two
+             PMC_WORKLOAD=$a PMC_ACCEL=$PACC PMC_FRAMES=${pw_frames:-32} PMC_SET=min timeout 1500 bash tools/pmc_passes.sh ${TAG}_$PSUF > $O/pmc_$PSUF.txt 2>&1
+             PMC_WORKLOAD=$a PMC_ACCEL=$PACC PMC_FRAMES=${pw_frames:-32} PMC_SET=min timeout 900 bash tools/pmc_binders.sh ${TAG}_$PSUF >> $O/pmc_$PSUF.txt 2>&1
+             for k in traffic valu binders; do [ -s gpurun_out/pmc_${TAG}_$PSUF/$k.json ] && cp gpurun_out/pmc_${TAG}_$PSUF/$k.json $O/${k}_$PSUF.json; done; tail -6 $O/pmc_$PSUF.txt | tee -a $O/log.txt ;;
     binders) PMC_FRAMES=${a:-64} PMC_TUNE=${b:-inflight=1,warm=0} timeout 1500 bash tools/pmc_binders.sh $TAG > $O/binders.txt 2>&1; cp gpurun_out/pmc_$TAG/binders.json $O/binders.json 2>/dev/null; tail -14 $O/binders.txt | tee -a $O/log.txt ;;
     shards)  for n in 1 2 4 8; do worst=0; for ((r = 0; r < n; r++)); do
                timeout 300 python bench.py --workload $a --emulate-shard $r/$n --steps $b --warmup 5 --no-cpu-baseline --no-profile --no-interactive > $O/shard_${a}_${r}of${n}_$b.json 2>/dev/null
