@@ -31,7 +31,8 @@ for G in "${GROUPS_[@]}"; do
   PT_TUNE=${PMC_TUNE:-inflight=1,warm=0} timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw$i -o p -- \
     python $REPO/bench.py --workload $WL --accel ${PMC_ACCEL:-flat} --steps $FRAMES --warmup 0 --repeats 1 --no-cpu-baseline --no-profile --no-interactive > $OUT/bench$i.json 2> $OUT/bench$i.err
   echo "pass $i ($CTRS): rc $?"
-  find $OUT/raw$i -name '*counter_collection.csv' -exec cp {} $OUT/counters$i.csv \;
+  # keep the rows of the render kernels only (a two-level build dispatches thousands of builder kernels: the merged output must stay small)
+  find $OUT/raw$i -name '*counter_collection.csv' -exec sh -c 'head -1 "$1" > "$2"; grep -E "k_(generate|closest|shade|shadow|trace|tail|accumulate)" "$1" >> "$2"' _ {} $OUT/counters$i.csv \;
   rm -rf $OUT/raw$i
 done
 python3 $REPO/tools/pmc_binders_json.py $OUT $FRAMES

@@ -128,7 +128,9 @@ int pt_merged_build(hipStream_t stream, const PtTuning& tune, const InstanceRec*
 #ifndef PT_DISPLAY_RING
 #define PT_DISPLAY_RING 8  // images pt_tonemap_begin may have in flight before pt_tonemap_end collects the oldest
 #endif
+#ifndef PT_PERSISTENT_WAVES
 #define PT_PERSISTENT_WAVES (256u * 20u)  // persistent trace kernels: waves per launch = what the chip holds at 5 waves / SIMD (profiles/r03h_tune_96.txt, r03i_*)
+#endif
 
 // POL: cache policy of the path-state accesses (pt_device.h)
 template <int POL>
