@@ -109,7 +109,7 @@ struct pt_context {
   uint64_t  qRatioSeq    = 0;   // launch they come from
   uint64_t  launchSeq    = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
-  DevBuf   dFrame, dSlotTile, dCounters;
+  DevBuf   dFrame, dSlotTile, dTilePrefix, dCounters;
   DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
@@ -743,8 +743,6 @@ void pt_parse_tuning(const char* tune, PtTuning& t, std::string& unknown)
           {
             t.*(k.field) = int(v);
             ok           = true;
-            if(k.field == &PtTuning::framesInFlight)
-              t.inflightSet = 1;
           }
           break;
         }
@@ -864,7 +862,7 @@ int pt_destroy(pt_context* c)
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   DevBuf* all[] = {&c->dMatLines, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
-                   &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
+                   &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dTilePrefix, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
@@ -1647,11 +1645,9 @@ int pt_resize(pt_context* c, int width, int height)
   const size_t perPath = 9 * sizeof(float4) + 6 * sizeof(uint32_t);
   c->inflight          = c->inflightMax;
   c->displaySlots      = c->displaySlotsMax;
-  // Shard policy by shard size (round 6; was left to PT_TUNE): a rank that renders a small shard -- 1/8 of a 1080p image is 259 k pixels -- keeps TWO
-  // frame slots: the pieces of its short batches are then large enough to fill the persistent kernels (3-4 % better at 20 steps, worse on a 1/4 shard:
-  // profiles/r05o_shard_pieces.txt).  An explicit PT_TUNE inflight= wins.
-  if(!c->tune.inflightSet && c->nranks > 1 && c->localPixels > 0 && c->localPixels <= 300000)
-    c->inflight = std::min(c->inflight, 2);
+  // (Round 6 tried a policy by shard size here -- two frame slots for a shard of at most 300 k pixels, what PT_TUNE inflight=2 showed on a 1/8 shard of a
+  // 1080p image at 20 steps: +5 % there, but -9 % at the configuration's own 256 steps, where four full batches want four slots: 89 % -> 81 % predicted
+  // efficiency at 8 GPUs (profiles/r06_shard_policy_experiment.txt).  Not adopted: the slot count stays what the context was created with.)
   {
     // what is free now PLUS what the frame slots already hold (those buffers are re-used or released below): a repeated pt_resize at the same
     // size must arrive at the same batch, not at half of it.  A failed query means "no cap" -- the retry loop below still shrinks on a failed allocation.
@@ -1729,6 +1725,15 @@ int pt_resize(pt_context* c, int width, int height)
   }
   if((rc = dev_alloc(c, c->dFrame, sizeof(float4) * size_t(c->maxTilesPerRank ? c->maxTilesPerRank : 1) * 1024u)) != PT_OK) return rc;
   if((rc = upload(c, c->dSlotTile, local.data(), 4 * local.size())) != PT_OK) return rc;
+  {  // valid pixels of the local tiles before each tile (k_generate's queue positions)
+    std::vector<uint32_t> prefix(local.size() + 1, 0u);
+    for(size_t i = 0; i < local.size(); ++i)
+    {
+      const int tx = int(local[i] % uint32_t(c->tilesX)), ty = int(local[i] / uint32_t(c->tilesX));
+      prefix[i + 1] = prefix[i] + uint32_t(std::min(PT_TILE, width - tx * PT_TILE)) * uint32_t(std::min(PT_TILE, height - ty * PT_TILE));
+    }
+    if((rc = upload(c, c->dTilePrefix, prefix.data(), 4 * prefix.size())) != PT_OK) return rc;
+  }
   HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
   if((rc = dev_alloc(c, c->dRowMajor, sizeof(float4) * size_t(width) * height)) != PT_OK) return rc;
   HIP_TRY(c, hipMemset(c->dRowMajor.p, 0, sizeof(float4) * size_t(width) * height));
@@ -1755,6 +1760,7 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.countsDone = (uint32_t*)fs.dCountsDone.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
+    fs.rb.tilePrefix = (uint32_t*)c->dTilePrefix.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
   }
   return warm_slots(c);
@@ -1901,6 +1907,7 @@ int flush_pending(pt_context* c)
     pt_context::FrameSlot& fs = slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c))));
     RenderBuffers  rbb = fs.rb;
     rbb.slotTile += t0;
+    rbb.tilePrefix += t0;
     rbb.frame += size_t(t0) * 1024u;
     plans.emplace_back();
     planSlot.push_back(&fs);

@@ -50,7 +50,6 @@ struct PtScratch {
 struct PtTuning {
   int packetClosestBounces = 1;   // bounces whose closest-hit stage walks one traversal per wavefront (pt_packet.h)
   int framesInFlight       = 4;    // independent frame batches overlapped on separate streams (accumulate stays ordered)
-  int inflightSet          = 0;    // (parser) PT_TUNE named inflight=: pt_resize then leaves the slot count alone instead of choosing it by shard size
   int stateGB              = 0;    // cap of the in-flight path state in GB (0: 85 % of the free device memory); the batch shrinks to fit
   int stateMB              = 0;    // the same cap in MB (tests of the shrink path: a budget smaller than one default batch)
   int sahBuild             = 3;    // 3: device binned SAH (default; pt_sahdev.h), 2: device PLOC, 1: host SAH topology (the cross-check of 3), 0: device LBVH (Karras radix tree)
@@ -146,6 +145,7 @@ struct RenderBuffersT {
   uint32_t* countsDone;  // the counter block of the latest finished sample pass (k_accumulate copies it here and clears `counts`)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
+  uint32_t* tilePrefix;  // [local tiles + 1]: valid pixels (inside the image) of the local tiles before tile i; k_generate places a tile's slots in the bounce-0 queue with it
   Counters* counters;
 };
 typedef RenderBuffersT<PT_STATE_POLICY> RenderBuffers;
