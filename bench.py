@@ -30,10 +30,12 @@ After the timed region (never part of `value`), rank 0 measures what the JSON li
   interactive        render + tonemap per frame (batch = 1, SampleExample's display loop)
   serialised         one batch on a second context with one frame slot and the SAME launch policy as the timed run (k_tail included):
                      standalone stage durations (HIP events on the launching stream, nothing overlapped)
-  roofline           the stage with the largest standalone time: `achieved` / `frac` = SURVEY.md 8(d) ALGORITHMIC bytes per launch / its average
-                     launch duration vs 8 TB/s (may exceed 1: most algorithmic bytes are served by L2 / Infinity Cache); `traffic` /
-                     `traffic_frac` = HBM bytes per launch from the newest round's PMC passes (profiles/rNN_traffic.json, tools/pmc_passes.sh);
-                     `l2_*` = L2 requests of the same stage (profiles/rNN_cache.json) against the 34.5 TB/s L2 ceiling
+  roofline           the stage with the largest standalone time against the ceiling that was MEASURED to bind it (round 6): `bound` = "valu_issue", `achieved` =
+                     VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/rNN_valu.json) / its average launch duration, `peak` = the issue rate
+                     tools/valu_mix.hip reaches for that kernel's own instruction mix at its occupancy (profiles/rNN_valu_mix.txt), `lanes_per_valu_instr` =
+                     hardware lane occupancy (profiles/rNN_binders.json); `traffic` / `hbm` = HBM bytes per launch from the PMC passes against 8 TB/s;
+                     `alg_*` = SURVEY.md 8(d)'s ALGORITHMIC bytes per launch / launch duration vs 8 TB/s (exceeds 1: those bytes are cache-served);
+                     `l2_*` = L2 requests of the stage (profiles/rNN_cache.json); `per_stage` = the same fractions for every stage
   hbm_measured       measured HBM bytes per sample x this run's rate
   issue_roofline     VALU wave-instructions per sample (profiles/rNN_valu.json, same PMC run) x this run's rate / the calibrated ceiling
   cpu_baseline       oracle/_ref (the reference's own pathtrace.comp compiled for the host, kind "reference") and the CPU oracle (the

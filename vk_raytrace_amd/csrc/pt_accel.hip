@@ -516,6 +516,36 @@ __global__ void k_sd_prims(uint32_t n, const TriRec* __restrict__ tris, float4* 
   idx[i]      = i;
   primWork[i] = rootWork;
 }
+// forest builds: every primitive starts in the work item of ITS root (TriRec::e1n.w = the instance = the root), SD_NONE for the roots that go
+// straight to the small-node list; and every root's parent is "none"
+__global__ void k_forest_prim_work(uint32_t n, const TriRec* __restrict__ tris, const uint32_t* __restrict__ rootWork, uint32_t* __restrict__ primWork)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < n)
+    primWork[i] = rootWork[__float_as_uint(tris[i].e1n.w)];
+}
+__global__ void k_forest_roots(uint32_t numRoots, const uint32_t* __restrict__ rootNode, uint32_t* __restrict__ parI)
+{
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if(r < numRoots)
+    parI[rootNode[r]] = BVH_NONE;
+}
+// the leaf records of a forest of BLASes in vertex form (k_blas_vertex_form with the mesh looked up through the record's instance = root)
+__global__ void k_forest_vertex_form(uint32_t n, TriRec* __restrict__ tris, const InstanceRec* __restrict__ pseudo, const float4* __restrict__ vertices, const uint32_t* __restrict__ indices)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const InstanceRec& I = pseudo[__float_as_uint(tris[i].e1n.w)];
+  const uint32_t     k = __float_as_uint(tris[i].e2p.w);
+  const uint32_t*    t = indices + I.firstIndex + 3 * size_t(k);
+  const f3           v0 = load_pos(vertices, I.vertexOffset + t[0]), v1 = load_pos(vertices, I.vertexOffset + t[1]), v2 = load_pos(vertices, I.vertexOffset + t[2]);
+  TriRec             r;
+  r.p0w   = make_float4(v0.x, v0.y, v0.z, __uint_as_float(k));
+  r.e1n   = make_float4(v1.x, v1.y, v1.z, 0.f);
+  r.e2p   = make_float4(v2.x, v2.y, v2.z, 0.f);
+  tris[i] = r;
+}
 __global__ void k_sd_init_bins(size_t nBins, uint32_t* __restrict__ binCnt, uint32_t* __restrict__ binBox)
 {
   size_t b = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -786,15 +816,16 @@ __global__ void k_rotate(int n, uint32_t* childL, uint32_t* childR, uint32_t* pa
 }
 
 // leaf reference of sorted slot `i`: non-opaque triangles are tagged so that traversal fetches their AlphaRec up front
-PT_DEV uint32_t leaf_ref(const TriRec* __restrict__ tris, uint32_t leaf)
+PT_DEV uint32_t leaf_ref(const TriRec* __restrict__ tris, uint32_t leaf, uint32_t leafOffset = 0u)
 {
   const uint32_t slot  = leaf & ~BVH_LEAF;
   const uint32_t flags = __float_as_uint(tris[slot].p0w.w) >> 29;
-  return BVH_LEAF | slot | ((flags & TRI_OPAQUE) ? 0u : BVH_ALPHA);
+  return BVH_LEAF | (slot + leafOffset) | ((flags & TRI_OPAQUE) ? 0u : BVH_ALPHA);
 }
 
 __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const uint32_t* __restrict__ childR, const float4* __restrict__ leafLo,
-                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, const TriRec* __restrict__ tris, BvhNode* __restrict__ out)
+                       const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, const TriRec* __restrict__ tris, BvhNode* __restrict__ out,
+                       uint32_t leafOffset = 0u)
 {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= numInner)
@@ -808,7 +839,7 @@ __global__ void k_emit(int numInner, const uint32_t* __restrict__ childL, const 
   nd.a   = make_float4(llo.x, llo.y, llo.z, lhi.x);
   nd.b   = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
   nd.c   = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
-  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l) : (l | (llo.w > 0.f ? BVH_ALPHA : 0u)), (r & BVH_LEAF) ? leaf_ref(tris, r) : (r | (rlo.w > 0.f ? BVH_ALPHA : 0u)), 0u, 0u);
+  nd.d   = make_uint4((l & BVH_LEAF) ? leaf_ref(tris, l, leafOffset) : (l | (llo.w > 0.f ? BVH_ALPHA : 0u)), (r & BVH_LEAF) ? leaf_ref(tris, r, leafOffset) : (r | (rlo.w > 0.f ? BVH_ALPHA : 0u)), 0u, 0u);
   out[i] = nd;
 }
 
@@ -963,6 +994,7 @@ __global__ void k_tlas_leaves(uint32_t n, const TriRec* __restrict__ leafOrder, 
 struct CollapseItem {
   uint32_t b2;    // binary node to expand
   uint32_t wide;  // wide node it becomes
+  uint32_t root;  // forest builds: the root it belongs to (its wide nodes come out of that root's range)
 };
 PT_DEV float half_area(float4 lo, float4 hi)
 {
@@ -970,7 +1002,7 @@ PT_DEV float half_area(float4 lo, float4 hi)
   return dx * dy + dy * dz + dz * dx;
 }
 __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* __restrict__ qin, uint32_t nIn, CollapseItem* __restrict__ qout, uint32_t* counters /* [0]=nOut [1]=wideCount */,
-                           WideNode* __restrict__ out)
+                           WideNode* __restrict__ out, uint32_t* __restrict__ rootCount = nullptr, const uint32_t* __restrict__ rootBase = nullptr)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= nIn)
@@ -1026,9 +1058,9 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
           ch[k] = id[c];
         else
         {
-          uint32_t wid = atomicAdd(&counters[1], 1u);
+          uint32_t wid = rootCount ? rootBase[it.root] + atomicAdd(&rootCount[it.root], 1u) : atomicAdd(&counters[1], 1u);
           uint32_t qi  = atomicAdd(&counters[0], 1u);
-          qout[qi]     = CollapseItem{id[c] & BVH_SLOT_MASK, wid};
+          qout[qi]     = CollapseItem{id[c] & BVH_SLOT_MASK, wid, it.root};
           ch[k]        = wid | (id[c] & BVH_ALPHA);  // inner reference: wide node index + "subtree holds non-opaque triangles"
         }
       }
@@ -1063,7 +1095,7 @@ __global__ void k_collapse(const BvhNode* __restrict__ b2, const CollapseItem* _
 // scratch (may be null): temporaries come out of the caller's arena instead of one device allocation each (a scene of hundreds of BLASes).
 int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
                    TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen, const TriRec* dProxies,
-                   PtScratch* scratch)
+                   PtScratch* scratch, const PtForest* forest)
 {
   *numWideOut = 0;
   if(numTris == 0)
@@ -1136,7 +1168,53 @@ int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* 
       sd_init_work(root, 0, n, 0);
       uint32_t zero2[2] = {0u, 0u};
       const uint32_t noneParent = BVH_NONE;
-      bool     ok = hipMemcpyAsync(dParI, &noneParent, 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+      bool     ok = true;
+      if(forest)
+      {  // one root per hierarchy: the big ones open the first level's work list, the small ones go to the small-node list
+        std::vector<SdWork>   big, little;
+        std::vector<uint32_t> rootWork(forest->numRoots), rootNode(forest->numRoots);
+        for(uint32_t r = 0; r < forest->numRoots; ++r)
+        {
+          SdWork w;
+          sd_init_work(w, forest->first[r], forest->count[r], forest->first[r]);
+          rootNode[r] = forest->first[r];
+          if(forest->count[r] <= SD_SMALL)
+          {
+            rootWork[r] = SD_NONE;
+            little.push_back(w);
+          }
+          else
+          {
+            rootWork[r] = uint32_t(big.size());
+            big.push_back(w);
+          }
+        }
+        nActive  = uint32_t(big.size());
+        nSmall   = uint32_t(little.size());
+        zero2[1] = nSmall;
+        uint32_t *dRootWork = nullptr, *dRootNode = nullptr;
+        ok = nActive <= maxWork && nSmall <= maxSmall && sc.get((void**)&dRootWork, 4 * size_t(forest->numRoots)) == hipSuccess && sc.get((void**)&dRootNode, 4 * size_t(forest->numRoots)) == hipSuccess;
+        ok = ok && hipMemcpyAsync(dRootWork, rootWork.data(), 4 * rootWork.size(), hipMemcpyHostToDevice, stream) == hipSuccess &&
+             hipMemcpyAsync(dRootNode, rootNode.data(), 4 * rootNode.size(), hipMemcpyHostToDevice, stream) == hipSuccess;
+        if(ok && nActive)
+          ok = hipMemcpyAsync(workA, big.data(), sizeof(SdWork) * big.size(), hipMemcpyHostToDevice, stream) == hipSuccess;
+        if(ok && nSmall)
+          ok = hipMemcpyAsync(small, little.data(), sizeof(SdWork) * little.size(), hipMemcpyHostToDevice, stream) == hipSuccess;
+        // ids nobody owns (one per root: a root of k leaves uses k - 1 of its k ids) must still be readable by k_emit
+        ok = ok && hipMemsetAsync(dChildL, 0, 4 * size_t(n), stream) == hipSuccess && hipMemsetAsync(dChildR, 0, 4 * size_t(n), stream) == hipSuccess &&
+             hipMemsetAsync(dNodeLo, 0, 16 * size_t(n), stream) == hipSuccess && hipMemsetAsync(dNodeHi, 0, 16 * size_t(n), stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(dCounts, zero2, 8, hipMemcpyHostToDevice, stream) == hipSuccess;
+        if(ok)
+        {
+          k_sd_prims<<<G, B, 0, stream>>>(n, dUnsorted, plo, phi, idxA, pwA, SD_NONE);
+          k_forest_prim_work<<<G, B, 0, stream>>>(n, dUnsorted, dRootWork, pwA);
+          k_forest_roots<<<(forest->numRoots + 255) / 256, 256, 0, stream>>>(forest->numRoots, dRootNode, dParI);
+          ok = hipStreamSynchronize(stream) == hipSuccess;  // the host vectors above die with this scope
+        }
+      }
+      else
+      {
+      ok = hipMemcpyAsync(dParI, &noneParent, 4, hipMemcpyHostToDevice, stream) == hipSuccess;
       if(n <= SD_SMALL)
       {
         nSmall   = 1;
@@ -1150,6 +1228,7 @@ int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* 
       }
       ok = ok && hipMemcpyAsync(dCounts, zero2, 8, hipMemcpyHostToDevice, stream) == hipSuccess;
       k_sd_prims<<<G, B, 0, stream>>>(n, dUnsorted, plo, phi, idxA, pwA, nActive ? 0u : SD_NONE);
+      }
       int levels = 0;
       while(nActive && ok && levels < 4096)
       {
@@ -1282,10 +1361,15 @@ int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* 
       (void)hipMemsetAsync(dArrive, 0, 4 * size_t(n), stream);
       k_rotate<<<G, B, 0, stream>>>(int(n), dChildL, dChildR, dParI, dParL, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dArrive);
     }
-    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut);
+    k_emit<<<(n - 1 + B - 1) / B, B, 0, stream>>>(int(n - 1), dChildL, dChildR, dLeafLo, dLeafHi, dNodeLo, dNodeHi, dTrisOut, dNodesOut, forest ? forest->leafOffset : 0u);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(stream));
+  if(forest && !sahDev)
+  {
+    snprintf(err, errLen, "a forest is built by the device SAH builder only");
+    goto fail;
+  }
 
   // ---- collapse to the wide layout, one BVH level per launch (the queue sizes come back to the host between levels;
   // the build is not on the timed path)
@@ -1295,16 +1379,32 @@ int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* 
     HIPCHK(sc.get((void**)&dQ[0], sizeof(CollapseItem) * size_t(n)));
     HIPCHK(sc.get((void**)&dQ[1], sizeof(CollapseItem) * size_t(n)));
     HIPCHK(sc.get((void**)&dCnt, 8));
-    CollapseItem first{0u, 0u};
+    CollapseItem first{0u, 0u, 0u};
     uint32_t     cnt[2] = {0u, 1u};  // next-queue size, wide nodes allocated (root = 0)
-    HIPCHK(hipMemcpyAsync(dQ[0], &first, sizeof(first), hipMemcpyHostToDevice, stream));
-    uint32_t nIn = 1;
+    uint32_t     nIn = 1;
+    uint32_t *   dRootCount = nullptr, *dRootBase = nullptr;
+    if(forest)
+    {  // every root starts a queue entry of its own: binary root first[r] becomes wide node wideBase[r], its descendants are allocated behind it
+      std::vector<CollapseItem> roots(forest->numRoots);
+      std::vector<uint32_t>     ones(forest->numRoots, 1u);
+      for(uint32_t r = 0; r < forest->numRoots; ++r)
+        roots[r] = CollapseItem{forest->first[r], forest->wideBase[r], r};
+      HIPCHK(sc.get((void**)&dRootCount, 4 * size_t(forest->numRoots)));
+      HIPCHK(sc.get((void**)&dRootBase, 4 * size_t(forest->numRoots)));
+      HIPCHK(hipMemcpyAsync(dQ[0], roots.data(), sizeof(CollapseItem) * roots.size(), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(dRootCount, ones.data(), 4 * ones.size(), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(dRootBase, forest->wideBase, 4 * size_t(forest->numRoots), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      nIn = forest->numRoots;
+    }
+    else
+      HIPCHK(hipMemcpyAsync(dQ[0], &first, sizeof(first), hipMemcpyHostToDevice, stream));
     int      cur = 0;
     bool     ok  = true;
     while(nIn && ok)
     {
       HIPCHK(hipMemcpyAsync(dCnt, cnt, 8, hipMemcpyHostToDevice, stream));
-      k_collapse<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, dWideOut);
+      k_collapse<<<(nIn + 63) / 64, 64, 0, stream>>>(dNodesOut, dQ[cur], nIn, dQ[cur ^ 1], dCnt, dWideOut, dRootCount, dRootBase);
       HIPCHK(hipMemcpyAsync(cnt, dCnt, 8, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
       nIn    = cnt[0];
@@ -1312,6 +1412,15 @@ int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* 
       cur ^= 1;
     }
     *numWideOut = cnt[1];
+    if(forest)
+    {
+      HIPCHK(hipMemcpyAsync(forest->numWide, dRootCount, 4 * size_t(forest->numRoots), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      uint32_t total = 0;
+      for(uint32_t r = 0; r < forest->numRoots; ++r)
+        total += forest->numWide[r];
+      *numWideOut = total;
+    }
   }
 
   sc.release();
@@ -1363,6 +1472,85 @@ int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, ui
     snprintf(err, errLen, "BLAS build: upload failed");
     return -1;
   }
+  // Round 6: with the device SAH builder ALL meshes of two or more triangles are built as one forest -- one level-synchronous pass over the concatenated
+  // triangles with a root per mesh (pt_internal.h PtForest) instead of one build and ~20 host round trips per mesh (C5 stand-in, 201 meshes: the two-level build 172 -> 70 ms, profiles/r06_forest_build.txt).
+  // The arrays' layout is unchanged: mesh b's leaf records at slotBase, its wide nodes from nodeBase on, references global.  What is left for the per-mesh
+  // path below: one-triangle meshes, and every mesh under the other builders (build=sah|ploc|lbvh).
+  std::vector<char> done(numBlas, 0);
+  if(tune.sahBuild == 3)
+  {
+    std::vector<uint32_t> ids;
+    for(uint32_t b = 0; b < numBlas; ++b)
+      if(blas[b].triCount >= 2)
+        ids.push_back(b);
+    // the forest wants its meshes contiguous in the slot range (they are: build_two_level hands out slotBase in order) -- take the longest run from the first
+    bool contiguous = !ids.empty();
+    for(size_t q = 1; q < ids.size() && contiguous; ++q)
+      contiguous = blas[ids[q]].slotBase == blas[ids[q - 1]].slotBase + blas[ids[q - 1]].triCount && ids[q] == ids[q - 1] + 1;
+    if(ids.size() >= 2 && contiguous)
+    {
+      const uint32_t b0 = ids.front(), slot0 = blas[b0].slotBase;
+      uint32_t       nF = 0;
+      std::vector<uint32_t> first(ids.size()), count(ids.size()), wideBase(ids.size()), numWide(ids.size(), 0u);
+      std::vector<InstanceRec> pf(ids.size());
+      for(size_t q = 0; q < ids.size(); ++q)
+      {
+        const PtBlasDesc& d = blas[ids[q]];
+        first[q] = d.slotBase - slot0; count[q] = d.triCount; wideBase[q] = d.nodeBase;
+        pf[q]         = pseudo[ids[q]];
+        pf[q].triBase = first[q];
+        nF += d.triCount;
+      }
+      InstanceRec* dPf    = nullptr;
+      BvhNode*     dNodes = nullptr;
+      PtScratch    arena;
+      uint32_t     total = 0;
+      char         msg[256] = "";
+      bool ok = hipMalloc(&dPf, sizeof(InstanceRec) * pf.size()) == hipSuccess && hipMalloc(&dNodes, sizeof(BvhNode) * size_t(nF)) == hipSuccess &&
+                hipMemcpyAsync(dPf, pf.data(), sizeof(InstanceRec) * pf.size(), hipMemcpyHostToDevice, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+      const size_t arenaBytes = size_t(nF) * 704 + (size_t(4) << 20);
+      if(ok && hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
+        arena.cap = arenaBytes;
+      else
+      {
+        arena.base = nullptr;
+        (void)hipGetLastError();
+      }
+      if(ok)
+      {
+        PtForest F{uint32_t(ids.size()), first.data(), count.data(), wideBase.data(), slot0, numWide.data()};
+        ok = pt_accel_build(stream, tune, dPf, uint32_t(pf.size()), dVertices, dIndices, nF, dTris + slot0, dAlpha + slot0, dNodes, dWide, &total, msg, sizeof(msg), nullptr, &arena, &F) == 0;
+      }
+      if(ok)
+      {
+        k_forest_vertex_form<<<(nF + 255) / 256, 256, 0, stream>>>(nF, dTris + slot0, dPf, dVertices, dIndices);
+        ok = hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+      }
+      for(size_t q = 0; q < ids.size() && ok; ++q)
+      {
+        PtBlasDesc& d = blas[ids[q]];
+        d.numWide     = numWide[q];
+        done[ids[q]]  = 1;
+        if(d.numWide == 0 || d.numWide > std::max(1u, d.triCount - 1))
+        {
+          snprintf(msg, sizeof(msg), "BLAS %u: %u wide nodes for %u triangles", ids[q], d.numWide, d.triCount);
+          ok = false;
+        }
+      }
+      arena.release();
+      if(arena.base)
+        (void)hipFree(arena.base);
+      (void)hipFree(dPf);
+      (void)hipFree(dNodes);
+      if(!ok)
+      {
+        (void)hipGetLastError();
+        (void)hipFree(dPseudo);
+        snprintf(err, errLen, "BLAS forest build: %s", msg[0] ? msg : "out of device memory or a kernel error");
+        return -1;
+      }
+    }
+  }
   // A build is a chain of small level-synchronous launches with a host round trip per level: one mesh alone leaves the GPU and the host idle
   // most of the time.  A few host threads, each with its own stream, arena and binary-node scratch, take the meshes from a shared counter
   // (largest first would balance better; the meshes of a scene are usually of similar size).
@@ -1393,6 +1581,8 @@ int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, ui
       const uint32_t b = next.fetch_add(1);
       if(b >= numBlas)
         break;
+      if(done[b])
+        continue;  // built in the forest above
       PtBlasDesc&    d = blas[b];
       const uint32_t n = d.triCount;
       if(pt_accel_build(ws, tune, dPseudo + b, 1, dVertices, dIndices, n, dTris + d.slotBase, dAlpha + d.slotBase, dNodes, dWide + d.nodeBase, &d.numWide, msg, sizeof(msg), nullptr, &arena) != 0)

@@ -109,7 +109,7 @@ struct pt_context {
   uint64_t  qRatioSeq    = 0;   // launch they come from
   uint64_t  launchSeq    = 0;
   hipEvent_t lastAccum   = nullptr;  // accumDone of the most recent frame (nullptr: none pending)
-  DevBuf   dFrame, dSlotTile, dTilePrefix, dCounters;
+  DevBuf   dFrame, dSlotTile, dCounters;
   DevBuf   dPick;
   DevBuf   dRowMajor, dRgba8, dMean, dMips, dGather, dFullTiles, dFullSlotTile, dTileLocalIndex;
   bool     haveFull = false;
@@ -862,7 +862,7 @@ int pt_destroy(pt_context* c)
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   DevBuf* all[] = {&c->dMatLines, &c->dVertices, &c->dIndices, &c->dInstances, &c->dMaterials, &c->dLights, &c->dTexRecs, &c->dTexels, &c->dBvh, &c->dWide, &c->dTris, &c->dAlphaRecs, &c->dCNodes, &c->dCTlas, &c->dInstBlock, &c->dShadeTris, &c->dAlphaMats, &c->dAlphaMaps, &c->dPick, &c->dEnv,
-                   &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dTilePrefix, &c->dCounters, &c->dRowMajor, &c->dRgba8,
+                   &c->dTlas, &c->dTlasLeaves, &c->dInstTriBase, &c->dActive, &c->dInstNodeBase, &c->dInstPad, &c->dEnvAccel, &c->dFrame, &c->dSlotTile, &c->dCounters, &c->dRowMajor, &c->dRgba8,
                    &c->dMean, &c->dMips, &c->dGather, &c->dFullTiles, &c->dFullSlotTile, &c->dTileLocalIndex};
   for(DevBuf* b : all)
     dev_free(*b);
@@ -1725,15 +1725,6 @@ int pt_resize(pt_context* c, int width, int height)
   }
   if((rc = dev_alloc(c, c->dFrame, sizeof(float4) * size_t(c->maxTilesPerRank ? c->maxTilesPerRank : 1) * 1024u)) != PT_OK) return rc;
   if((rc = upload(c, c->dSlotTile, local.data(), 4 * local.size())) != PT_OK) return rc;
-  {  // valid pixels of the local tiles before each tile (k_generate's queue positions)
-    std::vector<uint32_t> prefix(local.size() + 1, 0u);
-    for(size_t i = 0; i < local.size(); ++i)
-    {
-      const int tx = int(local[i] % uint32_t(c->tilesX)), ty = int(local[i] / uint32_t(c->tilesX));
-      prefix[i + 1] = prefix[i] + uint32_t(std::min(PT_TILE, width - tx * PT_TILE)) * uint32_t(std::min(PT_TILE, height - ty * PT_TILE));
-    }
-    if((rc = upload(c, c->dTilePrefix, prefix.data(), 4 * prefix.size())) != PT_OK) return rc;
-  }
   HIP_TRY(c, hipMemset(c->dFrame.p, 0, c->dFrame.bytes));
   if((rc = dev_alloc(c, c->dRowMajor, sizeof(float4) * size_t(width) * height)) != PT_OK) return rc;
   HIP_TRY(c, hipMemset(c->dRowMajor.p, 0, sizeof(float4) * size_t(width) * height));
@@ -1760,7 +1751,6 @@ int pt_resize(pt_context* c, int width, int height)
     fs.rb.countsDone = (uint32_t*)fs.dCountsDone.p;
     fs.rb.frame    = (float4*)c->dFrame.p;
     fs.rb.slotTile = (uint32_t*)c->dSlotTile.p;
-    fs.rb.tilePrefix = (uint32_t*)c->dTilePrefix.p;
     fs.rb.counters = (Counters*)c->dCounters.p;
   }
   return warm_slots(c);
@@ -1907,7 +1897,6 @@ int flush_pending(pt_context* c)
     pt_context::FrameSlot& fs = slot_at(c, int(c->displayCounter++ % uint64_t(slot_total(c))));
     RenderBuffers  rbb = fs.rb;
     rbb.slotTile += t0;
-    rbb.tilePrefix += t0;
     rbb.frame += size_t(t0) * 1024u;
     plans.emplace_back();
     planSlot.push_back(&fs);

@@ -81,9 +81,21 @@ void pt_parse_tuning(const char* tune, PtTuning& t, std::string& unknown);
 #define PT_ROTATE_PASSES 2            // device builders: bottom-up tree-rotation passes after the topology is built
 #define PT_PLOC_RADIUS 16             // PLOC: clusters examined on either side of a cluster per round
 
+// A FOREST (round 6): several hierarchies in ONE level-synchronous device-SAH build -- root r owns the primitives [first[r], first[r] + count[r]) (count >= 2;
+// the instances are numbered like the roots and their triBase is first[r]), its binary nodes take the ids first[r] .. first[r] + count[r] - 2, its wide nodes are
+// allocated from wideBase[r] on (global ids: dWideOut is then the base of the shared array) and its leaf references are offset by leafOffset.  All bottom-level
+// structures of the two-level mode are built this way in one pass instead of one build (and ~20 host round trips) per prim-mesh.
+struct PtForest {
+  uint32_t        numRoots;
+  const uint32_t* first;      // host arrays, numRoots entries each
+  const uint32_t* count;
+  const uint32_t* wideBase;
+  uint32_t        leafOffset;
+  uint32_t*       numWide;    // out: wide nodes of every root
+};
 int pt_accel_build(hipStream_t stream, const PtTuning& tune, const InstanceRec* dInst, uint32_t numInst, const float4* dVertices, const uint32_t* dIndices, uint32_t numTris,
                    TriRec* dTrisOut, AlphaRec* dAlphaOut, BvhNode* dNodesOut, WideNode* dWideOut, uint32_t* numWideOut, char* err, size_t errLen,
-                   const TriRec* dProxies = nullptr, PtScratch* scratch = nullptr);
+                   const TriRec* dProxies = nullptr, PtScratch* scratch = nullptr, const PtForest* forest = nullptr);
 // Two-level structure (reference: src/accelstruct.cpp:110-162).  One BLAS per prim-mesh in object space ...
 struct PtBlasDesc {
   uint32_t primMesh, vertexOffset, firstIndex, triCount, flags;  // flags: TRI_OPAQUE / TRI_NOCULL of the mesh's material (no TRI_FLIP: that is per instance)
@@ -145,7 +157,6 @@ struct RenderBuffersT {
   uint32_t* countsDone;  // the counter block of the latest finished sample pass (k_accumulate copies it here and clears `counts`)
   float4*   frame;     // accumulation tiles, slot order
   uint32_t* slotTile;  // local tile -> global tile id
-  uint32_t* tilePrefix;  // [local tiles + 1]: valid pixels (inside the image) of the local tiles before tile i; k_generate places a tile's slots in the bounce-0 queue with it
   Counters* counters;
 };
 typedef RenderBuffersT<PT_STATE_POLICY> RenderBuffers;

@@ -130,30 +130,14 @@ PT_DEV void stage_push(uint32_t* stage, uint32_t& n, bool valid, uint32_t slot, 
 // ---- k_generate -----------------------------------------------------------------------------------------
 // heat-map support: nanoseconds since t0 (low 32 bits of the 100 MHz wall clock)
 PT_DEV float heat_ns(uint32_t t0) { return float(uint32_t(wall_clock64()) - t0) * 10.0f; }
-// One block = one 32x32 tile of one frame of the batch.  The bounce-0 queue is every VALID path slot (edge tiles hang over the image); where a tile's slots go
-// in it follows from the tiles before it -- a prefix the host computed once (pt_resize: RenderBuffers::tilePrefix) -- so no block needs the returning atomic on the
-// queue counter it used to take: 40 k same-address atomics at ~11 ns each, serialised, were 0.45 of this kernel's 0.47 ms per 20-frame batch (round 6).
 __global__ void __launch_bounds__(1024) k_generate(DeviceScene S, RenderBuffers rb, FrameParams fp)
 {
-  __shared__ uint32_t sWave[16];
-  const uint32_t      slot = blockIdx.x * blockDim.x + threadIdx.x;  // the grid is exactly numLocalTiles x batch blocks
-  const uint32_t      fb   = blockIdx.x / fp.numLocalTiles;          // frame of the batch
-  const uint32_t      lt   = blockIdx.x - fb * fp.numLocalTiles;     // local tile
-  int                 px = 0, py = 0;
-  const bool          valid = slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py);
-  const unsigned long long m = __ballot(valid);
-  const uint32_t      wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  if(lane == 0)
-    sWave[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  uint32_t before = 0;
-  for(uint32_t w = 0; w < wave; ++w)
-    before += sWave[w];
-  const uint32_t p0 = rb.tilePrefix[0], perFrame = rb.tilePrefix[fp.numLocalTiles] - p0;  // (a band of a single frame sees its tiles through shifted pointers)
-  if(valid)
-    rb.queueA[fb * perFrame + (rb.tilePrefix[lt] - p0) + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;  // bounce 0 reads queueA
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-    rb.counts[CNT_IN] = perFrame * fp.batch;  // (the counter block is zero when a pass starts; nobody else writes bounce 0's input count)
+  uint32_t       slot  = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool     inRange = slot < fp.numSlots * fp.batch;
+  const uint32_t fb    = inRange ? slot / fp.numSlots : 0u;  // frame of the batch
+  int            px = 0, py = 0;
+  const bool     valid = inRange && slot_pixel(fp, rb.slotTile, slot - fb * fp.numSlots, px, py);
+  enqueue_block(rb.queueA, &rb.counts[CNT_IN], slot, valid);  // bounce 0 reads queueA
   if(!valid)
     return;
   if(fp.regen)
