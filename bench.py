@@ -861,7 +861,8 @@ def main():
         out["gather_error"] = job.get("gather")
         print(json.dumps(out))
         sys.stdout.flush()
-        os._exit(4)
+        with_timeout(job["cleanup"], 10, "control-plane barrier")  # let the other ranks leave (the control plane is independent of the wedged collective)
+        os._exit(4)  # (not sys.exit: the helper thread inside the collective would keep the interpreter alive)
     peaks = r.measure_peaks()
     out["calibration"] = {"valu_G_wave_instr_per_s": peaks["valuWaveInstrPerSec"] / 1e9, "hbm_copy_GBps": peaks["hbmCopyBytesPerSec"] / 1e9,
                           "hbm_read_GBps": peaks["hbmReadBytesPerSec"] / 1e9, "compute_units": peaks["computeUnits"], "clock_MHz": peaks["clockMHz"],
