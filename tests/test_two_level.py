@@ -308,6 +308,49 @@ def test_two_level_tiny_and_ragged_scenes(env_small, tail_policy):
 
 
 @gpu
+def test_two_level_forest_build_runs_and_small_meshes(env_small):
+    """Round 6: all BLASes of two or more triangles are built as ONE forest per contiguous run of meshes (csrc/pt_accel.hip pt_blas_build / PtForest); one-triangle
+    meshes between the runs keep the per-mesh path, meshes of <= 12 triangles start in the builder's small-node list, bigger ones open its first level.  Every
+    mesh is instantiated twice (so that none is merged into the world-space structure): the image must equal the oracle's and the flat structure's, bit for bit,
+    under the device SAH builder (forest) and under a per-mesh builder."""
+    from tests.common import Config, render_hip, render_oracle
+    rng = np.random.default_rng(77)
+    sc = Scene("forest")
+    mats = [sc.add_material(pbrBaseColorFactor=(0.3 + 0.1 * k, 0.8 - 0.1 * k, 0.5, 1), doubleSided=1, pbrRoughnessFactor=0.6) for k in range(3)]
+
+    def soup(n_tris, spread):
+        """n_tris random triangles around the origin"""
+        c = rng.uniform(-spread, spread, (n_tris, 1, 3))
+        v = (c + rng.normal(0, 0.25, (n_tris, 3, 3))).reshape(-1, 3)
+        nrm = np.tile((0.0, 0.0, 1.0), (len(v), 1))
+        uv = rng.uniform(0, 1, (len(v), 2))
+        return v, nrm, uv, np.arange(len(v), dtype=np.uint32)
+
+    sizes = [40, 2, 13, 1, 300, 12, 1, 1, 7, 90]   # runs: [40, 2, 13] | 1 | [300, 12] | 1 | 1 | [7, 90]
+    for i, n in enumerate(sizes):
+        pm = sc.add_prim_mesh(*soup(n, 0.8), mats[i % 3])
+        sc.add_node(pm, translate(-3.0 + 0.7 * i, 0.4 * ((i % 3) - 1), 0.0))
+        sc.add_node(pm, translate(-3.0 + 0.7 * i, -0.6 + 0.3 * (i % 2), -1.0) @ rotate_y(0.4 * i) @ scale(0.8, 1.1, 0.9))
+    sc.camera = Camera(eye=(0.2, 0.3, 6.5), center=(0, 0, 0), fov=50)
+    cfg = Config(sc, env_small, 192, 96, depth=5)
+    want = render_oracle(cfg, 3)
+    _assert_identical(render_hip(cfg, 3, accel=capi.PT_ACCEL_TWO_LEVEL), want, "forest build")
+    _assert_identical(render_hip(cfg, 3), want, "flat structure")
+    aov = Config(sc, env_small, 192, 96, debug=hd.eNormal)
+    assert np.array_equal(render_hip(aov, 1, accel=capi.PT_ACCEL_TWO_LEVEL), render_oracle(aov, 1))
+    # the per-mesh path (any builder but the device SAH one): PT_TUNE is read by pt_create into the context's own knobs
+    keep = os.environ.get("PT_TUNE")
+    os.environ["PT_TUNE"] = "build=lbvh"
+    try:
+        _assert_identical(render_hip(cfg, 3, accel=capi.PT_ACCEL_TWO_LEVEL), want, "one build per mesh")
+    finally:
+        if keep is None:
+            del os.environ["PT_TUNE"]
+        else:
+            os.environ["PT_TUNE"] = keep
+
+
+@gpu
 def test_two_level_ray_picker(env_small):
     """pt_pick walks the two-level structure: same instance / primitive / t / barycentrics as the oracle's probe"""
     from tests import orc

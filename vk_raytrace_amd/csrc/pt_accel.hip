@@ -1479,75 +1479,77 @@ int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, ui
   std::vector<char> done(numBlas, 0);
   if(tune.sahBuild == 3)
   {
-    std::vector<uint32_t> ids;
-    for(uint32_t b = 0; b < numBlas; ++b)
-      if(blas[b].triCount >= 2)
-        ids.push_back(b);
-    // the forest wants its meshes contiguous in the slot range (they are: build_two_level hands out slotBase in order) -- take the longest run from the first
-    bool contiguous = !ids.empty();
-    for(size_t q = 1; q < ids.size() && contiguous; ++q)
-      contiguous = blas[ids[q]].slotBase == blas[ids[q - 1]].slotBase + blas[ids[q - 1]].triCount && ids[q] == ids[q - 1] + 1;
-    if(ids.size() >= 2 && contiguous)
+    // a forest wants its meshes contiguous in the slot range (build_two_level hands out slotBase in order): every maximal run of two or more meshes with
+    // at least two triangles each is one forest; what lies between the runs (one-triangle meshes) takes the per-mesh path
+    for(uint32_t runStart = 0; runStart < numBlas;)
     {
-      const uint32_t b0 = ids.front(), slot0 = blas[b0].slotBase;
-      uint32_t       nF = 0;
-      std::vector<uint32_t> first(ids.size()), count(ids.size()), wideBase(ids.size()), numWide(ids.size(), 0u);
-      std::vector<InstanceRec> pf(ids.size());
-      for(size_t q = 0; q < ids.size(); ++q)
+      std::vector<uint32_t> ids;
+      uint32_t              b = runStart;
+      while(b < numBlas && blas[b].triCount >= 2 && (ids.empty() || blas[b].slotBase == blas[b - 1].slotBase + blas[b - 1].triCount))
+        ids.push_back(b++);
+      runStart = ids.empty() ? b + 1 : b;
+      if(ids.size() >= 2)
       {
-        const PtBlasDesc& d = blas[ids[q]];
-        first[q] = d.slotBase - slot0; count[q] = d.triCount; wideBase[q] = d.nodeBase;
-        pf[q]         = pseudo[ids[q]];
-        pf[q].triBase = first[q];
-        nF += d.triCount;
-      }
-      InstanceRec* dPf    = nullptr;
-      BvhNode*     dNodes = nullptr;
-      PtScratch    arena;
-      uint32_t     total = 0;
-      char         msg[256] = "";
-      bool ok = hipMalloc(&dPf, sizeof(InstanceRec) * pf.size()) == hipSuccess && hipMalloc(&dNodes, sizeof(BvhNode) * size_t(nF)) == hipSuccess &&
-                hipMemcpyAsync(dPf, pf.data(), sizeof(InstanceRec) * pf.size(), hipMemcpyHostToDevice, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-      const size_t arenaBytes = size_t(nF) * 704 + (size_t(4) << 20);
-      if(ok && hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
-        arena.cap = arenaBytes;
-      else
-      {
-        arena.base = nullptr;
-        (void)hipGetLastError();
-      }
-      if(ok)
-      {
-        PtForest F{uint32_t(ids.size()), first.data(), count.data(), wideBase.data(), slot0, numWide.data()};
-        ok = pt_accel_build(stream, tune, dPf, uint32_t(pf.size()), dVertices, dIndices, nF, dTris + slot0, dAlpha + slot0, dNodes, dWide, &total, msg, sizeof(msg), nullptr, &arena, &F) == 0;
-      }
-      if(ok)
-      {
-        k_forest_vertex_form<<<(nF + 255) / 256, 256, 0, stream>>>(nF, dTris + slot0, dPf, dVertices, dIndices);
-        ok = hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
-      }
-      for(size_t q = 0; q < ids.size() && ok; ++q)
-      {
-        PtBlasDesc& d = blas[ids[q]];
-        d.numWide     = numWide[q];
-        done[ids[q]]  = 1;
-        if(d.numWide == 0 || d.numWide > std::max(1u, d.triCount - 1))
+        const uint32_t b0 = ids.front(), slot0 = blas[b0].slotBase;
+        uint32_t       nF = 0;
+        std::vector<uint32_t> first(ids.size()), count(ids.size()), wideBase(ids.size()), numWide(ids.size(), 0u);
+        std::vector<InstanceRec> pf(ids.size());
+        for(size_t q = 0; q < ids.size(); ++q)
         {
-          snprintf(msg, sizeof(msg), "BLAS %u: %u wide nodes for %u triangles", ids[q], d.numWide, d.triCount);
-          ok = false;
+          const PtBlasDesc& d = blas[ids[q]];
+          first[q] = d.slotBase - slot0; count[q] = d.triCount; wideBase[q] = d.nodeBase;
+          pf[q]         = pseudo[ids[q]];
+          pf[q].triBase = first[q];
+          nF += d.triCount;
         }
-      }
-      arena.release();
-      if(arena.base)
-        (void)hipFree(arena.base);
-      (void)hipFree(dPf);
-      (void)hipFree(dNodes);
-      if(!ok)
-      {
-        (void)hipGetLastError();
-        (void)hipFree(dPseudo);
-        snprintf(err, errLen, "BLAS forest build: %s", msg[0] ? msg : "out of device memory or a kernel error");
-        return -1;
+        InstanceRec* dPf    = nullptr;
+        BvhNode*     dNodes = nullptr;
+        PtScratch    arena;
+        uint32_t     total = 0;
+        char         msg[256] = "";
+        bool ok = hipMalloc(&dPf, sizeof(InstanceRec) * pf.size()) == hipSuccess && hipMalloc(&dNodes, sizeof(BvhNode) * size_t(nF)) == hipSuccess &&
+                  hipMemcpyAsync(dPf, pf.data(), sizeof(InstanceRec) * pf.size(), hipMemcpyHostToDevice, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        const size_t arenaBytes = size_t(nF) * 704 + (size_t(4) << 20);
+        if(ok && hipMalloc((void**)&arena.base, arenaBytes) == hipSuccess)
+          arena.cap = arenaBytes;
+        else
+        {
+          arena.base = nullptr;
+          (void)hipGetLastError();
+        }
+        if(ok)
+        {
+          PtForest F{uint32_t(ids.size()), first.data(), count.data(), wideBase.data(), slot0, numWide.data()};
+          ok = pt_accel_build(stream, tune, dPf, uint32_t(pf.size()), dVertices, dIndices, nF, dTris + slot0, dAlpha + slot0, dNodes, dWide, &total, msg, sizeof(msg), nullptr, &arena, &F) == 0;
+        }
+        if(ok)
+        {
+          k_forest_vertex_form<<<(nF + 255) / 256, 256, 0, stream>>>(nF, dTris + slot0, dPf, dVertices, dIndices);
+          ok = hipStreamSynchronize(stream) == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+        for(size_t q = 0; q < ids.size() && ok; ++q)
+        {
+          PtBlasDesc& d = blas[ids[q]];
+          d.numWide     = numWide[q];
+          done[ids[q]]  = 1;
+          if(d.numWide == 0 || d.numWide > std::max(1u, d.triCount - 1))
+          {
+            snprintf(msg, sizeof(msg), "BLAS %u: %u wide nodes for %u triangles", ids[q], d.numWide, d.triCount);
+            ok = false;
+          }
+        }
+        arena.release();
+        if(arena.base)
+          (void)hipFree(arena.base);
+        (void)hipFree(dPf);
+        (void)hipFree(dNodes);
+        if(!ok)
+        {
+          (void)hipGetLastError();
+          (void)hipFree(dPseudo);
+          snprintf(err, errLen, "BLAS forest build: %s", msg[0] ? msg : "out of device memory or a kernel error");
+          return -1;
+        }
       }
     }
   }
