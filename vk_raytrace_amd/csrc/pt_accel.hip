@@ -1544,11 +1544,12 @@ int pt_blas_build(hipStream_t stream, const PtTuning& tune, PtBlasDesc* blas, ui
         (void)hipFree(dPf);
         (void)hipFree(dNodes);
         if(!ok)
-        {
+        {  // the forest is an optimisation: whatever stopped it (memory for its arena, a failed launch), these meshes take the per-mesh path below, which
+           // rewrites everything the attempt may have left in their ranges
+          (void)hipStreamSynchronize(stream);
           (void)hipGetLastError();
-          (void)hipFree(dPseudo);
-          snprintf(err, errLen, "BLAS forest build: %s", msg[0] ? msg : "out of device memory or a kernel error");
-          return -1;
+          for(uint32_t q : ids)
+            done[q] = 0;
         }
       }
     }
